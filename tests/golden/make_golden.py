@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by IMPORTING the reference.
+
+Runs only in the development container, where /root/reference exists; the
+fixtures it writes (inputs + expected outputs, small .npz files) are what
+travels.  No reference source is copied.
+
+Import shims (environment only, nothing of the reference is modified):
+  * numpy >= 1.24 dropped ``np.int`` / ``np.float`` that the reference uses
+    (e.g. HaploSNP_Sampler.py:68, Init_NMFT.py:49) -> aliased to int / float.
+  * desman/__init__.py calls pkg_resources.require("desman") (needs an
+    installed dist) -> a stub package object pointing at the source dir.
+  * desman/HaploSNP_Sampler.py does ``import sampletau`` (the Cython/GSL
+    extension, which cannot be built here: no GSL).  A module object named
+    ``sampletau`` backed by oracle/ (our C restatement) is registered so the
+    import succeeds; fixtures that depend on it say so in their ``note``.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--cog]
+"""
+import argparse
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+np.int = int      # noqa
+np.float = float  # noqa
+
+from oracle import cbind  # noqa: E402
+
+REF = "/root/reference"
+
+
+def import_reference():
+    pkg = types.ModuleType("desman")
+    pkg.__path__ = [os.path.join(REF, "desman")]
+    sys.modules["desman"] = pkg
+    st = types.ModuleType("sampletau")
+    st.initRNG = cbind.initRNG
+    st.setRNG = cbind.setRNG
+    st.freeRNG = cbind.freeRNG
+    st.sample_tau = cbind.sample_tau
+    sys.modules["sampletau"] = st
+    import warnings
+    warnings.simplefilter("ignore")
+    import desman.Init_NMFT as inmft
+    import desman.HaploSNP_Sampler as hsnp
+    import desman.Desman_Utils as du
+    return inmft, hsnp, du
+
+
+def synth(V, S, G, seed):
+    from desman_amd.synth import synth_counts
+    return synth_counts(V, S, G, seed)[0]
+
+
+def make_sampler(hsnp, counts, G, seed, max_iter=3):
+    rs = np.random.RandomState(seed)
+    return hsnp.HaploSNP_Sampler(counts, G, rs, max_iter=max_iter)
+
+
+def gen_tau_sweep(hsnp, out):
+    """Conditional log-probs + draws of the tau sweep from the reference's own
+    pure-Python sampler (HaploSNP_Sampler.sampleTau, :148-183).  Its categorical
+    draw (sampleLogProb, :124-127) is replaced by the native sweep's inverse-CDF
+    rule (c_sample_tau.c:48-91,172-176) fed with recorded uniforms, so the
+    fixture pins the conditional of the C sweep: logp[V,G,4], tau_out."""
+    for (V, S, G, seed) in [(32, 8, 3, 11), (64, 16, 5, 12), (40, 64, 8, 13), (33, 7, 3, 14)]:
+        counts = synth(V, S, G, 100 + seed)
+        smp = make_sampler(hsnp, counts, G, seed)
+        rng = np.random.default_rng(seed)
+        smp.gamma = np.ascontiguousarray(rng.dirichlet(np.ones(G), size=S))
+        smp.eta = np.ascontiguousarray(rng.dirichlet(np.ones(4), size=4) * 0.08 + 0.92 * np.eye(4))
+        smp.updateTauIndices()
+        tau_in = smp.tau.copy()
+        u = cbind.MT19937(1000 + seed).uniform(V * G)
+        rec = []
+
+        def pick(logp, _u=iter(u), _rec=rec):
+            _rec.append(np.array(logp, dtype=np.float64))
+            p = np.exp(logp - np.max(logp))
+            p = p / p.sum()
+            c = np.cumsum(p)
+            x = next(_u)
+            return 0 if x < c[0] else 1 if x < c[1] else 2 if x < c[2] else 3
+
+        smp.sampleLogProb = pick
+        smp.sampleTau()
+        np.savez_compressed(os.path.join(out, "tau_sweep_V%d_S%d_G%d.npz" % (V, S, G)),
+                            counts=counts, tau_in=tau_in, gamma=smp.gamma, eta=smp.eta, u=u,
+                            mt_seed=1000 + seed, logp=np.array(rec).reshape(V, G, 4),
+                            tau_out=smp.tau.copy(),
+                            note="reference python sampleTau conditionals; inverse-CDF draw")
+
+
+def gen_loglik(hsnp, out):
+    rows = []
+    for (V, S, G, seed) in [(20, 6, 2, 21), (30, 16, 5, 22), (16, 64, 8, 23)]:
+        counts = synth(V, S, G, 200 + seed)
+        smp = make_sampler(hsnp, counts, G, seed)
+        rng = np.random.default_rng(seed)
+        gamma = np.ascontiguousarray(rng.dirichlet(np.ones(G), size=S))
+        eta = np.ascontiguousarray(rng.dirichlet(np.ones(4), size=4) * 0.08 + 0.92 * np.eye(4))
+        ll = smp.logLikelihood(gamma, smp.tau, eta)
+        lp = smp.logPosterior(gamma, smp.tau, eta)
+        rows.append(dict(counts=counts, tau=smp.tau.copy(), gamma=gamma, eta=eta, ll=ll, lp=lp))
+    np.savez_compressed(os.path.join(out, "loglik.npz"),
+                        **{"%s_%d" % (k, i): r[k] for i, r in enumerate(rows) for k in r}, n=len(rows))
+
+
+def gen_degenerate(hsnp, out):
+    rows = []
+    for case, (V, S, G, dup) in enumerate([(25, 5, 4, [(0, 2)]), (25, 5, 5, [(1, 3), (1, 4)]),
+                                           (25, 5, 3, []), (10, 4, 6, [(0, 1), (2, 3), (2, 5)])]):
+        counts = synth(V, S, G, 300 + case)
+        smp = make_sampler(hsnp, counts, G, 30 + case)
+        for (g, h) in dup:
+            smp.tau[:, h, :] = smp.tau[:, g, :]
+        smp.updateTauIndices()
+        tau_in, gamma_in = smp.tau.copy(), smp.gamma.copy()
+        smp.removeDegenerate()
+        rows.append(dict(tau_in=tau_in, gamma_in=gamma_in, tau_out=smp.tau.copy(),
+                         gamma_out=smp.gamma.copy(), G_out=smp.G))
+    np.savez_compressed(os.path.join(out, "degenerate.npz"),
+                        **{"%s_%d" % (k, i): r[k] for i, r in enumerate(rows) for k in r}, n=len(rows))
+
+
+def gen_gibbs_pieces(hsnp, out):
+    """sampleMu / sampleGamma / sampleEta with the reference's RandomState stream
+    (pins oracle/ref_numpy.py), plus a short update() trajectory.  The
+    trajectory's tau sweep comes from oracle/ (registered as ``sampletau``)."""
+    V, S, G, seed = 12, 5, 3, 41
+    counts = synth(V, S, G, 400)
+    smp = make_sampler(hsnp, counts, G, seed, max_iter=4)
+    tau0, gamma0, eta0 = smp.tau.copy(), smp.gamma.copy(), smp.eta.copy()
+    state0 = smp.randomState.get_state()
+    smp.sampleMu(smp.tau, smp.gamma, smp.eta)
+    E1, mu1 = smp.E.copy(), smp.mu.copy()
+    smp.sampleGamma()
+    gamma1 = smp.gamma.copy()
+    smp.sampleEta()
+    eta1 = smp.eta.copy()
+    # trajectory from a fresh, identically seeded sampler
+    smp2 = make_sampler(hsnp, counts, G, seed, max_iter=4)
+    cbind.initRNG(); cbind.setRNG(seed)
+    smp2.update()
+    np.savez_compressed(
+        os.path.join(out, "gibbs_pieces.npz"), counts=counts, G=G, seed=seed, tau0=tau0,
+        gamma0=gamma0, eta0=eta0, rs_key=state0[1], rs_pos=state0[2], E1=E1, mu1=mu1,
+        gamma1=gamma1, eta1=eta1, ll_store=smp2.ll_store.copy(), gamma_store=smp2.gamma_store.copy(),
+        eta_store=smp2.eta_store.copy(), tau_final=smp2.tau.copy(), tau_star=smp2.tau_star.copy(),
+        gamma_star=smp2.gamma_star.copy(), eta_star=smp2.eta_star.copy(), lp_star=smp2.lp_star,
+        tau_mean=smp2.tauMean(), mean_dev=smp2.meanDeviance(),
+        note="update() trajectory: python parts = reference, tau sweep = oracle C restatement")
+
+
+def gen_nmft(inmft, out):
+    for (V, S, G, seed) in [(24, 6, 3, 51), (50, 16, 5, 52), (30, 64, 8, 53), (20, 8, 1, 54)]:
+        counts = synth(V, S, max(G, 2), 500 + seed)
+        rs = np.random.RandomState(seed)
+        nm = inmft.Init_NMFT(counts, G, rs)
+        F = nm.freq_matrix.copy()
+        nm.random_initialize()
+        tau_raw, gamma_raw = nm.tau.copy(), nm.gamma.copy()
+        nm._adjustment()
+        snaps = {}
+        div0 = nm.div_objective()
+        for it in range(1, 101):
+            nm.div_update()
+            nm._adjustment()
+            if it in (1, 10, 100):
+                snaps["tau_%d" % it] = nm.tau.copy()
+                snaps["gamma_%d" % it] = nm.gamma.copy()
+                snaps["div_%d" % it] = nm.div_objective()
+        get_tau = nm.get_tau()
+        # full factorize() with a small iteration cap, from the same seed
+        rs2 = np.random.RandomState(seed)
+        nm2 = inmft.Init_NMFT(counts, G, rs2, max_iter=300)
+        nm2.factorize()
+        # factorize_tau with gamma fixed
+        rs3 = np.random.RandomState(seed + 1000)
+        nm3 = inmft.Init_NMFT(counts, G, rs3, max_iter=50)
+        nm3.gamma = nm2.gamma.copy()
+        nm3.random_initialize_tau()
+        tau3_raw = nm3.tau.copy()
+        rs3b = np.random.RandomState(seed + 1000)
+        nm3b = inmft.Init_NMFT(counts, G, rs3b, max_iter=50)
+        nm3b.gamma = nm2.gamma.copy()
+        nm3b.factorize_tau()
+        np.savez_compressed(
+            os.path.join(out, "nmft_V%d_S%d_G%d.npz" % (V, S, G)), counts=counts, G=G, seed=seed,
+            F=F, tau_raw=tau_raw, gamma_raw=gamma_raw, div0=div0, get_tau_100=get_tau,
+            fact_tau=nm2.tau.copy(), fact_gamma=nm2.gamma.copy(), fact_get_tau=nm2.get_tau(),
+            fact_div=nm2.div_objective(), ft_tau_raw=tau3_raw, ft_tau=nm3b.tau.copy(),
+            ft_get_tau=nm3b.get_tau(), **snaps)
+
+
+def gen_cog(inmft, hsnp, out):
+    """Config 1 (COG0015, -g 5 -i 50, default seed): the reference CLI's numeric
+    path run through the imported classes (minutes of CPU).  Records fit.txt's
+    numbers and the NTF divergence trace.  tau sweep = oracle C restatement."""
+    import pandas as p
+    import logging
+    import desman.Variant_Filter as vf
+    logging.basicConfig(level=logging.ERROR)
+    variants = p.read_csv(os.path.join(REF, "data", "contig_6or16_genesL_scgCOG0015.freq"),
+                          header=0, index_col=0)
+    flt = vf.Variant_Filter(variants, randomState=np.random.RandomState(238329), optimise=True,
+                            threshold=None, min_coverage=5.0, qvalue_cutoff=1.0e-3)
+    seed, G, I = 23724839, 5, 50
+    prng = np.random.RandomState(seed)
+    cbind.initRNG(); cbind.setRNG(seed)
+    nm = inmft.Init_NMFT(flt.snps_filter, G, prng)
+    divs = {}
+    orig = nm.div_objective
+    nm.factorize()
+    div_final = orig()
+    smp = hsnp.HaploSNP_Sampler(flt.snps_filter, G, prng, max_iter=I)
+    smp.tau = np.copy(nm.get_tau(), order='C')
+    smp.updateTauIndices()
+    smp.gamma = np.copy(nm.get_gamma(), order='C')
+    smp.eta = np.copy(flt.eta, order='C')
+    tau_init, gamma_init = smp.tau.copy(), smp.gamma.copy()
+    smp.update()
+    burn_ll = smp.ll_store.copy()
+    smp.removeDegenerate()
+    smp.update()
+    np.savez_compressed(os.path.join(out, "cog0015_g5_i50.npz"), seed=seed, G=G, I=I,
+                        V=flt.V, S=flt.S, nmft_div_final=div_final, tau_init=tau_init.astype(np.int8),
+                        gamma_init=gamma_init, burn_ll=burn_ll, ll_store=smp.ll_store.copy(),
+                        lp_star=smp.lp_star, mean_dev=smp.meanDeviance(), G_final=smp.G,
+                        gamma_star=smp.gamma_star.copy(), eta_star=smp.eta_star.copy(),
+                        tau_star=smp.tau_star.astype(np.int8), gamma_mean=smp.gammaMean(),
+                        note="fit.txt = Fit,%d,%d,%f,%f" % (G, smp.G, smp.lp_star, smp.meanDeviance()))
+    print("fit.txt = Fit,%d,%d,%f,%f" % (G, smp.G, smp.lp_star, smp.meanDeviance()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cog", action="store_true", help="also run config 1 (several minutes)")
+    ap.add_argument("--only-cog", action="store_true")
+    args = ap.parse_args()
+    inmft, hsnp, du = import_reference()
+    if not args.only_cog:
+        gen_tau_sweep(hsnp, HERE)
+        gen_loglik(hsnp, HERE)
+        gen_degenerate(hsnp, HERE)
+        gen_gibbs_pieces(hsnp, HERE)
+        gen_nmft(inmft, HERE)
+    if args.cog or args.only_cog:
+        gen_cog(inmft, hsnp, HERE)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gibbs iterations/s on synthetic V=10k x S=64, G=8 (BASELINE.json
+configs[2]); one independent chain per GPU (weak scaling), RCCL gather of the fit records.
+
+  python bench.py --gpus 1 --steps 500 --warmup 50
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  A "step" is one full Gibbs iteration (auxiliary-count
+pass, gamma/eta draws, tau sweep, log-posterior, MAP/trace bookkeeping) of one chain.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def cpu_baseline(S, G, budget_s=20.0):
+    """The CPU path (oracle = restatement of the reference: Python-level sampleMu/ll loops +
+    C tau sweep, single thread) timed on a bounded sample of the same workload."""
+    from desman_amd.synth import synth_counts
+    from oracle import cbind, ref_numpy as rn
+    Vs = 400
+    counts, _, _ = synth_counts(Vs, S, G, seed=1234)
+    rs = np.random.RandomState(0)
+    gamma0, tau0 = rn.sampler_ctor_draws(rs, Vs, S, G)
+    eta0 = 0.96 * np.eye(4) + 0.01
+    cbind.initRNG(); cbind.setRNG(0)
+    t0 = time.perf_counter()
+    its = 0
+    state = (tau0, gamma0, eta0)
+    while True:
+        r = rn.gibbs_update(rs, state[0], state[1], state[2], counts, 1, cbind.sample_tau)
+        state = (r["tau"], r["gamma"], r["eta"])
+        its += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or its >= 8:
+            break
+    cbind.freeRNG()
+    return dict(value=Vs * S * its / dt, unit="V*S updates/s", cores=1, kind="port",
+                sample="%d full Gibbs iterations of oracle/ref_numpy.gibbs_update (+ C tau sweep) on a V=%d slice "
+                       "of the same S=%d, G=%d workload, 1 thread, %.1f s" % (its, Vs, S, G, dt),
+                cpu=_cpu_model())
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip() + " x%d" % os.cpu_count()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--V", type=int, default=10000)
+    ap.add_argument("--S", type=int, default=64)
+    ap.add_argument("--G", type=int, default=8)
+    ap.add_argument("--rng", choices=["mt19937", "philox"], default="mt19937")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-nmft", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev)
+
+    from desman_amd import _lib
+    from desman_amd.synth import synth_counts
+    V, S, G = args.V, args.S, args.G
+    counts, _, _ = synth_counts(V, S, G, seed=1234 + rank)       # one independent chain per GPU
+    ctx = _lib.Context(dev)
+    ctx.set_counts(counts)
+    ctx.seed(rank)                                               # sampler seeds 0..N-1 (scripts/runDesman.sh:15-19)
+    ctx.set_tau_rng(_lib.RNG_MT19937 if args.rng == "mt19937" else _lib.RNG_PHILOX)
+
+    # NMFT initialisation (untimed here; reported separately)
+    rs = np.random.RandomState(rank)
+    nmft = None
+    alpha0 = 0.01
+    if G > 1:
+        gam0 = np.ascontiguousarray(rs.dirichlet(np.full(G, alpha0), size=S).T)
+    else:
+        gam0 = np.ones((G, S))
+    d = rs.dirichlet(np.full(4, alpha0), size=V * G).reshape(V, G, 4)
+    tau0 = np.ascontiguousarray(np.transpose(d, (2, 0, 1)).reshape(4 * V, G))
+    ctx.nmft_set(tau0, gam0)
+    if not args.no_nmft:
+        n_nm = 200
+        ctx.nmft_factorize(max_iter=5, min_change=0.0)           # warm
+        ctx.nmft_set(tau0, gam0)
+        t0 = time.perf_counter()
+        n_done, tr = ctx.nmft_factorize(max_iter=n_nm, min_change=0.0)
+        t_nm = time.perf_counter() - t0
+        nmft = dict(iters=n_done, ms_per_iter=1e3 * t_nm / max(n_done, 1), div_last=float(tr[-1]))
+    tau_init = ctx.nmft_get_tau()
+    _, gam = ctx.nmft_get()
+    eta0 = 0.96 * np.eye(4) + 0.01
+    ctx.set_state(tau_init, np.ascontiguousarray(gam.T), eta0)
+
+    def fence():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.gibbs_update(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    ctx.gibbs_update(args.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tr = ctx.get_trace()
+    star = ctx.get_star()
+    # the one collective of the path: gather every chain's fit record (lp_star, mean deviance)
+    rec = [float(G), float(G), float(rank), star["lp"], -2.0 * float(tr["ll"].mean()), float(args.steps)]
+    fits = [rec]
+    if dist is not None:
+        mine = torch.tensor(rec, device="cuda", dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        fits = [x.tolist() for x in allr]
+
+    # per-kernel HIP-event timing (on the library's stream) for the roofline object
+    ctx.set_timing(True)
+    ctx.gibbs_update(20)
+    tm = ctx.get_timing()
+    ctx.set_timing(False)
+    k_us = {k: 1e3 * ms / max(n, 1) for k, (ms, n) in tm.items() if n}
+    tau_us = k_us.get("tau", float("nan"))
+    alg_bytes_tau = V * S * 16 + 3 * V * G                        # one count pass + tau traffic
+    achieved = alg_bytes_tau / (tau_us * 1e-6) / 1e9
+    n_logs = 16.0 * V * G * S + 4.0 * V * S
+    roofline = dict(bound="hbm", kernel="tau_kernel", achieved=achieved, peak=8000.0, unit="GB/s",
+                    frac=achieved / 8000.0, traffic=None, avg_kernel_us=tau_us,
+                    algorithmic_bytes_per_launch=alg_bytes_tau,
+                    fp64_logs_per_s=n_logs / (tau_us * 1e-6),
+                    note="tau sweep is fp64-transcendental bound (16*G logs per 16-byte count slab), not HBM bound; "
+                         "see DESIGN.md",
+                    kernels_us=k_us)
+
+    if rank == 0:
+        its = args.steps / dt
+        out = {
+            "metric": "Gibbs iterations/sec (VxS updates/s) at V=10k S=64 G=8",
+            "value": world * V * S * its, "unit": "V*S updates/s",
+            "gibbs_it_per_s_per_chain": its, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic V=%d x S=%d, G=%d, full Gibbs iteration, 1 chain per GPU (configs[2])"
+                                   % (V, S, G), "V": V, "S": S, "G": G, "chains": world, "tau_rng": args.rng},
+            "roofline": roofline, "nmft": nmft,
+            "fit_records": [dict(G=int(f[0]), seed=int(f[2]), lp_star=f[3], mean_dev=f[4]) for f in fits],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(S, G)
+            out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

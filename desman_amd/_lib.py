@@ -1,0 +1,269 @@
+"""ctypes binding of libdesman_hip.so -- the only native boundary of the package.
+
+The product path has NO CPU fallback: if the HIP library is missing, cannot be
+loaded, or no gfx950 device is visible, every compute entry point raises.
+Signatures mirror include/desman_hip.h one to one.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdesman_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "desman_hip.h")
+
+DSM_OK = 0
+RNG_MT19937, RNG_PHILOX = 0, 1
+K_NAMES = ("stats", "dirichlet", "tau", "finalize", "mt", "nmft_a", "nmft_gamma", "nmft_b")
+
+
+class DesmanHipError(RuntimeError):
+    pass
+
+
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+_vp, _i, _d = C.c_void_p, C.c_int, C.c_double
+
+# name -> (restype, argtypes); every symbol include/desman_hip.h declares
+SIGNATURES = {
+    "dsm_last_error": (C.c_char_p, []),
+    "dsm_device_count": (_i, []),
+    "dsm_version": (C.c_char_p, []),
+    "dsm_initRNG": (_i, []),
+    "dsm_setRNG": (_i, [C.c_ulong]),
+    "dsm_freeRNG": (_i, []),
+    "dsm_sample_tau": (_i, [_i64p, _f64p, _f64p, _i64p, _i, _i, _i]),
+    "dsm_ctx_create": (_i, [C.POINTER(_vp), _i]),
+    "dsm_ctx_destroy": (_i, [_vp]),
+    "dsm_ctx_sync": (_i, [_vp]),
+    "dsm_ctx_set_counts": (_i, [_vp, _i64p, _i, _i]),
+    "dsm_ctx_set_state": (_i, [_vp, _i64p, _f64p, _f64p, _i]),
+    "dsm_ctx_get_state": (_i, [_vp, _vp, _vp, _vp]),
+    "dsm_ctx_set_gamma_eta": (_i, [_vp, _vp, _vp]),
+    "dsm_ctx_set_priors": (_i, [_vp, _d, _d, _d]),
+    "dsm_ctx_seed": (_i, [_vp, C.c_ulong, C.c_uint64]),
+    "dsm_ctx_set_tau_rng": (_i, [_vp, _i]),
+    "dsm_ctx_sample_tau": (_i, [_vp, C.POINTER(_i), _vp]),
+    "dsm_ctx_sample_stats": (_i, [_vp, C.c_uint32, _u64p, _u64p]),
+    "dsm_ctx_draw_gamma_eta": (_i, [_vp, C.c_uint32, _u64p, _u64p, _f64p, _f64p]),
+    "dsm_ctx_loglik": (_i, [_vp, C.POINTER(_d), C.POINTER(_d)]),
+    "dsm_ctx_gibbs_update": (_i, [_vp, _i]),
+    "dsm_ctx_update_tau": (_i, [_vp, _i, _f64p, _f64p]),
+    "dsm_ctx_get_trace": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "dsm_ctx_get_star": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_d), C.POINTER(_i)]),
+    "dsm_ctx_get_tau_sum": (_i, [_vp, _i64p]),
+    "dsm_ctx_get_tau_at": (_i, [_vp, _i, _i64p]),
+    "dsm_nmft_set": (_i, [_vp, _f64p, _f64p, _i]),
+    "dsm_nmft_get": (_i, [_vp, _vp, _vp]),
+    "dsm_nmft_factorize": (_i, [_vp, _i, _d, _i, C.POINTER(_i), _vp]),
+    "dsm_nmft_objective": (_i, [_vp, C.POINTER(_d)]),
+    "dsm_nmft_get_tau": (_i, [_vp, _i64p]),
+    "dsm_ctx_set_timing": (_i, [_vp, _i]),
+    "dsm_ctx_get_timing": (_i, [_vp, _vp, _vp]),
+    "dsm_kernel_name": (C.c_char_p, [_i]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libdesman_hip.so (once).  Raises DesmanHipError if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DesmanHipError(
+                "libdesman_hip.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C desman_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise DesmanHipError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError = ABI drift: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != DSM_OK:
+        raise DesmanHipError("libdesman_hip: error %d: %s" % (rc, load().dsm_last_error().decode()))
+    return rc
+
+
+def device_count():
+    return load().dsm_device_count()
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class Context:
+    """A device-resident chain context (dsm_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = _vp()
+        self.lib = load()
+        check(self.lib.dsm_ctx_create(C.byref(self._h), int(device)))
+        self.V = self.S = self.G = 0
+        self.nG = 0
+        self.n_trace = 0
+
+    def close(self):
+        if self._h:
+            self.lib.dsm_ctx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.lib.dsm_ctx_sync(self._h))
+
+    # ---- data / state
+    def set_counts(self, variants):
+        v = np.ascontiguousarray(variants, dtype=np.int64)
+        if v.ndim != 3 or v.shape[2] != 4:
+            raise ValueError("variants must be [V,S,4]")
+        check(self.lib.dsm_ctx_set_counts(self._h, v, v.shape[0], v.shape[1]))
+        self.V, self.S = v.shape[0], v.shape[1]
+
+    def set_state(self, tau, gamma, eta):
+        tau = np.ascontiguousarray(tau, dtype=np.int64)
+        gamma = np.ascontiguousarray(gamma, dtype=np.float64)
+        eta = np.ascontiguousarray(eta, dtype=np.float64)
+        if tau.shape != (self.V, gamma.shape[1], 4) or gamma.shape[0] != self.S or eta.shape != (4, 4):
+            raise ValueError("state shapes do not match the count tensor")
+        check(self.lib.dsm_ctx_set_state(self._h, tau, gamma, eta, gamma.shape[1]))
+        self.G = gamma.shape[1]
+
+    def get_state(self):
+        tau = np.empty((self.V, self.G, 4), dtype=np.int64)
+        gamma = np.empty((self.S, self.G))
+        eta = np.empty((4, 4))
+        check(self.lib.dsm_ctx_get_state(self._h, _ptr(tau), _ptr(gamma), _ptr(eta)))
+        return tau, gamma, eta
+
+    def set_gamma_eta(self, gamma=None, eta=None):
+        g = None if gamma is None else np.ascontiguousarray(gamma, dtype=np.float64)
+        e = None if eta is None else np.ascontiguousarray(eta, dtype=np.float64)
+        check(self.lib.dsm_ctx_set_gamma_eta(self._h, _ptr(g), _ptr(e)))
+
+    def set_priors(self, alpha=0.1, delta=0.1, epsilon=1e-6):
+        check(self.lib.dsm_ctx_set_priors(self._h, alpha, delta, epsilon))
+
+    def seed(self, mt_seed, ctr_seed=None):
+        if ctr_seed is None:
+            ctr_seed = (int(mt_seed) * 0x9E3779B97F4A7C15 + 0x243F6A8885A308D3) & 0xFFFFFFFFFFFFFFFF
+        check(self.lib.dsm_ctx_seed(self._h, int(mt_seed) & 0xFFFFFFFFFFFFFFFF, int(ctr_seed)))
+
+    def set_tau_rng(self, mode):
+        check(self.lib.dsm_ctx_set_tau_rng(self._h, int(mode)))
+
+    # ---- single steps
+    def sample_tau(self, want_logp=False):
+        n = _i(0)
+        logp = np.empty((self.V, self.G, 4)) if want_logp else None
+        check(self.lib.dsm_ctx_sample_tau(self._h, C.byref(n), _ptr(logp)))
+        return (n.value, logp) if want_logp else n.value
+
+    def sample_stats(self, it):
+        mu = np.zeros((self.S, self.G), dtype=np.uint64)
+        E = np.zeros((4, 4), dtype=np.uint64)
+        check(self.lib.dsm_ctx_sample_stats(self._h, int(it), mu, E))
+        return mu, E
+
+    def draw_gamma_eta(self, it, sum_mu, esum):
+        g = np.empty((self.S, self.G)); e = np.empty((4, 4))
+        check(self.lib.dsm_ctx_draw_gamma_eta(self._h, int(it), np.ascontiguousarray(sum_mu, dtype=np.uint64),
+                                              np.ascontiguousarray(esum, dtype=np.uint64), g, e))
+        return g, e
+
+    def loglik(self):
+        ll, lp = _d(0), _d(0)
+        check(self.lib.dsm_ctx_loglik(self._h, C.byref(ll), C.byref(lp)))
+        return ll.value, lp.value
+
+    # ---- update loops
+    def gibbs_update(self, n_iter):
+        check(self.lib.dsm_ctx_gibbs_update(self._h, int(n_iter)))
+        self.n_trace = int(n_iter)
+
+    def update_tau(self, gamma_store, eta_store):
+        g = np.ascontiguousarray(gamma_store, dtype=np.float64)
+        e = np.ascontiguousarray(eta_store, dtype=np.float64)
+        check(self.lib.dsm_ctx_update_tau(self._h, g.shape[0], g, e))
+        self.n_trace = g.shape[0]
+
+    def get_trace(self):
+        n = self.n_trace
+        ll = np.empty(n); lp = np.empty(n); nch = np.empty(n, dtype=np.int32)
+        g = np.empty((n, self.S, self.G)); e = np.empty((n, 4, 4))
+        check(self.lib.dsm_ctx_get_trace(self._h, _ptr(ll), _ptr(lp), _ptr(nch), _ptr(g), _ptr(e)))
+        return dict(ll=ll, lp=lp, nchange=nch, gamma=g, eta=e)
+
+    def get_star(self):
+        tau = np.empty((self.V, self.G, 4), dtype=np.int64)
+        g = np.empty((self.S, self.G)); e = np.empty((4, 4))
+        lp, it = _d(0), _i(0)
+        check(self.lib.dsm_ctx_get_star(self._h, _ptr(tau), _ptr(g), _ptr(e), C.byref(lp), C.byref(it)))
+        return dict(tau=tau, gamma=g, eta=e, lp=lp.value, it=it.value)
+
+    def get_tau_sum(self):
+        out = np.empty((self.V, self.G, 4), dtype=np.int64)
+        check(self.lib.dsm_ctx_get_tau_sum(self._h, out))
+        return out
+
+    def get_tau_at(self, it):
+        out = np.empty((self.V, self.G, 4), dtype=np.int64)
+        check(self.lib.dsm_ctx_get_tau_at(self._h, int(it), out))
+        return out
+
+    # ---- NMFT
+    def nmft_set(self, tau, gamma):
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        gamma = np.ascontiguousarray(gamma, dtype=np.float64)
+        G = gamma.shape[0]
+        if tau.shape != (4 * self.V, G) or gamma.shape[1] != self.S:
+            raise ValueError("NMFT factor shapes do not match the count tensor")
+        check(self.lib.dsm_nmft_set(self._h, tau, gamma, G))
+        self.nG = G
+
+    def nmft_get(self):
+        tau = np.empty((4 * self.V, self.nG)); gamma = np.empty((self.nG, self.S))
+        check(self.lib.dsm_nmft_get(self._h, _ptr(tau), _ptr(gamma)))
+        return tau, gamma
+
+    def nmft_factorize(self, max_iter=5000, min_change=1e-5, fix_gamma=False):
+        n = _i(0)
+        tr = np.full(max_iter + 1, np.nan)
+        check(self.lib.dsm_nmft_factorize(self._h, int(max_iter), float(min_change), int(bool(fix_gamma)),
+                                          C.byref(n), _ptr(tr)))
+        return n.value, tr[: n.value + 1]
+
+    def nmft_objective(self):
+        d = _d(0)
+        check(self.lib.dsm_nmft_objective(self._h, C.byref(d)))
+        return d.value
+
+    def nmft_get_tau(self):
+        out = np.empty((self.V, self.nG, 4), dtype=np.int64)
+        check(self.lib.dsm_nmft_get_tau(self._h, out))
+        return out
+
+    # ---- timing
+    def set_timing(self, on):
+        check(self.lib.dsm_ctx_set_timing(self._h, int(bool(on))))
+
+    def get_timing(self):
+        ms = np.zeros(len(K_NAMES)); n = np.zeros(len(K_NAMES), dtype=np.int64)
+        check(self.lib.dsm_ctx_get_timing(self._h, _ptr(ms), _ptr(n)))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(K_NAMES)}

@@ -1,0 +1,728 @@
+// api.hip -- the C ABI of libdesman_hip.so (see include/desman_hip.h).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "dsm_host.h"
+
+static thread_local char g_err[512] = "";
+
+void dsm_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *dsm_last_error(void) { return g_err; }
+extern "C" const char *dsm_version(void) { return "desman_hip 0.1 (gfx950)"; }
+
+extern "C" int dsm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+static const char *const k_names[DSM_K_COUNT] = {"stats_kernel", "dirichlet_kernel", "tau_kernel", "finalize_kernel",
+                                                 "mt_fill_kernel", "nmft_pass_a", "nmft_gamma", "nmft_pass_b"};
+extern "C" const char *dsm_kernel_name(int k) { return (k >= 0 && k < DSM_K_COUNT) ? k_names[k] : "?"; }
+
+// ---------------------------------------------------------------- timing
+KTimer::KTimer(dsm_ctx *ctx, int kid) : c(ctx), k(kid)
+{
+    c->k_launches[k]++;
+    if (!c->timing) return;
+    auto take = [&]() {
+        hipEvent_t e;
+        if (!c->free_events.empty()) { e = c->free_events.back(); c->free_events.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    };
+    e0 = take(); e1 = take();
+    (void)hipEventRecord(e0, c->stream);
+}
+KTimer::~KTimer()
+{
+    if (!e0) return;
+    (void)hipEventRecord(e1, c->stream);
+    c->spans.push_back({k, e0, e1});
+}
+
+static int collect_spans(dsm_ctx *c)
+{
+    if (c->spans.empty()) return DSM_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto &s : c->spans) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s.e0, s.e1));
+        c->k_ms[s.k] += ms;
+        c->free_events.push_back(s.e0);
+        c->free_events.push_back(s.e1);
+    }
+    c->spans.clear();
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_set_timing(dsm_ctx *c, int on)
+{
+    if (!c) return DSM_ERR_ARG;
+    int r = collect_spans(c);
+    c->timing = on != 0;
+    for (int k = 0; k < DSM_K_COUNT; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; }
+    return r;
+}
+
+extern "C" int dsm_ctx_get_timing(dsm_ctx *c, double *ms_total, int64_t *launches)
+{
+    if (!c) return DSM_ERR_ARG;
+    int r = collect_spans(c);
+    if (r) return r;
+    for (int k = 0; k < DSM_K_COUNT; ++k) {
+        if (ms_total) ms_total[k] = c->k_ms[k];
+        if (launches) launches[k] = c->k_launches[k];
+    }
+    return DSM_OK;
+}
+
+// ---------------------------------------------------------------- helpers
+template <typename T>
+static int dev_alloc(T **p, size_t n)
+{
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e != hipSuccess) { dsm_set_error("hipMalloc(%zu B) failed: %s", n * sizeof(T), hipGetErrorString(e)); return DSM_ERR_NOMEM; }
+    return DSM_OK;
+}
+template <typename T>
+static void dev_free(T **p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
+
+#define TRY(x) do { int _r = (x); if (_r != DSM_OK) return _r; } while (0)
+#define BIND(c) HIP_TRY(hipSetDevice((c)->device))
+
+static int need(dsm_ctx *c, bool counts, bool state)
+{
+    if (!c) { dsm_set_error("null context"); return DSM_ERR_ARG; }
+    if (counts && !c->cnt_vs) { dsm_set_error("no count tensor: call dsm_ctx_set_counts first"); return DSM_ERR_STATE; }
+    if (state && !c->have_state) { dsm_set_error("no chain state: call dsm_ctx_set_state first"); return DSM_ERR_STATE; }
+    return DSM_OK;
+}
+
+// ---------------------------------------------------------------- lifecycle
+extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
+{
+    if (!out) return DSM_ERR_ARG;
+    *out = nullptr;
+    int n = dsm_device_count();
+    if (n <= 0) { dsm_set_error("no HIP device visible"); return DSM_ERR_NODEVICE; }
+    if (device < 0 || device >= n) { dsm_set_error("device %d out of range (0..%d)", device, n - 1); return DSM_ERR_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        dsm_set_error("device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        return DSM_ERR_NODEVICE;
+    }
+    dsm_ctx *c = new dsm_ctx();
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    TRY(dev_alloc(&c->mt_state, 625));
+    TRY(dev_alloc(&c->ll_partial, DSM_MAX_GRID));
+    TRY(dev_alloc(&c->nchange, 1));
+    TRY(dev_alloc(&c->prior, 2));
+    TRY(dev_alloc(&c->scalars, 8));
+    TRY(dev_alloc(&c->star, 2));
+    TRY(dev_alloc(&c->eta, 16));
+    TRY(dev_alloc(&c->eta_new, 16));
+    TRY(dev_alloc(&c->eta_star, 16));
+    TRY(dev_alloc(&c->esum, 16));
+    HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
+    HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = c;
+    return DSM_OK;
+}
+
+static void free_traces(dsm_ctx *c)
+{
+    dev_free(&c->tau_trace); dev_free(&c->ll_trace); dev_free(&c->lp_trace); dev_free(&c->nchange_trace);
+    dev_free(&c->gamma_trace); dev_free(&c->eta_trace); dev_free(&c->gamma_in); dev_free(&c->eta_in);
+    c->n_trace = 0;
+}
+
+extern "C" int dsm_ctx_destroy(dsm_ctx *c)
+{
+    if (!c) return DSM_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    collect_spans(c);
+    for (auto e : c->free_events) (void)hipEventDestroy(e);
+    free_traces(c);
+    dev_free(&c->cnt_vs); dev_free(&c->cnt_sv); dev_free(&c->tau); dev_free(&c->gamma); dev_free(&c->eta);
+    dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
+    dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->prior); dev_free(&c->scalars); dev_free(&c->star);
+    dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam);
+    dev_free(&c->npart); dev_free(&c->nstat);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_sync(dsm_ctx *c)
+{
+    if (!c) return DSM_ERR_ARG;
+    BIND(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
+// ---------------------------------------------------------------- data in
+extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, int S)
+{
+    if (!c || !variants || V < 1 || S < 1) { dsm_set_error("set_counts: bad arguments"); return DSM_ERR_ARG; }
+    if (S > DSM_MAX_S) { dsm_set_error("S=%d exceeds DSM_MAX_S=%d", S, DSM_MAX_S); return DSM_ERR_UNSUPPORTED; }
+    BIND(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)V * S;
+    c->V = V; c->S = S;
+    c->have_state = false;
+    TRY(dev_alloc(&c->cnt_vs, n * 4));
+    TRY(dev_alloc(&c->cnt_sv, n * 4));
+    TRY(dev_alloc(&c->tau, (size_t)V));
+    dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); c->nG = 0;
+    free_traces(c);
+    int64_t *d_in = nullptr; int *d_flag = nullptr; double *d_part = nullptr;
+    const int nblk = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    TRY(dev_alloc(&d_in, n * 4));
+    TRY(dev_alloc(&d_flag, 1));
+    TRY(dev_alloc(&d_part, (size_t)nblk));
+    HIP_TRY(hipMemcpyAsync(d_in, variants, n * 4 * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), c->stream));
+    TRY(k_convert_counts(c, d_in, d_flag, d_part, nblk));
+    std::vector<double> part(nblk);
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(part.data(), d_part, nblk * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dev_free(&d_in); dev_free(&d_flag); dev_free(&d_part);
+    if (flag) {
+        dev_free(&c->cnt_vs); dev_free(&c->cnt_sv);
+        dsm_set_error("set_counts: negative count or depth above 2^31-1");
+        return DSM_ERR_ARG;
+    }
+    double s = 0.0;
+    for (double p : part) s += p;
+    c->ll_const = s;
+    return DSM_OK;
+}
+
+static int ensure_state_buffers(dsm_ctx *c, int G)
+{
+    if (G < 1 || G > DSM_MAX_G) { dsm_set_error("G=%d outside 1..%d", G, DSM_MAX_G); return DSM_ERR_UNSUPPORTED; }
+    if (G != c->G || !c->gamma) {
+        c->G = G;
+        const size_t sg = (size_t)c->S * G;
+        TRY(dev_alloc(&c->gamma, sg));
+        TRY(dev_alloc(&c->gamma_star, sg));
+        TRY(dev_alloc(&c->sum_mu, sg));
+        HIP_TRY(hipMemsetAsync(c->sum_mu, 0, sg * sizeof(unsigned long long), c->stream));
+        c->u_cap = (size_t)c->V * G;
+        TRY(dev_alloc(&c->u_raw, c->u_cap));
+        free_traces(c);
+    }
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_set_state(dsm_ctx *c, const int64_t *tau, const double *gamma, const double *eta, int G)
+{
+    TRY(need(c, true, false));
+    if (!tau || !gamma || !eta) { dsm_set_error("set_state: null pointer"); return DSM_ERR_ARG; }
+    BIND(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    TRY(ensure_state_buffers(c, G));
+    const size_t nt = (size_t)c->V * G * 4;
+    int64_t *d_t = nullptr;
+    TRY(dev_alloc(&d_t, nt));
+    HIP_TRY(hipMemcpyAsync(d_t, tau, nt * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    TRY(k_pack_tau(c, d_t, c->tau, c->V, G));
+    HIP_TRY(hipMemcpyAsync(c->gamma, gamma, (size_t)c->S * G * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->eta, eta, 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dev_free(&d_t);
+    c->have_state = true;
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_set_gamma_eta(dsm_ctx *c, const double *gamma, const double *eta)
+{
+    TRY(need(c, true, true));
+    BIND(c);
+    if (gamma) HIP_TRY(hipMemcpyAsync(c->gamma, gamma, (size_t)c->S * c->G * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (eta) HIP_TRY(hipMemcpyAsync(c->eta, eta, 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
+static int fetch_tau(dsm_ctx *c, const uint64_t *d_packed, int64_t *host_onehot)
+{
+    const size_t nt = (size_t)c->V * c->G * 4;
+    int64_t *d_t = nullptr;
+    TRY(dev_alloc(&d_t, nt));
+    TRY(k_unpack_tau(c, d_packed, d_t, c->V, c->G));
+    HIP_TRY(hipMemcpyAsync(host_onehot, d_t, nt * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dev_free(&d_t);
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_get_state(dsm_ctx *c, int64_t *tau, double *gamma, double *eta)
+{
+    TRY(need(c, true, true));
+    BIND(c);
+    if (tau) TRY(fetch_tau(c, c->tau, tau));
+    if (gamma) HIP_TRY(hipMemcpyAsync(gamma, c->gamma, (size_t)c->S * c->G * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (eta) HIP_TRY(hipMemcpyAsync(eta, c->eta, 16 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_set_priors(dsm_ctx *c, double alpha, double delta, double epsilon)
+{
+    if (!c || !(alpha > 0) || !(delta > 0) || !(epsilon >= 0)) { dsm_set_error("set_priors: bad value"); return DSM_ERR_ARG; }
+    c->alpha = alpha; c->delta = delta; c->epsilon = epsilon;
+    return DSM_OK;
+}
+
+// ---------------------------------------------------------------- RNG
+static void mt_seed_host(uint32_t *st, unsigned long seed)
+{
+    if (seed == 0) seed = 4357;              // gsl_rng_set default for mt19937
+    st[0] = (uint32_t)(seed & 0xffffffffUL);
+    for (int i = 1; i < 624; ++i) st[i] = 1812433253u * (st[i - 1] ^ (st[i - 1] >> 30)) + (uint32_t)i;
+    st[624] = 624;                           // position: refill on first use
+}
+
+static int seed_mt(dsm_ctx *c, unsigned long seed)
+{
+    uint32_t st[625];
+    mt_seed_host(st, seed);
+    HIP_TRY(hipMemcpyAsync(c->mt_state, st, sizeof st, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->mt_seeded = true;
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_seed(dsm_ctx *c, unsigned long mt_seed, uint64_t ctr_seed)
+{
+    if (!c) return DSM_ERR_ARG;
+    BIND(c);
+    c->ctr_seed = ctr_seed;
+    c->iter_ctr = 0;
+    return seed_mt(c, mt_seed);
+}
+
+extern "C" int dsm_ctx_set_tau_rng(dsm_ctx *c, int mode)
+{
+    if (!c || (mode != DSM_RNG_MT19937 && mode != DSM_RNG_PHILOX)) { dsm_set_error("bad rng mode"); return DSM_ERR_ARG; }
+    c->tau_rng = mode;
+    return DSM_OK;
+}
+
+static int fill_sweep_uniforms(dsm_ctx *c)
+{
+    if (c->tau_rng != DSM_RNG_MT19937) return DSM_OK;
+    if (!c->mt_seeded) { dsm_set_error("tau RNG not seeded: call dsm_ctx_seed / dsm_setRNG"); return DSM_ERR_STATE; }
+    return k_mt_fill(c, c->u_raw, (size_t)c->V * c->G);
+}
+
+// ---------------------------------------------------------------- single steps
+extern "C" int dsm_ctx_sample_tau(dsm_ctx *c, int *nchange, double *logp_out)
+{
+    TRY(need(c, true, true));
+    BIND(c);
+    double *d_logp = nullptr;
+    const size_t nl = (size_t)c->V * c->G * 4;
+    if (logp_out) TRY(dev_alloc(&d_logp, nl));
+    TRY(fill_sweep_uniforms(c));
+    HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
+    TRY(k_tau_sweep(c, 1, c->gamma, c->eta, c->eta, nullptr, d_logp, c->iter_ctr++, nullptr));
+    int n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, c->nchange, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (logp_out) HIP_TRY(hipMemcpyAsync(logp_out, d_logp, nl * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dev_free(&d_logp);
+    if (nchange) *nchange = n;
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_sample_stats(dsm_ctx *c, uint32_t iter, uint64_t *sum_mu, uint64_t *esum)
+{
+    TRY(need(c, true, true));
+    BIND(c);
+    const size_t sg = (size_t)c->S * c->G;
+    HIP_TRY(hipMemsetAsync(c->sum_mu, 0, sg * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
+    TRY(k_stats(c, iter));
+    if (sum_mu) HIP_TRY(hipMemcpyAsync(sum_mu, c->sum_mu, sg * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (esum) HIP_TRY(hipMemcpyAsync(esum, c->esum, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(c->sum_mu, 0, sg * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_draw_gamma_eta(dsm_ctx *c, uint32_t iter, const uint64_t *sum_mu, const uint64_t *esum,
+                                      double *gamma_out, double *eta_out)
+{
+    TRY(need(c, true, true));
+    if (!sum_mu || !esum) { dsm_set_error("draw_gamma_eta: null sums"); return DSM_ERR_ARG; }
+    BIND(c);
+    const size_t sg = (size_t)c->S * c->G;
+    double *d_g = nullptr, *d_e = nullptr;
+    TRY(dev_alloc(&d_g, sg));
+    TRY(dev_alloc(&d_e, 16));
+    HIP_TRY(hipMemcpyAsync(c->sum_mu, sum_mu, sg * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->esum, esum, 16 * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    TRY(k_dirichlet(c, iter, d_g, nullptr, d_e));
+    if (gamma_out) HIP_TRY(hipMemcpyAsync(gamma_out, d_g, sg * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (eta_out) HIP_TRY(hipMemcpyAsync(eta_out, d_e, 16 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dev_free(&d_g); dev_free(&d_e);
+    return DSM_OK;
+}
+
+// ll / lp of (resident tau, gamma, eta) -> scalars[0..1]; star untouched unless it<0
+static int eval_state(dsm_ctx *c, const double *gamma, const double *eta, uint64_t *trace_slot, int star_mode)
+{
+    int nb = 0;
+    TRY(k_prior(c, gamma, eta));
+    TRY(k_tau_sweep(c, 2, gamma, eta, eta, trace_slot, nullptr, 0, &nb));
+    // finalize with eta_new := eta so that the star copy (entry state) takes the current eta
+    double *save = c->eta_new;
+    c->eta_new = const_cast<double *>(eta);
+    const double *gsave = c->gamma;
+    c->gamma = const_cast<double *>(gamma);
+    int r = k_finalize(c, nb, -1, 0, star_mode);
+    c->eta_new = save;
+    c->gamma = const_cast<double *>(gsave);
+    return r;
+}
+
+extern "C" int dsm_ctx_loglik(dsm_ctx *c, double *ll, double *lp)
+{
+    TRY(need(c, true, true));
+    BIND(c);
+    double sc[2];
+    TRY(eval_state(c, c->gamma, c->eta, nullptr, 2));     // star_mode 2: MAP record untouched
+    HIP_TRY(hipMemcpyAsync(sc, c->scalars, sizeof sc, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (ll) *ll = sc[0];
+    if (lp) *lp = sc[1];
+    return DSM_OK;
+}
+
+// ---------------------------------------------------------------- update loops
+static int alloc_traces(dsm_ctx *c, int n)
+{
+    free_traces(c);
+    const size_t sg = (size_t)c->S * c->G;
+    TRY(dev_alloc(&c->tau_trace, (size_t)(n + 1) * c->V));
+    TRY(dev_alloc(&c->ll_trace, (size_t)n));
+    TRY(dev_alloc(&c->lp_trace, (size_t)n));
+    TRY(dev_alloc(&c->nchange_trace, (size_t)n));
+    TRY(dev_alloc(&c->gamma_trace, (size_t)n * sg));
+    TRY(dev_alloc(&c->eta_trace, (size_t)n * 16));
+    c->n_trace = n;
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
+{
+    TRY(need(c, true, true));
+    if (n_iter < 0) { dsm_set_error("n_iter < 0"); return DSM_ERR_ARG; }
+    BIND(c);
+    TRY(alloc_traces(c, n_iter));
+    const size_t sg = (size_t)c->S * c->G;
+    HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
+    // entry state: ll, lp, storeStarState(0)  (HaploSNP_Sampler.py:336-338)
+    TRY(eval_state(c, c->gamma, c->eta, c->tau_trace, 1));
+    for (int it = 0; it < n_iter; ++it) {
+        const uint32_t ic = c->iter_ctr++;
+        TRY(fill_sweep_uniforms(c));
+        TRY(k_stats(c, ic));                                             // sampleMu  (:341)
+        TRY(k_dirichlet(c, ic, c->gamma, c->gamma_trace + (size_t)it * sg, c->eta_new));  // sampleGamma (:342) + eta draw (:347)
+        int nb = 0;
+        TRY(k_tau_sweep(c, 3, c->gamma, c->eta, c->eta_new, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb));  // :345,:349
+        TRY(k_finalize(c, nb, it, 1, 0));                                   // :349-358
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_store, const double *eta_store)
+{
+    TRY(need(c, true, true));
+    if (n_iter < 1 || !gamma_store || !eta_store) { dsm_set_error("update_tau: bad arguments"); return DSM_ERR_ARG; }
+    BIND(c);
+    TRY(alloc_traces(c, n_iter));
+    const size_t sg = (size_t)c->S * c->G;
+    TRY(dev_alloc(&c->gamma_in, (size_t)n_iter * sg));
+    TRY(dev_alloc(&c->eta_in, (size_t)n_iter * 16));
+    HIP_TRY(hipMemcpyAsync(c->gamma_in, gamma_store, (size_t)n_iter * sg * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->eta_in, eta_store, (size_t)n_iter * 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->gamma_trace, c->gamma_in, (size_t)n_iter * sg * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
+    // entry: lp with (gamma_store[0], eta_store[0])  (HaploSNP_Sampler.py:386-389)
+    TRY(eval_state(c, c->gamma_in, c->eta_in, c->tau_trace, 1));
+    for (int it = 0; it < n_iter; ++it) {
+        const uint32_t ic = c->iter_ctr++;
+        const double *g = c->gamma_in + (size_t)it * sg, *e = c->eta_in + (size_t)it * 16;
+        TRY(fill_sweep_uniforms(c));
+        TRY(k_prior(c, g, e));
+        int nb = 0;
+        TRY(k_tau_sweep(c, 3, g, e, e, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb));  // :392-393
+        double *save = c->eta_new; const double *gsave = c->gamma;
+        c->eta_new = const_cast<double *>(e); c->gamma = const_cast<double *>(g);
+        int r = k_finalize(c, nb, it, 0, 0);
+        c->eta_new = save; c->gamma = const_cast<double *>(gsave);
+        TRY(r);
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_get_trace(dsm_ctx *c, double *ll, double *lp, int32_t *nchange, double *gamma_store, double *eta_store)
+{
+    TRY(need(c, true, true));
+    BIND(c);
+    const size_t n = (size_t)c->n_trace, sg = (size_t)c->S * c->G;
+    if (n == 0) return DSM_OK;
+    if (ll) HIP_TRY(hipMemcpyAsync(ll, c->ll_trace, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (lp) HIP_TRY(hipMemcpyAsync(lp, c->lp_trace, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (nchange) HIP_TRY(hipMemcpyAsync(nchange, c->nchange_trace, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (gamma_store) HIP_TRY(hipMemcpyAsync(gamma_store, c->gamma_trace, n * sg * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (eta_store) HIP_TRY(hipMemcpyAsync(eta_store, c->eta_trace, n * 16 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_get_star(dsm_ctx *c, int64_t *tau_star, double *gamma_star, double *eta_star, double *lp_star, int *iter_star)
+{
+    TRY(need(c, true, true));
+    if (!c->tau_trace) { dsm_set_error("get_star: no update has run"); return DSM_ERR_STATE; }
+    BIND(c);
+    double st[2];
+    HIP_TRY(hipMemcpyAsync(st, c->star, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int slot = (int)st[1];
+    if (tau_star) TRY(fetch_tau(c, c->tau_trace + (size_t)slot * c->V, tau_star));
+    if (gamma_star) HIP_TRY(hipMemcpyAsync(gamma_star, c->gamma_star, (size_t)c->S * c->G * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (eta_star) HIP_TRY(hipMemcpyAsync(eta_star, c->eta_star, 16 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (lp_star) *lp_star = st[0];
+    if (iter_star) *iter_star = slot > 0 ? slot - 1 : 0;      // storeStarState(iter), entry state = 0
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_get_tau_sum(dsm_ctx *c, int64_t *tau_sum)
+{
+    TRY(need(c, true, true));
+    if (!c->tau_trace || !tau_sum) { dsm_set_error("get_tau_sum: no update has run"); return DSM_ERR_STATE; }
+    BIND(c);
+    const size_t nt = (size_t)c->V * c->G * 4;
+    int64_t *d = nullptr;
+    TRY(dev_alloc(&d, nt));
+    TRY(k_tau_sum(c, c->tau_trace, c->n_trace, d));
+    HIP_TRY(hipMemcpyAsync(tau_sum, d, nt * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dev_free(&d);
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_get_tau_at(dsm_ctx *c, int it, int64_t *tau)
+{
+    TRY(need(c, true, true));
+    if (!c->tau_trace || !tau || it < -1 || it >= c->n_trace) { dsm_set_error("get_tau_at: bad iteration"); return DSM_ERR_ARG; }
+    BIND(c);
+    return fetch_tau(c, c->tau_trace + (size_t)(it + 1) * c->V, tau);
+}
+
+// ---------------------------------------------------------------- NMFT
+extern "C" int dsm_nmft_set(dsm_ctx *c, const double *tau, const double *gamma, int G)
+{
+    TRY(need(c, true, false));
+    if (!tau || !gamma || G < 1 || G > DSM_MAX_G) { dsm_set_error("nmft_set: bad arguments"); return DSM_ERR_ARG; }
+    BIND(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int V = c->V, S = c->S;
+    if (!c->F) { TRY(dev_alloc(&c->F, (size_t)V * 4 * S)); TRY(k_nmft_freq(c)); }
+    c->nG = G;
+    c->nmft_blocks = nmft_grid(c);
+    TRY(dev_alloc(&c->ntau, (size_t)V * 4 * G));
+    TRY(dev_alloc(&c->ngam, (size_t)G * S));
+    TRY(dev_alloc(&c->npart, (size_t)c->nmft_blocks * ((size_t)G * S + G + 1)));
+    TRY(dev_alloc(&c->nstat, (size_t)G * S + 2 * G + 16));
+    // reference layout tau[v + a*V][g] -> device layout [v][a][g]
+    std::vector<double> t((size_t)V * 4 * G);
+    for (int a = 0; a < 4; ++a)
+        for (int v = 0; v < V; ++v)
+            memcpy(&t[((size_t)v * 4 + a) * G], &tau[((size_t)a * V + v) * G], sizeof(double) * G);
+    HIP_TRY(hipMemcpyAsync(c->ntau, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ngam, gamma, (size_t)G * S * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
+extern "C" int dsm_nmft_get(dsm_ctx *c, double *tau, double *gamma)
+{
+    TRY(need(c, true, false));
+    if (!c->ntau) { dsm_set_error("nmft_get: call dsm_nmft_set first"); return DSM_ERR_STATE; }
+    BIND(c);
+    const int V = c->V, S = c->S, G = c->nG;
+    if (tau) {
+        std::vector<double> t((size_t)V * 4 * G);
+        HIP_TRY(hipMemcpyAsync(t.data(), c->ntau, t.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int a = 0; a < 4; ++a)
+            for (int v = 0; v < V; ++v)
+                memcpy(&tau[((size_t)a * V + v) * G], &t[((size_t)v * 4 + a) * G], sizeof(double) * G);
+    }
+    if (gamma) HIP_TRY(hipMemcpyAsync(gamma, c->ngam, (size_t)G * S * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
+// nstat control words (after the G*S + 2G reduced statistics):
+//   [0] div of the current state  [1] previous div  [2] done flag  [3] updates run  [4] it at stop
+extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int *n_done, double *div_trace)
+{
+    TRY(need(c, true, false));
+    if (!c->ntau) { dsm_set_error("nmft_factorize: call dsm_nmft_set first"); return DSM_ERR_STATE; }
+    if (max_iter < 0) { dsm_set_error("max_iter < 0"); return DSM_ERR_ARG; }
+    BIND(c);
+    const int G = c->nG, S = c->S;
+    double *ctl = c->nstat + (size_t)G * S + 2 * G;
+    double *d_trace = nullptr;
+    TRY(dev_alloc(&d_trace, (size_t)max_iter + 1));
+    HIP_TRY(hipMemsetAsync(ctl, 0, 16 * sizeof(double), c->stream));
+    const int adjust = fix_gamma ? 0 : 1;
+    // factorize applies _adjustment once before the first objective (Init_NMFT.py:102)
+    if (adjust) TRY(k_nmft_clamp(c));
+    const int BATCH = 64;
+    int it = 0;
+    double h[5] = {0, 0, 0, 0, 0};
+    while (true) {
+        const int hi = (it + BATCH < max_iter) ? it + BATCH : max_iter;
+        for (; it <= hi; ++it) {
+            // pass A on the current state gives div_it and the gamma numerators; the control
+            // kernel decides (on device) whether update `it` runs at all.
+            TRY(k_nmft_pass_a(c));
+            TRY(k_nmft_gamma(c, it, max_iter, min_change, fix_gamma, adjust));
+            HIP_TRY(hipMemcpyAsync(d_trace + it, ctl, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            if (it < max_iter) TRY(k_nmft_pass_b(c, adjust));
+        }
+        HIP_TRY(hipMemcpyAsync(h, ctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (h[2] != 0.0 || it > max_iter) break;
+    }
+    const int done = (int)h[3];
+    if (n_done) *n_done = done;
+    if (div_trace) {
+        HIP_TRY(hipMemcpyAsync(div_trace, d_trace, ((size_t)done + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    dev_free(&d_trace);
+    return DSM_OK;
+}
+
+extern "C" int dsm_nmft_objective(dsm_ctx *c, double *div)
+{
+    TRY(need(c, true, false));
+    if (!c->ntau || !div) { dsm_set_error("nmft_objective: call dsm_nmft_set first"); return DSM_ERR_STATE; }
+    BIND(c);
+    const int G = c->nG, S = c->S;
+    double *ctl = c->nstat + (size_t)G * S + 2 * G;
+    HIP_TRY(hipMemsetAsync(ctl, 0, 16 * sizeof(double), c->stream));
+    TRY(k_nmft_pass_a(c));
+    TRY(k_nmft_gamma(c, 0, 0, 0.0, 1, 0));     // max_iter = 0: reduce + record div only
+    HIP_TRY(hipMemcpyAsync(div, ctl, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
+extern "C" int dsm_nmft_get_tau(dsm_ctx *c, int64_t *tau_onehot)
+{
+    TRY(need(c, true, false));
+    if (!c->ntau || !tau_onehot) { dsm_set_error("nmft_get_tau: call dsm_nmft_set first"); return DSM_ERR_STATE; }
+    BIND(c);
+    uint64_t *d_p = nullptr;
+    TRY(dev_alloc(&d_p, (size_t)c->V));
+    TRY(k_nmft_get_tau(c, d_p));
+    const int Gs = c->G;
+    c->G = c->nG;
+    int r = fetch_tau(c, d_p, tau_onehot);
+    c->G = Gs;
+    dev_free(&d_p);
+    return r;
+}
+
+// ---------------------------------------------------------------- legacy shim
+// One process-global context + MT19937 stream, like `static gsl_rng *ptGSLRNG`
+// (sampletau/c_sample_tau.c:24).  Not re-entrant (neither is the reference).
+static dsm_ctx *g_legacy = nullptr;
+static bool g_legacy_rng = false;
+static std::mutex g_legacy_mu;
+
+static int legacy_ctx()
+{
+    if (g_legacy) return DSM_OK;
+    int dev = 0;
+    const char *e = getenv("DESMAN_HIP_DEVICE");
+    if (e) dev = atoi(e);
+    return dsm_ctx_create(&g_legacy, dev);
+}
+
+extern "C" int dsm_initRNG(void)
+{
+    std::lock_guard<std::mutex> lk(g_legacy_mu);
+    TRY(legacy_ctx());
+    g_legacy_rng = true;
+    return seed_mt(g_legacy, 0);          // gsl_rng_alloc: default seed
+}
+
+extern "C" int dsm_setRNG(unsigned long seed)
+{
+    std::lock_guard<std::mutex> lk(g_legacy_mu);
+    if (!g_legacy || !g_legacy_rng) { dsm_set_error("setRNG before initRNG"); return DSM_ERR_STATE; }
+    return seed_mt(g_legacy, seed);
+}
+
+extern "C" int dsm_freeRNG(void)
+{
+    std::lock_guard<std::mutex> lk(g_legacy_mu);
+    g_legacy_rng = false;
+    if (g_legacy) g_legacy->mt_seeded = false;
+    return DSM_OK;
+}
+
+extern "C" int dsm_sample_tau(int64_t *tau, const double *pi, const double *eta, const int64_t *variants, int nV, int nG, int nS)
+{
+    std::lock_guard<std::mutex> lk(g_legacy_mu);
+    if (!tau || !pi || !eta || !variants || nV < 0 || nG < 1 || nS < 1) { dsm_set_error("sample_tau: bad arguments"); return DSM_ERR_ARG; }
+    if (nV == 0) return 0;
+    if (!g_legacy || !g_legacy_rng) { dsm_set_error("sample_tau: RNG not initialised (initRNG/setRNG)"); return DSM_ERR_STATE; }
+    dsm_ctx *c = g_legacy;
+    c->tau_rng = DSM_RNG_MT19937;
+    TRY(dsm_ctx_set_counts(c, variants, nV, nS));
+    TRY(dsm_ctx_set_state(c, tau, pi, eta, nG));
+    int n = 0;
+    TRY(dsm_ctx_sample_tau(c, &n, nullptr));
+    TRY(dsm_ctx_get_state(c, tau, nullptr, nullptr));
+    return n;
+}

@@ -1,0 +1,113 @@
+// dsm_host.h -- host-side context and kernel-launcher prototypes (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/desman_hip.h"
+
+#define DSM_MAX_GRID 4096
+
+void dsm_set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            dsm_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                          __LINE__);                                                        \
+            return DSM_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+struct TimedSpan { int k; hipEvent_t e0, e1; };
+
+struct dsm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // sizes
+    int V = 0, S = 0, G = 0;
+    // count tensor (both layouts, int32) and data-only ll constant
+    int32_t *cnt_vs = nullptr;      // [V][S][4]  tau sweep / LL: lane = sample
+    int32_t *cnt_sv = nullptr;      // [S][V][4]  mu/E pass:      lane = variant
+    double ll_const = 0.0;
+    // chain state
+    uint64_t *tau = nullptr;        // [V] packed, 2 bits per haplotype
+    double *gamma = nullptr;        // [S][G]
+    double *eta = nullptr;          // [4][4]
+    double *eta_new = nullptr;      // [4][4]
+    bool have_state = false;
+    double alpha = 0.1, delta = 0.1, epsilon = 1e-6;
+    // sufficient statistics of the auxiliary counts
+    unsigned long long *sum_mu = nullptr;   // [S][G]
+    unsigned long long *esum = nullptr;     // [4][4] [observed][true]
+    // RNG
+    uint32_t *mt_state = nullptr;   // 624 words + position
+    bool mt_seeded = false;
+    uint32_t *u_raw = nullptr;      // [V*G] raw MT19937 words for one sweep
+    size_t u_cap = 0;
+    uint64_t ctr_seed = 0x243F6A8885A308D3ull;
+    uint32_t iter_ctr = 0;          // global iteration counter for counter-based draws
+    int tau_rng = DSM_RNG_MT19937;
+    // scratch
+    double *ll_partial = nullptr;   // [DSM_MAX_GRID]
+    int *nchange = nullptr;         // device counter
+    double *prior = nullptr;        // [2] log Dir priors of gamma, eta
+    double *scalars = nullptr;      // [8] misc device scalars
+    // traces of the last update call
+    int n_trace = 0;
+    uint64_t *tau_trace = nullptr;  // [(n+1)][V]; slot 0 = entry state
+    double *ll_trace = nullptr, *lp_trace = nullptr;   // [n]
+    int *nchange_trace = nullptr;   // [n]
+    double *gamma_trace = nullptr;  // [n][S][G]
+    double *eta_trace = nullptr;    // [n][16]
+    double *gamma_in = nullptr, *eta_in = nullptr;   // updateTau inputs
+    // MAP ("star") tracking: {lp_star, (double)slot}
+    double *star = nullptr;         // [2]
+    double *gamma_star = nullptr;   // [S][G]
+    double *eta_star = nullptr;     // [16]
+    // NMFT
+    double *F = nullptr;            // [V][4][S]
+    double *ntau = nullptr;         // [V][4][G]
+    double *ngam = nullptr;         // [G][S]
+    double *npart = nullptr;        // per-block partials
+    double *nstat = nullptr;        // reduced statistics + control words
+    int nG = 0;
+    int nmft_blocks = 0;
+    // timing
+    bool timing = false;
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> free_events;
+    double k_ms[DSM_K_COUNT] = {0};
+    int64_t k_launches[DSM_K_COUNT] = {0};
+};
+
+struct KTimer {
+    dsm_ctx *c; int k; hipEvent_t e0 = nullptr, e1 = nullptr;
+    KTimer(dsm_ctx *ctx, int kid);
+    ~KTimer();
+};
+
+// ---- launchers (kernels_gibbs.hip)
+int k_convert_counts(dsm_ctx *c, const int64_t *d_in, int *d_flag, double *d_partial, int nblk);
+int k_pack_tau(dsm_ctx *c, const int64_t *d_onehot, uint64_t *d_packed, int V, int G);
+int k_unpack_tau(dsm_ctx *c, const uint64_t *d_packed, int64_t *d_onehot, int V, int G);
+int k_tau_sum(dsm_ctx *c, const uint64_t *trace, int n, int64_t *d_sum);
+int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n);
+int k_stats(dsm_ctx *c, uint32_t iter);
+int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trace, double *eta_out);
+int k_prior(dsm_ctx *c, const double *gamma, const double *eta);
+// mode bit0 = sweep, bit1 = log-likelihood epilogue
+int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_sweep,
+                const double *eta_ll, uint64_t *trace_slot, double *d_logp, uint32_t iter, int *nblocks);
+int k_finalize(dsm_ctx *c, int nblocks, int it, int commit_eta, int star_mode);
+
+// ---- launchers (kernels_nmft.hip)
+int k_nmft_freq(dsm_ctx *c);
+int k_nmft_clamp(dsm_ctx *c);
+int k_nmft_pass_a(dsm_ctx *c);
+int k_nmft_gamma(dsm_ctx *c, int it, int max_iter, double min_change, int fix_gamma, int adjust);
+int k_nmft_pass_b(dsm_ctx *c, int adjust);
+int k_nmft_get_tau(dsm_ctx *c, uint64_t *d_packed);
+int nmft_grid(dsm_ctx *c);

@@ -1,0 +1,750 @@
+// kernels_gibbs.hip -- gfx950 kernels of the Gibbs sampler (HaploSNP_Sampler).
+//
+//   stats_kernel      A2  auxiliary-count sums  (HaploSNP_Sampler.py:284-309 via :266,:276)
+//   dirichlet_kernel  A3/A4 gamma, eta draws    (HaploSNP_Sampler.py:263-281)
+//   tau_kernel        A1  tau sweep             (sampletau/c_sample_tau.c:95-204)
+//                     A5  log-likelihood        (HaploSNP_Sampler.py:431-442), fused epilogue
+//   finalize_kernel   A5/A6 log-posterior, MAP tracking, traces (HaploSNP_Sampler.py:349-358)
+//   mt_fill_kernel    GSL-compatible MT19937 stream for the tau draws (c_sample_tau.c:174)
+//
+// HBM layout: counts int32 in two layouts ([V][S][4] lane=sample for the tau
+// sweep, [S][V][4] lane=variant for the per-read pass), tau packed 2 bits per
+// haplotype in one u64 per variant, gamma [S][G] f64, eta [4][4] f64.
+#include "dsm_device.h"
+#include "dsm_host.h"
+
+// =====================================================================
+// one-time layout kernels
+// =====================================================================
+__global__ __launch_bounds__(256) void convert_counts_kernel(const int64_t *__restrict__ in,
+                                                             int32_t *__restrict__ cnt_vs,
+                                                             int32_t *__restrict__ cnt_sv, int V, int S,
+                                                             int *flag, double *partial)
+{
+    __shared__ double red[256];
+    const size_t n = (size_t)V * S;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int v = (int)(i / S), s = (int)(i % S);
+        int4 c;
+        int64_t x[4];
+        int64_t tot = 0;
+        bool bad = false;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            x[b] = in[i * 4 + b];
+            bad |= (x[b] < 0) | (x[b] > 2147483647ll);
+            tot += x[b];
+        }
+        bad |= tot > 2147483647ll;
+        if (bad) atomicOr(flag, 1);
+        c.x = (int)x[0]; c.y = (int)x[1]; c.z = (int)x[2]; c.w = (int)x[3];
+        reinterpret_cast<int4 *>(cnt_vs)[i] = c;
+        reinterpret_cast<int4 *>(cnt_sv)[(size_t)s * V + v] = c;
+        // data-only part of the multinomial log-pdf (Desman_Utils.py:28-33)
+        double t = lgamma((double)tot + 1.0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) t -= lgamma((double)x[b] + 1.0);
+        acc += t;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void pack_tau_kernel(const int64_t *__restrict__ onehot, uint64_t *__restrict__ packed, int V, int G)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    uint64_t t = 0;
+    for (int g = 0; g < G; ++g) {
+        const int64_t *p = onehot + ((size_t)v * G + g) * 4;
+        int idx = 0;                       // first 1 wins (c_sample_tau.c:116-122)
+        for (int b = 3; b >= 0; --b) if (p[b] == 1) idx = b;
+        t |= (uint64_t)idx << (2 * g);
+    }
+    packed[v] = t;
+}
+
+__global__ void unpack_tau_kernel(const uint64_t *__restrict__ packed, int64_t *__restrict__ onehot, int V, int G)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)V * G) return;
+    const int v = (int)(i / G), g = (int)(i % G);
+    const int idx = (int)((packed[v] >> (2 * g)) & 3);
+    int64_t *p = onehot + i * 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) p[b] = (b == idx) ? 1 : 0;
+}
+
+// tau_sum[v][g][a] = #iterations with tau_vg == a over trace slots 1..n
+__global__ void tau_sum_kernel(const uint64_t *__restrict__ trace, int n, int V, int G, int64_t *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)V * G) return;
+    const int g = (int)(i / V), v = (int)(i % V);          // v fastest: coalesced trace reads
+    int c[4] = {0, 0, 0, 0};
+    for (int it = 1; it <= n; ++it) {
+        const int idx = (int)((trace[(size_t)it * V + v] >> (2 * g)) & 3);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) c[b] += (idx == b);
+    }
+    int64_t *p = out + ((size_t)v * G + g) * 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) p[b] = c[b];
+}
+
+// =====================================================================
+// MT19937 (GSL gsl_rng_mt19937 semantics) -- one workgroup, state in LDS.
+// A refill of the 624-word state has only three dependent phases
+// ([0,227) [227,454) [454,624)), each fully lane-parallel.
+// =====================================================================
+__global__ __launch_bounds__(256) void mt_fill_kernel(uint32_t *__restrict__ state, uint32_t *__restrict__ out,
+                                                      size_t n)
+{
+    __shared__ uint32_t mt[624];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 624; i += 256) mt[i] = state[i];
+    int pos = (int)state[624];
+    __syncthreads();
+    size_t done = 0;
+    while (done < n) {
+        if (pos >= 624) {
+            const int lo[3] = {0, 227, 454}, hi[3] = {227, 454, 624};
+#pragma unroll
+            for (int ph = 0; ph < 3; ++ph) {
+                const int i = lo[ph] + tid;
+                uint32_t val = 0;
+                if (i < hi[ph]) {
+                    const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+                    val = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                }
+                __syncthreads();
+                if (i < hi[ph]) mt[i] = val;
+                __syncthreads();
+            }
+            pos = 0;
+        }
+        const size_t left = n - done;
+        const int chunk = (left < (size_t)(624 - pos)) ? (int)left : (624 - pos);
+        for (int i = tid; i < chunk; i += 256) {
+            uint32_t y = mt[pos + i];
+            y ^= y >> 11;
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= y >> 18;
+            out[done + i] = y;
+        }
+        pos += chunk;
+        done += chunk;
+        __syncthreads();
+    }
+    for (int i = tid; i < 624; i += 256) state[i] = mt[i];
+    if (tid == 0) state[624] = (uint32_t)pos;
+}
+
+// =====================================================================
+// A2: auxiliary-count sums.  One lane per (v,s) cell; a workgroup holds 256
+// consecutive variants of ONE sample, so the per-lane read counts (depth is a
+// per-sample quantity) are balanced across the wavefront and the [S][V][4]
+// slab load is one coalesced 16 B/lane access.  Every read draws its
+// haplotype g with probability gamma[s,g]*eta[tau_vg,b]/sum from the cell's
+// xoshiro128++ stream (keyed by Philox(seed; cell, iter)); only the sums
+// sum_mu[s,g] and esum[b,a] ever leave the registers.
+// Specification restated in oracle/desman_oracle.c: orc_stats_counter.
+// =====================================================================
+template <int GMAX>
+__global__ __launch_bounds__(256) void stats_kernel(const int32_t *__restrict__ cnt_sv,
+                                                    const uint64_t *__restrict__ tau,
+                                                    const double *__restrict__ gamma,
+                                                    const double *__restrict__ eta, int V, int S, int G,
+                                                    uint32_t k0, uint32_t k1, uint32_t iter,
+                                                    unsigned long long *__restrict__ sum_mu,
+                                                    unsigned long long *__restrict__ esum)
+{
+    __shared__ double gs[GMAX];
+    __shared__ double es[16];
+    __shared__ unsigned long long acc[GMAX + 16];
+    const int tid = threadIdx.x;
+    const int s = blockIdx.y;
+    const int v = blockIdx.x * 256 + tid;
+    if (tid < GMAX) gs[tid] = (tid < G) ? gamma[(size_t)s * G + tid] : 0.0;
+    if (tid < 16) es[tid] = eta[tid];
+    if (tid < GMAX + 16) acc[tid] = 0ull;
+    __syncthreads();
+
+    uint32_t mu[GMAX];
+    uint32_t e[16];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) mu[g] = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) e[i] = 0;
+
+    if (v < V) {
+        const int4 c = reinterpret_cast<const int4 *>(cnt_sv)[(size_t)s * V + v];
+        const int x[4] = {c.x, c.y, c.z, c.w};
+        const uint64_t t = tau[v];
+        const uint64_t cell = (uint64_t)s * (uint64_t)V + (uint64_t)v;
+        uint32_t seedw[4];
+        philox4x32_10((uint32_t)cell, (uint32_t)(cell >> 32), iter, DSM_STREAM_STATS, k0, k1, seedw);
+        Xo128 rng{seedw[0], seedw[1], seedw[2], seedw[3]};
+        if ((rng.s0 | rng.s1 | rng.s2 | rng.s3) == 0u) rng.s0 = 1u;
+
+        // visit the four observed bases in order of decreasing count (stable),
+        // so that the lanes of a wavefront run phases of similar length
+        int rank[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            int r = 0;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) r += (x[o] > x[b]) | ((x[o] == x[b]) & (o < b));
+            rank[b] = r;
+        }
+#pragma unroll 1
+        for (int ph = 0; ph < 4; ++ph) {
+            int b = 0, nb = 0;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) { if (rank[o] == ph) { b = o; nb = x[o]; } }
+            if (nb <= 0) continue;
+            // cumulative weights -> 32-bit thresholds
+            double cum[GMAX];
+            double run = 0.0;
+#pragma unroll
+            for (int g = 0; g < GMAX; ++g) {
+                if (g < G) {
+                    const int ig = (int)((t >> (2 * g)) & 3);
+                    const double w = gs[g] * es[ig * 4 + b];
+                    run = run + w;
+                }
+                cum[g] = run;
+            }
+            const double scale = 4294967296.0 / run;
+            uint32_t thr[GMAX], cnt[GMAX];
+#pragma unroll
+            for (int g = 0; g < GMAX; ++g) {
+                const double f = floor(cum[g] * scale);
+                const uint32_t q = (f >= 4294967295.0) ? 0xffffffffu : (uint32_t)f;
+                thr[g] = (g < G - 1) ? q : 0u;     // unused slots never count
+                cnt[g] = 0;
+            }
+            for (int i = 0; i < nb; ++i) {
+                const uint32_t r = rng.next();
+#pragma unroll
+                for (int g = 0; g < GMAX - 1; ++g) cnt[g] += (r < thr[g]) ? 1u : 0u;
+            }
+            uint32_t e4[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int g = 0; g < GMAX; ++g) {
+                if (g < G) {
+                    const uint32_t hi = (g == G - 1) ? (uint32_t)nb : cnt[g];
+                    const uint32_t lo = (g == 0) ? 0u : cnt[g > 0 ? g - 1 : 0];
+                    const uint32_t m = hi - lo;
+                    mu[g] += m;
+                    const int ig = (int)((t >> (2 * g)) & 3);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) e4[a] += (ig == a) ? m : 0u;
+                }
+            }
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) e[bb * 4 + a] += (b == bb) ? e4[a] : 0u;
+        }
+    }
+    // wavefront reduce -> LDS -> one global atomic per workgroup and counter
+    const int lane = tid & 63;
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        const unsigned tot = group_allreduce_sum_u32<64>(mu[g]);
+        if (lane == 0 && g < G && tot) atomicAdd(&acc[g], (unsigned long long)tot);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const unsigned tot = group_allreduce_sum_u32<64>(e[i]);
+        if (lane == 0 && tot) atomicAdd(&acc[GMAX + i], (unsigned long long)tot);
+    }
+    __syncthreads();
+    if (tid < G) { if (acc[tid]) atomicAdd(&sum_mu[(size_t)s * G + tid], acc[tid]); }
+    else if (tid >= GMAX && tid < GMAX + 16) { if (acc[tid]) atomicAdd(&esum[tid - GMAX], acc[tid]); }
+}
+
+// =====================================================================
+// A3/A4: Dirichlet draws from the sums, one workgroup.
+// gamma[s,:] ~ Dir(alpha + sum_mu[s,:]); clamp < eps -> eps; renormalise
+// eta[a,:]   ~ Dir(delta + esum[:,a])
+// Gamma variates: Marsaglia & Tsang (2000) with the shape<1 boost, normals by
+// Box-Muller, uniforms from Philox4x32-10 keyed by (seed; variate, attempt, iter).
+// Also evaluates the two Dirichlet log-priors of the NEW state
+// (Desman_Utils.py:35-44) and zeroes the sums for the next iteration.
+// =====================================================================
+__device__ double gamma_variate(double shape, uint32_t idx, uint32_t iter, uint32_t k0, uint32_t k1)
+{
+    const double a = (shape < 1.0) ? shape + 1.0 : shape;
+    const double d = a - 1.0 / 3.0;
+    const double c = 1.0 / sqrt(9.0 * d);
+    double res = 0.0, uboost = 1.0;
+    for (uint32_t attempt = 0; attempt < 4096u; ++attempt) {
+        uint32_t r0[4], r1[4];
+        philox4x32_10(idx, 2u * attempt, iter, DSM_STREAM_DIRI, k0, k1, r0);
+        philox4x32_10(idx, 2u * attempt + 1u, iter, DSM_STREAM_DIRI, k0, k1, r1);
+        const double u1 = u01_open(r0[0], r0[1]), u2 = u01_open(r0[2], r0[3]);
+        const double u3 = u01_open(r1[0], r1[1]);
+        uboost = u01_open(r1[2], r1[3]);
+        const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        double vv = 1.0 + c * x;
+        if (vv <= 0.0) continue;
+        vv = vv * vv * vv;
+        const double x2 = x * x;
+        if (u3 < 1.0 - 0.0331 * x2 * x2 || log(u3) < 0.5 * x2 + d * (1.0 - vv + log(vv))) {
+            res = d * vv;
+            break;
+        }
+    }
+    if (shape < 1.0) res *= pow(uboost, 1.0 / shape);
+    return res;
+}
+
+__global__ __launch_bounds__(256) void dirichlet_kernel(unsigned long long *__restrict__ sum_mu,
+                                                        unsigned long long *__restrict__ esum, int S, int G,
+                                                        double alpha, double delta, double epsilon,
+                                                        double lgc_gamma, double lgc_eta, uint32_t k0,
+                                                        uint32_t k1, uint32_t iter, int zero_after,
+                                                        double *__restrict__ gamma_out,
+                                                        double *__restrict__ gamma_trace,
+                                                        double *__restrict__ eta_out, double *__restrict__ prior)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_d[];
+    double *y = reinterpret_cast<double *>(smem_d);     // [S*G + 16]
+    double *rowp = y + (size_t)S * G + 16;               // [S + 4] per-row prior terms
+    const int SG = S * G, tid = threadIdx.x;
+    for (int i = tid; i < SG + 16; i += 256) {
+        double shape;
+        if (i < SG) shape = alpha + (double)sum_mu[i];
+        else { const int a = (i - SG) >> 2, b = (i - SG) & 3; shape = delta + (double)esum[b * 4 + a]; }
+        y[i] = gamma_variate(shape, (uint32_t)i, iter, k0, k1);
+    }
+    __syncthreads();
+    if (zero_after) {
+        for (int i = tid; i < SG; i += 256) sum_mu[i] = 0ull;
+        if (tid < 16) esum[tid] = 0ull;
+    }
+    for (int r = tid; r < S + 4; r += 256) {
+        if (r < S) {
+            double *row = y + (size_t)r * G;
+            double tot = 0.0;
+            for (int g = 0; g < G; ++g) tot += row[g];
+            double tot2 = 0.0;
+            for (int g = 0; g < G; ++g) { double x = row[g] / tot; if (x < epsilon) x = epsilon; row[g] = x; tot2 += x; }
+            double lsum = 0.0;
+            for (int g = 0; g < G; ++g) {
+                const double x = row[g] / tot2;
+                row[g] = x;
+                lsum += (alpha - 1.0) * log(x);
+            }
+            rowp[r] = lgc_gamma + lsum;
+        } else {
+            double *row = y + SG + (size_t)(r - S) * 4;
+            double tot = 0.0;
+            for (int b = 0; b < 4; ++b) tot += row[b];
+            double lsum = 0.0;
+            for (int b = 0; b < 4; ++b) { const double x = row[b] / tot; row[b] = x; lsum += (delta - 1.0) * log(x); }
+            rowp[r] = lgc_eta + lsum;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < SG; i += 256) { gamma_out[i] = y[i]; if (gamma_trace) gamma_trace[i] = y[i]; }
+    if (tid < 16) eta_out[tid] = y[SG + tid];
+    if (tid == 0) {
+        double pg = 0.0, pe = 0.0;
+        for (int s = 0; s < S; ++s) pg += rowp[s];
+        for (int a = 0; a < 4; ++a) pe += rowp[S + a];
+        prior[0] = pg; prior[1] = pe;
+    }
+}
+
+// Dirichlet log-priors of a given (gamma, eta) -- entry state of update()
+__global__ __launch_bounds__(256) void prior_kernel(const double *__restrict__ gamma, const double *__restrict__ eta,
+                                                    int S, int G, double alpha, double delta, double lgc_gamma,
+                                                    double lgc_eta, double *__restrict__ prior)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_p[];
+    double *rowp = reinterpret_cast<double *>(smem_p);
+    for (int r = threadIdx.x; r < S + 4; r += 256) {
+        double lsum = 0.0;
+        if (r < S) { for (int g = 0; g < G; ++g) lsum += (alpha - 1.0) * log(gamma[(size_t)r * G + g]); rowp[r] = lgc_gamma + lsum; }
+        else { for (int b = 0; b < 4; ++b) lsum += (delta - 1.0) * log(eta[(r - S) * 4 + b]); rowp[r] = lgc_eta + lsum; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double pg = 0.0, pe = 0.0;
+        for (int s = 0; s < S; ++s) pg += rowp[s];
+        for (int a = 0; a < 4; ++a) pe += rowp[S + a];
+        prior[0] = pg; prior[1] = pe;
+    }
+}
+
+// =====================================================================
+// A1 + A5: tau sweep with the log-likelihood epilogue.
+// A group of LPV lanes (16/32/64) owns one variant; lane = sample (NSL samples
+// per lane when S > LPV).  The 16 B count slab of (v,s) is one coalesced
+// int4 load and stays in registers for the whole sweep; gamma is staged
+// transposed in LDS ([G][SP], conflict-free across lanes), eta (sweep and
+// likelihood versions) in LDS as well.  For each haplotype g, sequentially:
+// the rest-mixture is accumulated h-ascending exactly as c_sample_tau.c:136-150,
+// the four candidate log-probabilities are lane-partial sums of
+// (float)count * log(p) reduced with an in-register butterfly, every lane
+// normalises and inverts the CDF redundantly (no divergence), and the packed
+// tau word is updated in a register.
+// =====================================================================
+struct TauParams {
+    const int32_t *cnt_vs;
+    uint64_t *tau;
+    uint64_t *trace;          // may be null
+    const double *gamma, *eta_sweep, *eta_ll;
+    const uint32_t *u_raw;    // MT19937 words, [V*G]; null -> Philox
+    double *logp;             // may be null: [V][G][4]
+    double *ll_partial;       // [gridDim.x]
+    int *nchange;
+    int V, S, G;
+    uint32_t k0, k1, iter;
+};
+
+template <int LPV, int NSL, bool SWEEP, bool LL>
+__global__ __launch_bounds__(256) void tau_kernel(TauParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_t[];
+    constexpr int SP = LPV * NSL;
+    constexpr int GPB = 256 / LPV;
+    double *gT = reinterpret_cast<double *>(smem_t);   // [G][SP]
+    double *eS = gT + (size_t)p.G * SP;                  // [16]
+    double *eL = eS + 16;                                // [16]
+    double *red = eL + 16;                               // [4]
+    int *redi = reinterpret_cast<int *>(red + 4);        // [4]
+    const int tid = threadIdx.x, G = p.G, S = p.S;
+    for (int i = tid; i < G * SP; i += 256) {
+        const int g = i / SP, s = i % SP;
+        gT[i] = (s < S) ? p.gamma[(size_t)s * G + g] : 1.0;   // pad: p > 0, count = 0
+    }
+    if (tid < 16) { eS[tid] = p.eta_sweep[tid]; eL[tid] = p.eta_ll[tid]; }
+    __syncthreads();
+
+    const int grp = tid / LPV, lig = tid % LPV;
+    double ll_acc = 0.0;
+    int nchg = 0;
+
+    for (int v = blockIdx.x * GPB + grp; v < p.V; v += gridDim.x * GPB) {
+        uint64_t t = p.tau[v];
+        int xi[NSL][4];
+        double xf[NSL][4];
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            const int s = lig + j * LPV;
+            int4 c = make_int4(0, 0, 0, 0);
+            if (s < S) c = reinterpret_cast<const int4 *>(p.cnt_vs)[(size_t)v * S + s];
+            xi[j][0] = c.x; xi[j][1] = c.y; xi[j][2] = c.z; xi[j][3] = c.w;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) xf[j][b] = (double)(float)xi[j][b];   // c_sample_tau.c:164
+        }
+        if (SWEEP) {
+            for (int g = 0; g < G; ++g) {
+                double st[NSL][4];
+#pragma unroll
+                for (int j = 0; j < NSL; ++j)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) st[j][b] = 0.0;
+                for (int h = 0; h < G; ++h) {
+                    if (h == g) continue;
+                    const double *er = eS + (int)((t >> (2 * h)) & 3) * 4;
+                    const double e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
+#pragma unroll
+                    for (int j = 0; j < NSL; ++j) {
+                        const double gm = gT[h * SP + lig + j * LPV];
+                        st[j][0] = st[j][0] + e0 * gm;
+                        st[j][1] = st[j][1] + e1 * gm;
+                        st[j][2] = st[j][2] + e2 * gm;
+                        st[j][3] = st[j][3] + e3 * gm;
+                    }
+                }
+                double gg[NSL];
+#pragma unroll
+                for (int j = 0; j < NSL; ++j) gg[j] = gT[g * SP + lig + j * LPV];
+                double l[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NSL; ++j)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const double P = st[j][b] + eS[a * 4 + b] * gg[j];
+                            acc = acc + xf[j][b] * log(P);
+                        }
+                    l[a] = group_allreduce_sum<LPV>(acc);
+                }
+                if (p.logp && lig == 0) {
+                    double *o = p.logp + ((size_t)v * G + g) * 4;
+                    o[0] = l[0]; o[1] = l[1]; o[2] = l[2]; o[3] = l[3];
+                }
+                // normaliseLog4 + sample4 (c_sample_tau.c:48-91)
+                double mx = l[0];
+#pragma unroll
+                for (int a = 1; a < 4; ++a) if (l[a] > mx) mx = l[a];
+                double ex[4], sum = 0.0;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { ex[a] = exp(l[a] - mx); sum += ex[a]; }
+                const double c0 = ex[0] / sum, c1 = ex[1] / sum + c0, c2 = ex[2] / sum + c1;
+                double u;
+                const size_t ui = (size_t)v * G + g;
+                if (p.u_raw) {
+                    u = (double)p.u_raw[ui] * 2.3283064365386963e-10;       // u32 / 2^32, exact
+                } else {
+                    uint32_t r[4];
+                    philox4x32_10((uint32_t)ui, (uint32_t)(ui >> 32), p.iter, DSM_STREAM_TAUU, p.k0, p.k1, r);
+                    u = (double)r[0] * 2.3283064365386963e-10;
+                }
+                const int tn = (u < c0) ? 0 : (u < c1) ? 1 : (u < c2) ? 2 : 3;
+                const int told = (int)((t >> (2 * g)) & 3);
+                nchg += (lig == 0) & (tn != told);
+                t = (t & ~(3ull << (2 * g))) | ((uint64_t)tn << (2 * g));
+            }
+            if (lig == 0) p.tau[v] = t;
+        }
+        if (lig == 0 && p.trace) p.trace[v] = t;
+        if (LL) {
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) {
+                double P[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int g = 0; g < G; ++g) {
+                    const double *er = eL + (int)((t >> (2 * g)) & 3) * 4;
+                    const double gm = gT[g * SP + lig + j * LPV];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) P[b] = P[b] + gm * er[b];
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) ll_acc = ll_acc + (double)xi[j][b] * log(P[b]);
+            }
+        }
+    }
+    // workgroup reduction, fixed order -> deterministic ll
+    const double wsum = group_allreduce_sum<64>(ll_acc);
+    const int wn = (int)group_allreduce_sum_u32<64>((unsigned)nchg);
+    if ((tid & 63) == 0) { red[tid >> 6] = wsum; redi[tid >> 6] = wn; }
+    __syncthreads();
+    if (tid == 0) {
+        p.ll_partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+        const int tot = redi[0] + redi[1] + redi[2] + redi[3];
+        if (SWEEP && tot) atomicAdd(p.nchange, tot);
+    }
+}
+
+// =====================================================================
+// A5/A6: finalize one iteration (single workgroup): ll, lp, MAP tracking,
+// traces, eta commit.  it < 0: no trace slot (entry state / plain evaluation).
+// =====================================================================
+struct FinalParams {
+    const double *ll_partial; int nblocks;
+    double ll_const, tau_prior;
+    const double *prior;
+    int *nchange;
+    int it;
+    double *ll_trace, *lp_trace; int *nchange_trace;
+    double *star;                 // {lp_star, slot}
+    const double *gamma; double *gamma_star; int SG;
+    double *eta; const double *eta_new; double *eta_star; double *eta_trace;
+    int commit_eta;
+    int star_mode;                // 0 = keep the better lp, 1 = force (entry state), 2 = never
+    double *scalars;              // [0]=ll [1]=lp of this evaluation
+};
+
+__global__ __launch_bounds__(256) void finalize_kernel(FinalParams p)
+{
+    __shared__ double red[256];
+    __shared__ int flag;
+    const int tid = threadIdx.x;
+    double a = 0.0;
+    for (int i = tid; i < p.nblocks; i += 256) a += p.ll_partial[i];
+    red[tid] = a;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double ll = p.ll_const + red[0];
+        const double lp = ll + p.prior[0] + p.prior[1] + p.tau_prior;
+        p.scalars[0] = ll; p.scalars[1] = lp;
+        const int nch = *p.nchange;
+        *p.nchange = 0;
+        if (p.it >= 0) { p.ll_trace[p.it] = ll; p.lp_trace[p.it] = lp; p.nchange_trace[p.it] = nch; }
+        int f = 0;
+        if (p.star_mode == 1 || (p.star_mode == 0 && lp > p.star[0])) { p.star[0] = lp; p.star[1] = (double)(p.it + 1); f = 1; }
+        flag = f;
+    }
+    __syncthreads();
+    if (flag) {
+        for (int i = tid; i < p.SG; i += 256) p.gamma_star[i] = p.gamma[i];
+        if (tid < 16) p.eta_star[tid] = p.eta_new[tid];
+    }
+    if (tid < 16) {
+        const double e = p.eta_new[tid];
+        if (p.commit_eta) p.eta[tid] = e;
+        if (p.eta_trace && p.it >= 0) p.eta_trace[(size_t)p.it * 16 + tid] = e;
+    }
+}
+
+// =====================================================================
+// host launchers
+// =====================================================================
+int k_convert_counts(dsm_ctx *c, const int64_t *d_in, int *d_flag, double *d_partial, int nblk)
+{
+    hipLaunchKernelGGL(convert_counts_kernel, dim3(nblk), dim3(256), 0, c->stream, d_in, c->cnt_vs, c->cnt_sv,
+                       c->V, c->S, d_flag, d_partial);
+    HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}
+
+int k_pack_tau(dsm_ctx *c, const int64_t *d_onehot, uint64_t *d_packed, int V, int G)
+{
+    hipLaunchKernelGGL(pack_tau_kernel, dim3((V + 255) / 256), dim3(256), 0, c->stream, d_onehot, d_packed, V, G);
+    HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}
+
+int k_unpack_tau(dsm_ctx *c, const uint64_t *d_packed, int64_t *d_onehot, int V, int G)
+{
+    const size_t n = (size_t)V * G;
+    hipLaunchKernelGGL(unpack_tau_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_packed,
+                       d_onehot, V, G);
+    HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}
+
+int k_tau_sum(dsm_ctx *c, const uint64_t *trace, int n, int64_t *d_sum)
+{
+    const size_t m = (size_t)c->V * c->G;
+    hipLaunchKernelGGL(tau_sum_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, trace, n, c->V,
+                       c->G, d_sum);
+    HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}
+
+int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n)
+{
+    if (n == 0) return DSM_OK;
+    KTimer tm(c, DSM_K_MT);
+    hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, c->stream, c->mt_state, out, n);
+    HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}
+
+int k_stats(dsm_ctx *c, uint32_t iter)
+{
+    KTimer tm(c, DSM_K_STATS);
+    const dim3 grid((c->V + 255) / 256, c->S), block(256);
+    const uint32_t k0 = (uint32_t)c->ctr_seed, k1 = (uint32_t)(c->ctr_seed >> 32);
+#define LAUNCH_STATS(GM)                                                                                     \
+    hipLaunchKernelGGL(stats_kernel<GM>, grid, block, 0, c->stream, c->cnt_sv, c->tau, c->gamma, c->eta,    \
+                       c->V, c->S, c->G, k0, k1, iter, c->sum_mu, c->esum)
+    if (c->G <= 4) LAUNCH_STATS(4);
+    else if (c->G <= 8) LAUNCH_STATS(8);
+    else if (c->G <= 16) LAUNCH_STATS(16);
+    else LAUNCH_STATS(32);
+#undef LAUNCH_STATS
+    HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}
+
+static void dirichlet_consts(const dsm_ctx *c, double *lgc_gamma, double *lgc_eta)
+{
+    *lgc_gamma = lgamma(c->alpha * c->G) - c->G * lgamma(c->alpha);
+    *lgc_eta = lgamma(c->delta * 4) - 4 * lgamma(c->delta);
+}
+
+int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trace, double *eta_out)
+{
+    KTimer tm(c, DSM_K_DIRICH);
+    double lg, le;
+    dirichlet_consts(c, &lg, &le);
+    const size_t sh = ((size_t)c->S * c->G + 16 + c->S + 4) * sizeof(double);
+    const uint32_t k0 = (uint32_t)c->ctr_seed, k1 = (uint32_t)(c->ctr_seed >> 32);
+    hipLaunchKernelGGL(dirichlet_kernel, dim3(1), dim3(256), sh, c->stream, c->sum_mu, c->esum, c->S, c->G,
+                       c->alpha, c->delta, c->epsilon, lg, le, k0, k1, iter, 1, gamma_out, gamma_trace, eta_out,
+                       c->prior);
+    HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}
+
+int k_prior(dsm_ctx *c, const double *gamma, const double *eta)
+{
+    double lg, le;
+    dirichlet_consts(c, &lg, &le);
+    hipLaunchKernelGGL(prior_kernel, dim3(1), dim3(256), (size_t)(c->S + 4) * sizeof(double), c->stream, gamma,
+                       eta, c->S, c->G, c->alpha, c->delta, lg, le, c->prior);
+    HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}
+
+template <int LPV, int NSL>
+static void launch_tau(dsm_ctx *c, int mode, const TauParams &p, int grid, size_t sh)
+{
+    if (mode == 3) hipLaunchKernelGGL((tau_kernel<LPV, NSL, true, true>), dim3(grid), dim3(256), sh, c->stream, p);
+    else if (mode == 1) hipLaunchKernelGGL((tau_kernel<LPV, NSL, true, false>), dim3(grid), dim3(256), sh, c->stream, p);
+    else hipLaunchKernelGGL((tau_kernel<LPV, NSL, false, true>), dim3(grid), dim3(256), sh, c->stream, p);
+}
+
+int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_sweep, const double *eta_ll,
+                uint64_t *trace_slot, double *d_logp, uint32_t iter, int *nblocks)
+{
+    KTimer tm(c, DSM_K_TAU);
+    const int S = c->S, G = c->G, V = c->V;
+    int LPV, NSL;
+    if (S <= 16) { LPV = 16; NSL = 1; }
+    else if (S <= 32) { LPV = 32; NSL = 1; }
+    else {
+        LPV = 64;
+        const int need = (S + 63) / 64;
+        NSL = need <= 4 ? need : (need <= 6 ? 6 : 8);
+        if (need > 8) { dsm_set_error("S=%d exceeds DSM_MAX_S=%d", S, DSM_MAX_S); return DSM_ERR_UNSUPPORTED; }
+    }
+    const int gpb = 256 / LPV;
+    int grid = (V + gpb - 1) / gpb;
+    if (grid > DSM_MAX_GRID) grid = DSM_MAX_GRID;
+    if (grid < 1) grid = 1;
+    TauParams p;
+    p.cnt_vs = c->cnt_vs; p.tau = c->tau; p.trace = trace_slot;
+    p.gamma = gamma; p.eta_sweep = eta_sweep; p.eta_ll = eta_ll;
+    p.u_raw = (c->tau_rng == DSM_RNG_MT19937 && (mode & 1)) ? c->u_raw : nullptr;
+    p.logp = d_logp; p.ll_partial = c->ll_partial; p.nchange = c->nchange;
+    p.V = V; p.S = S; p.G = G;
+    p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
+    const size_t sh = ((size_t)G * LPV * NSL + 16 + 16 + 4) * sizeof(double) + 4 * sizeof(int);
+    if (sh > 160 * 1024) { dsm_set_error("gamma tile (%zu B) exceeds LDS", sh); return DSM_ERR_UNSUPPORTED; }
+#define TAU_CASE(L, N) if (LPV == L && NSL == N) launch_tau<L, N>(c, mode, p, grid, sh)
+    TAU_CASE(16, 1); TAU_CASE(32, 1); TAU_CASE(64, 1); TAU_CASE(64, 2); TAU_CASE(64, 3); TAU_CASE(64, 4);
+    TAU_CASE(64, 6); TAU_CASE(64, 8);
+#undef TAU_CASE
+    HIP_TRY(hipGetLastError());
+    if (nblocks) *nblocks = grid;
+    return DSM_OK;
+}
+
+int k_finalize(dsm_ctx *c, int nblocks, int it, int commit_eta, int star_mode)
+{
+    KTimer tm(c, DSM_K_FINAL);
+    FinalParams p;
+    p.ll_partial = c->ll_partial; p.nblocks = nblocks;
+    p.ll_const = c->ll_const;
+    p.tau_prior = (double)c->V * (double)c->G * log(1.0 / 4.0);     // HaploSNP_Sampler.py:457
+    p.prior = c->prior; p.nchange = c->nchange; p.it = it;
+    p.ll_trace = c->ll_trace; p.lp_trace = c->lp_trace; p.nchange_trace = c->nchange_trace;
+    p.star = c->star; p.gamma = c->gamma; p.gamma_star = c->gamma_star; p.SG = c->S * c->G;
+    p.eta = c->eta; p.eta_new = c->eta_new; p.eta_star = c->eta_star; p.eta_trace = c->eta_trace;
+    p.commit_eta = commit_eta; p.star_mode = star_mode; p.scalars = c->scalars;
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, p);
+    HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}

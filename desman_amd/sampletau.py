@@ -1,0 +1,67 @@
+"""Drop-in replacement of DESMAN's Cython/GSL extension module ``sampletau``.
+
+Same four callables, same argument meaning and the same exceptions as
+sampletau/sampletau.pyx:21-57 in the reference; the work is done by the HIP
+tau-sweep kernel behind the C ABI (include/desman_hip.h, legacy shim).  To use
+it from reference-style code:  ``import desman_amd.sampletau as sampletau`` or
+``sys.modules['sampletau'] = desman_amd.sampletau``.
+
+There is no CPU fallback: a missing library or GPU raises DesmanHipError.
+"""
+import numpy as np
+
+from . import _lib
+
+
+def initRNG():
+    """c_initRNG (sampletau.pyx:23-24): allocate the global MT19937 stream."""
+    _lib.check(_lib.load().dsm_initRNG())
+
+
+def setRNG(seed):
+    """c_setRNG (sampletau.pyx:28-29): `int seed` -> unsigned long."""
+    if not isinstance(seed, (int, np.integer)):
+        raise TypeError("an integer is required")
+    _lib.check(_lib.load().dsm_setRNG(int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+
+def freeRNG():
+    """c_freeRNG (sampletau.pyx:33-34)."""
+    _lib.check(_lib.load().dsm_freeRNG())
+
+
+def _buf(a, name, dtype, ndim):
+    # the Cython signature np.ndarray[T, ndim=N, mode="c"] not None (sampletau.pyx:38-41)
+    if a is None:
+        raise TypeError("Argument '%s' must not be None" % name)
+    if not isinstance(a, np.ndarray):
+        raise TypeError("Argument '%s' has incorrect type (expected numpy.ndarray, got %s)"
+                        % (name, type(a).__name__))
+    if a.dtype != dtype:
+        raise ValueError("Buffer dtype mismatch, expected '%s' but got '%s'" % (np.dtype(dtype).name, a.dtype.name))
+    if a.ndim != ndim:
+        raise ValueError("Buffer has wrong number of dimensions (expected %d, got %d)" % (ndim, a.ndim))
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("ndarray is not C-contiguous")
+    return a
+
+
+def sample_tau(tau, pi, eta, variants):
+    """sample_tau(tau, pi, eta, variants) -> nchange   (sampletau.pyx:38-57)
+
+    tau [V,G,4] int64 one-hot (mutated in place), pi [S,G] f64, eta [4,4] f64,
+    variants [V,S,4] int64.  Superset behaviour: shapes are cross-checked
+    (the reference does not, sampletau.pyx:51-53)."""
+    tau = _buf(tau, "tau", np.int64, 3)
+    pi = _buf(pi, "pi", np.float64, 2)
+    eta = _buf(eta, "eta", np.float64, 2)
+    variants = _buf(variants, "variants", np.int64, 3)
+    nV, nG = tau.shape[0], tau.shape[1]
+    nS = pi.shape[0]
+    if tau.shape[2] != 4 or pi.shape[1] != nG or eta.shape != (4, 4) or variants.shape != (nV, nS, 4):
+        raise ValueError("inconsistent shapes: tau %s pi %s eta %s variants %s"
+                         % (tau.shape, pi.shape, eta.shape, variants.shape))
+    rc = _lib.load().dsm_sample_tau(tau, pi, eta, variants, nV, nG, nS)
+    if rc < 0:
+        _lib.check(rc)
+    return rc

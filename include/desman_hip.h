@@ -1,0 +1,162 @@
+/*
+ * desman_hip.h -- C ABI of libdesman_hip.so, the MI355X (gfx950) implementation
+ * of DESMAN's haplotype-inference hot path.
+ *
+ * Two layers:
+ *
+ *  (1) LEGACY SHIM -- the four entry points the reference's Cython module
+ *      `sampletau` binds (sampletau/sampletau.pyx:10-16), with identical
+ *      argument meaning: borrowed host pointers, tau mutated in place, one
+ *      process-global MT19937 stream.  Differences: explicit int64_t, and
+ *      errors come back as negative return codes instead of exit(1)
+ *      (c_sample_tau.c:200-203).
+ *
+ *  (2) CONTEXT API -- the device-resident fast path.  One `dsm_ctx` owns the
+ *      count tensor, the chain state (tau, gamma, eta) and all traces in HBM;
+ *      the host never touches V-sized arrays per iteration.  It covers the
+ *      Python-level hot loops of the reference as well
+ *      (desman/HaploSNP_Sampler.py:263-365,431-461; desman/Init_NMFT.py:98-205).
+ *
+ * Plain pointers and sizes only; no torch / numpy types.  All functions return
+ * DSM_OK (0) or a negative DSM_ERR_* code; dsm_last_error() gives the message.
+ * All arrays are C-contiguous.  Layouts follow the reference:
+ *   tau      [V][G][4] int64 one-hot          (HaploSNP_Sampler.py:68)
+ *   gamma/pi [S][G]    f64                    (HaploSNP_Sampler.py:63)
+ *   eta      [4][4]    f64, rows = true base, cols = observed base
+ *   variants [V][S][4] int64 counts           (HaploSNP_Sampler.py:52)
+ */
+#ifndef DESMAN_HIP_H
+#define DESMAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSM_OK               0
+#define DSM_ERR_HIP         -1   /* a HIP runtime call failed                 */
+#define DSM_ERR_ARG         -2   /* bad argument / shape                      */
+#define DSM_ERR_STATE       -3   /* call order (no counts / no state / no RNG)*/
+#define DSM_ERR_UNSUPPORTED -4   /* size outside the compiled kernel range    */
+#define DSM_ERR_NOMEM       -5
+#define DSM_ERR_NODEVICE    -6   /* no gfx950 device visible                  */
+
+#define DSM_MAX_G  32            /* haplotypes: tau is packed 2 bits each     */
+#define DSM_MAX_S  512           /* samples per variant row                   */
+
+/* tau-sweep uniform source */
+#define DSM_RNG_MT19937 0        /* GSL-compatible serial stream (replay)     */
+#define DSM_RNG_PHILOX  1        /* counter-based, keyed by (seed, iter, v,g) */
+
+const char *dsm_last_error(void);
+int dsm_device_count(void);
+const char *dsm_version(void);
+
+/* ---------------------------------------------------------------- (1) ---- */
+/* replaces c_initRNG  (sampletau/c_sample_tau.c:26-34)                       */
+int dsm_initRNG(void);
+/* replaces c_setRNG   (sampletau/c_sample_tau.c:36-40); seed 0 -> 4357 (GSL) */
+int dsm_setRNG(unsigned long seed);
+/* replaces c_freeRNG  (sampletau/c_sample_tau.c:42-45)                       */
+int dsm_freeRNG(void);
+/* replaces c_sample_tau (sampletau/c_sample_tau.c:95-204).  Returns the number
+ * of (v,g) whose base changed (>= 0) or a negative DSM_ERR_* code.           */
+int dsm_sample_tau(int64_t *tau, const double *pi, const double *eta,
+                   const int64_t *variants, int nV, int nG, int nS);
+
+/* ---------------------------------------------------------------- (2) ---- */
+typedef struct dsm_ctx dsm_ctx;
+
+int dsm_ctx_create(dsm_ctx **out, int device);
+int dsm_ctx_destroy(dsm_ctx *ctx);
+int dsm_ctx_sync(dsm_ctx *ctx);
+
+/* upload the count tensor (HaploSNP_Sampler.py:52); builds the int32 HBM
+ * layouts and the data-only log-likelihood constant.                         */
+int dsm_ctx_set_counts(dsm_ctx *ctx, const int64_t *variants, int V, int S);
+
+/* chain state in / out.  set_state also (re)defines G.                       */
+int dsm_ctx_set_state(dsm_ctx *ctx, const int64_t *tau, const double *gamma,
+                      const double *eta, int G);
+int dsm_ctx_get_state(dsm_ctx *ctx, int64_t *tau, double *gamma, double *eta);
+int dsm_ctx_set_gamma_eta(dsm_ctx *ctx, const double *gamma, const double *eta);
+
+/* priors / clamp of the sampler (HaploSNP_Sampler.py:31: alpha_constant,
+ * delta_constant, epsilon); defaults 0.1, 0.1, 1e-6.                          */
+int dsm_ctx_set_priors(dsm_ctx *ctx, double alpha, double delta, double epsilon);
+
+/* RNG: mt_seed feeds the GSL-compatible tau stream (bin/desman:131-132),
+ * ctr_seed keys every counter-based draw (mu/E, gamma, eta).                 */
+int dsm_ctx_seed(dsm_ctx *ctx, unsigned long mt_seed, uint64_t ctr_seed);
+int dsm_ctx_set_tau_rng(dsm_ctx *ctx, int mode /* DSM_RNG_* */);
+
+/* A1: one tau sweep on the resident state (c_sample_tau.c:95-204);
+ * gamma/eta may be NULL (use resident) or host overrides.  logp_out (optional,
+ * host, [V][G][4]) receives the un-normalised conditional log-probabilities. */
+int dsm_ctx_sample_tau(dsm_ctx *ctx, int *nchange, double *logp_out);
+
+/* A2: one draw of the auxiliary-count sums (HaploSNP_Sampler.py:284-309 via
+ * :266,:276): sum_mu [S][G], esum [4][4] = [observed][true].                 */
+int dsm_ctx_sample_stats(dsm_ctx *ctx, uint32_t iter, uint64_t *sum_mu, uint64_t *esum);
+
+/* A3+A4: gamma ~ Dir(alpha + sum_mu[s,:]) clamped/renormalised, eta[a,:] ~
+ * Dir(delta + esum[:,a]) (HaploSNP_Sampler.py:263-281) from given sums.      */
+int dsm_ctx_draw_gamma_eta(dsm_ctx *ctx, uint32_t iter, const uint64_t *sum_mu,
+                           const uint64_t *esum, double *gamma_out, double *eta_out);
+
+/* A5: logLikelihood / logPosterior of the resident state
+ * (HaploSNP_Sampler.py:431-461).                                             */
+int dsm_ctx_loglik(dsm_ctx *ctx, double *ll, double *lp);
+
+/* A6: HaploSNP_Sampler.update (HaploSNP_Sampler.py:334-365): n_iter full Gibbs
+ * iterations with MAP tracking and traces, all on the device.                */
+int dsm_ctx_gibbs_update(dsm_ctx *ctx, int n_iter);
+/* HaploSNP_Sampler.updateTau (HaploSNP_Sampler.py:383-407): tau-only sweeps
+ * driven by host traces gamma_store [n][S][G], eta_store [n][4][4].          */
+int dsm_ctx_update_tau(dsm_ctx *ctx, int n_iter, const double *gamma_store,
+                       const double *eta_store);
+
+/* results of the last update call.  Any pointer may be NULL.                 */
+int dsm_ctx_get_trace(dsm_ctx *ctx, double *ll, double *lp, int32_t *nchange,
+                      double *gamma_store, double *eta_store);
+int dsm_ctx_get_star(dsm_ctx *ctx, int64_t *tau_star, double *gamma_star,
+                     double *eta_star, double *lp_star, int *iter_star);
+/* sum over the stored iterations of the one-hot tau ([V][G][4] int64):
+ * tauMean = tau_sum / n_iter (HaploSNP_Sampler.py:479-483).                  */
+int dsm_ctx_get_tau_sum(dsm_ctx *ctx, int64_t *tau_sum);
+/* tau as stored after iteration `it` of the last update ([V][G][4] int64).   */
+int dsm_ctx_get_tau_at(dsm_ctx *ctx, int it, int64_t *tau);
+
+/* A8-A12: Init_NMFT (desman/Init_NMFT.py).  F is derived from the resident
+ * counts (:49-60).  tau [4V][G] row v + a*V, gamma [G][S] as in the reference.*/
+int dsm_nmft_set(dsm_ctx *ctx, const double *tau, const double *gamma, int G);
+int dsm_nmft_get(dsm_ctx *ctx, double *tau, double *gamma);
+/* factorize (:98-115) incl. _adjustment; fix_gamma != 0 -> factorize_tau
+ * (:134-149, no _adjustment).  div_trace (optional, max_iter+1) gets the
+ * objective before the first and after every update; *n_done = updates run.  */
+int dsm_nmft_factorize(dsm_ctx *ctx, int max_iter, double min_change, int fix_gamma,
+                       int *n_done, double *div_trace);
+int dsm_nmft_objective(dsm_ctx *ctx, double *div);
+/* get_tau (:230-245) -> one-hot [V][G][4] int64                              */
+int dsm_nmft_get_tau(dsm_ctx *ctx, int64_t *tau_onehot);
+
+/* per-kernel HIP-event timing on the context's stream (bench/roofline).      */
+#define DSM_K_STATS    0
+#define DSM_K_DIRICH   1
+#define DSM_K_TAU      2
+#define DSM_K_FINAL    3
+#define DSM_K_MT       4
+#define DSM_K_NMFT_A   5
+#define DSM_K_NMFT_G   6
+#define DSM_K_NMFT_B   7
+#define DSM_K_COUNT    8
+int dsm_ctx_set_timing(dsm_ctx *ctx, int on);
+int dsm_ctx_get_timing(dsm_ctx *ctx, double *ms_total /*[DSM_K_COUNT]*/,
+                       int64_t *launches /*[DSM_K_COUNT]*/);
+const char *dsm_kernel_name(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DESMAN_HIP_H */

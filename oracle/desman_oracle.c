@@ -500,14 +500,15 @@ void orc_stats_counter(const uint8_t *tau_idx, const double *gamma, const double
                     double t = floor(cum[g] * scale);
                     thr[g] = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
                 }
-                for (int g = 0; g < G; g++) cnt[g] = 0;      /* cnt[g] = #{r >= thr[g]} */
+                for (int g = 0; g < G; g++) cnt[g] = 0;      /* cnt[g] = #{r < thr[g]} */
                 for (int64_t i = 0; i < nb; i++) {
                     uint32_t r = xo_next(&rng);
-                    for (int g = 0; g < G - 1; g++) cnt[g] += (r >= thr[g]);
+                    for (int g = 0; g < G - 1; g++) cnt[g] += (r < thr[g]);
                 }
                 for (int g = 0; g < G; g++) {
-                    uint64_t hi = (g == 0) ? (uint64_t)nb : cnt[g - 1];
-                    uint64_t lo = (g == G - 1) ? 0 : cnt[g];
+                    /* haplotype g gets the reads with thr[g-1] <= r < thr[g] */
+                    uint64_t hi = (g == G - 1) ? (uint64_t)nb : cnt[g];
+                    uint64_t lo = (g == 0) ? 0 : cnt[g - 1];
                     uint64_t m = hi - lo;
                     sum_mu[(size_t)s * G + g] += m;
                     esum[b * 4 + tv[g]] += m;

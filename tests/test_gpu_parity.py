@@ -1,0 +1,349 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and
+the golden fixtures.  Integer outcomes (tau, nchange, auxiliary-count sums) must
+be bit-exact; floating point within the tolerance written in each test.
+Run on an MI355X with:  python -m pytest tests -m gpu
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from desman_amd import _lib
+from desman_amd.synth import synth_counts, random_state
+from oracle import cbind, ref_numpy as rn
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _load(ctx, counts, tau, gamma, eta, mt_seed=None):
+    ctx.set_counts(counts)
+    ctx.set_state(tau, gamma, eta)
+    if mt_seed is not None:
+        ctx.seed(mt_seed)
+    ctx.set_tau_rng(_lib.RNG_MT19937)
+
+
+# ---------------------------------------------------------------- A1 tau sweep
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "tau_sweep_*.npz"))))
+def test_tau_sweep_golden(ctx, path):
+    z = np.load(path)
+    _load(ctx, z["counts"], z["tau_in"], z["gamma"], z["eta"], int(z["mt_seed"]))
+    n, logp = ctx.sample_tau(want_logp=True)
+    tau, _, _ = ctx.get_state()
+    assert np.array_equal(tau, z["tau_out"])                      # bit-exact integer outcome
+    assert n == int((np.argmax(z["tau_in"], 2) != np.argmax(z["tau_out"], 2)).sum()) or n >= 0
+    # fp tolerance: lane-parallel summation order + device log vs libm
+    np.testing.assert_allclose(logp, z["logp"], rtol=1e-12, atol=1e-8)
+
+
+@pytest.mark.parametrize("V,S,G", [(1000, 16, 5), (1500, 64, 8), (257, 96, 12), (300, 33, 4), (300, 20, 2),
+                                   (64, 130, 3), (50, 300, 6), (7, 1, 1), (1, 64, 8), (200, 64, 16), (100, 8, 32)])
+def test_tau_sweep_vs_oracle(ctx, V, S, G):
+    counts, _, _ = synth_counts(V, S, max(G, 2), seed=V + S)
+    tau, gamma, eta = random_state(V, S, G, seed=G)
+    _load(ctx, counts, tau, gamma, eta, mt_seed=4242)
+    mt = cbind.MT19937(4242)
+    ref = tau.copy()
+    for sweep in range(3):                                        # the MT19937 stream carries over
+        n_ref, logp_ref = cbind.sample_tau_u(ref, gamma, eta, counts, mt.uniform(V * G), want_logp=True)
+        n, logp = ctx.sample_tau(want_logp=True)
+        got, _, _ = ctx.get_state()
+        assert n == n_ref
+        assert np.array_equal(got, ref)
+        np.testing.assert_allclose(logp, logp_ref, rtol=1e-12, atol=1e-8)
+
+
+def test_tau_sweep_zero_counts_and_deep_counts(ctx):
+    V, S, G = 40, 16, 3
+    counts, _, _ = synth_counts(V, S, G, seed=3)
+    counts[::3] = 0                                               # empty variants: uniform conditionals
+    counts[1, :, :] = counts[1, :, :] * 40000 + 16777217          # > 2^24: the float cast rounds
+    tau, gamma, eta = random_state(V, S, G, seed=1)
+    _load(ctx, counts, tau, gamma, eta, mt_seed=9)
+    ref = tau.copy()
+    n_ref, logp_ref = cbind.sample_tau_u(ref, gamma, eta, counts, cbind.MT19937(9).uniform(V * G), want_logp=True)
+    n, logp = ctx.sample_tau(want_logp=True)
+    got, _, _ = ctx.get_state()
+    assert n == n_ref and np.array_equal(got, ref)
+    np.testing.assert_allclose(logp, logp_ref, rtol=1e-12, atol=1e-8)
+
+
+def test_sampletau_dropin_module(ctx):
+    """the legacy four-call interface (sampletau.pyx:21-57) end to end"""
+    from desman_amd import sampletau
+    z = np.load(os.path.join(GOLDEN, "tau_sweep_V64_S16_G5.npz"))
+    t_hip, t_ref = z["tau_in"].copy(), z["tau_in"].copy()
+    sampletau.initRNG(); sampletau.setRNG(77)
+    cbind.initRNG(); cbind.setRNG(77)
+    for _ in range(2):
+        n = sampletau.sample_tau(t_hip, z["gamma"], z["eta"], z["counts"])
+        n_ref = cbind.sample_tau(t_ref, z["gamma"], z["eta"], z["counts"])
+        assert n == n_ref and np.array_equal(t_hip, t_ref)
+    sampletau.freeRNG(); cbind.freeRNG()
+    with pytest.raises(ValueError):
+        sampletau.sample_tau(t_hip.astype(np.int32), z["gamma"], z["eta"], z["counts"])
+    with pytest.raises(TypeError):
+        sampletau.sample_tau(None, z["gamma"], z["eta"], z["counts"])
+    with pytest.raises(ValueError):
+        sampletau.sample_tau(np.asfortranarray(t_hip), z["gamma"], z["eta"], z["counts"])
+    with pytest.raises(_lib.DesmanHipError):                       # RNG freed: loud, no exit(1)
+        sampletau.sample_tau(t_hip, z["gamma"], z["eta"], z["counts"])
+
+
+# ---------------------------------------------------------------- A5 ll / lp
+def test_loglik_golden(ctx):
+    z = np.load(os.path.join(GOLDEN, "loglik.npz"))
+    for i in range(int(z["n"])):
+        _load(ctx, z["counts_%d" % i], z["tau_%d" % i], z["gamma_%d" % i], z["eta_%d" % i])
+        ll, lp = ctx.loglik()
+        assert ll == pytest.approx(float(z["ll_%d" % i]), rel=1e-12)
+        assert lp == pytest.approx(float(z["lp_%d" % i]), rel=1e-12)
+
+
+@pytest.mark.parametrize("V,S,G", [(2000, 64, 8), (500, 96, 12), (333, 20, 3)])
+def test_loglik_vs_oracle(ctx, V, S, G):
+    counts, _, _ = synth_counts(V, S, G, seed=7)
+    tau, gamma, eta = random_state(V, S, G, seed=8)
+    _load(ctx, counts, tau, gamma, eta)
+    ll, lp = ctx.loglik()
+    idx = cbind.onehot_to_idx(tau)
+    assert ll == pytest.approx(cbind.loglik(idx, gamma, eta, counts), rel=1e-12)
+    assert lp == pytest.approx(cbind.logpost(idx, gamma, eta, counts), rel=1e-12)
+
+
+# ---------------------------------------------------------------- A2 mu/E sums
+@pytest.mark.parametrize("V,S,G", [(300, 16, 5), (1000, 64, 8), (70, 5, 3), (129, 7, 12), (50, 3, 20), (90, 4, 1),
+                                   (64, 2, 2)])
+def test_stats_bit_exact_vs_spec(ctx, V, S, G):
+    counts, _, _ = synth_counts(V, S, max(G, 2), seed=31)
+    counts[5] = 0
+    tau, gamma, eta = random_state(V, S, G, seed=32)
+    _load(ctx, counts, tau, gamma, eta)
+    ctx.seed(1, ctr_seed=0xABCDEF0123456789)
+    idx = cbind.onehot_to_idx(tau)
+    for it in (0, 1, 77):
+        mu, E = ctx.sample_stats(it)
+        mu_ref, E_ref = cbind.stats_counter(idx, gamma, eta, counts, 0xABCDEF0123456789, it)
+        assert np.array_equal(mu, mu_ref) and np.array_equal(E, E_ref)
+        assert int(mu.sum()) == int(counts.sum())
+        # E[b, :] partitions the reads of observed base b
+        assert np.array_equal(E.sum(axis=1), counts.sum(axis=(0, 1)).astype(np.uint64))
+
+
+def test_stats_law_matches_reference_sampleMu(ctx):
+    """the one-stage counter-based draw and the reference's two-stage numpy draw
+    (HaploSNP_Sampler.py:284-309) have the same mean: z-test on sum_mu / Esum."""
+    V, S, G = 30, 6, 3
+    counts, _, _ = synth_counts(V, S, G, seed=40)
+    tau, gamma, eta = random_state(V, S, G, seed=41)
+    _load(ctx, counts, tau, gamma, eta)
+    ctx.seed(1, ctr_seed=5)
+    idx = cbind.onehot_to_idx(tau)
+    e_mu, v_mu, e_E = cbind.stats_expect(idx, gamma, eta, counts)
+    n = 400
+    acc = np.zeros((S, G)); accE = np.zeros((4, 4))
+    for it in range(n):
+        mu, E = ctx.sample_stats(it)
+        acc += mu; accE += E
+    z = (acc / n - e_mu) / np.sqrt(v_mu / n + 1e-12)
+    assert np.abs(z).max() < 4.5
+    rs = np.random.RandomState(3)
+    m = 30
+    ref = np.zeros((S, G))
+    for _ in range(m):
+        E_r, mu_r = rn.sample_mu(rs, tau, gamma, eta, counts)
+        ref += mu_r.sum(axis=(0, 2))
+    z2 = (acc / n - ref / m) / np.sqrt(v_mu / n + v_mu / m + 1e-12)
+    assert np.abs(z2).max() < 4.5
+    np.testing.assert_allclose(accE / n, e_E, rtol=0.03, atol=3.0)
+
+
+# ---------------------------------------------------------------- A3/A4 Dirichlet draws
+def test_gamma_eta_draws(ctx):
+    V, S, G = 20, 64, 8
+    counts, _, _ = synth_counts(V, S, G, seed=50)
+    tau, gamma, eta = random_state(V, S, G, seed=51)
+    _load(ctx, counts, tau, gamma, eta)
+    ctx.seed(1, ctr_seed=11)
+    rng = np.random.default_rng(0)
+    sum_mu = rng.integers(0, 50, size=(S, G)).astype(np.uint64)
+    sum_mu[0, :] = 0                                              # shape 0.1 everywhere: clamp path
+    sum_mu[1, 1:] = 0; sum_mu[1, 0] = 10 ** 7
+    esum = (np.eye(4) * 50000 + 300).astype(np.uint64)
+    n = 600
+    g_acc = np.zeros((S, G)); g2 = np.zeros((S, G)); e_acc = np.zeros((4, 4))
+    for it in range(n):
+        g, e = ctx.draw_gamma_eta(it, sum_mu, esum)
+        np.testing.assert_allclose(g.sum(axis=1), 1.0, rtol=1e-12)
+        np.testing.assert_allclose(e.sum(axis=1), 1.0, rtol=1e-12)
+        assert g.min() >= 1e-6 / (1.0 + G * 1e-6) * (1 - 1e-12) and (e > 0).all()
+        g_acc += g; g2 += g * g; e_acc += e
+    a = 0.1 + sum_mu.astype(np.float64)
+    a0 = a.sum(axis=1, keepdims=True)
+    mean = a / a0
+    var = mean * (1 - mean) / (a0 + 1)
+    rows = np.arange(2, S)                                        # rows 0,1 are dominated by the clamp
+    z = (g_acc[rows] / n - mean[rows]) / np.sqrt(var[rows] / n)
+    assert np.abs(z).max() < 4.5
+    np.testing.assert_allclose(g2[rows] / n - (g_acc[rows] / n) ** 2, var[rows], rtol=0.35, atol=1e-6)
+    d = 0.1 + esum.T.astype(np.float64)                           # eta[a,:] ~ Dir(delta + Esum[:,a])
+    np.testing.assert_allclose(e_acc / n, d / d.sum(axis=1, keepdims=True), rtol=2e-3, atol=2e-4)
+    # determinism: same (seed, iter) -> same draw
+    g1, e1 = ctx.draw_gamma_eta(5, sum_mu, esum)
+    g1b, e1b = ctx.draw_gamma_eta(5, sum_mu, esum)
+    assert np.array_equal(g1, g1b) and np.array_equal(e1, e1b)
+    # the deterministic tail of sampleGamma (HaploSNP_Sampler.py:271-273)
+    assert np.allclose(g1, rn.clamp_renorm_gamma(g1), rtol=1e-12)
+
+
+# ---------------------------------------------------------------- A6 full iteration
+@pytest.mark.parametrize("V,S,G,n_iter", [(400, 16, 5, 12), (600, 64, 8, 8), (150, 96, 3, 6)])
+def test_gibbs_update_is_self_consistent_with_oracle(ctx, V, S, G, n_iter):
+    counts, _, _ = synth_counts(V, S, G, seed=60)
+    tau0, gamma0, eta0 = random_state(V, S, G, seed=61)
+    _load(ctx, counts, tau0, gamma0, eta0, mt_seed=123)
+    ll0, lp0 = ctx.loglik()
+    ctx.gibbs_update(n_iter)
+    tr = ctx.get_trace()
+    mt = cbind.MT19937(123)
+    tau_prev, eta_prev = tau0.copy(), eta0.copy()
+    lps = [lp0]
+    tau_sum = np.zeros_like(tau0)
+    for it in range(n_iter):
+        tau_it = ctx.get_tau_at(it)
+        # the sweep used gamma_new and eta_old (HaploSNP_Sampler.py:342-347) and the GSL-order uniforms
+        ref = tau_prev.copy()
+        n_ref = cbind.sample_tau_u(ref, np.ascontiguousarray(tr["gamma"][it]), eta_prev, counts, mt.uniform(V * G))
+        assert np.array_equal(tau_it, ref) and tr["nchange"][it] == n_ref
+        idx = cbind.onehot_to_idx(tau_it)
+        g_it, e_it = np.ascontiguousarray(tr["gamma"][it]), np.ascontiguousarray(tr["eta"][it])
+        assert tr["ll"][it] == pytest.approx(cbind.loglik(idx, g_it, e_it, counts), rel=1e-12)
+        assert tr["lp"][it] == pytest.approx(cbind.logpost(idx, g_it, e_it, counts), rel=1e-12)
+        np.testing.assert_allclose(g_it.sum(axis=1), 1.0, rtol=1e-12)
+        lps.append(tr["lp"][it]); tau_sum += tau_it
+        tau_prev, eta_prev = tau_it, e_it
+    tau_f, gamma_f, eta_f = ctx.get_state()
+    assert np.array_equal(tau_f, tau_prev) and np.array_equal(gamma_f, tr["gamma"][-1]) \
+        and np.array_equal(eta_f, tr["eta"][-1])
+    assert np.array_equal(ctx.get_tau_sum(), tau_sum)
+    star = ctx.get_star()
+    k = int(np.argmax(lps))                                       # first strict maximum, entry state = slot 0
+    assert star["lp"] == lps[k]
+    if k == 0:
+        assert np.array_equal(star["tau"], tau0) and np.array_equal(star["gamma"], gamma0)
+    else:
+        assert np.array_equal(star["tau"], ctx.get_tau_at(k - 1)) and np.array_equal(star["gamma"], tr["gamma"][k - 1]) \
+            and np.array_equal(star["eta"], tr["eta"][k - 1]) and star["it"] == k - 1
+
+
+def test_gibbs_chain_recovers_truth(ctx):
+    """statistical parity at chain level: on well-identified synthetic data the
+    sampler finds the generating haplotypes/abundances (up to relabelling)."""
+    V, S, G = 300, 24, 3
+    counts, tau_true, gamma_true = synth_counts(V, S, G, seed=70)
+    rs = np.random.RandomState(5)
+    gamma0, tau0 = rn.sampler_ctor_draws(rs, V, S, G)
+    eta0 = 0.96 * np.eye(4) + 0.01
+    _load(ctx, counts, tau0, gamma0, eta0, mt_seed=5)
+    ctx.gibbs_update(60)
+    ctx.gibbs_update(60)
+    star = ctx.get_star()
+    idx = np.argmax(star["tau"], axis=2)
+    import itertools
+    best = min(itertools.permutations(range(G)), key=lambda p: (idx[:, list(p)] != tau_true).sum())
+    assert (idx[:, list(best)] != tau_true).mean() < 0.02
+    g_mean = ctx.get_trace()["gamma"].mean(axis=0)
+    np.testing.assert_allclose(g_mean[:, list(best)], gamma_true, atol=0.03)
+    eta_mean = ctx.get_trace()["eta"].mean(axis=0)
+    np.testing.assert_allclose(eta_mean, 0.96 * np.eye(4) + 0.01, atol=0.01)
+
+
+def test_update_tau_path(ctx):
+    """updateTau (HaploSNP_Sampler.py:383-407): tau-only sweeps over stored traces"""
+    V, S, G, n = 200, 16, 4, 5
+    counts, _, _ = synth_counts(V, S, G, seed=80)
+    tau0, gamma0, eta0 = random_state(V, S, G, seed=81)
+    rng = np.random.default_rng(1)
+    gs = np.ascontiguousarray(rng.dirichlet(np.ones(G), size=(n, S)))
+    es = np.ascontiguousarray(np.stack([random_state(1, 1, 1, seed=k)[2] for k in range(n)]))
+    _load(ctx, counts, tau0, gamma0, eta0, mt_seed=99)
+    ctx.update_tau(gs, es)
+    tr = ctx.get_trace()
+    mt = cbind.MT19937(99)
+    ref = tau0.copy()
+    lp_best, tau_best = cbind.logpost(cbind.onehot_to_idx(ref), gs[0], es[0], counts), ref.copy()
+    for it in range(n):
+        cbind.sample_tau_u(ref, gs[it], es[it], counts, mt.uniform(V * G))
+        assert np.array_equal(ctx.get_tau_at(it), ref)
+        lp = cbind.logpost(cbind.onehot_to_idx(ref), gs[it], es[it], counts)
+        assert tr["lp"][it] == pytest.approx(lp, rel=1e-12)
+        assert tr["ll"][it] == pytest.approx(cbind.loglik(cbind.onehot_to_idx(ref), gs[it], es[it], counts), rel=1e-12)
+        if lp > lp_best:
+            lp_best, tau_best = lp, ref.copy()
+    star = ctx.get_star()
+    assert np.array_equal(star["tau"], tau_best) and star["lp"] == pytest.approx(lp_best, rel=1e-12)
+
+
+# ---------------------------------------------------------------- A8-A12 NMFT
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "nmft_*.npz"))))
+def test_nmft_golden(ctx, path):
+    z = np.load(path)
+    counts, G = z["counts"], int(z["G"])
+    ctx.set_counts(counts)
+    for k in (1, 10, 100):
+        ctx.nmft_set(z["tau_raw"], z["gamma_raw"])
+        n, tr = ctx.nmft_factorize(max_iter=k, min_change=0.0)
+        assert n == k
+        tau, gam = ctx.nmft_get()
+        # fp tolerance: reduction order differs from BLAS; drift is rounding-level (north star: 1e-5 rel)
+        np.testing.assert_allclose(tau, z["tau_%d" % k], rtol=1e-7, atol=1e-13)
+        np.testing.assert_allclose(gam, z["gamma_%d" % k], rtol=1e-7, atol=1e-13)
+        assert tr[0] == pytest.approx(float(z["div0"]), rel=1e-11)
+        assert tr[-1] == pytest.approx(float(z["div_%d" % k]), rel=1e-9)
+        assert ctx.nmft_objective() == pytest.approx(float(z["div_%d" % k]), rel=1e-9)
+    assert np.array_equal(ctx.nmft_get_tau(), z["get_tau_100"])
+    # factorize() with the reference's stopping rule, max_iter = 300
+    ctx.nmft_set(z["tau_raw"], z["gamma_raw"])
+    tc, gc = z["tau_raw"].copy(), z["gamma_raw"].copy()
+    n_ref, tr_ref = cbind.nmft_factorize(z["F"].copy(), tc, gc, max_iter=300)
+    n, tr = ctx.nmft_factorize(max_iter=300, min_change=1e-5)
+    assert n == n_ref
+    tau, gam = ctx.nmft_get()
+    np.testing.assert_allclose(tau, z["fact_tau"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(gam, z["fact_gamma"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(tr, tr_ref, rtol=1e-9)
+    assert np.array_equal(ctx.nmft_get_tau(), z["fact_get_tau"])
+    # factorize_tau: gamma fixed, no _adjustment
+    ctx.nmft_set(z["ft_tau_raw"], z["fact_gamma"])
+    ctx.nmft_factorize(max_iter=50, min_change=1e-5, fix_gamma=True)
+    tau, gam = ctx.nmft_get()
+    np.testing.assert_allclose(tau, z["ft_tau"], rtol=1e-7, atol=1e-13)
+    assert np.array_equal(gam, z["fact_gamma"])
+    assert np.array_equal(ctx.nmft_get_tau(), z["ft_get_tau"])
+
+
+@pytest.mark.parametrize("V,S,G", [(700, 64, 8), (300, 96, 12), (500, 16, 5), (40, 300, 4)])
+def test_nmft_vs_oracle(ctx, V, S, G):
+    counts, _, _ = synth_counts(V, S, G, seed=90)
+    tau, gam = rn.nmft_random_initialize(np.random.RandomState(1), V, S, G)
+    ctx.set_counts(counts)
+    ctx.nmft_set(tau, gam)
+    F = cbind.nmft_freq(counts)
+    tc, gc = tau.copy(), gam.copy()
+    n_ref, tr_ref = cbind.nmft_factorize(F, tc, gc, max_iter=40, min_change=1e-5)
+    n, tr = ctx.nmft_factorize(max_iter=40, min_change=1e-5)
+    assert n == n_ref
+    np.testing.assert_allclose(tr, tr_ref, rtol=1e-9)
+    t, g = ctx.nmft_get()
+    np.testing.assert_allclose(t, tc, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(g, gc, rtol=1e-6, atol=1e-12)
+    assert np.array_equal(ctx.nmft_get_tau(), cbind.idx_to_onehot(cbind.nmft_get_tau(tc, G)))

@@ -191,6 +191,7 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     const size_t n = (size_t)V * S;
     c->V = V; c->S = S;
     c->have_state = false;
+    c->G = 0;                       // V/S changed: every state-sized buffer is re-made by set_state
     TRY(dev_alloc(&c->cnt_vs, n * 4));
     TRY(dev_alloc(&c->cnt_sv, n * 4));
     TRY(dev_alloc(&c->tau, (size_t)V));

@@ -302,7 +302,8 @@ def test_nmft_golden(ctx, path):
     for k in (1, 10, 100):
         ctx.nmft_set(z["tau_raw"], z["gamma_raw"])
         n, tr = ctx.nmft_factorize(max_iter=k, min_change=0.0)
-        assert n == k
+        # min_change = 0 stops only at an exact fixed point (G = 1 reaches one after 2 updates)
+        assert n == k or (n < k and tr[-1] == tr[-2])
         tau, gam = ctx.nmft_get()
         # fp tolerance: reduction order differs from BLAS; drift is rounding-level (north star: 1e-5 rel)
         np.testing.assert_allclose(tau, z["tau_%d" % k], rtol=1e-7, atol=1e-13)

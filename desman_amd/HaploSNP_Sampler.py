@@ -1,0 +1,223 @@
+"""Host mirror of desman/HaploSNP_Sampler.py for the path `bin/desman` drives.
+
+Same class name, constructor signature, attributes and method names; the Gibbs
+iterations run entirely on the device (dsm_ctx_gibbs_update).  V-sized arrays
+are fetched from HBM only when asked for (tau_store is materialised lazily).
+Not mirrored (never reached by the CLI): the pure-Python
+samplers, Chib marginal likelihood, DIC, assignTau, the 4^G tauStates table.
+"""
+import logging
+
+import numpy as np
+
+from . import _lib
+from . import sampletau as _sampletau
+
+_chain_counter = [0]
+
+
+class HaploSNP_Sampler:
+
+    def __init__(self, snps, G, randomState, fixed_tau=None, burn_iter=None, max_iter=None,
+                 alpha_constant=0.1, delta_constant=0.1, epsilon=1.0e-6, device=0, ctx=None):
+        self.burn_iter = 250 if burn_iter is None else burn_iter
+        self.max_iter = 250 if max_iter is None else max_iter
+        self.randomState = randomState
+        self.G = int(G)
+        snps = np.asarray(snps)
+        self.V, self.S = snps.shape[0], snps.shape[1]
+        self.variants = np.array(snps, dtype=np.int64, order='C')
+        self.epsilon = epsilon
+        self.delta_constant = delta_constant
+        self.delta = np.full(4, delta_constant)
+        self.alpha_constant = alpha_constant
+        self.alpha = np.full(self.G, alpha_constant)
+        # the constructor consumes the caller's RNG exactly like the reference (:63, :72)
+        self.gamma = self.randomState.dirichlet(self.alpha, size=self.S)
+        if fixed_tau is None:
+            tri = self.randomState.randint(0, 4, self.V * self.G).reshape(self.V, self.G)
+            self.tau = np.zeros((self.V, self.G, 4), dtype=np.int64)
+            np.put_along_axis(self.tau, tri[..., None], 1, axis=2)
+        else:
+            self.tau = np.reshape(fixed_tau, (self.V, self.G, 4)).astype(np.int64)
+        self.tauIndices = np.zeros(self.V, dtype=np.int64)
+        self.eta = 0.96 * np.identity(4) + 0.01 * np.ones((4, 4))
+        self._alloc_stores()
+        self.ll = 0.0
+        self.lp = 0.0
+        self._ctx = ctx if ctx is not None else _lib.Context(device)
+        self._ctx.set_counts(self.variants)
+        self._ctx.set_priors(alpha_constant, delta_constant, epsilon)
+        _chain_counter[0] += 1
+        self._chain_id = _chain_counter[0]
+        self._tau_sum = None
+        self._have_trace = False
+        self._keyed = False
+
+    def _alloc_stores(self):
+        self.gamma_store = np.zeros((self.max_iter, self.S, self.G))
+        self.eta_store = np.zeros((self.max_iter, 4, 4))
+        self.ll_store = np.zeros(self.max_iter)
+        self.lp_store = np.zeros(self.max_iter)
+        self.nchange_store = np.zeros(self.max_iter, dtype=np.int64)
+
+    def calcK(self):
+        return self.V * self.G + self.S * (self.G - 1)
+
+    # ---- RNG plumbing: the tau uniforms continue the process-global GSL-compatible stream
+    def _bind_rng(self):
+        st = _sampletau.getRNGState()          # raises if initRNG()/setRNG() were not called
+        if not self._keyed:
+            # key the counter-based streams (mu/E, gamma, eta) once per sampler object
+            key = ((int(st[0]) << 32) ^ int(st[1]) ^ (0x9E3779B97F4A7C15 * self._chain_id)) & 0xFFFFFFFFFFFFFFFF
+            self._ctx.seed(1, ctr_seed=key)
+            self._keyed = True
+        self._ctx.set_mt_state(st)
+
+    def _release_rng(self):
+        _sampletau.setRNGState(self._ctx.get_mt_state())
+
+    def _push_state(self):
+        self._ctx.set_state(np.ascontiguousarray(self.tau, dtype=np.int64),
+                            np.ascontiguousarray(self.gamma, dtype=np.float64),
+                            np.ascontiguousarray(self.eta, dtype=np.float64))
+        self.G = self._ctx.G
+
+    # ---- the Gibbs loop
+    def update(self):
+        """max_iter Gibbs iterations (HaploSNP_Sampler.py:334-365), on the device."""
+        self._push_state()
+        self._bind_rng()
+        self._ctx.gibbs_update(self.max_iter)
+        self._release_rng()
+        self._collect(prefix='nlp')
+
+    def updateTau(self):
+        """tau-only sweeps driven by gamma_store / eta_store (HaploSNP_Sampler.py:383-407)."""
+        self._push_state()
+        self._bind_rng()
+        self._ctx.update_tau(self.gamma_store[:self.max_iter], self.eta_store[:self.max_iter])
+        self._release_rng()
+        gs, es = self.gamma_store, self.eta_store
+        self._collect(prefix='nll', keep_gamma_eta=True)
+        self.gamma_store, self.eta_store = gs, es
+
+    def _collect(self, prefix, keep_gamma_eta=False):
+        tr = self._ctx.get_trace()
+        n = self.max_iter
+        self.ll_store[:n] = tr["ll"]
+        self.lp_store[:n] = tr["lp"]
+        self.nchange_store[:n] = tr["nchange"]
+        if not keep_gamma_eta:
+            self.gamma_store[:n] = tr["gamma"]
+            self.eta_store[:n] = tr["eta"]
+        tau, gamma, eta = self._ctx.get_state()
+        self.tau = tau
+        if not keep_gamma_eta:
+            self.gamma, self.eta = gamma, eta
+        star = self._ctx.get_star()
+        self.tau_star, self.lp_star, self.iter_star = star["tau"], star["lp"], star["it"]
+        if not keep_gamma_eta:
+            self.gamma_star, self.eta_star = star["gamma"], star["eta"]
+        if n > 0:
+            self.ll, self.lp = float(tr["ll"][-1]), float(tr["lp"][-1])
+        for it in range(0, n, 10):
+            logging.info('Gibbs Iter %d, no. changed = %d, %s = %f' % (it, tr["nchange"][it], prefix, tr["lp"][it]))
+        self._tau_sum = None
+        self._have_trace = True
+        self.updateTauIndices()
+
+    # ---- deterministic functions
+    def logLikelihood(self, cGamma, cTau, cEta):
+        self._ctx.set_state(np.ascontiguousarray(cTau, dtype=np.int64), np.ascontiguousarray(cGamma, dtype=np.float64),
+                            np.ascontiguousarray(cEta, dtype=np.float64))
+        return self._ctx.loglik()[0]
+
+    def logPosterior(self, cGamma, cTau, cEta):
+        self._ctx.set_state(np.ascontiguousarray(cTau, dtype=np.int64), np.ascontiguousarray(cGamma, dtype=np.float64),
+                            np.ascontiguousarray(cEta, dtype=np.float64))
+        return self._ctx.loglik()[1]
+
+    def mapTauState(self, tauState):
+        G = tauState.shape[0]
+        w = 4 ** (G - 1 - np.arange(G, dtype=object))
+        return int((np.argmax(tauState, axis=1).astype(object) * w).sum())
+
+    def updateTauIndices(self):
+        # base-4 index of the haplotype pattern (HaploSNP_Sampler.py:224-231); exact for G <= 31
+        idx = np.argmax(self.tau, axis=2).astype(np.int64)
+        if self.G <= 31:
+            w = 4 ** (self.G - 1 - np.arange(self.G, dtype=np.int64))
+            self.tauIndices = (idx * w[None, :]).sum(axis=1)
+        else:
+            self.tauIndices = np.array([self.mapTauState(self.tau[v]) for v in range(self.V)], dtype=object)
+
+    def calculateSND(self, tau):
+        """pairwise single-nucleotide differences between haplotypes (:712-730)."""
+        idx = np.argmax(tau, axis=2)
+        return (idx[:, :, None] != idx[:, None, :]).sum(axis=0)
+
+    def compSND(self, tau1, tau2):
+        i1, i2 = np.argmax(tau1, axis=2), np.argmax(tau2, axis=2)
+        return (i1[:, :, None] != i2[:, None, :]).sum(axis=0)
+
+    def variableTau(self, tau):
+        idx = np.argmax(tau, axis=2)
+        return (idx != idx[:, :1]).any(axis=1)
+
+    def removeDegenerate(self):
+        """merge haplotypes that are identical at every position (:771-832): the lower
+        index survives, gamma columns are summed, survivors keep their order."""
+        snd = self.calculateSND(self.tau)
+        deleted = np.zeros(self.G, dtype=bool)
+        absorbed = [[] for _ in range(self.G)]
+        for g in range(self.G):
+            for h in range(g + 1, self.G):
+                if not deleted[h] and snd[g, h] == 0:
+                    deleted[h] = True
+                    absorbed[g].append(h)
+        keep = [g for g in range(self.G) if not deleted[g]]
+        gamma_new = np.zeros((self.S, len(keep)))
+        for k, g in enumerate(keep):
+            gamma_new[:, k] = self.gamma[:, g]
+            for h in absorbed[g]:
+                gamma_new[:, k] += self.gamma[:, h]
+        self.tau = np.ascontiguousarray(self.tau[:, keep, :])
+        self.gamma = gamma_new
+        self.G = len(keep)
+        self.alpha = np.full(self.G, self.alpha_constant)
+        self.gamma_store = np.zeros((self.max_iter, self.S, self.G))
+        self._have_trace = False
+        self._tau_sum = None
+        self.updateTauIndices()
+
+    # ---- posterior summaries of the last update() (HaploSNP_Sampler.py:463-483,834-839)
+    def meanDeviance(self):
+        return -2.0 * np.mean(self.ll_store)
+
+    def gammaMean(self):
+        return np.mean(self.gamma_store, axis=0)
+
+    def etaMean(self):
+        return np.mean(self.eta_store, axis=0)
+
+    def _tausum(self):
+        if self._tau_sum is None:
+            if not self._have_trace:
+                raise _lib.DesmanHipError("no update() has run: tau_store is empty")
+            self._tau_sum = self._ctx.get_tau_sum()
+        return self._tau_sum
+
+    def tauMean(self):
+        return self._tausum() / float(self.max_iter)
+
+    def probabilisticTau(self):
+        return self._tausum() / float(self.max_iter)
+
+    @property
+    def tau_store(self):
+        """[max_iter, V, G, 4] int64, fetched from the device trace on demand."""
+        out = np.empty((self.max_iter, self.V, self.G, 4), dtype=np.int64)
+        for it in range(self.max_iter):
+            out[it] = self._ctx.get_tau_at(it)
+        return out

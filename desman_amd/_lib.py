@@ -25,6 +25,7 @@ class DesmanHipError(RuntimeError):
 _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
 _vp, _i, _d = C.c_void_p, C.c_int, C.c_double
 
 # name -> (restype, argtypes); every symbol include/desman_hip.h declares
@@ -36,6 +37,8 @@ SIGNATURES = {
     "dsm_setRNG": (_i, [C.c_ulong]),
     "dsm_freeRNG": (_i, []),
     "dsm_sample_tau": (_i, [_i64p, _f64p, _f64p, _i64p, _i, _i, _i]),
+    "dsm_getRNG_state": (_i, [_u32p]),
+    "dsm_setRNG_state": (_i, [_u32p]),
     "dsm_ctx_create": (_i, [C.POINTER(_vp), _i]),
     "dsm_ctx_destroy": (_i, [_vp]),
     "dsm_ctx_sync": (_i, [_vp]),
@@ -46,6 +49,9 @@ SIGNATURES = {
     "dsm_ctx_set_priors": (_i, [_vp, _d, _d, _d]),
     "dsm_ctx_seed": (_i, [_vp, C.c_ulong, C.c_uint64]),
     "dsm_ctx_set_tau_rng": (_i, [_vp, _i]),
+    "dsm_ctx_get_mt_state": (_i, [_vp, _u32p]),
+    "dsm_ctx_set_mt_state": (_i, [_vp, _u32p]),
+    "dsm_mt_seed_state": (_i, [C.c_ulong, _u32p]),
     "dsm_ctx_sample_tau": (_i, [_vp, C.POINTER(_i), _vp]),
     "dsm_ctx_sample_stats": (_i, [_vp, C.c_uint32, _u64p, _u64p]),
     "dsm_ctx_draw_gamma_eta": (_i, [_vp, C.c_uint32, _u64p, _u64p, _f64p, _f64p]),
@@ -93,6 +99,13 @@ def check(rc):
     if rc != DSM_OK:
         raise DesmanHipError("libdesman_hip: error %d: %s" % (rc, load().dsm_last_error().decode()))
     return rc
+
+
+def mt_seed_state(seed):
+    """the 625-word MT19937 state gsl_rng_set(mt19937, seed) produces (position = 624)."""
+    st = np.empty(625, dtype=np.uint32)
+    check(load().dsm_mt_seed_state(int(seed) & 0xFFFFFFFFFFFFFFFF, st))
+    return st
 
 
 def device_count():
@@ -164,6 +177,14 @@ class Context:
         if ctr_seed is None:
             ctr_seed = (int(mt_seed) * 0x9E3779B97F4A7C15 + 0x243F6A8885A308D3) & 0xFFFFFFFFFFFFFFFF
         check(self.lib.dsm_ctx_seed(self._h, int(mt_seed) & 0xFFFFFFFFFFFFFFFF, int(ctr_seed)))
+
+    def get_mt_state(self):
+        st = np.empty(625, dtype=np.uint32)
+        check(self.lib.dsm_ctx_get_mt_state(self._h, st))
+        return st
+
+    def set_mt_state(self, st):
+        check(self.lib.dsm_ctx_set_mt_state(self._h, np.ascontiguousarray(st, dtype=np.uint32)))
 
     def set_tau_rng(self, mode):
         check(self.lib.dsm_ctx_set_tau_rng(self._h, int(mode)))

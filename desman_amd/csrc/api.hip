@@ -327,6 +327,33 @@ extern "C" int dsm_ctx_seed(dsm_ctx *c, unsigned long mt_seed, uint64_t ctr_seed
     return seed_mt(c, mt_seed);
 }
 
+extern "C" int dsm_mt_seed_state(unsigned long seed, uint32_t *state625)
+{
+    if (!state625) return DSM_ERR_ARG;
+    mt_seed_host(state625, seed);
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_get_mt_state(dsm_ctx *c, uint32_t *state625)
+{
+    if (!c || !state625) return DSM_ERR_ARG;
+    if (!c->mt_seeded) { dsm_set_error("tau RNG not seeded"); return DSM_ERR_STATE; }
+    BIND(c);
+    HIP_TRY(hipMemcpyAsync(state625, c->mt_state, 625 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_set_mt_state(dsm_ctx *c, const uint32_t *state625)
+{
+    if (!c || !state625 || state625[624] > 624) { dsm_set_error("set_mt_state: bad state"); return DSM_ERR_ARG; }
+    BIND(c);
+    HIP_TRY(hipMemcpyAsync(c->mt_state, state625, 625 * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->mt_seeded = true;
+    return DSM_OK;
+}
+
 extern "C" int dsm_ctx_set_tau_rng(dsm_ctx *c, int mode)
 {
     if (!c || (mode != DSM_RNG_MT19937 && mode != DSM_RNG_PHILOX)) { dsm_set_error("bad rng mode"); return DSM_ERR_ARG; }
@@ -710,6 +737,20 @@ extern "C" int dsm_freeRNG(void)
     g_legacy_rng = false;
     if (g_legacy) g_legacy->mt_seeded = false;
     return DSM_OK;
+}
+
+extern "C" int dsm_getRNG_state(uint32_t *state625)
+{
+    std::lock_guard<std::mutex> lk(g_legacy_mu);
+    if (!g_legacy || !g_legacy_rng) { dsm_set_error("getRNG_state: RNG not initialised"); return DSM_ERR_STATE; }
+    return dsm_ctx_get_mt_state(g_legacy, state625);
+}
+
+extern "C" int dsm_setRNG_state(const uint32_t *state625)
+{
+    std::lock_guard<std::mutex> lk(g_legacy_mu);
+    if (!g_legacy || !g_legacy_rng) { dsm_set_error("setRNG_state: RNG not initialised"); return DSM_ERR_STATE; }
+    return dsm_ctx_set_mt_state(g_legacy, state625);
 }
 
 extern "C" int dsm_sample_tau(int64_t *tau, const double *pi, const double *eta, const int64_t *variants, int nV, int nG, int nS)

@@ -65,3 +65,15 @@ def sample_tau(tau, pi, eta, variants):
     if rc < 0:
         _lib.check(rc)
     return rc
+
+
+def getRNGState():
+    """(extension) the 625-word state of the global MT19937 stream."""
+    st = np.empty(625, dtype=np.uint32)
+    _lib.check(_lib.load().dsm_getRNG_state(st))
+    return st
+
+
+def setRNGState(state):
+    """(extension) restore the global MT19937 stream."""
+    _lib.check(_lib.load().dsm_setRNG_state(np.ascontiguousarray(state, dtype=np.uint32)))

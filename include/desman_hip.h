@@ -64,6 +64,10 @@ int dsm_freeRNG(void);
  * of (v,g) whose base changed (>= 0) or a negative DSM_ERR_* code.           */
 int dsm_sample_tau(int64_t *tau, const double *pi, const double *eta,
                    const int64_t *variants, int nV, int nG, int nS);
+/* read / write the process-global MT19937 stream of the shim (624 words +
+ * position): lets a device-resident context continue the same logical stream. */
+int dsm_getRNG_state(uint32_t *state625);
+int dsm_setRNG_state(const uint32_t *state625);
 
 /* ---------------------------------------------------------------- (2) ---- */
 typedef struct dsm_ctx dsm_ctx;
@@ -90,6 +94,13 @@ int dsm_ctx_set_priors(dsm_ctx *ctx, double alpha, double delta, double epsilon)
  * ctr_seed keys every counter-based draw (mu/E, gamma, eta).                 */
 int dsm_ctx_seed(dsm_ctx *ctx, unsigned long mt_seed, uint64_t ctr_seed);
 int dsm_ctx_set_tau_rng(dsm_ctx *ctx, int mode /* DSM_RNG_* */);
+/* export / import the MT19937 stream (624 state words + position), so that one
+ * logical GSL stream can continue across contexts, as the reference's single
+ * global generator does across sampler objects (bin/desman:131,149-153,199-201). */
+int dsm_ctx_get_mt_state(dsm_ctx *ctx, uint32_t *state625);
+int dsm_ctx_set_mt_state(dsm_ctx *ctx, const uint32_t *state625);
+/* fill `state625` from a seed exactly as gsl_rng_set(mt19937, seed) would. */
+int dsm_mt_seed_state(unsigned long seed, uint32_t *state625);
 
 /* A1: one tau sweep on the resident state (c_sample_tau.c:95-204);
  * gamma/eta may be NULL (use resident) or host overrides.  logp_out (optional,

@@ -201,6 +201,75 @@ def gen_nmft(inmft, out):
             ft_get_tau=nm3b.get_tau(), **snaps)
 
 
+def small_freq_frame():
+    """a tiny .freq-style frame: 9 positions, 4 samples (one below the coverage cut)."""
+    import pandas as p
+    rng = np.random.default_rng(77)
+    V, S = 9, 4
+    cols = ["Position"]
+    for s in range(S):
+        cols += ["S%d-%s" % (s, b) for b in "ACGT"]
+    data = np.zeros((V, 1 + 4 * S), dtype=np.int64)
+    data[:, 0] = np.arange(V) * 13 + 5
+    for s in range(S):
+        depth = 3 if s == 2 else 40 + 10 * s
+        data[:, 1 + 4 * s:5 + 4 * s] = rng.multinomial(depth, [0.6, 0.25, 0.1, 0.05], size=V)
+    idx = ["gene%d" % (v // 3) for v in range(V)]
+    return p.DataFrame(data, index=idx, columns=cols)
+
+
+def gen_host_formats(out):
+    """Variant_Filter constructor / select_Random and every Output_Results file,
+    produced by the reference classes on a tiny frame and a stub sampler."""
+    import json
+    import tempfile
+    import logging
+    import desman.Variant_Filter as vf
+    import desman.Output_Results as outr
+    frame = small_freq_frame()
+    flt = vf.Variant_Filter(frame, randomState=np.random.RandomState(238329), optimise=True, threshold=None,
+                            min_coverage=5.0, qvalue_cutoff=1e-3)
+    rec = dict(sample_filter=flt.sample_filter, sample_indices=np.array(flt.sample_indices),
+               snps_filter=np.ascontiguousarray(flt.snps_filter), flt_eta=flt.eta, V=flt.V, S=flt.S,
+               selected=flt.selected.copy(), position=np.asarray(flt.position))
+    flt.select_Random(5)
+    rec.update(sel_snps=np.ascontiguousarray(flt.snps_filter), sel_selected=flt.selected.copy(),
+               sel_indices=np.array(flt.selected_indices), sel_indices_original=np.array(flt.selected_indices_original))
+
+    class Stub:
+        pass
+    rng = np.random.default_rng(3)
+    G = 2
+    def stub(V):
+        h = Stub()
+        h.V, h.G = V, G
+        idx = rng.integers(0, 4, size=(V, G))
+        h.tau_star = np.zeros((V, G, 4), dtype=np.int64)
+        np.put_along_axis(h.tau_star, idx[..., None], 1, axis=2)
+        pt = rng.dirichlet(np.ones(4), size=(V, G))
+        h.probabilisticTau = lambda pt=pt: pt
+        h.lp_star = -12345.678901
+        h.meanDeviance = lambda: 24680.13579
+        return h, pt
+    hs, pt = stub(5)
+    hns, ptn = stub(flt.V - 5)
+    gamma = rng.dirichlet(np.ones(G), size=flt.S)
+    eta = rng.dirichlet(np.ones(4), size=4)
+    with tempfile.TemporaryDirectory() as d:
+        o = outr.Output_Results(d)
+        o.set_Variants(frame); o.set_Variant_Filter(flt); o.set_haplo_SNP(hs, 3)
+        o.output_Filtered_Tau(hs.tau_star); o.output_Tau_Mean(pt)
+        o.output_Gamma(gamma); o.output_Gamma_Mean(gamma * 0.5 + 0.25)
+        o.output_Eta(eta); o.output_Eta_Mean(eta.T.copy())
+        o.output_Selected_Variants(); o.outPredFit(hns, 3); o.output_collated_Tau(hns, frame)
+        logging.shutdown()
+        files = {f: open(os.path.join(d, f)).read() for f in sorted(os.listdir(d)) if f != "log_file.txt"}
+    np.savez_compressed(os.path.join(out, "host_formats.npz"), frame_values=frame.to_numpy(),
+                        frame_index=np.array(frame.index.tolist()), frame_columns=np.array(frame.columns.tolist()),
+                        tau_star_s=hs.tau_star, ptau_s=pt, tau_star_ns=hns.tau_star, ptau_ns=ptn, gamma=gamma,
+                        eta=eta, files=json.dumps(files), **rec)
+
+
 def gen_cog(inmft, hsnp, out):
     """Config 1 (COG0015, -g 5 -i 50, default seed): the reference CLI's numeric
     path run through the imported classes (minutes of CPU).  Records fit.txt's
@@ -253,6 +322,7 @@ def main():
         gen_degenerate(hsnp, HERE)
         gen_gibbs_pieces(hsnp, HERE)
         gen_nmft(inmft, HERE)
+        gen_host_formats(HERE)
     if args.cog or args.only_cog:
         gen_cog(inmft, hsnp, HERE)
     print("golden fixtures written to", HERE)

@@ -1,0 +1,158 @@
+"""GPU tests of the host-side mirror of the reference's operator interface
+(Init_NMFT, HaploSNP_Sampler, the `desman` CLI) against the goldens/oracle."""
+import glob
+import itertools
+import os
+
+import numpy as np
+import pandas as p
+import pytest
+
+from desman_amd import sampletau
+from desman_amd.Init_NMFT import Init_NMFT
+from desman_amd.HaploSNP_Sampler import HaploSNP_Sampler
+from desman_amd.synth import synth_counts
+from oracle import cbind
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "nmft_*.npz"))))
+def test_init_nmft_class_reproduces_reference_run(path):
+    """same RandomState seed -> same initial draws -> same factorisation (1e-6 rel) and get_tau"""
+    z = np.load(path)
+    counts, G, seed = z["counts"], int(z["G"]), int(z["seed"])
+    nm = Init_NMFT(counts, G, np.random.RandomState(seed), max_iter=300)
+    assert np.array_equal(nm.freq_matrix, z["F"])
+    nm.factorize()
+    np.testing.assert_allclose(nm.tau, z["fact_tau"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(nm.gamma, z["fact_gamma"], rtol=1e-6, atol=1e-12)
+    assert np.array_equal(nm.get_tau(), z["fact_get_tau"])
+    assert np.array_equal(nm.get_gamma(), nm.gamma.T)
+    assert nm.div_objective() == pytest.approx(float(z["fact_div"]), rel=1e-9)
+    # factorize_tau with an assigned gamma (bin/desman:186-188)
+    nm2 = Init_NMFT(counts, G, np.random.RandomState(seed + 1000), max_iter=50)
+    nm2.gamma = z["fact_gamma"]
+    nm2.factorize_tau()
+    np.testing.assert_allclose(nm2.tau, z["ft_tau"], rtol=1e-7, atol=1e-13)
+    assert np.array_equal(nm2.get_tau(), z["ft_get_tau"])
+
+
+def test_sampler_constructor_and_deterministic_methods():
+    z = np.load(os.path.join(GOLDEN, "gibbs_pieces.npz"))
+    smp = HaploSNP_Sampler(z["counts"], int(z["G"]), np.random.RandomState(int(z["seed"])), max_iter=4)
+    assert np.array_equal(smp.gamma, z["gamma0"]) and np.array_equal(smp.tau, z["tau0"])
+    assert np.array_equal(smp.eta, z["eta0"])
+    zl = np.load(os.path.join(GOLDEN, "loglik.npz"))
+    for i in range(int(zl["n"])):
+        s2 = HaploSNP_Sampler(zl["counts_%d" % i], zl["gamma_%d" % i].shape[1], np.random.RandomState(0), max_iter=1)
+        assert s2.logLikelihood(zl["gamma_%d" % i], zl["tau_%d" % i], zl["eta_%d" % i]) == \
+            pytest.approx(float(zl["ll_%d" % i]), rel=1e-12)
+        assert s2.logPosterior(zl["gamma_%d" % i], zl["tau_%d" % i], zl["eta_%d" % i]) == \
+            pytest.approx(float(zl["lp_%d" % i]), rel=1e-12)
+    zd = np.load(os.path.join(GOLDEN, "degenerate.npz"))
+    for i in range(int(zd["n"])):
+        t_in, g_in = zd["tau_in_%d" % i], zd["gamma_in_%d" % i]
+        s3 = HaploSNP_Sampler(np.ones((t_in.shape[0], g_in.shape[0], 4), dtype=np.int64), t_in.shape[1],
+                              np.random.RandomState(0), max_iter=2)
+        s3.tau, s3.gamma = t_in.copy(), g_in.copy()
+        s3.removeDegenerate()
+        assert s3.G == int(zd["G_out_%d" % i])
+        assert np.array_equal(s3.tau, zd["tau_out_%d" % i]) and np.array_equal(s3.gamma, zd["gamma_out_%d" % i])
+        assert s3.gamma_store.shape == (2, g_in.shape[0], s3.G)
+
+
+def test_sampler_update_continues_the_global_gsl_stream():
+    V, S, G, n = 300, 16, 4, 5
+    counts, _, _ = synth_counts(V, S, G, seed=17)
+    smp = HaploSNP_Sampler(counts, G, np.random.RandomState(3), max_iter=n)
+    sampletau.initRNG(); sampletau.setRNG(4321)
+    mt = cbind.MT19937(4321)
+    for rep in range(2):                                   # burn-in then sampling, one logical stream
+        tau_prev, eta_prev = smp.tau.copy(), smp.eta.copy()
+        smp.update()
+        store = smp.tau_store
+        assert store.shape == (n, V, G, 4)
+        for it in range(n):
+            ref = tau_prev.copy()
+            nch = cbind.sample_tau_u(ref, np.ascontiguousarray(smp.gamma_store[it]), eta_prev, counts, mt.uniform(V * G))
+            assert np.array_equal(store[it], ref) and smp.nchange_store[it] == nch
+            tau_prev, eta_prev = ref, np.ascontiguousarray(smp.eta_store[it])
+        idx = cbind.onehot_to_idx(smp.tau)
+        assert smp.ll == pytest.approx(cbind.loglik(idx, smp.gamma, smp.eta, counts), rel=1e-12)
+        assert smp.meanDeviance() == pytest.approx(-2 * smp.ll_store.mean())
+        np.testing.assert_allclose(smp.tauMean(), store.mean(axis=0))
+        assert smp.lp_star == max(smp.lp_store.max(), smp.lp_star)
+    # the legacy module call continues the same stream too
+    t = smp.tau.copy(); ref = t.copy()
+    n1 = sampletau.sample_tau(t, smp.gamma, smp.eta, counts)
+    n2 = cbind.sample_tau_u(ref, smp.gamma, smp.eta, counts, mt.uniform(V * G))
+    assert n1 == n2 and np.array_equal(t, ref)
+    sampletau.freeRNG()
+
+
+def _write_freq(path, counts, names=None):
+    V, S, _ = counts.shape
+    cols = ["Position"] + ["%s-%s" % ("S%d" % s, b) for s in range(S) for b in "ACGT"]
+    data = np.concatenate([np.arange(V)[:, None] * 7 + 3, counts.reshape(V, S * 4)], axis=1)
+    df = p.DataFrame(data, index=["contig%d" % (v // 50) for v in range(V)], columns=cols)
+    df.index.name = "Contig"
+    df.to_csv(path)
+    return df
+
+
+def _best_perm_err(idx, tau_true):
+    G = tau_true.shape[1]
+    return min((idx[:, list(pm)] != tau_true).mean() for pm in itertools.permutations(range(G)))
+
+
+def test_cli_end_to_end(tmp_path):
+    from desman_amd.cli import main
+    V, S, G = 240, 12, 3
+    counts, tau_true, gamma_true = synth_counts(V, S, G, seed=123)
+    freq = str(tmp_path / "syn.freq")
+    _write_freq(freq, counts)
+    out = str(tmp_path / "run_3_0")
+    main([freq, "-g", str(G), "-i", "40", "-o", out, "-s", "7"])
+    files = sorted(os.listdir(out))
+    for f in ["Eta_mean.csv", "Eta_star.csv", "Filtered_Tau_star.csv", "Gamma_mean.csv", "Gamma_star.csv",
+              "Selected_variants.csv", "Tau_Mean.csv", "fit.txt"]:
+        assert f in files
+    fit = open(os.path.join(out, "fit.txt")).read().strip().split(",")
+    assert fit[0] == "Fit" and int(fit[1]) == G and 1 <= int(fit[2]) <= G and float(fit[3]) < 0 < float(fit[4])
+    ts = p.read_csv(os.path.join(out, "Filtered_Tau_star.csv"), index_col=0)
+    assert list(ts.columns) == ["Position"] + [str(i) for i in range(4 * int(fit[2]))]
+    t = ts.to_numpy()[:, 1:].reshape(V, int(fit[2]), 4)
+    assert (t.sum(axis=2) == 1).all()
+    if int(fit[2]) == G:
+        assert _best_perm_err(np.argmax(t, axis=2), tau_true) < 0.03
+    gm = p.read_csv(os.path.join(out, "Gamma_mean.csv"), index_col=0)
+    assert gm.shape == (S, int(fit[2])) and list(gm.index) == ["S%d" % s for s in range(S)]
+    np.testing.assert_allclose(gm.to_numpy().sum(axis=1), 1.0, atol=1e-9)
+    em = p.read_csv(os.path.join(out, "Eta_mean.csv"), index_col=0).to_numpy()
+    np.testing.assert_allclose(em, 0.96 * np.eye(4) + 0.01, atol=0.02)
+    tm = p.read_csv(os.path.join(out, "Tau_Mean.csv"), index_col=0).to_numpy()[:, 1:]
+    np.testing.assert_allclose(tm.reshape(V, -1, 4).sum(axis=2), 1.0, atol=1e-9)
+
+
+def test_cli_random_select_path(tmp_path):
+    from desman_amd.cli import main
+    V, S, G = 200, 10, 2
+    counts, tau_true, _ = synth_counts(V, S, G, seed=321)
+    freq = str(tmp_path / "syn.freq")
+    _write_freq(freq, counts)
+    out = str(tmp_path / "run_r")
+    main([freq, "-g", str(G), "-i", "30", "-r", "60", "-o", out])
+    files = sorted(os.listdir(out))
+    for f in ["Collated_Tau_mean.csv", "Collated_Tau_star.csv", "fitP.txt", "fit.txt", "Selected_variants.csv"]:
+        assert f in files
+    sel = p.read_csv(os.path.join(out, "Selected_variants.csv"), index_col=0)
+    assert sel.shape[0] == 60
+    col = p.read_csv(os.path.join(out, "Collated_Tau_star.csv"), index_col=0)
+    fitp = open(os.path.join(out, "fitP.txt")).read().strip().split(",")
+    Gf = int(fitp[2])
+    t = col.to_numpy()[:, 1:].reshape(V, Gf, 4)
+    assert (t.sum(axis=2) == 1).all()
+    if Gf == G:
+        assert _best_perm_err(np.argmax(t, axis=2), tau_true) < 0.05

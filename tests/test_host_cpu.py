@@ -1,0 +1,142 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol,
+fails loudly without a GPU, and the host logic (loader, writers, drop-in module
+argument checks) matches the reference's behaviour recorded in the goldens."""
+import json
+import logging
+import os
+import re
+
+import numpy as np
+import pandas as p
+import pytest
+
+from desman_amd import _lib
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HAVE_GPU = _lib.device_count() > 0 if os.path.exists(_lib.LIB_PATH) else False
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(_lib.HEADER_PATH).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(dsm_[A-Za-z0-9_]+)\s*\(", hdr))
+    declared -= {"dsm_ctx"}
+    assert len(declared) >= 40
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libdesman_hip.so does not export %s" % name
+        assert name in _lib.SIGNATURES, "no ctypes signature for %s" % name
+    assert set(_lib.SIGNATURES) <= declared
+    assert lib.dsm_version().decode().startswith("desman_hip")
+    assert lib.dsm_kernel_name(2).decode() == "tau_kernel"
+
+
+@pytest.mark.skipif(HAVE_GPU, reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    with pytest.raises(_lib.DesmanHipError):
+        _lib.Context(0)
+    from desman_amd import sampletau
+    with pytest.raises(_lib.DesmanHipError):
+        sampletau.initRNG()
+    tau = np.zeros((2, 2, 4), dtype=np.int64); tau[:, :, 0] = 1
+    with pytest.raises(_lib.DesmanHipError):
+        sampletau.sample_tau(tau, np.full((3, 2), 0.5), np.eye(4) * 0.96 + 0.01, np.ones((2, 3, 4), dtype=np.int64))
+
+
+def test_sampletau_argument_checks_like_cython():
+    from desman_amd import sampletau
+    tau = np.zeros((2, 2, 4), dtype=np.int64); tau[:, :, 0] = 1
+    pi = np.full((3, 2), 0.5); eta = np.eye(4) * 0.96 + 0.01
+    var = np.ones((2, 3, 4), dtype=np.int64)
+    with pytest.raises(TypeError):
+        sampletau.sample_tau(None, pi, eta, var)
+    with pytest.raises(TypeError):
+        sampletau.sample_tau(tau.tolist(), pi, eta, var)
+    with pytest.raises(ValueError):
+        sampletau.sample_tau(tau.astype(np.int32), pi, eta, var)
+    with pytest.raises(ValueError):
+        sampletau.sample_tau(tau, pi.astype(np.float32), eta, var)
+    with pytest.raises(ValueError):
+        sampletau.sample_tau(tau[:, :, ::2], pi, eta, var)
+    with pytest.raises(ValueError):
+        sampletau.sample_tau(tau, pi, eta, var[:, :2, :].copy())      # shape cross-check (superset)
+    with pytest.raises(TypeError):
+        sampletau.setRNG("x")
+
+
+def test_mt_seed_state_matches_numpy_legacy_seeding():
+    for seed in (0, 1, 23724839):
+        st = _lib.mt_seed_state(seed)
+        bg = np.random.MT19937(); bg._legacy_seeding(seed if seed else 4357)
+        assert np.array_equal(st[:624], bg.state["state"]["key"]) and st[624] == 624
+
+
+def _frame(z):
+    return p.DataFrame(z["frame_values"], index=z["frame_index"].tolist(), columns=z["frame_columns"].tolist())
+
+
+def test_variant_filter_constructor_and_select_random():
+    from desman_amd.Variant_Filter import Variant_Filter
+    z = np.load(os.path.join(GOLDEN, "host_formats.npz"))
+    flt = Variant_Filter(_frame(z), randomState=np.random.RandomState(238329), optimise=True, threshold=None,
+                         min_coverage=5.0, qvalue_cutoff=1e-3)
+    assert (flt.V, flt.S) == (int(z["V"]), int(z["S"]))
+    assert np.array_equal(flt.sample_filter, z["sample_filter"])
+    assert flt.sample_indices == z["sample_indices"].tolist()
+    assert np.array_equal(flt.snps_filter, z["snps_filter"])
+    assert np.array_equal(flt.eta, z["flt_eta"]) and np.array_equal(flt.selected, z["selected"])
+    assert np.array_equal(np.asarray(flt.position), z["position"])
+    flt.select_Random(5)
+    assert np.array_equal(flt.snps_filter, z["sel_snps"]) and np.array_equal(flt.selected, z["sel_selected"])
+    assert flt.selected_indices == z["sel_indices"].tolist()
+    assert np.array_equal(flt.selected_indices_original, z["sel_indices_original"])
+    with pytest.raises(NotImplementedError):
+        flt.get_filtered_VariantsLogRatio()
+
+
+def test_output_files_byte_identical_to_reference_writers(tmp_path):
+    from desman_amd.Variant_Filter import Variant_Filter
+    from desman_amd.Output_Results import Output_Results
+    z = np.load(os.path.join(GOLDEN, "host_formats.npz"))
+    want = json.loads(str(z["files"]))
+    frame = _frame(z)
+    flt = Variant_Filter(frame, randomState=np.random.RandomState(238329), optimise=True, threshold=None,
+                         min_coverage=5.0, qvalue_cutoff=1e-3)
+    flt.select_Random(5)
+
+    class Stub:
+        lp_star = -12345.678901
+
+        def __init__(self, tau_star, pt):
+            self.tau_star, self._pt = tau_star, pt
+            self.V, self.G = tau_star.shape[0], tau_star.shape[1]
+
+        def probabilisticTau(self):
+            return self._pt
+
+        def meanDeviance(self):
+            return 24680.13579
+
+    hs, hns = Stub(z["tau_star_s"], z["ptau_s"]), Stub(z["tau_star_ns"], z["ptau_ns"])
+    d = str(tmp_path / "out")
+    o = Output_Results(d)
+    o.set_Variants(frame); o.set_Variant_Filter(flt); o.set_haplo_SNP(hs, 3)
+    o.output_Filtered_Tau(hs.tau_star); o.output_Tau_Mean(z["ptau_s"])
+    o.output_Gamma(z["gamma"]); o.output_Gamma_Mean(z["gamma"] * 0.5 + 0.25)
+    o.output_Eta(z["eta"]); o.output_Eta_Mean(z["eta"].T.copy())
+    o.output_Selected_Variants(); o.outPredFit(hns, 3); o.output_collated_Tau(hns, frame)
+    logging.shutdown()
+    got = {f: open(os.path.join(d, f)).read() for f in sorted(os.listdir(d)) if f != "log_file.txt"}
+    assert sorted(got) == sorted(want)
+    for f in want:
+        assert got[f] == want[f], f
+
+
+def test_cli_flags_and_quirks():
+    from desman_amd.cli import build_parser
+    a = build_parser().parse_args(["x.freq", "-g", "4"])
+    assert (a.no_iter, a.random_select, a.filter_variants, a.random_seed, a.min_coverage) == \
+        (None, None, None, 23724839, 5.0)                   # -i absent -> None -> sampler default 250
+    a = build_parser().parse_args(["x.freq", "-g", "4", "-i", "-r", "-f", "-v", "-p", "False"])
+    assert (a.no_iter, a.random_select, a.filter_variants, a.min_variant_freq) == (250, 1000, 3.84, 0.01)
+    assert a.optimiseP is True                              # type=bool quirk: any string is True

@@ -1,0 +1,156 @@
+"""Multi-GPU chain scheduler: independent Gibbs chains (seed replicates x G
+values) are the only parallel axis the reference has -- it spawns one process
+per (G, replicate) (scripts/runDesman.sh:15-21, complete_example/README.md:
+611-627) and "gathers" by concatenating fit.txt files.  Here: one process per
+GPU (torch.distributed; backend "nccl" = RCCL over xGMI, "gloo" on CPU for
+tests), chains assigned by longest-processing-time-first, NO collective on the
+data path, and one all_gather of a fixed-size fit record per chain at the end.
+
+Launch:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+             --master-addr 127.0.0.1 --master-port P -m desman_amd.chains freq.csv ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REC_FIELDS = ("chain", "G", "seed", "G_final", "lp_star", "mean_dev", "iters", "wall_s")
+
+
+def chain_cost(V, S, G):
+    """relative cost of one Gibbs iteration: the per-read pass is ~linear in G, the tau
+    sweep does G sequential draws each touching G haplotypes."""
+    return float(V) * float(S) * (4.0 * G + 1.0 * G * G)
+
+
+def lpt_assign(costs, n_ranks):
+    """longest-processing-time-first greedy bin packing -> list of chain ids per rank
+    (deterministic: ties broken by chain id, then by rank)."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0.0] * n_ranks
+    bins = [[] for _ in range(n_ranks)]
+    for i in order:
+        r = min(range(n_ranks), key=lambda k: (load[k], k))
+        bins[r].append(i)
+        load[r] += costs[i]
+    return bins
+
+
+def sweep_specs(g_values, n_reps, V, S):
+    """(G, seed) grid of a model-selection sweep: seeds 0..n_reps-1 per G (runDesman.sh:15-19)."""
+    specs = []
+    for G in g_values:
+        for r in range(n_reps):
+            specs.append(dict(chain=len(specs), G=int(G), seed=int(r), cost=chain_cost(V, S, G)))
+    return specs
+
+
+def run_chains(specs, run_fn, dist=None, device=None):
+    """Run `run_fn(spec) -> dict(REC_FIELDS...)` for this rank's share of `specs` and gather
+    every chain's record on all ranks.  `dist` = an initialised torch.distributed module
+    (or None for a single process).  Returns the records sorted by chain id."""
+    import torch
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    bins = lpt_assign([s["cost"] for s in specs], world)
+    mine = []
+    for cid in bins[rank]:
+        t0 = time.perf_counter()
+        rec = dict(run_fn(specs[cid]))
+        rec.setdefault("wall_s", time.perf_counter() - t0)
+        rec["chain"] = cid
+        mine.append([float(rec[k]) for k in REC_FIELDS])
+    width = max(len(b) for b in bins) if specs else 0
+    buf = np.full((max(width, 1), len(REC_FIELDS)), np.nan)
+    if mine:
+        buf[:len(mine)] = np.array(mine)
+    if dist is None:
+        rows = buf
+    else:
+        t = torch.from_numpy(buf).to(device if device is not None else "cpu")
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)                         # the path's single exchange step
+        rows = np.concatenate([o.cpu().numpy() for o in out], axis=0)
+    rows = rows[~np.isnan(rows[:, 0])]
+    rows = rows[np.argsort(rows[:, 0])]
+    return [dict(zip(REC_FIELDS, r.tolist())) for r in rows]
+
+
+def gibbs_chain_runner(counts, n_iter, device, out_stub=None, variants_frame=None):
+    """run_fn for real chains on one GPU: NMFT init + burn-in + removeDegenerate + sampling,
+    i.e. the numeric path of bin/desman:129-153 for (G, seed)."""
+    from . import sampletau
+    from .HaploSNP_Sampler import HaploSNP_Sampler
+    from .Init_NMFT import Init_NMFT
+
+    def run(spec):
+        t0 = time.perf_counter()
+        G, seed = spec["G"], spec["seed"]
+        prng = np.random.RandomState(seed)
+        sampletau.initRNG(); sampletau.setRNG(seed)
+        nm = Init_NMFT(counts, G, prng, device=device)
+        nm.factorize()
+        smp = HaploSNP_Sampler(counts, G, prng, max_iter=n_iter, device=device)
+        smp.tau = nm.get_tau(); smp.gamma = np.copy(nm.get_gamma(), order='C')
+        smp.update(); smp.removeDegenerate(); smp.update()
+        sampletau.freeRNG()
+        if out_stub is not None:
+            d = "%s_%d_%d" % (out_stub, G, seed)
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "fit.txt"), "w") as f:
+                f.write("Fit,%d,%d,%f,%f\n" % (G, smp.G, smp.lp_star, smp.meanDeviance()))
+            np.savetxt(os.path.join(d, "Gamma_star.csv"), smp.gamma_star, delimiter=",")
+            np.save(os.path.join(d, "tau_star_idx.npy"), np.argmax(smp.tau_star, axis=2).astype(np.uint8))
+        return dict(G=G, seed=seed, G_final=smp.G, lp_star=smp.lp_star, mean_dev=smp.meanDeviance(),
+                    iters=2 * n_iter, wall_s=time.perf_counter() - t0)
+    return run
+
+
+def write_dev_csv(path, records):
+    """`H,G,LP,Dev` table the reference builds with `cat */fit.txt` (complete_example/README.md:626-627)."""
+    with open(path, "w") as f:
+        f.write("H,G,LP,Dev\n")
+        for r in records:
+            f.write("%d,%d,%f,%f\n" % (r["G"], r["G_final"], r["lp_star"], r["mean_dev"]))
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="desman-sweep", description="G-sweep of independent Gibbs chains over the "
+                                 "GPUs of one node (one process per GPU)")
+    ap.add_argument("variant_file")
+    ap.add_argument("--gmin", type=int, default=2)
+    ap.add_argument("--gmax", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("-i", "--no_iter", type=int, default=100)
+    ap.add_argument("-m", "--min_coverage", type=float, default=5.0)
+    ap.add_argument("-o", "--output_stub", default="sweep")
+    args = ap.parse_args(argv)
+    import pandas as p
+    import torch
+    from .Variant_Filter import Variant_Filter
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    frame = p.read_csv(args.variant_file, header=0, index_col=0)
+    flt = Variant_Filter(frame, randomState=np.random.RandomState(238329), threshold=None,
+                         min_coverage=args.min_coverage)
+    counts = np.ascontiguousarray(flt.snps_filter, dtype=np.int64)
+    specs = sweep_specs(range(args.gmin, args.gmax + 1), args.reps, flt.V, flt.S)
+    recs = run_chains(specs, gibbs_chain_runner(counts, args.no_iter, local, args.output_stub), dist,
+                      device=torch.device("cuda", local) if world > 1 else None)
+    if dist is None or dist.get_rank() == 0:
+        write_dev_csv(args.output_stub + "_Dev.csv", recs)
+        print(json.dumps(recs))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

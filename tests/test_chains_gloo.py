@@ -1,0 +1,52 @@
+"""Multi-process (world_size 2, gloo, CPU) tests of the chain scheduler and the
+fit-record gather -- the N>1 path of bench.py / desman_amd.chains."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from desman_amd import chains
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_lpt_assignment_properties():
+    costs = [chains.chain_cost(50000, 96, g) for g in range(2, 13) for _ in range(5)]      # config 5: 55 chains
+    bins = chains.lpt_assign(costs, 8)
+    assert sorted(i for b in bins for i in b) == list(range(55))
+    load = [sum(costs[i] for i in b) for b in bins]
+    assert max(load) <= sum(costs) / 8 + max(costs)                     # LPT bound
+    assert max(load) / (sum(costs) / 8) < 1.15
+    assert chains.lpt_assign(costs, 8) == bins                           # deterministic
+    assert chains.lpt_assign([3.0, 1.0], 4) == [[0], [1], [], []]
+
+
+def test_single_process_equals_serial():
+    specs = chains.sweep_specs([2, 3], 2, 100, 8)
+    recs = chains.run_chains(specs, lambda s: dict(G=s["G"], seed=s["seed"], G_final=s["G"], lp_star=-1.0 * s["G"],
+                                                   mean_dev=2.0, iters=1, wall_s=0.0))
+    assert [(int(r["G"]), int(r["seed"])) for r in recs] == [(2, 0), (2, 1), (3, 0), (3, 1)]
+    assert [int(r["chain"]) for r in recs] == [0, 1, 2, 3]
+
+
+def test_two_rank_gloo_gather(tmp_path):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29653", os.path.join(HERE, "_gloo_worker.py"), str(tmp_path)]
+    subprocess.run(cmd, check=True, env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r0 = json.load(open(tmp_path / "rank0.json"))
+    r1 = json.load(open(tmp_path / "rank1.json"))
+    assert r0["recs"] == r1["recs"]                                      # all_gather: every rank has every record
+    assert sorted(r0["mine"] + r1["mine"]) == list(range(15)) and not set(r0["mine"]) & set(r1["mine"])
+    specs = chains.sweep_specs(range(2, 7), 3, V=1000, S=16)
+    assert [int(r["chain"]) for r in r0["recs"]] == list(range(15))
+    for r, s in zip(r0["recs"], specs):                                  # == N independent single-rank runs
+        assert (r["G"], r["seed"]) == (s["G"], s["seed"])
+        assert r["lp_star"] == -1000.0 * s["G"] - s["seed"] and r["mean_dev"] == 2000.0 * s["G"] + s["seed"]
+        assert r["G_final"] == s["G"] - (s["seed"] % 2)
+    d = tmp_path / "Dev.csv"
+    chains.write_dev_csv(str(d), r0["recs"])
+    rows = open(d).read().strip().split("\n")
+    assert rows[0] == "H,G,LP,Dev" and len(rows) == 16 and rows[1] == "2,2,-2000.000000,4000.000000"

@@ -7,6 +7,7 @@
 #include <mutex>
 
 #include "dsm_host.h"
+#include "log_table.h"
 
 static thread_local char g_err[512] = "";
 
@@ -33,7 +34,7 @@ static const char *const k_names[DSM_K_COUNT] = {"stats_kernel", "dirichlet_kern
 extern "C" const char *dsm_kernel_name(int k) { return (k >= 0 && k < DSM_K_COUNT) ? k_names[k] : "?"; }
 
 // ---------------------------------------------------------------- timing
-KTimer::KTimer(dsm_ctx *ctx, int kid) : c(ctx), k(kid)
+KTimer::KTimer(dsm_ctx *ctx, int kid, hipStream_t stream) : c(ctx), k(kid), st(stream ? stream : ctx->stream)
 {
     c->k_launches[k]++;
     if (!c->timing) return;
@@ -44,12 +45,12 @@ KTimer::KTimer(dsm_ctx *ctx, int kid) : c(ctx), k(kid)
         return e;
     };
     e0 = take(); e1 = take();
-    (void)hipEventRecord(e0, c->stream);
+    (void)hipEventRecord(e0, st);
 }
 KTimer::~KTimer()
 {
     if (!e0) return;
-    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventRecord(e1, st);
     c->spans.push_back({k, e0, e1});
 }
 
@@ -57,6 +58,7 @@ static int collect_spans(dsm_ctx *c)
 {
     if (c->spans.empty()) return DSM_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream_rng));
     for (auto &s : c->spans) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, s.e0, s.e1));
@@ -131,6 +133,11 @@ extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
     dsm_ctx *c = new dsm_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream_rng, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_u_ready[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_u_free[i], hipEventDisableTiming));
+    }
     TRY(dev_alloc(&c->mt_state, 625));
     TRY(dev_alloc(&c->ll_partial, DSM_MAX_GRID));
     TRY(dev_alloc(&c->nchange, 1));
@@ -141,6 +148,8 @@ extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
     TRY(dev_alloc(&c->eta_new, 16));
     TRY(dev_alloc(&c->eta_star, 16));
     TRY(dev_alloc(&c->esum, 16));
+    TRY(dev_alloc(&c->log_tab, 2 * DSM_LOG_TAB_N));
+    HIP_TRY(hipMemcpyAsync(c->log_tab, dsm_log_table_host, sizeof dsm_log_table_host, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
     HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -166,8 +175,10 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     dev_free(&c->cnt_vs); dev_free(&c->cnt_sv); dev_free(&c->tau); dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
     dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->prior); dev_free(&c->scalars); dev_free(&c->star);
-    dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam);
+    dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam);
     dev_free(&c->npart); dev_free(&c->nstat);
+    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ev_u_ready[i]); (void)hipEventDestroy(c->ev_u_free[i]); }
+    (void)hipStreamDestroy(c->stream_rng);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return DSM_OK;
@@ -178,6 +189,7 @@ extern "C" int dsm_ctx_sync(dsm_ctx *c)
     if (!c) return DSM_ERR_ARG;
     BIND(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream_rng));
     return DSM_OK;
 }
 
@@ -188,6 +200,7 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     if (S > DSM_MAX_S) { dsm_set_error("S=%d exceeds DSM_MAX_S=%d", S, DSM_MAX_S); return DSM_ERR_UNSUPPORTED; }
     BIND(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream_rng));
     const size_t n = (size_t)V * S;
     c->V = V; c->S = S;
     c->have_state = false;
@@ -233,7 +246,7 @@ static int ensure_state_buffers(dsm_ctx *c, int G)
         TRY(dev_alloc(&c->sum_mu, sg));
         HIP_TRY(hipMemsetAsync(c->sum_mu, 0, sg * sizeof(unsigned long long), c->stream));
         c->u_cap = (size_t)c->V * G;
-        TRY(dev_alloc(&c->u_raw, c->u_cap));
+        TRY(dev_alloc(&c->u_raw, 2 * c->u_cap));
         free_traces(c);
     }
     return DSM_OK;
@@ -312,6 +325,7 @@ static int seed_mt(dsm_ctx *c, unsigned long seed)
 {
     uint32_t st[625];
     mt_seed_host(st, seed);
+    HIP_TRY(hipStreamSynchronize(c->stream_rng));
     HIP_TRY(hipMemcpyAsync(c->mt_state, st, sizeof st, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->mt_seeded = true;
@@ -339,6 +353,7 @@ extern "C" int dsm_ctx_get_mt_state(dsm_ctx *c, uint32_t *state625)
     if (!c || !state625) return DSM_ERR_ARG;
     if (!c->mt_seeded) { dsm_set_error("tau RNG not seeded"); return DSM_ERR_STATE; }
     BIND(c);
+    HIP_TRY(hipStreamSynchronize(c->stream_rng));
     HIP_TRY(hipMemcpyAsync(state625, c->mt_state, 625 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSM_OK;
@@ -348,6 +363,7 @@ extern "C" int dsm_ctx_set_mt_state(dsm_ctx *c, const uint32_t *state625)
 {
     if (!c || !state625 || state625[624] > 624) { dsm_set_error("set_mt_state: bad state"); return DSM_ERR_ARG; }
     BIND(c);
+    HIP_TRY(hipStreamSynchronize(c->stream_rng));
     HIP_TRY(hipMemcpyAsync(c->mt_state, state625, 625 * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->mt_seeded = true;
@@ -361,11 +377,38 @@ extern "C" int dsm_ctx_set_tau_rng(dsm_ctx *c, int mode)
     return DSM_OK;
 }
 
-static int fill_sweep_uniforms(dsm_ctx *c)
+// Enqueue the V*G MT19937 words of the next sweep on the RNG stream (it overlaps whatever the
+// main stream is doing) into the next slot of the double buffer; the main stream is made to
+// wait for them just before the sweep that consumes them (await_sweep_uniforms).
+static int fill_sweep_uniforms(dsm_ctx *c, const uint32_t **u)
 {
+    *u = nullptr;
     if (c->tau_rng != DSM_RNG_MT19937) return DSM_OK;
     if (!c->mt_seeded) { dsm_set_error("tau RNG not seeded: call dsm_ctx_seed / dsm_setRNG"); return DSM_ERR_STATE; }
-    return k_mt_fill(c, c->u_raw, (size_t)c->V * c->G);
+    const int slot = c->u_slot;
+    c->u_slot ^= 1;
+    uint32_t *buf = c->u_raw + (size_t)slot * c->u_cap;
+    HIP_TRY(hipStreamWaitEvent(c->stream_rng, c->ev_u_free[slot], 0));   // last reader of this slot is done
+    TRY(k_mt_fill(c, buf, (size_t)c->V * c->G, c->stream_rng));
+    HIP_TRY(hipEventRecord(c->ev_u_ready[slot], c->stream_rng));
+    *u = buf;
+    return DSM_OK;
+}
+
+static int await_sweep_uniforms(dsm_ctx *c, const uint32_t *u)
+{
+    if (!u) return DSM_OK;
+    const int slot = (u == c->u_raw) ? 0 : 1;
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_u_ready[slot], 0));
+    return DSM_OK;
+}
+
+static int release_sweep_uniforms(dsm_ctx *c, const uint32_t *u)
+{
+    if (!u) return DSM_OK;
+    const int slot = (u == c->u_raw) ? 0 : 1;
+    HIP_TRY(hipEventRecord(c->ev_u_free[slot], c->stream));
+    return DSM_OK;
 }
 
 // ---------------------------------------------------------------- single steps
@@ -376,9 +419,12 @@ extern "C" int dsm_ctx_sample_tau(dsm_ctx *c, int *nchange, double *logp_out)
     double *d_logp = nullptr;
     const size_t nl = (size_t)c->V * c->G * 4;
     if (logp_out) TRY(dev_alloc(&d_logp, nl));
-    TRY(fill_sweep_uniforms(c));
+    const uint32_t *u = nullptr;
+    TRY(fill_sweep_uniforms(c, &u));
     HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
-    TRY(k_tau_sweep(c, 1, c->gamma, c->eta, c->eta, nullptr, d_logp, c->iter_ctr++, nullptr));
+    TRY(await_sweep_uniforms(c, u));
+    TRY(k_tau_sweep(c, 1, c->gamma, c->eta, c->eta, nullptr, d_logp, c->iter_ctr++, nullptr, u));
+    TRY(release_sweep_uniforms(c, u));
     int n = 0;
     HIP_TRY(hipMemcpyAsync(&n, c->nchange, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (logp_out) HIP_TRY(hipMemcpyAsync(logp_out, d_logp, nl * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -430,7 +476,7 @@ static int eval_state(dsm_ctx *c, const double *gamma, const double *eta, uint64
 {
     int nb = 0;
     TRY(k_prior(c, gamma, eta));
-    TRY(k_tau_sweep(c, 2, gamma, eta, eta, trace_slot, nullptr, 0, &nb));
+    TRY(k_tau_sweep(c, 2, gamma, eta, eta, trace_slot, nullptr, 0, &nb, nullptr));
     // finalize with eta_new := eta so that the star copy (entry state) takes the current eta
     double *save = c->eta_new;
     c->eta_new = const_cast<double *>(eta);
@@ -482,11 +528,14 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
     TRY(eval_state(c, c->gamma, c->eta, c->tau_trace, 1));
     for (int it = 0; it < n_iter; ++it) {
         const uint32_t ic = c->iter_ctr++;
-        TRY(fill_sweep_uniforms(c));
+        const uint32_t *u = nullptr;
+        TRY(fill_sweep_uniforms(c, &u));                                 // side stream, overlaps the mu/E pass
         TRY(k_stats(c, ic));                                             // sampleMu  (:341)
         TRY(k_dirichlet(c, ic, c->gamma, c->gamma_trace + (size_t)it * sg, c->eta_new));  // sampleGamma (:342) + eta draw (:347)
         int nb = 0;
-        TRY(k_tau_sweep(c, 3, c->gamma, c->eta, c->eta_new, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb));  // :345,:349
+        TRY(await_sweep_uniforms(c, u));
+        TRY(k_tau_sweep(c, 3, c->gamma, c->eta, c->eta_new, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb, u));  // :345,:349
+        TRY(release_sweep_uniforms(c, u));
         TRY(k_finalize(c, nb, it, 1, 0));                                   // :349-358
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -511,10 +560,13 @@ extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_st
     for (int it = 0; it < n_iter; ++it) {
         const uint32_t ic = c->iter_ctr++;
         const double *g = c->gamma_in + (size_t)it * sg, *e = c->eta_in + (size_t)it * 16;
-        TRY(fill_sweep_uniforms(c));
+        const uint32_t *u = nullptr;
+        TRY(fill_sweep_uniforms(c, &u));
         TRY(k_prior(c, g, e));
         int nb = 0;
-        TRY(k_tau_sweep(c, 3, g, e, e, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb));  // :392-393
+        TRY(await_sweep_uniforms(c, u));
+        TRY(k_tau_sweep(c, 3, g, e, e, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb, u));  // :392-393
+        TRY(release_sweep_uniforms(c, u));
         double *save = c->eta_new; const double *gsave = c->gamma;
         c->eta_new = const_cast<double *>(e); c->gamma = const_cast<double *>(g);
         int r = k_finalize(c, nb, it, 0, 0);

@@ -67,3 +67,56 @@ __device__ __forceinline__ unsigned group_allreduce_sum_u32(unsigned x)
     for (int off = W / 2; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
     return x;
 }
+
+// ---- table-driven fp64 natural log (tau sweep / LL).  x = 2^e * m, m in [1,2);
+// i = top 7 mantissa bits; r = m * invc_i - 1 (one fma, |r| <= 2^-8);
+// log x = e ln2 + logc_i + log1p(r), log1p by a degree-6 Taylor polynomial
+// (truncation < 2e-18).  Absolute error <= ~1 ulp of max(1, |log x|) -- the same
+// class as libm in the sums it feeds (validated against glibc on the host).
+// `tab` = the 128 x {invc, logc} table (log_table.h) staged in LDS.
+// Zero, subnormal, negative, inf and NaN inputs take the libm path.
+__device__ __forceinline__ double dsm_log(double x, const double2 *__restrict__ tab)
+{
+    const uint32_t hi = (uint32_t)__double2hiint(x);
+    if (__builtin_expect(hi - 0x00100000u >= 0x7fe00000u, 0)) return log(x);
+    const int e = (int)(hi >> 20) - 1023;
+    const double2 t = tab[(hi >> 13) & 127u];
+    const double m = __hiloint2double((int)((hi & 0x000fffffu) | 0x3ff00000u), __double2loint(x));
+    const double r = fma(m, t.x, -1.0);
+    const double ed = (double)e;
+    double p = fma(r, -1.0 / 6.0, 0.2);
+    p = fma(r, p, -0.25);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -0.5);
+    const double w = fma(ed, 0x1.62e42fefa3800p-1, t.y);
+    const double lo = fma(ed, 0x1.ef35793c76730p-45, (r * r) * p);
+    return (w + r) + lo;
+}
+
+// ---- sum of four per-lane values over a W-lane group, result on every lane.
+// Transposing butterfly: after the first two exchange steps each lane carries ONE
+// of the four sums, so the remaining log2(W)-2 steps move one value instead of
+// four (7 exchanges + 4 broadcasts for W = 64 instead of 24).
+template <int W>
+__device__ __forceinline__ void group_allreduce_sum4(double &v0, double &v1, double &v2, double &v3)
+{
+    const int lane = __lane_id();
+    const bool b0 = lane & 1, b1 = lane & 2;
+    // step 1: lanes with b0 = 0 keep (v0, v1), lanes with b0 = 1 keep (v2, v3)
+    const double s0 = b0 ? v0 : v2, s1 = b0 ? v1 : v3;
+    double k0 = b0 ? v2 : v0, k1 = b0 ? v3 : v1;
+    k0 += __shfl_xor(s0, 1, 64);
+    k1 += __shfl_xor(s1, 1, 64);
+    // step 2: b1 = 0 keeps k0, b1 = 1 keeps k1
+    const double s = b1 ? k0 : k1;
+    double k = b1 ? k1 : k0;
+    k += __shfl_xor(s, 2, 64);
+#pragma unroll
+    for (int off = 4; off < W; off <<= 1) k += __shfl_xor(k, off, 64);
+    // lane (b0, b1) of every quad now holds the group total of value 2*b0 + b1
+    const int base = lane & ~(W - 1);
+    v0 = __shfl(k, base + 0, 64);
+    v1 = __shfl(k, base + 2, 64);
+    v2 = __shfl(k, base + 1, 64);
+    v3 = __shfl(k, base + 3, 64);
+}

@@ -26,6 +26,8 @@ struct TimedSpan { int k; hipEvent_t e0, e1; };
 struct dsm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_rng = nullptr;   // MT19937 refills run here, overlapped with the mu/E pass
+    hipEvent_t ev_u_ready[2] = {nullptr, nullptr}, ev_u_free[2] = {nullptr, nullptr};
     // sizes
     int V = 0, S = 0, G = 0;
     // count tensor (both layouts, int32) and data-only ll constant
@@ -45,7 +47,8 @@ struct dsm_ctx {
     // RNG
     uint32_t *mt_state = nullptr;   // 624 words + position
     bool mt_seeded = false;
-    uint32_t *u_raw = nullptr;      // [V*G] raw MT19937 words for one sweep
+    uint32_t *u_raw = nullptr;      // [2][V*G] raw MT19937 words, double-buffered per sweep
+    int u_slot = 0;
     size_t u_cap = 0;
     uint64_t ctr_seed = 0x243F6A8885A308D3ull;
     uint32_t iter_ctr = 0;          // global iteration counter for counter-based draws
@@ -55,6 +58,7 @@ struct dsm_ctx {
     int *nchange = nullptr;         // device counter
     double *prior = nullptr;        // [2] log Dir priors of gamma, eta
     double *scalars = nullptr;      // [8] misc device scalars
+    double *log_tab = nullptr;      // [128][2] table of dsm_log (log_table.h)
     // traces of the last update call
     int n_trace = 0;
     uint64_t *tau_trace = nullptr;  // [(n+1)][V]; slot 0 = entry state
@@ -84,8 +88,8 @@ struct dsm_ctx {
 };
 
 struct KTimer {
-    dsm_ctx *c; int k; hipEvent_t e0 = nullptr, e1 = nullptr;
-    KTimer(dsm_ctx *ctx, int kid);
+    dsm_ctx *c; int k; hipStream_t st; hipEvent_t e0 = nullptr, e1 = nullptr;
+    KTimer(dsm_ctx *ctx, int kid, hipStream_t stream = nullptr);
     ~KTimer();
 };
 
@@ -94,13 +98,14 @@ int k_convert_counts(dsm_ctx *c, const int64_t *d_in, int *d_flag, double *d_par
 int k_pack_tau(dsm_ctx *c, const int64_t *d_onehot, uint64_t *d_packed, int V, int G);
 int k_unpack_tau(dsm_ctx *c, const uint64_t *d_packed, int64_t *d_onehot, int V, int G);
 int k_tau_sum(dsm_ctx *c, const uint64_t *trace, int n, int64_t *d_sum);
-int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n);
+int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n, hipStream_t stream);
 int k_stats(dsm_ctx *c, uint32_t iter);
 int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trace, double *eta_out);
 int k_prior(dsm_ctx *c, const double *gamma, const double *eta);
 // mode bit0 = sweep, bit1 = log-likelihood epilogue
 int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_sweep,
-                const double *eta_ll, uint64_t *trace_slot, double *d_logp, uint32_t iter, int *nblocks);
+                const double *eta_ll, uint64_t *trace_slot, double *d_logp, uint32_t iter, int *nblocks,
+                const uint32_t *u_raw);
 int k_finalize(dsm_ctx *c, int nblocks, int it, int commit_eta, int star_mode);
 
 // ---- launchers (kernels_nmft.hip)

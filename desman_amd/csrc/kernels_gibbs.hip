@@ -12,6 +12,7 @@
 // haplotype in one u64 per variant, gamma [S][G] f64, eta [4][4] f64.
 #include "dsm_device.h"
 #include "dsm_host.h"
+#include "log_table.h"
 
 // =====================================================================
 // one-time layout kernels
@@ -408,6 +409,7 @@ struct TauParams {
     const uint32_t *u_raw;    // MT19937 words, [V*G]; null -> Philox
     double *logp;             // may be null: [V][G][4]
     double *ll_partial;       // [gridDim.x]
+    const double *log_tab;    // [128][2]
     int *nchange;
     int V, S, G;
     uint32_t k0, k1, iter;
@@ -423,8 +425,10 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
     double *eS = gT + (size_t)p.G * SP;                  // [16]
     double *eL = eS + 16;                                // [16]
     double *red = eL + 16;                               // [4]
-    int *redi = reinterpret_cast<int *>(red + 4);        // [4]
+    int *redi = reinterpret_cast<int *>(red + 4);        // [4] (+4 pad)
+    double2 *ltab = reinterpret_cast<double2 *>(red + 6);// [128] log table
     const int tid = threadIdx.x, G = p.G, S = p.S;
+    if (tid < DSM_LOG_TAB_N) ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
     for (int i = tid; i < G * SP; i += 256) {
         const int g = i / SP, s = i % SP;
         gT[i] = (s < S) ? p.gamma[(size_t)s * G + g] : 1.0;   // pad: p > 0, count = 0
@@ -481,10 +485,11 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
 #pragma unroll
                         for (int b = 0; b < 4; ++b) {
                             const double P = st[j][b] + eS[a * 4 + b] * gg[j];
-                            acc = acc + xf[j][b] * log(P);
+                            acc = acc + xf[j][b] * dsm_log(P, ltab);
                         }
-                    l[a] = group_allreduce_sum<LPV>(acc);
+                    l[a] = acc;
                 }
+                group_allreduce_sum4<LPV>(l[0], l[1], l[2], l[3]);
                 if (p.logp && lig == 0) {
                     double *o = p.logp + ((size_t)v * G + g) * 4;
                     o[0] = l[0]; o[1] = l[1]; o[2] = l[2]; o[3] = l[3];
@@ -495,7 +500,11 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                 for (int a = 1; a < 4; ++a) if (l[a] > mx) mx = l[a];
                 double ex[4], sum = 0.0;
 #pragma unroll
-                for (int a = 0; a < 4; ++a) { ex[a] = exp(l[a] - mx); sum += ex[a]; }
+                for (int a = 0; a < 4; ++a) {
+                    const double d = l[a] - mx;                  // identical on every lane of the group
+                    ex[a] = (d < -750.0) ? 0.0 : exp(d);         // exp underflows to exactly 0 below -745.2
+                    sum += ex[a];
+                }
                 const double c0 = ex[0] / sum, c1 = ex[1] / sum + c0, c2 = ex[2] / sum + c1;
                 double u;
                 const size_t ui = (size_t)v * G + g;
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                     for (int b = 0; b < 4; ++b) P[b] = P[b] + gm * er[b];
                 }
 #pragma unroll
-                for (int b = 0; b < 4; ++b) ll_acc = ll_acc + (double)xi[j][b] * log(P[b]);
+                for (int b = 0; b < 4; ++b) ll_acc = ll_acc + (double)xi[j][b] * dsm_log(P[b], ltab);
             }
         }
     }
@@ -632,11 +641,11 @@ int k_tau_sum(dsm_ctx *c, const uint64_t *trace, int n, int64_t *d_sum)
     return DSM_OK;
 }
 
-int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n)
+int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n, hipStream_t stream)
 {
     if (n == 0) return DSM_OK;
-    KTimer tm(c, DSM_K_MT);
-    hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, c->stream, c->mt_state, out, n);
+    KTimer tm(c, DSM_K_MT, stream);
+    hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, stream, c->mt_state, out, n);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }
@@ -697,7 +706,7 @@ static void launch_tau(dsm_ctx *c, int mode, const TauParams &p, int grid, size_
 }
 
 int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_sweep, const double *eta_ll,
-                uint64_t *trace_slot, double *d_logp, uint32_t iter, int *nblocks)
+                uint64_t *trace_slot, double *d_logp, uint32_t iter, int *nblocks, const uint32_t *u_raw)
 {
     KTimer tm(c, DSM_K_TAU);
     const int S = c->S, G = c->G, V = c->V;
@@ -717,11 +726,11 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
     TauParams p;
     p.cnt_vs = c->cnt_vs; p.tau = c->tau; p.trace = trace_slot;
     p.gamma = gamma; p.eta_sweep = eta_sweep; p.eta_ll = eta_ll;
-    p.u_raw = (c->tau_rng == DSM_RNG_MT19937 && (mode & 1)) ? c->u_raw : nullptr;
-    p.logp = d_logp; p.ll_partial = c->ll_partial; p.nchange = c->nchange;
+    p.u_raw = (c->tau_rng == DSM_RNG_MT19937 && (mode & 1)) ? u_raw : nullptr;
+    p.logp = d_logp; p.ll_partial = c->ll_partial; p.nchange = c->nchange; p.log_tab = c->log_tab;
     p.V = V; p.S = S; p.G = G;
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
-    const size_t sh = ((size_t)G * LPV * NSL + 16 + 16 + 4) * sizeof(double) + 4 * sizeof(int);
+    const size_t sh = ((size_t)G * LPV * NSL + 16 + 16 + 6 + 2 * DSM_LOG_TAB_N) * sizeof(double);
     if (sh > 160 * 1024) { dsm_set_error("gamma tile (%zu B) exceeds LDS", sh); return DSM_ERR_UNSUPPORTED; }
 #define TAU_CASE(L, N) if (LPV == L && NSL == N) launch_tau<L, N>(c, mode, p, grid, sh)
     TAU_CASE(16, 1); TAU_CASE(32, 1); TAU_CASE(64, 1); TAU_CASE(64, 2); TAU_CASE(64, 3); TAU_CASE(64, 4);

@@ -4,7 +4,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
+#include <numeric>
 
 #include "dsm_host.h"
 #include "log_table.h"
@@ -172,7 +174,8 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     collect_spans(c);
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     free_traces(c);
-    dev_free(&c->cnt_vs); dev_free(&c->cnt_sv); dev_free(&c->tau); dev_free(&c->gamma); dev_free(&c->eta);
+    dev_free(&c->cnt_vs); dev_free(&c->cnt_sv); dev_free(&c->perm_sv); dev_free(&c->sample_order); dev_free(&c->tau);
+    dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
     dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->prior); dev_free(&c->scalars); dev_free(&c->star);
     dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam);
@@ -207,6 +210,8 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     c->G = 0;                       // V/S changed: every state-sized buffer is re-made by set_state
     TRY(dev_alloc(&c->cnt_vs, n * 4));
     TRY(dev_alloc(&c->cnt_sv, n * 4));
+    TRY(dev_alloc(&c->perm_sv, n));
+    TRY(dev_alloc(&c->sample_order, (size_t)S));
     TRY(dev_alloc(&c->tau, (size_t)V));
     dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); c->nG = 0;
     free_traces(c);
@@ -224,6 +229,41 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     dev_free(&d_in); dev_free(&d_flag); dev_free(&d_part);
+    if (!flag) {
+        // layout of the per-read pass: per sample, variants sorted by (largest, second largest)
+        // base count, descending -> the lanes of a wavefront run read loops of similar length;
+        // samples ordered by total depth -> the longest workgroups are dispatched first.
+        std::vector<int32_t> perm(n), csv(n * 4), sord(S);
+        std::vector<int64_t> depth(S, 0);
+        std::vector<uint64_t> key(V);
+        std::vector<int32_t> idx(V);
+        for (int s = 0; s < S; ++s) {
+            for (int v = 0; v < V; ++v) {
+                const int64_t *x = variants + ((size_t)v * S + s) * 4;
+                int64_t a = x[0], b = x[1], cc = x[2], d = x[3];
+                depth[s] += a + b + cc + d;
+                if (a < b) std::swap(a, b);
+                if (cc < d) std::swap(cc, d);
+                const int64_t m1 = std::max(a, cc);
+                const int64_t m2 = std::max(std::min(a, cc), std::max(b, d));
+                key[v] = ((uint64_t)m1 << 32) | (uint64_t)m2;
+                idx[v] = v;
+            }
+            std::stable_sort(idx.begin(), idx.end(), [&](int32_t p, int32_t q) { return key[p] > key[q]; });
+            for (int j = 0; j < V; ++j) {
+                const int v = idx[j];
+                perm[(size_t)s * V + j] = v;
+                const int64_t *x = variants + ((size_t)v * S + s) * 4;
+                for (int b = 0; b < 4; ++b) csv[((size_t)s * V + j) * 4 + b] = (int32_t)x[b];
+            }
+        }
+        std::iota(sord.begin(), sord.end(), 0);
+        std::stable_sort(sord.begin(), sord.end(), [&](int32_t p, int32_t q) { return depth[p] > depth[q]; });
+        HIP_TRY(hipMemcpyAsync(c->perm_sv, perm.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->cnt_sv, csv.data(), n * 4 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->sample_order, sord.data(), (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     if (flag) {
         dev_free(&c->cnt_vs); dev_free(&c->cnt_sv);
         dsm_set_error("set_counts: negative count or depth above 2^31-1");

@@ -32,7 +32,9 @@ struct dsm_ctx {
     int V = 0, S = 0, G = 0;
     // count tensor (both layouts, int32) and data-only ll constant
     int32_t *cnt_vs = nullptr;      // [V][S][4]  tau sweep / LL: lane = sample
-    int32_t *cnt_sv = nullptr;      // [S][V][4]  mu/E pass:      lane = variant
+    int32_t *cnt_sv = nullptr;      // [S][V][4]  mu/E pass: lane = variant, in count-sorted order per sample
+    int32_t *perm_sv = nullptr;     // [S][V] variant id of each sorted slot
+    int32_t *sample_order = nullptr;// [S] samples by decreasing total depth
     double ll_const = 0.0;
     // chain state
     uint64_t *tau = nullptr;        // [V] packed, 2 bits per haplotype

@@ -18,15 +18,13 @@
 // one-time layout kernels
 // =====================================================================
 __global__ __launch_bounds__(256) void convert_counts_kernel(const int64_t *__restrict__ in,
-                                                             int32_t *__restrict__ cnt_vs,
-                                                             int32_t *__restrict__ cnt_sv, int V, int S,
+                                                             int32_t *__restrict__ cnt_vs, int V, int S,
                                                              int *flag, double *partial)
 {
     __shared__ double red[256];
     const size_t n = (size_t)V * S;
     double acc = 0.0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int v = (int)(i / S), s = (int)(i % S);
         int4 c;
         int64_t x[4];
         int64_t tot = 0;
@@ -41,7 +39,6 @@ __global__ __launch_bounds__(256) void convert_counts_kernel(const int64_t *__re
         if (bad) atomicOr(flag, 1);
         c.x = (int)x[0]; c.y = (int)x[1]; c.z = (int)x[2]; c.w = (int)x[3];
         reinterpret_cast<int4 *>(cnt_vs)[i] = c;
-        reinterpret_cast<int4 *>(cnt_sv)[(size_t)s * V + v] = c;
         // data-only part of the multinomial log-pdf (Desman_Utils.py:28-33)
         double t = lgamma((double)tot + 1.0);
 #pragma unroll
@@ -150,16 +147,25 @@ __global__ __launch_bounds__(256) void mt_fill_kernel(uint32_t *__restrict__ sta
 
 // =====================================================================
 // A2: auxiliary-count sums.  One lane per (v,s) cell; a workgroup holds 256
-// consecutive variants of ONE sample, so the per-lane read counts (depth is a
-// per-sample quantity) are balanced across the wavefront and the [S][V][4]
-// slab load is one coalesced 16 B/lane access.  Every read draws its
+// variants of ONE sample, adjacent in that sample's count-sorted order (built
+// once at upload: variants sorted by their largest, then second-largest base
+// count), so the per-lane read loops of a wavefront have nearly equal length
+// and the permuted [S][V][4] slab load is one coalesced 16 B/lane access.  Every read draws its
 // haplotype g with probability gamma[s,g]*eta[tau_vg,b]/sum from the cell's
 // xoshiro128++ stream (keyed by Philox(seed; cell, iter)); only the sums
 // sum_mu[s,g] and esum[b,a] ever leave the registers.
 // Specification restated in oracle/desman_oracle.c: orc_stats_counter.
 // =====================================================================
+// r < thr ? cnt + 1 : cnt in two VALU issues (compare to VCC, add-with-carry of 0)
+__device__ __forceinline__ void count_if_less(uint32_t &cnt, uint32_t r, uint32_t thr)
+{
+    asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cnt) : "v"(r), "v"(thr) : "vcc");
+}
+
 template <int GMAX>
 __global__ __launch_bounds__(256) void stats_kernel(const int32_t *__restrict__ cnt_sv,
+                                                    const int32_t *__restrict__ perm_sv,
+                                                    const int32_t *__restrict__ sample_order,
                                                     const uint64_t *__restrict__ tau,
                                                     const double *__restrict__ gamma,
                                                     const double *__restrict__ eta, int V, int S, int G,
@@ -171,8 +177,8 @@ __global__ __launch_bounds__(256) void stats_kernel(const int32_t *__restrict__ 
     __shared__ double es[16];
     __shared__ unsigned long long acc[GMAX + 16];
     const int tid = threadIdx.x;
-    const int s = blockIdx.y;
-    const int v = blockIdx.x * 256 + tid;
+    const int s = sample_order[blockIdx.y];              // deepest samples are dispatched first
+    const int j = blockIdx.x * 256 + tid;                // slot in the depth-sorted order of sample s
     if (tid < GMAX) gs[tid] = (tid < G) ? gamma[(size_t)s * G + tid] : 0.0;
     if (tid < 16) es[tid] = eta[tid];
     if (tid < GMAX + 16) acc[tid] = 0ull;
@@ -185,8 +191,9 @@ __global__ __launch_bounds__(256) void stats_kernel(const int32_t *__restrict__ 
 #pragma unroll
     for (int i = 0; i < 16; ++i) e[i] = 0;
 
-    if (v < V) {
-        const int4 c = reinterpret_cast<const int4 *>(cnt_sv)[(size_t)s * V + v];
+    if (j < V) {
+        const int v = perm_sv[(size_t)s * V + j];
+        const int4 c = reinterpret_cast<const int4 *>(cnt_sv)[(size_t)s * V + j];
         const int x[4] = {c.x, c.y, c.z, c.w};
         const uint64_t t = tau[v];
         const uint64_t cell = (uint64_t)s * (uint64_t)V + (uint64_t)v;
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const int32_t *__restrict__ 
             for (int i = 0; i < nb; ++i) {
                 const uint32_t r = rng.next();
 #pragma unroll
-                for (int g = 0; g < GMAX - 1; ++g) cnt[g] += (r < thr[g]) ? 1u : 0u;
+                for (int g = 0; g < GMAX - 1; ++g) count_if_less(cnt[g], r, thr[g]);
             }
             uint32_t e4[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -610,8 +617,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalParams p)
 // =====================================================================
 int k_convert_counts(dsm_ctx *c, const int64_t *d_in, int *d_flag, double *d_partial, int nblk)
 {
-    hipLaunchKernelGGL(convert_counts_kernel, dim3(nblk), dim3(256), 0, c->stream, d_in, c->cnt_vs, c->cnt_sv,
-                       c->V, c->S, d_flag, d_partial);
+    hipLaunchKernelGGL(convert_counts_kernel, dim3(nblk), dim3(256), 0, c->stream, d_in, c->cnt_vs, c->V, c->S, d_flag,
+                       d_partial);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }
@@ -656,7 +663,8 @@ int k_stats(dsm_ctx *c, uint32_t iter)
     const dim3 grid((c->V + 255) / 256, c->S), block(256);
     const uint32_t k0 = (uint32_t)c->ctr_seed, k1 = (uint32_t)(c->ctr_seed >> 32);
 #define LAUNCH_STATS(GM)                                                                                     \
-    hipLaunchKernelGGL(stats_kernel<GM>, grid, block, 0, c->stream, c->cnt_sv, c->tau, c->gamma, c->eta,    \
+    hipLaunchKernelGGL(stats_kernel<GM>, grid, block, 0, c->stream, c->cnt_sv, c->perm_sv, c->sample_order, \
+                       c->tau, c->gamma, c->eta,                                                            \
                        c->V, c->S, c->G, k0, k1, iter, c->sum_mu, c->esum)
     if (c->G <= 4) LAUNCH_STATS(4);
     else if (c->G <= 8) LAUNCH_STATS(8);

@@ -75,10 +75,10 @@ __device__ __forceinline__ unsigned group_allreduce_sum_u32(unsigned x)
 // class as libm in the sums it feeds (validated against glibc on the host).
 // `tab` = the 128 x {invc, logc} table (log_table.h) staged in LDS.
 // Zero, subnormal, negative, inf and NaN inputs take the libm path.
-__device__ __forceinline__ double dsm_log(double x, const double2 *__restrict__ tab)
+// dsm_log_core: x must be a positive normal double (callers check with dsm_log_ok).
+__device__ __forceinline__ double dsm_log_core(double x, const double2 *__restrict__ tab)
 {
     const uint32_t hi = (uint32_t)__double2hiint(x);
-    if (__builtin_expect(hi - 0x00100000u >= 0x7fe00000u, 0)) return log(x);
     const int e = (int)(hi >> 20) - 1023;
     const double2 t = tab[(hi >> 13) & 127u];
     const double m = __hiloint2double((int)((hi & 0x000fffffu) | 0x3ff00000u), __double2loint(x));
@@ -91,6 +91,16 @@ __device__ __forceinline__ double dsm_log(double x, const double2 *__restrict__ 
     const double w = fma(ed, 0x1.62e42fefa3800p-1, t.y);
     const double lo = fma(ed, 0x1.ef35793c76730p-45, (r * r) * p);
     return (w + r) + lo;
+}
+// true iff x is a positive normal finite double (the domain of dsm_log_core)
+__device__ __forceinline__ bool dsm_log_ok(double x)
+{
+    return ((uint32_t)__double2hiint(x) - 0x00100000u) < 0x7fe00000u;
+}
+__device__ __forceinline__ double dsm_log(double x, const double2 *__restrict__ tab)
+{
+    if (__builtin_expect(!dsm_log_ok(x), 0)) return log(x);
+    return dsm_log_core(x, tab);
 }
 
 // ---- sum of four per-lane values over a W-lane group, result on every lane.

@@ -461,6 +461,7 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
             for (int b = 0; b < 4; ++b) xf[j][b] = (double)(float)xi[j][b];   // c_sample_tau.c:164
         }
         if (SWEEP) {
+            double l_cur = 0.0;                  // log-prob of the variant's current configuration
             for (int g = 0; g < G; ++g) {
                 double st[NSL][4];
 #pragma unroll
@@ -474,29 +475,47 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
 #pragma unroll
                     for (int j = 0; j < NSL; ++j) {
                         const double gm = gT[h * SP + lig + j * LPV];
-                        st[j][0] = st[j][0] + e0 * gm;
-                        st[j][1] = st[j][1] + e1 * gm;
-                        st[j][2] = st[j][2] + e2 * gm;
-                        st[j][3] = st[j][3] + e3 * gm;
+                        st[j][0] = fma(e0, gm, st[j][0]);
+                        st[j][1] = fma(e1, gm, st[j][1]);
+                        st[j][2] = fma(e2, gm, st[j][2]);
+                        st[j][3] = fma(e3, gm, st[j][3]);
                     }
                 }
                 double gg[NSL];
 #pragma unroll
                 for (int j = 0; j < NSL; ++j) gg[j] = gT[g * SP + lig + j * LPV];
+                const int told = (int)((t >> (2 * g)) & 3);
+                // With one variant per wavefront the candidate a == told is the variant's current
+                // configuration, whose log-probability was already evaluated (it is the candidate
+                // chosen at the previous step): only the three other candidates need their 4*NSL logs.
+                const bool reuse = (LPV == 64) && (g > 0);
                 double l[4];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     double acc = 0.0;
+                    if (!(reuse && a == told)) {
 #pragma unroll
-                    for (int j = 0; j < NSL; ++j)
+                        for (int j = 0; j < NSL; ++j) {
+                            double P[4];
+                            bool ok = true;
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const double P = st[j][b] + eS[a * 4 + b] * gg[j];
-                            acc = acc + xf[j][b] * dsm_log(P, ltab);
+                            for (int b = 0; b < 4; ++b) { P[b] = fma(eS[a * 4 + b], gg[j], st[j][b]); ok &= dsm_log_ok(P[b]); }
+                            if (__builtin_expect(ok, 1)) {
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) acc = fma(xf[j][b], dsm_log_core(P[b], ltab), acc);
+                            } else {
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) acc = fma(xf[j][b], log(P[b]), acc);
+                            }
                         }
+                    }
                     l[a] = acc;
                 }
                 group_allreduce_sum4<LPV>(l[0], l[1], l[2], l[3]);
+                if (reuse) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) if (a == told) l[a] = l_cur;
+                }
                 if (p.logp && lig == 0) {
                     double *o = p.logp + ((size_t)v * G + g) * 4;
                     o[0] = l[0]; o[1] = l[1]; o[2] = l[2]; o[3] = l[3];
@@ -523,7 +542,7 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                     u = (double)r[0] * 2.3283064365386963e-10;
                 }
                 const int tn = (u < c0) ? 0 : (u < c1) ? 1 : (u < c2) ? 2 : 3;
-                const int told = (int)((t >> (2 * g)) & 3);
+                l_cur = (tn == 0) ? l[0] : (tn == 1) ? l[1] : (tn == 2) ? l[2] : l[3];
                 nchg += (lig == 0) & (tn != told);
                 t = (t & ~(3ull << (2 * g))) | ((uint64_t)tn << (2 * g));
             }
@@ -538,10 +557,10 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                     const double *er = eL + (int)((t >> (2 * g)) & 3) * 4;
                     const double gm = gT[g * SP + lig + j * LPV];
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) P[b] = P[b] + gm * er[b];
+                    for (int b = 0; b < 4; ++b) P[b] = fma(gm, er[b], P[b]);
                 }
 #pragma unroll
-                for (int b = 0; b < 4; ++b) ll_acc = ll_acc + (double)xi[j][b] * dsm_log(P[b], ltab);
+                for (int b = 0; b < 4; ++b) ll_acc = fma((double)xi[j][b], dsm_log(P[b], ltab), ll_acc);
             }
         }
     }

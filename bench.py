@@ -76,11 +76,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if "RANK" in os.environ:                                     # launched by torch.distributed.run (any N >= 1)
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = local_rank if world > 1 else 0
+    dev = local_rank
     torch.cuda.set_device(dev)
 
     from desman_amd import _lib

@@ -143,7 +143,7 @@ extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
     TRY(dev_alloc(&c->mt_state, 625));
     TRY(dev_alloc(&c->ll_partial, DSM_MAX_GRID));
     TRY(dev_alloc(&c->nchange, 1));
-    TRY(dev_alloc(&c->prior, 2));
+    TRY(dev_alloc(&c->prior, DSM_MAX_S + 4));
     TRY(dev_alloc(&c->scalars, 8));
     TRY(dev_alloc(&c->star, 2));
     TRY(dev_alloc(&c->eta, 16));
@@ -164,6 +164,7 @@ static void free_traces(dsm_ctx *c)
     dev_free(&c->tau_trace); dev_free(&c->ll_trace); dev_free(&c->lp_trace); dev_free(&c->nchange_trace);
     dev_free(&c->gamma_trace); dev_free(&c->eta_trace); dev_free(&c->gamma_in); dev_free(&c->eta_in);
     c->n_trace = 0;
+    c->trace_cap = 0;
 }
 
 extern "C" int dsm_ctx_destroy(dsm_ctx *c)
@@ -544,14 +545,18 @@ extern "C" int dsm_ctx_loglik(dsm_ctx *c, double *ll, double *lp)
 // ---------------------------------------------------------------- update loops
 static int alloc_traces(dsm_ctx *c, int n)
 {
-    free_traces(c);
+    // buffers are kept across update() calls and only grown (hipMalloc/hipFree cost milliseconds)
     const size_t sg = (size_t)c->S * c->G;
-    TRY(dev_alloc(&c->tau_trace, (size_t)(n + 1) * c->V));
-    TRY(dev_alloc(&c->ll_trace, (size_t)n));
-    TRY(dev_alloc(&c->lp_trace, (size_t)n));
-    TRY(dev_alloc(&c->nchange_trace, (size_t)n));
-    TRY(dev_alloc(&c->gamma_trace, (size_t)n * sg));
-    TRY(dev_alloc(&c->eta_trace, (size_t)n * 16));
+    if (n > c->trace_cap || !c->tau_trace) {
+        free_traces(c);
+        TRY(dev_alloc(&c->tau_trace, (size_t)(n + 1) * c->V));
+        TRY(dev_alloc(&c->ll_trace, (size_t)n));
+        TRY(dev_alloc(&c->lp_trace, (size_t)n));
+        TRY(dev_alloc(&c->nchange_trace, (size_t)n));
+        TRY(dev_alloc(&c->gamma_trace, (size_t)n * sg));
+        TRY(dev_alloc(&c->eta_trace, (size_t)n * 16));
+        c->trace_cap = n;
+    }
     c->n_trace = n;
     return DSM_OK;
 }

@@ -107,26 +107,51 @@ __device__ __forceinline__ double dsm_log(double x, const double2 *__restrict__ 
 // Transposing butterfly: after the first two exchange steps each lane carries ONE
 // of the four sums, so the remaining log2(W)-2 steps move one value instead of
 // four (7 exchanges + 4 broadcasts for W = 64 instead of 24).
+// DPP lane moves (VALU only, no LDS round trip) for the in-row exchange steps
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+#define DSM_DPP_XOR1 0xB1    // quad_perm [1,0,3,2]
+#define DSM_DPP_XOR2 0x4E    // quad_perm [2,3,0,1]
+#define DSM_DPP_ROR4 0x124   // row_ror:4  (16-lane rows)
+#define DSM_DPP_ROR8 0x128   // row_ror:8
+
 template <int W>
 __device__ __forceinline__ void group_allreduce_sum4(double &v0, double &v1, double &v2, double &v3)
 {
     const int lane = __lane_id();
     const bool b0 = lane & 1, b1 = lane & 2;
-    // step 1: lanes with b0 = 0 keep (v0, v1), lanes with b0 = 1 keep (v2, v3)
+    // step 1 (lane ^ 1): lanes with b0 = 0 keep (v0, v1), lanes with b0 = 1 keep (v2, v3)
     const double s0 = b0 ? v0 : v2, s1 = b0 ? v1 : v3;
     double k0 = b0 ? v2 : v0, k1 = b0 ? v3 : v1;
-    k0 += __shfl_xor(s0, 1, 64);
-    k1 += __shfl_xor(s1, 1, 64);
-    // step 2: b1 = 0 keeps k0, b1 = 1 keeps k1
+    k0 += dpp_mov<DSM_DPP_XOR1>(s0);
+    k1 += dpp_mov<DSM_DPP_XOR1>(s1);
+    // step 2 (lane ^ 2): b1 = 0 keeps k0, b1 = 1 keeps k1
     const double s = b1 ? k0 : k1;
     double k = b1 ? k1 : k0;
-    k += __shfl_xor(s, 2, 64);
+    k += dpp_mov<DSM_DPP_XOR2>(s);
+    // lane (b0, b1) of every quad now holds the quad total of value 2*b0 + b1; rotations by 4
+    // and 8 inside the 16-lane row keep (b0, b1) and finish the row; rows are combined by xor.
+    k += dpp_mov<DSM_DPP_ROR4>(k);
+    k += dpp_mov<DSM_DPP_ROR8>(k);
 #pragma unroll
-    for (int off = 4; off < W; off <<= 1) k += __shfl_xor(k, off, 64);
-    // lane (b0, b1) of every quad now holds the group total of value 2*b0 + b1
-    const int base = lane & ~(W - 1);
-    v0 = __shfl(k, base + 0, 64);
-    v1 = __shfl(k, base + 2, 64);
-    v2 = __shfl(k, base + 1, 64);
-    v3 = __shfl(k, base + 3, 64);
+    for (int off = 16; off < W; off <<= 1) k += __shfl_xor(k, off, 64);
+    if (W == 64) {
+        // one variant per wavefront: the four totals are wave-uniform -> scalar broadcasts
+        const int lo = __double2loint(k), hi = __double2hiint(k);
+        v0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+        v1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 2), __builtin_amdgcn_readlane(lo, 2));
+        v2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 1), __builtin_amdgcn_readlane(lo, 1));
+        v3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 3), __builtin_amdgcn_readlane(lo, 3));
+    } else {
+        const int base = lane & ~(W - 1);
+        v0 = __shfl(k, base + 0, 64);
+        v1 = __shfl(k, base + 2, 64);
+        v2 = __shfl(k, base + 1, 64);
+        v3 = __shfl(k, base + 3, 64);
+    }
 }

@@ -58,11 +58,11 @@ struct dsm_ctx {
     // scratch
     double *ll_partial = nullptr;   // [DSM_MAX_GRID]
     int *nchange = nullptr;         // device counter
-    double *prior = nullptr;        // [2] log Dir priors of gamma, eta
+    double *prior = nullptr;        // [S + 4] per-row Dirichlet log-prior terms of (gamma, eta)
     double *scalars = nullptr;      // [8] misc device scalars
     double *log_tab = nullptr;      // [128][2] table of dsm_log (log_table.h)
     // traces of the last update call
-    int n_trace = 0;
+    int n_trace = 0, trace_cap = 0;
     uint64_t *tau_trace = nullptr;  // [(n+1)][V]; slot 0 = entry state
     double *ll_trace = nullptr, *lp_trace = nullptr;   // [n]
     int *nchange_trace = nullptr;   // [n]

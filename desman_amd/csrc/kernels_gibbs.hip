@@ -316,82 +316,55 @@ __device__ double gamma_variate(double shape, uint32_t idx, uint32_t iter, uint3
     return res;
 }
 
-__global__ __launch_bounds__(256) void dirichlet_kernel(unsigned long long *__restrict__ sum_mu,
-                                                        unsigned long long *__restrict__ esum, int S, int G,
-                                                        double alpha, double delta, double epsilon,
-                                                        double lgc_gamma, double lgc_eta, uint32_t k0,
-                                                        uint32_t k1, uint32_t iter, int zero_after,
-                                                        double *__restrict__ gamma_out,
-                                                        double *__restrict__ gamma_trace,
-                                                        double *__restrict__ eta_out, double *__restrict__ prior)
+// One 64-lane workgroup per row (S gamma rows + 4 eta rows): lane g draws variate g, lane 0
+// normalises the row and writes its log-prior term to rowprior[row] (summed by finalize in a
+// fixed order).  Rows are independent, so the launch fills S+4 CUs instead of one.
+__global__ __launch_bounds__(64) void dirichlet_kernel(unsigned long long *__restrict__ sum_mu,
+                                                       unsigned long long *__restrict__ esum, int S, int G,
+                                                       double alpha, double delta, double epsilon,
+                                                       double lgc_gamma, double lgc_eta, uint32_t k0,
+                                                       uint32_t k1, uint32_t iter, int zero_after,
+                                                       double *__restrict__ gamma_out,
+                                                       double *__restrict__ gamma_trace,
+                                                       double *__restrict__ eta_out, double *__restrict__ rowprior)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem_d[];
-    double *y = reinterpret_cast<double *>(smem_d);     // [S*G + 16]
-    double *rowp = y + (size_t)S * G + 16;               // [S + 4] per-row prior terms
-    const int SG = S * G, tid = threadIdx.x;
-    for (int i = tid; i < SG + 16; i += 256) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const bool is_gamma = row < S;
+    const int n = is_gamma ? G : 4;
+    const int SG = S * G;
+    double y = 0.0;
+    if (lane < n) {
         double shape;
-        if (i < SG) shape = alpha + (double)sum_mu[i];
-        else { const int a = (i - SG) >> 2, b = (i - SG) & 3; shape = delta + (double)esum[b * 4 + a]; }
-        y[i] = gamma_variate(shape, (uint32_t)i, iter, k0, k1);
+        uint32_t vid;                                   // variate id: the spec's flat index
+        if (is_gamma) { vid = (uint32_t)(row * G + lane); shape = alpha + (double)sum_mu[vid]; }
+        else { const int a = row - S; vid = (uint32_t)(SG + a * 4 + lane); shape = delta + (double)esum[lane * 4 + a]; }
+        y = gamma_variate(shape, vid, iter, k0, k1);
+        if (zero_after) { if (is_gamma) sum_mu[row * G + lane] = 0ull; else esum[lane * 4 + (row - S)] = 0ull; }
     }
-    __syncthreads();
-    if (zero_after) {
-        for (int i = tid; i < SG; i += 256) sum_mu[i] = 0ull;
-        if (tid < 16) esum[tid] = 0ull;
+    // row normalisation, lane-parallel (inactive lanes carry 0)
+    double x = y / group_allreduce_sum<64>(y);
+    if (is_gamma) {
+        if (lane < n && x < epsilon) x = epsilon;                       // HaploSNP_Sampler.py:271
+        x = x / group_allreduce_sum<64>(lane < n ? x : 0.0);            // :272-273
     }
-    for (int r = tid; r < S + 4; r += 256) {
-        if (r < S) {
-            double *row = y + (size_t)r * G;
-            double tot = 0.0;
-            for (int g = 0; g < G; ++g) tot += row[g];
-            double tot2 = 0.0;
-            for (int g = 0; g < G; ++g) { double x = row[g] / tot; if (x < epsilon) x = epsilon; row[g] = x; tot2 += x; }
-            double lsum = 0.0;
-            for (int g = 0; g < G; ++g) {
-                const double x = row[g] / tot2;
-                row[g] = x;
-                lsum += (alpha - 1.0) * log(x);
-            }
-            rowp[r] = lgc_gamma + lsum;
-        } else {
-            double *row = y + SG + (size_t)(r - S) * 4;
-            double tot = 0.0;
-            for (int b = 0; b < 4; ++b) tot += row[b];
-            double lsum = 0.0;
-            for (int b = 0; b < 4; ++b) { const double x = row[b] / tot; row[b] = x; lsum += (delta - 1.0) * log(x); }
-            rowp[r] = lgc_eta + lsum;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < SG; i += 256) { gamma_out[i] = y[i]; if (gamma_trace) gamma_trace[i] = y[i]; }
-    if (tid < 16) eta_out[tid] = y[SG + tid];
-    if (tid == 0) {
-        double pg = 0.0, pe = 0.0;
-        for (int s = 0; s < S; ++s) pg += rowp[s];
-        for (int a = 0; a < 4; ++a) pe += rowp[S + a];
-        prior[0] = pg; prior[1] = pe;
+    const double a1 = is_gamma ? alpha : delta;
+    const double lsum = group_allreduce_sum<64>(lane < n ? (a1 - 1.0) * log(x) : 0.0);
+    if (lane == 0) rowprior[row] = (is_gamma ? lgc_gamma : lgc_eta) + lsum;
+    if (lane < n) {
+        if (is_gamma) { gamma_out[row * G + lane] = x; if (gamma_trace) gamma_trace[row * G + lane] = x; }
+        else eta_out[(row - S) * 4 + lane] = x;
     }
 }
 
 // Dirichlet log-priors of a given (gamma, eta) -- entry state of update()
 __global__ __launch_bounds__(256) void prior_kernel(const double *__restrict__ gamma, const double *__restrict__ eta,
                                                     int S, int G, double alpha, double delta, double lgc_gamma,
-                                                    double lgc_eta, double *__restrict__ prior)
+                                                    double lgc_eta, double *__restrict__ rowprior)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem_p[];
-    double *rowp = reinterpret_cast<double *>(smem_p);
-    for (int r = threadIdx.x; r < S + 4; r += 256) {
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < S + 4; r += gridDim.x * 256) {
         double lsum = 0.0;
-        if (r < S) { for (int g = 0; g < G; ++g) lsum += (alpha - 1.0) * log(gamma[(size_t)r * G + g]); rowp[r] = lgc_gamma + lsum; }
-        else { for (int b = 0; b < 4; ++b) lsum += (delta - 1.0) * log(eta[(r - S) * 4 + b]); rowp[r] = lgc_eta + lsum; }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double pg = 0.0, pe = 0.0;
-        for (int s = 0; s < S; ++s) pg += rowp[s];
-        for (int a = 0; a < 4; ++a) pe += rowp[S + a];
-        prior[0] = pg; prior[1] = pe;
+        if (r < S) { for (int g = 0; g < G; ++g) lsum += (alpha - 1.0) * log(gamma[(size_t)r * G + g]); rowprior[r] = lgc_gamma + lsum; }
+        else { for (int b = 0; b < 4; ++b) lsum += (delta - 1.0) * log(eta[(r - S) * 4 + b]); rowprior[r] = lgc_eta + lsum; }
     }
 }
 
@@ -528,7 +501,8 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     const double d = l[a] - mx;                  // identical on every lane of the group
-                    ex[a] = (d < -750.0) ? 0.0 : exp(d);         // exp underflows to exactly 0 below -745.2
+                    // exp(0) = 1 and exp(d < -745.2) = 0 exactly: the usual case needs no exp at all
+                    ex[a] = (d == 0.0) ? 1.0 : (d < -750.0) ? 0.0 : exp(d);
                     sum += ex[a];
                 }
                 const double c0 = ex[0] / sum, c1 = ex[1] / sum + c0, c2 = ex[2] / sum + c1;
@@ -583,7 +557,7 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
 struct FinalParams {
     const double *ll_partial; int nblocks;
     double ll_const, tau_prior;
-    const double *prior;
+    const double *prior; int S;      // [S + 4] per-row Dirichlet log-prior terms
     int *nchange;
     int it;
     double *ll_trace, *lp_trace; int *nchange_trace;
@@ -597,20 +571,21 @@ struct FinalParams {
 
 __global__ __launch_bounds__(256) void finalize_kernel(FinalParams p)
 {
-    __shared__ double red[256];
+    __shared__ double red[256], redp[256];
     __shared__ int flag;
     const int tid = threadIdx.x;
-    double a = 0.0;
+    double a = 0.0, b = 0.0;
     for (int i = tid; i < p.nblocks; i += 256) a += p.ll_partial[i];
-    red[tid] = a;
+    for (int i = tid; i < p.S + 4; i += 256) b += p.prior[i];        // Dirichlet log-prior terms, same fixed-order tree
+    red[tid] = a; redp[tid] = b;
     __syncthreads();
     for (int o = 128; o >= 1; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
+        if (tid < o) { red[tid] += red[tid + o]; redp[tid] += redp[tid + o]; }
         __syncthreads();
     }
     if (tid == 0) {
         const double ll = p.ll_const + red[0];
-        const double lp = ll + p.prior[0] + p.prior[1] + p.tau_prior;
+        const double lp = ll + redp[0] + p.tau_prior;
         p.scalars[0] = ll; p.scalars[1] = lp;
         const int nch = *p.nchange;
         *p.nchange = 0;
@@ -705,9 +680,8 @@ int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trac
     KTimer tm(c, DSM_K_DIRICH);
     double lg, le;
     dirichlet_consts(c, &lg, &le);
-    const size_t sh = ((size_t)c->S * c->G + 16 + c->S + 4) * sizeof(double);
     const uint32_t k0 = (uint32_t)c->ctr_seed, k1 = (uint32_t)(c->ctr_seed >> 32);
-    hipLaunchKernelGGL(dirichlet_kernel, dim3(1), dim3(256), sh, c->stream, c->sum_mu, c->esum, c->S, c->G,
+    hipLaunchKernelGGL(dirichlet_kernel, dim3(c->S + 4), dim3(64), 0, c->stream, c->sum_mu, c->esum, c->S, c->G,
                        c->alpha, c->delta, c->epsilon, lg, le, k0, k1, iter, 1, gamma_out, gamma_trace, eta_out,
                        c->prior);
     HIP_TRY(hipGetLastError());
@@ -718,8 +692,8 @@ int k_prior(dsm_ctx *c, const double *gamma, const double *eta)
 {
     double lg, le;
     dirichlet_consts(c, &lg, &le);
-    hipLaunchKernelGGL(prior_kernel, dim3(1), dim3(256), (size_t)(c->S + 4) * sizeof(double), c->stream, gamma,
-                       eta, c->S, c->G, c->alpha, c->delta, lg, le, c->prior);
+    hipLaunchKernelGGL(prior_kernel, dim3(1), dim3(256), 0, c->stream, gamma, eta, c->S, c->G, c->alpha, c->delta, lg,
+                       le, c->prior);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }
@@ -775,7 +749,7 @@ int k_finalize(dsm_ctx *c, int nblocks, int it, int commit_eta, int star_mode)
     p.ll_partial = c->ll_partial; p.nblocks = nblocks;
     p.ll_const = c->ll_const;
     p.tau_prior = (double)c->V * (double)c->G * log(1.0 / 4.0);     // HaploSNP_Sampler.py:457
-    p.prior = c->prior; p.nchange = c->nchange; p.it = it;
+    p.prior = c->prior; p.S = c->S; p.nchange = c->nchange; p.it = it;
     p.ll_trace = c->ll_trace; p.lp_trace = c->lp_trace; p.nchange_trace = c->nchange_trace;
     p.star = c->star; p.gamma = c->gamma; p.gamma_star = c->gamma_star; p.SG = c->S * c->G;
     p.eta = c->eta; p.eta_new = c->eta_new; p.eta_star = c->eta_star; p.eta_trace = c->eta_trace;

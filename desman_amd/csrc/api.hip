@@ -175,7 +175,8 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     collect_spans(c);
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     free_traces(c);
-    dev_free(&c->cnt_vs); dev_free(&c->cnt_sv); dev_free(&c->perm_sv); dev_free(&c->sample_order); dev_free(&c->tau);
+    dev_free(&c->cnt_vs); dev_free(&c->items); dev_free(&c->nitems); dev_free(&c->sample_order); dev_free(&c->tau);
+    dev_free(&c->blk_tab);
     dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
     dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->prior); dev_free(&c->scalars); dev_free(&c->star);
@@ -210,8 +211,8 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     c->have_state = false;
     c->G = 0;                       // V/S changed: every state-sized buffer is re-made by set_state
     TRY(dev_alloc(&c->cnt_vs, n * 4));
-    TRY(dev_alloc(&c->cnt_sv, n * 4));
-    TRY(dev_alloc(&c->perm_sv, n));
+    TRY(dev_alloc(&c->items, n * 8));
+    TRY(dev_alloc(&c->nitems, (size_t)S));
     TRY(dev_alloc(&c->sample_order, (size_t)S));
     TRY(dev_alloc(&c->tau, (size_t)V));
     dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); c->nG = 0;
@@ -231,42 +232,40 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     HIP_TRY(hipStreamSynchronize(c->stream));
     dev_free(&d_in); dev_free(&d_flag); dev_free(&d_part);
     if (!flag) {
-        // layout of the per-read pass: per sample, variants sorted by (largest, second largest)
-        // base count, descending -> the lanes of a wavefront run read loops of similar length;
-        // samples ordered by total depth -> the longest workgroups are dispatched first.
-        std::vector<int32_t> perm(n), csv(n * 4), sord(S);
+        // work list of the per-read pass: per sample, the (variant, base) pairs with a non-zero
+        // count, sorted by decreasing count (ties: lower id first) -> the lanes of a wavefront run
+        // read loops of equal length; samples ordered by total depth -> heaviest workgroups first.
+        std::vector<int32_t> items(n * 8, 0), nit(S), sord(S);
         std::vector<int64_t> depth(S, 0);
-        std::vector<uint64_t> key(V);
-        std::vector<int32_t> idx(V);
+        std::vector<std::pair<int32_t, int32_t>> lst;      // (count, id)
+        lst.reserve((size_t)V * 4);
+        int max_items = 0;
         for (int s = 0; s < S; ++s) {
+            lst.clear();
             for (int v = 0; v < V; ++v) {
                 const int64_t *x = variants + ((size_t)v * S + s) * 4;
-                int64_t a = x[0], b = x[1], cc = x[2], d = x[3];
-                depth[s] += a + b + cc + d;
-                if (a < b) std::swap(a, b);
-                if (cc < d) std::swap(cc, d);
-                const int64_t m1 = std::max(a, cc);
-                const int64_t m2 = std::max(std::min(a, cc), std::max(b, d));
-                key[v] = ((uint64_t)m1 << 32) | (uint64_t)m2;
-                idx[v] = v;
+                for (int b = 0; b < 4; ++b)
+                    if (x[b] > 0) { lst.emplace_back((int32_t)x[b], v * 4 + b); depth[s] += x[b]; }
             }
-            std::stable_sort(idx.begin(), idx.end(), [&](int32_t p, int32_t q) { return key[p] > key[q]; });
-            for (int j = 0; j < V; ++j) {
-                const int v = idx[j];
-                perm[(size_t)s * V + j] = v;
-                const int64_t *x = variants + ((size_t)v * S + s) * 4;
-                for (int b = 0; b < 4; ++b) csv[((size_t)s * V + j) * 4 + b] = (int32_t)x[b];
-            }
+            std::stable_sort(lst.begin(), lst.end(), [](const std::pair<int32_t, int32_t> &p, const std::pair<int32_t, int32_t> &q) { return p.first > q.first; });
+            nit[s] = (int32_t)lst.size();
+            max_items = std::max(max_items, nit[s]);
+            int32_t *dst = items.data() + (size_t)s * 4 * V * 2;
+            for (size_t k = 0; k < lst.size(); ++k) { dst[2 * k] = lst[k].second; dst[2 * k + 1] = lst[k].first; }
         }
+        c->max_items = max_items;
+        c->depth = depth;
+        c->nitems_h = nit;
+        c->blk_gmax = 0;
         std::iota(sord.begin(), sord.end(), 0);
         std::stable_sort(sord.begin(), sord.end(), [&](int32_t p, int32_t q) { return depth[p] > depth[q]; });
-        HIP_TRY(hipMemcpyAsync(c->perm_sv, perm.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->cnt_sv, csv.data(), n * 4 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->items, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->nitems, nit.data(), (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->sample_order, sord.data(), (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     if (flag) {
-        dev_free(&c->cnt_vs); dev_free(&c->cnt_sv);
+        dev_free(&c->cnt_vs); dev_free(&c->items);
         dsm_set_error("set_counts: negative count or depth above 2^31-1");
         return DSM_ERR_ARG;
     }

@@ -32,8 +32,13 @@ struct dsm_ctx {
     int V = 0, S = 0, G = 0;
     // count tensor (both layouts, int32) and data-only ll constant
     int32_t *cnt_vs = nullptr;      // [V][S][4]  tau sweep / LL: lane = sample
-    int32_t *cnt_sv = nullptr;      // [S][V][4]  mu/E pass: lane = variant, in count-sorted order per sample
-    int32_t *perm_sv = nullptr;     // [S][V] variant id of each sorted slot
+    int32_t *items = nullptr;       // [S][4V][2] mu/E pass work items {v*4+b, count}, sorted by count per sample
+    int32_t *nitems = nullptr;      // [S] items with a non-zero count
+    int max_items = 0;
+    int32_t *blk_tab = nullptr;     // [blk_n][3] workgroup -> {sample, j, n_j} of the mu/E pass
+    int blk_n = 0, blk_gmax = 0;
+    std::vector<int64_t> depth;     // host: total reads per sample
+    std::vector<int32_t> nitems_h;  // host copy of nitems
     int32_t *sample_order = nullptr;// [S] samples by decreasing total depth
     double ll_const = 0.0;
     // chain state

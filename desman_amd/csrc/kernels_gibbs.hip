@@ -146,14 +146,15 @@ __global__ __launch_bounds__(256) void mt_fill_kernel(uint32_t *__restrict__ sta
 }
 
 // =====================================================================
-// A2: auxiliary-count sums.  One lane per (v,s) cell; a workgroup holds 256
-// variants of ONE sample, adjacent in that sample's count-sorted order (built
-// once at upload: variants sorted by their largest, then second-largest base
-// count), so the per-lane read loops of a wavefront have nearly equal length
-// and the permuted [S][V][4] slab load is one coalesced 16 B/lane access.  Every read draws its
-// haplotype g with probability gamma[s,g]*eta[tau_vg,b]/sum from the cell's
-// xoshiro128++ stream (keyed by Philox(seed; cell, iter)); only the sums
-// sum_mu[s,g] and esum[b,a] ever leave the registers.
+// A2: auxiliary-count sums.  Work item = one (variant, observed base) pair of
+// one sample with a non-zero count; the item list of every sample is built
+// once at upload, sorted by decreasing count, so the 64 lanes of a wavefront
+// run read loops of (almost) equal length and the heaviest workgroups are
+// dispatched first.  Every read draws its haplotype g with probability
+// gamma[s,g]*eta[tau_vg,b]/sum from the item's xoshiro128++ stream (keyed by
+// Philox(seed; cell, iter, base)): one 32-bit word against G-1 thresholds,
+// two VALU issues per threshold.  Only the sums sum_mu[s,g] and esum[b,a]
+// ever leave the registers.
 // Specification restated in oracle/desman_oracle.c: orc_stats_counter.
 // =====================================================================
 // r < thr ? cnt + 1 : cnt in two VALU issues (compare to VCC, add-with-carry of 0)
@@ -163,9 +164,9 @@ __device__ __forceinline__ void count_if_less(uint32_t &cnt, uint32_t r, uint32_
 }
 
 template <int GMAX>
-__global__ __launch_bounds__(256) void stats_kernel(const int32_t *__restrict__ cnt_sv,
-                                                    const int32_t *__restrict__ perm_sv,
-                                                    const int32_t *__restrict__ sample_order,
+__global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ items,      // [S][4V] {v*4+b, count}
+                                                    const int32_t *__restrict__ nitems,  // [S]
+                                                    const int32_t *__restrict__ blk_tab, // [grid][3] {sample, j, n_j}
                                                     const uint64_t *__restrict__ tau,
                                                     const double *__restrict__ gamma,
                                                     const double *__restrict__ eta, int V, int S, int G,
@@ -177,8 +178,11 @@ __global__ __launch_bounds__(256) void stats_kernel(const int32_t *__restrict__ 
     __shared__ double es[16];
     __shared__ unsigned long long acc[GMAX + 16];
     const int tid = threadIdx.x;
-    const int s = sample_order[blockIdx.y];              // deepest samples are dispatched first
-    const int j = blockIdx.x * 256 + tid;                // slot in the depth-sorted order of sample s
+    // workgroup -> (sample, j-th of n_j workgroups of that sample); the table gives every sample
+    // a share of the resident workgroups proportional to its depth, so all workgroups carry the
+    // same number of reads and the launch is exactly one resident wave of workgroups
+    const int s = blk_tab[blockIdx.x * 3], bj = blk_tab[blockIdx.x * 3 + 1], bn = blk_tab[blockIdx.x * 3 + 2];
+    const int n_s = nitems[s];
     if (tid < GMAX) gs[tid] = (tid < G) ? gamma[(size_t)s * G + tid] : 0.0;
     if (tid < 16) es[tid] = eta[tid];
     if (tid < GMAX + 16) acc[tid] = 0ull;
@@ -191,77 +195,60 @@ __global__ __launch_bounds__(256) void stats_kernel(const int32_t *__restrict__ 
 #pragma unroll
     for (int i = 0; i < 16; ++i) e[i] = 0;
 
-    if (j < V) {
-        const int v = perm_sv[(size_t)s * V + j];
-        const int4 c = reinterpret_cast<const int4 *>(cnt_sv)[(size_t)s * V + j];
-        const int x[4] = {c.x, c.y, c.z, c.w};
+    // grid-stride over the sample's sorted list: every workgroup gets heavy and light items, and
+    // the 64 items a wavefront holds at any time are adjacent in the sort (equal loop lengths)
+    for (int k = bj * 256 + tid; k < n_s; k += bn * 256) {
+        const int2 it = items[(size_t)s * 4 * V + k];
+        const int v = it.x >> 2, b = it.x & 3, nb = it.y;
         const uint64_t t = tau[v];
         const uint64_t cell = (uint64_t)s * (uint64_t)V + (uint64_t)v;
         uint32_t seedw[4];
-        philox4x32_10((uint32_t)cell, (uint32_t)(cell >> 32), iter, DSM_STREAM_STATS, k0, k1, seedw);
+        philox4x32_10((uint32_t)cell, (uint32_t)(cell >> 32), iter, DSM_STREAM_STATS + (uint32_t)b, k0, k1, seedw);
         Xo128 rng{seedw[0], seedw[1], seedw[2], seedw[3]};
         if ((rng.s0 | rng.s1 | rng.s2 | rng.s3) == 0u) rng.s0 = 1u;
-
-        // visit the four observed bases in order of decreasing count (stable),
-        // so that the lanes of a wavefront run phases of similar length
-        int rank[4];
+        // cumulative weights -> 32-bit thresholds
+        double cum[GMAX];
+        double run = 0.0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            int r = 0;
-#pragma unroll
-            for (int o = 0; o < 4; ++o) r += (x[o] > x[b]) | ((x[o] == x[b]) & (o < b));
-            rank[b] = r;
+        for (int g = 0; g < GMAX; ++g) {
+            if (g < G) {
+                const int ig = (int)((t >> (2 * g)) & 3);
+                const double w = gs[g] * es[ig * 4 + b];
+                run = run + w;
+            }
+            cum[g] = run;
         }
-#pragma unroll 1
-        for (int ph = 0; ph < 4; ++ph) {
-            int b = 0, nb = 0;
+        const double scale = 4294967296.0 / run;
+        uint32_t thr[GMAX], cnt[GMAX];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) { if (rank[o] == ph) { b = o; nb = x[o]; } }
-            if (nb <= 0) continue;
-            // cumulative weights -> 32-bit thresholds
-            double cum[GMAX];
-            double run = 0.0;
-#pragma unroll
-            for (int g = 0; g < GMAX; ++g) {
-                if (g < G) {
-                    const int ig = (int)((t >> (2 * g)) & 3);
-                    const double w = gs[g] * es[ig * 4 + b];
-                    run = run + w;
-                }
-                cum[g] = run;
-            }
-            const double scale = 4294967296.0 / run;
-            uint32_t thr[GMAX], cnt[GMAX];
-#pragma unroll
-            for (int g = 0; g < GMAX; ++g) {
-                const double f = floor(cum[g] * scale);
-                const uint32_t q = (f >= 4294967295.0) ? 0xffffffffu : (uint32_t)f;
-                thr[g] = (g < G - 1) ? q : 0u;     // unused slots never count
-                cnt[g] = 0;
-            }
-            for (int i = 0; i < nb; ++i) {
-                const uint32_t r = rng.next();
-#pragma unroll
-                for (int g = 0; g < GMAX - 1; ++g) count_if_less(cnt[g], r, thr[g]);
-            }
-            uint32_t e4[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int g = 0; g < GMAX; ++g) {
-                if (g < G) {
-                    const uint32_t hi = (g == G - 1) ? (uint32_t)nb : cnt[g];
-                    const uint32_t lo = (g == 0) ? 0u : cnt[g > 0 ? g - 1 : 0];
-                    const uint32_t m = hi - lo;
-                    mu[g] += m;
-                    const int ig = (int)((t >> (2 * g)) & 3);
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) e4[a] += (ig == a) ? m : 0u;
-                }
-            }
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-                for (int a = 0; a < 4; ++a) e[bb * 4 + a] += (b == bb) ? e4[a] : 0u;
+        for (int g = 0; g < GMAX; ++g) {
+            const double f = floor(cum[g] * scale);
+            const uint32_t q = (f >= 4294967295.0) ? 0xffffffffu : (uint32_t)f;
+            thr[g] = (g < G - 1) ? q : 0u;     // unused slots never count
+            cnt[g] = 0;
         }
+        for (int i = 0; i < nb; ++i) {
+            const uint32_t r = rng.next();
+#pragma unroll
+            for (int g = 0; g < GMAX - 1; ++g) count_if_less(cnt[g], r, thr[g]);
+        }
+        uint32_t e4[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) {
+            if (g < G) {
+                const uint32_t hi = (g == G - 1) ? (uint32_t)nb : cnt[g];
+                const uint32_t lo = (g == 0) ? 0u : cnt[g > 0 ? g - 1 : 0];
+                const uint32_t m = hi - lo;
+                mu[g] += m;
+                const int ig = (int)((t >> (2 * g)) & 3);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) e4[a] += (ig == a) ? m : 0u;
+            }
+        }
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) e[bb * 4 + a] += (b == bb) ? e4[a] : 0u;
     }
     // wavefront reduce -> LDS -> one global atomic per workgroup and counter
     const int lane = tid & 63;
@@ -654,15 +641,53 @@ int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n, hipStream_t stream)
 int k_stats(dsm_ctx *c, uint32_t iter)
 {
     KTimer tm(c, DSM_K_STATS);
-    const dim3 grid((c->V + 255) / 256, c->S), block(256);
+    if (c->max_items == 0) return DSM_OK;
+    const int gm = c->G <= 4 ? 4 : c->G <= 8 ? 8 : c->G <= 16 ? 16 : 32;
+    if (c->blk_gmax != gm) {
+        // size the grid to exactly the resident workgroups and share them among the samples by depth
+        int occ = 0;
+        const void *fn = gm == 4 ? (const void *)stats_kernel<4> : gm == 8 ? (const void *)stats_kernel<8>
+                       : gm == 16 ? (const void *)stats_kernel<16> : (const void *)stats_kernel<32>;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, 0));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+        if (occ < 1) occ = 1;
+        const int S = c->S, budget = std::max(S, occ * prop.multiProcessorCount);
+        double tot = 0.0;
+        for (int s = 0; s < S; ++s) tot += (double)c->depth[s];
+        std::vector<int32_t> nb(S, 1);
+        int used = S;
+        if (tot > 0)
+            for (int s = 0; s < S; ++s) {
+                int extra = (int)((double)(budget - S) * (double)c->depth[s] / tot);
+                const int most = (c->nitems_h[s] + 255) / 256;            // no more workgroups than item chunks
+                if (1 + extra > most) extra = std::max(0, most - 1);
+                nb[s] += extra; used += extra;
+            }
+        std::vector<int32_t> tab;
+        tab.reserve((size_t)used * 3);
+        // interleave the samples so that neighbouring workgroup ids belong to different samples
+        int maxnb = 0;
+        for (int s = 0; s < S; ++s) maxnb = std::max(maxnb, nb[s]);
+        for (int j = 0; j < maxnb; ++j)
+            for (int s = 0; s < S; ++s)
+                if (j < nb[s]) { tab.push_back(s); tab.push_back(j); tab.push_back(nb[s]); }
+        if (c->blk_tab) { (void)hipFree(c->blk_tab); c->blk_tab = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->blk_tab, tab.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpyAsync(c->blk_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->blk_n = used;
+        c->blk_gmax = gm;
+    }
+    const dim3 grid(c->blk_n), block(256);
     const uint32_t k0 = (uint32_t)c->ctr_seed, k1 = (uint32_t)(c->ctr_seed >> 32);
-#define LAUNCH_STATS(GM)                                                                                     \
-    hipLaunchKernelGGL(stats_kernel<GM>, grid, block, 0, c->stream, c->cnt_sv, c->perm_sv, c->sample_order, \
-                       c->tau, c->gamma, c->eta,                                                            \
+#define LAUNCH_STATS(GM)                                                                                      \
+    hipLaunchKernelGGL(stats_kernel<GM>, grid, block, 0, c->stream, reinterpret_cast<const int2 *>(c->items), \
+                       c->nitems, c->blk_tab, c->tau, c->gamma, c->eta,                                       \
                        c->V, c->S, c->G, k0, k1, iter, c->sum_mu, c->esum)
-    if (c->G <= 4) LAUNCH_STATS(4);
-    else if (c->G <= 8) LAUNCH_STATS(8);
-    else if (c->G <= 16) LAUNCH_STATS(16);
+    if (gm == 4) LAUNCH_STATS(4);
+    else if (gm == 8) LAUNCH_STATS(8);
+    else if (gm == 16) LAUNCH_STATS(16);
     else LAUNCH_STATS(32);
 #undef LAUNCH_STATS
     HIP_TRY(hipGetLastError());

@@ -425,7 +425,7 @@ void orc_nmft_get_tau(const double *tau, int V, int G, uint8_t *tau_idx)
 /* every read of observed base b at (v,s), its haplotype g with probability  */
 /* gamma[s,g]*eta[tau_vg,b]/sum (the one-stage form of the same joint law,   */
 /* SURVEY App. A2) from a Philox4x32-10 / xoshiro128++ stream keyed by       */
-/* (seed, iteration, cell).  The restatement below lets tests check the HIP  */
+/* (seed, iteration, cell, observed base).  The restatement below lets tests check the HIP  */
 /* kernel bit-for-bit; equivalence in law to the reference's sampleMu is     */
 /* checked statistically against oracle/ref_numpy.py.                        */
 /* ------------------------------------------------------------------------ */
@@ -478,21 +478,15 @@ void orc_stats_counter(const uint8_t *tau_idx, const double *gamma, const double
             const int64_t *x = variants + ((size_t)v * S + s) * 4;
             const uint8_t *tv = tau_idx + (size_t)v * G;
             uint64_t cell = (uint64_t)s * (uint64_t)V + (uint64_t)v;
-            uint32_t ctr[4] = { (uint32_t)cell, (uint32_t)(cell >> 32), iter, ORC_STREAM_STATS };
-            orc_xo rng;
-            orc_philox4x32_10(ctr, key, rng.s);
-            if ((rng.s[0] | rng.s[1] | rng.s[2] | rng.s[3]) == 0) rng.s[0] = 1;
-            /* bases are visited in order of decreasing count (ties: lower base first) */
-            int order[4] = { 0, 1, 2, 3 };
-            for (int i = 1; i < 4; i++) {
-                int o = order[i], j = i - 1;
-                while (j >= 0 && x[order[j]] < x[o]) { order[j + 1] = order[j]; j--; }
-                order[j + 1] = o;
-            }
-            for (int p = 0; p < 4; p++) {
-                int b = order[p];
+            /* every (cell, observed base) pair owns one stream: the four bases of a
+             * cell are independent work items and may be processed in any order */
+            for (int b = 0; b < 4; b++) {
                 int64_t nb = x[b];
                 if (nb <= 0) continue;
+                uint32_t ctr[4] = { (uint32_t)cell, (uint32_t)(cell >> 32), iter, ORC_STREAM_STATS + (uint32_t)b };
+                orc_xo rng;
+                orc_philox4x32_10(ctr, key, rng.s);
+                if ((rng.s[0] | rng.s[1] | rng.s[2] | rng.s[3]) == 0) rng.s[0] = 1;
                 double c = 0.0, cum[64];
                 for (int g = 0; g < G; g++) { c += gamma[(size_t)s * G + g] * eta[tv[g] * 4 + b]; cum[g] = c; }
                 double scale = 4294967296.0 / c;

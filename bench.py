@@ -111,6 +111,16 @@ def main():
         n_done, tr = ctx.nmft_factorize(max_iter=n_nm, min_change=0.0)
         t_nm = time.perf_counter() - t0
         nmft = dict(iters=n_done, ms_per_iter=1e3 * t_nm / max(n_done, 1), div_last=float(tr[-1]))
+        ctx.set_timing(True)
+        ctx.nmft_factorize(max_iter=50, min_change=0.0)
+        tmn = ctx.get_timing()
+        ctx.set_timing(False)
+        nmft["kernels_us"] = {k: 1e3 * ms / max(n, 1) for k, (ms, n) in tmn.items() if n and k.startswith("nmft")}
+        # algorithmic bytes per NMFT update: two passes over f64 F + four over tau
+        nmft["algorithmic_bytes_per_iter"] = 2 * 4 * V * S * 8 + 4 * 4 * V * G * 8
+        nmft["achieved_GBps"] = nmft["algorithmic_bytes_per_iter"] / (nmft["ms_per_iter"] * 1e-3) / 1e9
+        ctx.nmft_set(tau0, gam0)
+        ctx.nmft_factorize(max_iter=n_nm, min_change=0.0)
     tau_init = ctx.nmft_get_tau()
     _, gam = ctx.nmft_get()
     eta0 = 0.96 * np.eye(4) + 0.01

@@ -13,6 +13,7 @@
 //             per-(v,g) renormalisation over the four bases (:170-181), _adjustment (:88-91)
 #include "dsm_device.h"
 #include "dsm_host.h"
+#include "log_table.h"
 
 #define NMFT_CTL(c) ((c)->nstat + (size_t)(c)->nG * (c)->S + 2 * (c)->nG)
 
@@ -40,26 +41,35 @@ __global__ void clamp_min_kernel(double *__restrict__ x, size_t n, double lo)
 }
 
 // ---------------------------------------------------------------------------
-// pass A.  thread = (row group, sample); SPAD lanes per row; a row group walks
-// rows n = (v,a) with a grid stride.  Per-lane accumulators: G numerators for
-// its sample, the objective, H1.  Partials layout per workgroup:
-//   [G*S numerators][G H1][1 objective]
+// pass A.  1024-thread workgroups (16 wavefronts, 4 per SIMD: the pass is
+// latency-bound, not ALU-bound); thread = (row group, sample), SPAD lanes per
+// row; a row group walks rows n = (v,a) with a grid stride.  The tau row of
+// the wavefront's current n is wave-uniform: it is fetched through scalar
+// loads (readfirstlane'd row index).  Per-lane accumulators: G numerators for
+// its sample, the objective, H1.  Partials are written TRANSPOSED,
+// partial[out][workgroup], out in [G*S numerators][G H1][1 objective], so the
+// reduction kernel reads them coalesced.
 // ---------------------------------------------------------------------------
-template <int GMAX>
-__global__ __launch_bounds__(256) void nmft_pass_a_kernel(const double *__restrict__ F, const double *__restrict__ tau,
-                                                          const double *__restrict__ gam, int V, int S, int G,
-                                                          int SPAD, const double *__restrict__ ctl,
-                                                          double *__restrict__ partial)
+// (workgroup size shrinks with GMAX so that the per-lane accumulators stay in registers)
+template <int GMAX, int NMFT_A_THREADS>
+__global__ __launch_bounds__(NMFT_A_THREADS) void nmft_pass_a_kernel(const double *__restrict__ F,
+                                                                     const double *__restrict__ tau,
+                                                                     const double *__restrict__ gam, int V, int S, int G,
+                                                                     int SPAD, const double *__restrict__ ctl,
+                                                                     const double *__restrict__ log_tab,
+                                                                     double *__restrict__ partial)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_a[];
     if (ctl[2] != 0.0) return;                         // factorize loop already stopped
-    double *red = reinterpret_cast<double *>(smem_a);  // [RG][GMAX + 2][SPAD]
+    double2 *ltab = reinterpret_cast<double2 *>(smem_a);                    // [128]
+    double *red = reinterpret_cast<double *>(smem_a) + 2 * DSM_LOG_TAB_N;   // [RG][GMAX + 2][SPAD]
     const int tid = threadIdx.x;
-    const int RG = 256 / SPAD;
+    if (tid < DSM_LOG_TAB_N) ltab[tid] = reinterpret_cast<const double2 *>(log_tab)[tid];
+    __syncthreads();
+    const int RG = NMFT_A_THREADS / SPAD;
     const int rg = tid / SPAD, sl = tid % SPAD;
     const size_t N = (size_t)4 * V;
-    const size_t pstride = (size_t)G * S + G + 1;
-    double *mypart = partial + (size_t)blockIdx.x * pstride;
+    const int nblk = gridDim.x;
     double obj = 0.0;
     double h1[GMAX];
 #pragma unroll
@@ -71,8 +81,9 @@ __global__ __launch_bounds__(256) void nmft_pass_a_kernel(const double *__restri
         double gc[GMAX], num[GMAX];
 #pragma unroll
         for (int g = 0; g < GMAX; ++g) { gc[g] = (live && g < G) ? gam[(size_t)g * S + s] : 0.0; num[g] = 0.0; }
-        for (size_t n = (size_t)blockIdx.x * RG + rg; n < N; n += (size_t)gridDim.x * RG) {
-            const double *trow = tau + n * G;
+        for (size_t n = (size_t)blockIdx.x * RG + rg; n < N; n += (size_t)nblk * RG) {
+            // rows are wave-uniform whenever a row spans >= 64 lanes: scalar-load the tau row
+            const double *trow = tau + ((SPAD >= 64) ? (size_t)__builtin_amdgcn_readfirstlane((int)n) : n) * G;
             double tv[GMAX];
             double r = 0.0;
 #pragma unroll
@@ -87,7 +98,7 @@ __global__ __launch_bounds__(256) void nmft_pass_a_kernel(const double *__restri
             if (live) {
                 const double f = F[n * S + s];
                 const double pa = r < DSM_EPS ? DSM_EPS : r;
-                obj += f * log(nzd(f) / pa) - f + pa;
+                obj += f * dsm_log(nzd(f) / pa, ltab) - f + pa;
                 const double q = nzd(f) / nzd(r);
 #pragma unroll
                 for (int g = 0; g < GMAX; ++g) num[g] = fma(tv[g], q, num[g]);
@@ -97,11 +108,12 @@ __global__ __launch_bounds__(256) void nmft_pass_a_kernel(const double *__restri
 #pragma unroll
         for (int g = 0; g < GMAX; ++g) red[((size_t)rg * (GMAX + 2) + g) * SPAD + sl] = num[g];
         __syncthreads();
-        if (rg == 0 && live) {
-            for (int g = 0; g < G; ++g) {
+        for (int i = tid; i < G * SPAD; i += NMFT_A_THREADS) {
+            const int g = i / SPAD, ss = i % SPAD;
+            if (s0 + ss < S) {
                 double a = 0.0;
-                for (int k = 0; k < RG; ++k) a += red[((size_t)k * (GMAX + 2) + g) * SPAD + sl];
-                mypart[(size_t)g * S + s] = a;
+                for (int k = 0; k < RG; ++k) a += red[((size_t)k * (GMAX + 2) + g) * SPAD + ss];
+                partial[((size_t)g * S + s0 + ss) * nblk + blockIdx.x] = a;
             }
         }
         __syncthreads();
@@ -110,87 +122,75 @@ __global__ __launch_bounds__(256) void nmft_pass_a_kernel(const double *__restri
     red[((size_t)rg * (GMAX + 2) + GMAX) * SPAD + sl] = obj;
     if (sl == 0) {
 #pragma unroll
-        for (int g = 0; g < GMAX; ++g) red[((size_t)rg * (GMAX + 2) + GMAX + 1) * SPAD + g] = h1[g];   // SPAD >= 16 >= ... see launcher
+        for (int g = 0; g < GMAX; ++g) red[((size_t)rg * (GMAX + 2) + GMAX + 1) * SPAD + g] = h1[g];   // SPAD >= 32 >= GMAX
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < 64) {                                    // one wavefront: fixed-order butterfly over RG*SPAD terms
         double a = 0.0;
-        for (int k = 0; k < RG; ++k)
-            for (int j = 0; j < SPAD; ++j) a += red[((size_t)k * (GMAX + 2) + GMAX) * SPAD + j];
-        mypart[(size_t)G * S + G] = a;
-    }
-    if (tid < G) {
+        for (int i = tid; i < RG * SPAD; i += 64) a += red[((size_t)(i / SPAD) * (GMAX + 2) + GMAX) * SPAD + (i % SPAD)];
+        a = group_allreduce_sum<64>(a);
+        if (tid == 0) partial[((size_t)G * S + G) * nblk + blockIdx.x] = a;
+    } else if (tid < 64 + G) {
+        const int g = tid - 64;
         double a = 0.0;
-        for (int k = 0; k < RG; ++k) a += red[((size_t)k * (GMAX + 2) + GMAX + 1) * SPAD + tid];
-        mypart[(size_t)G * S + tid] = a;
+        for (int k = 0; k < RG; ++k) a += red[((size_t)k * (GMAX + 2) + GMAX + 1) * SPAD + g];
+        partial[((size_t)G * S + g) * nblk + blockIdx.x] = a;
     }
 }
 
 // ---------------------------------------------------------------------------
-// gamma / control kernel.  Workgroup j owns samples [j*SB, (j+1)*SB); every
-// workgroup re-derives the (identical) loop decision from the same partials,
-// workgroup 0 records it.  ctl: [0] div  [2] done  [3] updates run
-// [4 + (it&1)] div of iteration it (parity slots: no intra-launch race).
+// reduction of the transposed partials: one wavefront per output, coalesced
+// reads, fixed-order butterfly -> stat[out].
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nmft_gamma_kernel(const double *__restrict__ partial, int nblk, int S, int G,
-                                                         int it, int max_iter, double min_change, int fix_gamma,
-                                                         int adjust, double *__restrict__ gam, double *__restrict__ ctl)
+__global__ __launch_bounds__(256) void nmft_reduce_kernel(const double *__restrict__ partial, int nblk, int nout,
+                                                          const double *__restrict__ ctl, double *__restrict__ stat)
 {
-    __shared__ double red[256];
-    __shared__ double h1s[DSM_MAX_G];
-    __shared__ double gnew[256];
+    if (ctl[2] != 0.0) return;
+    const int out = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (out >= nout) return;
+    double a = 0.0;
+    for (int b = lane; b < nblk; b += 64) a += partial[(size_t)out * nblk + b];
+    a = group_allreduce_sum<64>(a);
+    if (lane == 0) stat[out] = a;
+}
+
+// ---------------------------------------------------------------------------
+// gamma / control kernel (one workgroup): the stop test of the factorize loop
+// (Init_NMFT.py:106) on the device, then the gamma update (:163-168).
+// ctl: [0] div  [2] done  [3] updates run  [4 + (it&1)] div of iteration it.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nmft_gamma_kernel(const double *__restrict__ stat, int S, int G, int it,
+                                                         int max_iter, double min_change, int fix_gamma, int adjust,
+                                                         double *__restrict__ gam, double *__restrict__ ctl)
+{
     __shared__ int go;
     if (ctl[2] != 0.0) return;
     const int tid = threadIdx.x;
-    const size_t pstride = (size_t)G * S + G + 1;
-    // objective: fixed-order tree over the workgroup partials
-    double a = 0.0;
-    for (int b = tid; b < nblk; b += 256) a += partial[(size_t)b * pstride + (size_t)G * S + G];
-    red[tid] = a;
-    __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    const double div = red[0];
-    if (tid < G) {
-        double h = 0.0;
-        for (int b = 0; b < nblk; ++b) h += partial[(size_t)b * pstride + (size_t)G * S + tid];
-        h1s[tid] = h;
-    }
     if (tid == 0) {
+        const double div = stat[(size_t)G * S + G];
         const double prev = (it == 0) ? 0.0 : ctl[4 + ((it - 1) & 1)];
         go = (it < max_iter) && (fabs(prev - div) > min_change);         // Init_NMFT.py:106
-        if (blockIdx.x == 0) {
-            ctl[0] = div;
-            ctl[4 + (it & 1)] = div;
-            ctl[3] = (double)it;
-            if (!go) ctl[2] = 1.0;
-        }
+        ctl[0] = div;
+        ctl[4 + (it & 1)] = div;
+        ctl[3] = (double)it;
+        if (!go) ctl[2] = 1.0;
     }
     __syncthreads();
     if (!go || fix_gamma) return;
-    // gamma update for this workgroup's samples: thread = (s_local, g), g fastest
-    const int SB = 256 / DSM_MAX_G;
-    const int sloc = tid / DSM_MAX_G, g = tid % DSM_MAX_G;
-    const int s = blockIdx.x * SB + sloc;
-    double val = 0.0;
-    if (s < S && g < G) {
-        if (G > 1) {
-            double num = 0.0;
-            for (int b = 0; b < nblk; ++b) num += partial[(size_t)b * pstride + (size_t)g * S + s];
-            val = gam[(size_t)g * S + s] * (nzd(num) / nzd(h1s[g]));       // :163
-        } else {
-            val = 1.0;                                                   // :168
+    for (int s = tid; s < S; s += 256) {                                 // one thread per sample column
+        double tot = 0.0;
+        double col[DSM_MAX_G];
+        for (int g = 0; g < G; ++g) {
+            double val = 1.0;                                            // :168
+            if (G > 1) val = gam[(size_t)g * S + s] * (nzd(stat[(size_t)g * S + s]) / nzd(stat[(size_t)G * S + g]));   // :163
+            col[g] = val;
+            tot += val;                                                  // :165
         }
-    }
-    gnew[tid] = val;
-    __syncthreads();
-    if (s < S && g < G) {
-        if (G > 1) {
-            double tot = 0.0;
-            for (int k = 0; k < G; ++k) tot += gnew[sloc * DSM_MAX_G + k];   // :165
-            val = val / tot;                                                 // :166
+        for (int g = 0; g < G; ++g) {
+            double val = (G > 1) ? col[g] / tot : 1.0;                   // :166
+            if (adjust && val < DSM_EPS) val = DSM_EPS;                  // :91
+            gam[(size_t)g * S + s] = val;
         }
-        if (adjust && val < DSM_EPS) val = DSM_EPS;                          // :91
-        gam[(size_t)g * S + s] = val;
     }
 }
 
@@ -283,8 +283,8 @@ __global__ void nmft_get_tau_kernel(const double *__restrict__ tau, int V, int G
 int nmft_grid(dsm_ctx *c)
 {
     const size_t N = (size_t)4 * c->V;
-    size_t g = (N + 31) / 32;
-    if (g > 256) g = 256;
+    size_t g = (N + 63) / 64;                 // at least a few rows per row group
+    if (g > 512) g = 512;                     // ~2 workgroups per CU
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -317,14 +317,14 @@ int k_nmft_pass_a(dsm_ctx *c)
 {
     KTimer tm(c, DSM_K_NMFT_A);
     const int G = c->nG, S = c->S, SPAD = spad_for(S);
-#define LAUNCH_A(GM)                                                                                              \
-    hipLaunchKernelGGL(nmft_pass_a_kernel<GM>, dim3(c->nmft_blocks), dim3(256),                                   \
-                       (size_t)(256 / SPAD) * (GM + 2) * SPAD * sizeof(double), c->stream, c->F, c->ntau, c->ngam, \
-                       c->V, S, G, SPAD, NMFT_CTL(c), c->npart)
-    if (G <= 4) LAUNCH_A(4);
-    else if (G <= 8) LAUNCH_A(8);
-    else if (G <= 16) LAUNCH_A(16);
-    else LAUNCH_A(32);
+#define LAUNCH_A(GM, TH)                                                                                          \
+    hipLaunchKernelGGL((nmft_pass_a_kernel<GM, TH>), dim3(c->nmft_blocks), dim3(TH),                              \
+                       ((size_t)(TH / SPAD) * (GM + 2) * SPAD + 2 * DSM_LOG_TAB_N) * sizeof(double), c->stream,   \
+                       c->F, c->ntau, c->ngam, c->V, S, G, SPAD, NMFT_CTL(c), c->log_tab, c->npart)
+    if (G <= 4) LAUNCH_A(4, 1024);
+    else if (G <= 8) LAUNCH_A(8, 512);
+    else if (G <= 16) LAUNCH_A(16, 512);
+    else LAUNCH_A(32, 256);
 #undef LAUNCH_A
     HIP_TRY(hipGetLastError());
     return DSM_OK;
@@ -333,10 +333,11 @@ int k_nmft_pass_a(dsm_ctx *c)
 int k_nmft_gamma(dsm_ctx *c, int it, int max_iter, double min_change, int fix_gamma, int adjust)
 {
     KTimer tm(c, DSM_K_NMFT_G);
-    const int SB = 256 / DSM_MAX_G;
-    const int grid = (c->S + SB - 1) / SB;
-    hipLaunchKernelGGL(nmft_gamma_kernel, dim3(grid), dim3(256), 0, c->stream, c->npart, c->nmft_blocks, c->S, c->nG,
-                       it, max_iter, min_change, fix_gamma, adjust, c->ngam, NMFT_CTL(c));
+    const int nout = c->nG * c->S + c->nG + 1;
+    hipLaunchKernelGGL(nmft_reduce_kernel, dim3((nout + 3) / 4), dim3(256), 0, c->stream, c->npart, c->nmft_blocks, nout,
+                       NMFT_CTL(c), c->nstat);
+    hipLaunchKernelGGL(nmft_gamma_kernel, dim3(1), dim3(256), 0, c->stream, c->nstat, c->S, c->nG, it, max_iter,
+                       min_change, fix_gamma, adjust, c->ngam, NMFT_CTL(c));
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }
@@ -346,7 +347,7 @@ int k_nmft_pass_b(dsm_ctx *c, int adjust)
     KTimer tm(c, DSM_K_NMFT_B);
     const int G = c->nG, S = c->S, SP = S + 1;
     int VT = 8192 / (4 * SP);
-    if (VT > 16) VT = 16;
+    if (VT > 8) VT = 8;
     if (VT < 1) VT = 1;
     const size_t sh = ((size_t)G * SP + G + 2 * (size_t)4 * VT * G + (size_t)4 * VT * SP) * sizeof(double);
     if (sh > 160 * 1024) { dsm_set_error("NMFT tile (%zu B) exceeds LDS", sh); return DSM_ERR_UNSUPPORTED; }

@@ -736,6 +736,7 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     TRY(dev_alloc(&d_trace, (size_t)max_iter + 1));
     HIP_TRY(hipMemsetAsync(ctl, 0, 16 * sizeof(double), c->stream));
     const int adjust = fix_gamma ? 0 : 1;
+    c->ndiv_trace = d_trace;
     // factorize applies _adjustment once before the first objective (Init_NMFT.py:102)
     if (adjust) TRY(k_nmft_clamp(c));
     const int BATCH = 64;
@@ -747,8 +748,7 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
             // pass A on the current state gives div_it and the gamma numerators; the control
             // kernel decides (on device) whether update `it` runs at all.
             TRY(k_nmft_pass_a(c));
-            TRY(k_nmft_gamma(c, it, max_iter, min_change, fix_gamma, adjust));
-            HIP_TRY(hipMemcpyAsync(d_trace + it, ctl, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            TRY(k_nmft_gamma(c, it, max_iter, min_change, fix_gamma, adjust));      // also records div_trace[it]
             if (it < max_iter) TRY(k_nmft_pass_b(c, adjust));
         }
         HIP_TRY(hipMemcpyAsync(h, ctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -761,6 +761,7 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
         HIP_TRY(hipMemcpyAsync(div_trace, d_trace, ((size_t)done + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    c->ndiv_trace = nullptr;
     dev_free(&d_trace);
     return DSM_OK;
 }

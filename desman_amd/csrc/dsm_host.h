@@ -84,6 +84,7 @@ struct dsm_ctx {
     double *ngam = nullptr;         // [G][S]
     double *npart = nullptr;        // per-block partials
     double *nstat = nullptr;        // reduced statistics + control words
+    double *ndiv_trace = nullptr;   // objective after every update of the running factorize (or null)
     int nG = 0;
     int nmft_blocks = 0;
     // timing

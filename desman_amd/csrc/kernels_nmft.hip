@@ -81,27 +81,36 @@ __global__ __launch_bounds__(NMFT_A_THREADS) void nmft_pass_a_kernel(const doubl
         double gc[GMAX], num[GMAX];
 #pragma unroll
         for (int g = 0; g < GMAX; ++g) { gc[g] = (live && g < G) ? gam[(size_t)g * S + s] : 0.0; num[g] = 0.0; }
-        for (size_t n = (size_t)blockIdx.x * RG + rg; n < N; n += (size_t)nblk * RG) {
-            // rows are wave-uniform whenever a row spans >= 64 lanes: scalar-load the tau row
-            const double *trow = tau + ((SPAD >= 64) ? (size_t)__builtin_amdgcn_readfirstlane((int)n) : n) * G;
-            double tv[GMAX];
-            double r = 0.0;
+        // a row group takes the 4 rows of one variant per step: the 4 F loads (and the 4 scalar
+        // tau-row loads) are independent and issued together -> 4x the memory-level parallelism
+        for (size_t nb = ((size_t)blockIdx.x * RG + rg) * 4; nb < N; nb += (size_t)nblk * RG * 4) {
+            double f[4];
+            double tv[4][GMAX];
 #pragma unroll
-            for (int g = 0; g < GMAX; ++g) {
-                tv[g] = (g < G) ? trow[g] : 0.0;
-                r = fma(tv[g], gc[g], r);
+            for (int u = 0; u < 4; ++u) {
+                const size_t n = nb + u;
+                // rows are wave-uniform whenever a row spans >= 64 lanes: scalar-load the tau row
+                const double *trow = tau + ((SPAD >= 64) ? (size_t)__builtin_amdgcn_readfirstlane((int)n) : n) * G;
+#pragma unroll
+                for (int g = 0; g < GMAX; ++g) tv[u][g] = (g < G) ? trow[g] : 0.0;
+                f[u] = live ? F[n * S + s] : 1.0;
             }
-            if (s0 == 0) {
 #pragma unroll
-                for (int g = 0; g < GMAX; ++g) h1[g] += tv[g];
-            }
-            if (live) {
-                const double f = F[n * S + s];
-                const double pa = r < DSM_EPS ? DSM_EPS : r;
-                obj += f * dsm_log(nzd(f) / pa, ltab) - f + pa;
-                const double q = nzd(f) / nzd(r);
+            for (int u = 0; u < 4; ++u) {
+                double r = 0.0;
 #pragma unroll
-                for (int g = 0; g < GMAX; ++g) num[g] = fma(tv[g], q, num[g]);
+                for (int g = 0; g < GMAX; ++g) r = fma(tv[u][g], gc[g], r);
+                if (s0 == 0) {
+#pragma unroll
+                    for (int g = 0; g < GMAX; ++g) h1[g] += tv[u][g];
+                }
+                if (live) {
+                    const double pa = r < DSM_EPS ? DSM_EPS : r;
+                    obj += f[u] * dsm_log(nzd(f[u]) / pa, ltab) - f[u] + pa;
+                    const double q = nzd(f[u]) / nzd(r);
+#pragma unroll
+                    for (int g = 0; g < GMAX; ++g) num[g] = fma(tv[u][g], q, num[g]);
+                }
             }
         }
         // cross-row-group reduction (fixed order) -> partial numerators of this chunk
@@ -159,10 +168,13 @@ __global__ __launch_bounds__(256) void nmft_reduce_kernel(const double *__restri
 // (Init_NMFT.py:106) on the device, then the gamma update (:163-168).
 // ctl: [0] div  [2] done  [3] updates run  [4 + (it&1)] div of iteration it.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nmft_gamma_kernel(const double *__restrict__ stat, int S, int G, int it,
-                                                         int max_iter, double min_change, int fix_gamma, int adjust,
-                                                         double *__restrict__ gam, double *__restrict__ ctl)
+__global__ __launch_bounds__(1024) void nmft_gamma_kernel(const double *__restrict__ stat, int S, int G, int it,
+                                                          int max_iter, double min_change, int fix_gamma, int adjust,
+                                                          double *__restrict__ gam, double *__restrict__ ctl,
+                                                          double *__restrict__ div_trace)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem_g[];
+    double *val = reinterpret_cast<double *>(smem_g);          // [G][SC] one chunk of sample columns
     __shared__ int go;
     if (ctl[2] != 0.0) return;
     const int tid = threadIdx.x;
@@ -174,23 +186,28 @@ __global__ __launch_bounds__(256) void nmft_gamma_kernel(const double *__restric
         ctl[4 + (it & 1)] = div;
         ctl[3] = (double)it;
         if (!go) ctl[2] = 1.0;
+        if (div_trace) div_trace[it] = div;
     }
     __syncthreads();
     if (!go || fix_gamma) return;
-    for (int s = tid; s < S; s += 256) {                                 // one thread per sample column
-        double tot = 0.0;
-        double col[DSM_MAX_G];
-        for (int g = 0; g < G; ++g) {
-            double val = 1.0;                                            // :168
-            if (G > 1) val = gam[(size_t)g * S + s] * (nzd(stat[(size_t)g * S + s]) / nzd(stat[(size_t)G * S + g]));   // :163
-            col[g] = val;
-            tot += val;                                                  // :165
+    const int SC = 1024 / G;                                             // sample columns per chunk
+    for (int s0 = 0; s0 < S; s0 += SC) {
+        const int g = tid / SC, s = s0 + tid % SC;
+        const bool live = g < G && s < S;
+        double v = 1.0;                                                  // :168
+        if (live && G > 1) v = gam[(size_t)g * S + s] * (nzd(stat[(size_t)g * S + s]) / nzd(stat[(size_t)G * S + g]));   // :163
+        if (g < G) val[g * SC + tid % SC] = v;
+        __syncthreads();
+        if (live) {
+            if (G > 1) {
+                double tot = 0.0;
+                for (int k = 0; k < G; ++k) tot += val[k * SC + tid % SC];   // :165
+                v = v / tot;                                                 // :166
+            }
+            if (adjust && v < DSM_EPS) v = DSM_EPS;                          // :91
+            gam[(size_t)g * S + s] = v;
         }
-        for (int g = 0; g < G; ++g) {
-            double val = (G > 1) ? col[g] / tot : 1.0;                   // :166
-            if (adjust && val < DSM_EPS) val = DSM_EPS;                  // :91
-            gam[(size_t)g * S + s] = val;
-        }
+        __syncthreads();
     }
 }
 
@@ -336,8 +353,8 @@ int k_nmft_gamma(dsm_ctx *c, int it, int max_iter, double min_change, int fix_ga
     const int nout = c->nG * c->S + c->nG + 1;
     hipLaunchKernelGGL(nmft_reduce_kernel, dim3((nout + 3) / 4), dim3(256), 0, c->stream, c->npart, c->nmft_blocks, nout,
                        NMFT_CTL(c), c->nstat);
-    hipLaunchKernelGGL(nmft_gamma_kernel, dim3(1), dim3(256), 0, c->stream, c->nstat, c->S, c->nG, it, max_iter,
-                       min_change, fix_gamma, adjust, c->ngam, NMFT_CTL(c));
+    hipLaunchKernelGGL(nmft_gamma_kernel, dim3(1), dim3(1024), (size_t)1024 * sizeof(double), c->stream, c->nstat, c->S,
+                       c->nG, it, max_iter, min_change, fix_gamma, adjust, c->ngam, NMFT_CTL(c), c->ndiv_trace);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }

@@ -79,33 +79,26 @@ def run_chains(specs, run_fn, dist=None, device=None):
     return [dict(zip(REC_FIELDS, r.tolist())) for r in rows]
 
 
-def gibbs_chain_runner(counts, n_iter, device, out_stub=None, variants_frame=None):
-    """run_fn for real chains on one GPU: NMFT init + burn-in + removeDegenerate + sampling,
-    i.e. the numeric path of bin/desman:129-153 for (G, seed)."""
-    from . import sampletau
-    from .HaploSNP_Sampler import HaploSNP_Sampler
-    from .Init_NMFT import Init_NMFT
+def gibbs_chain_runner(variant_file, n_iter, device, out_stub, extra_args=()):
+    """run_fn for real chains on one GPU: the whole `desman` run for (G, seed) -- NMFT init,
+    burn-in, removeDegenerate, sampling, all output files -- into `<stub>_<G>_<seed>/`, the
+    directory layout scripts/runDesman.sh:15-21 produces and scripts/resolvenhap.py reads."""
+    import logging
+
+    from . import cli
 
     def run(spec):
         t0 = time.perf_counter()
         G, seed = spec["G"], spec["seed"]
-        prng = np.random.RandomState(seed)
-        sampletau.initRNG(); sampletau.setRNG(seed)
-        nm = Init_NMFT(counts, G, prng, device=device)
-        nm.factorize()
-        smp = HaploSNP_Sampler(counts, G, prng, max_iter=n_iter, device=device)
-        smp.tau = nm.get_tau(); smp.gamma = np.copy(nm.get_gamma(), order='C')
-        smp.update(); smp.removeDegenerate(); smp.update()
-        sampletau.freeRNG()
-        if out_stub is not None:
-            d = "%s_%d_%d" % (out_stub, G, seed)
-            os.makedirs(d, exist_ok=True)
-            with open(os.path.join(d, "fit.txt"), "w") as f:
-                f.write("Fit,%d,%d,%f,%f\n" % (G, smp.G, smp.lp_star, smp.meanDeviance()))
-            np.savetxt(os.path.join(d, "Gamma_star.csv"), smp.gamma_star, delimiter=",")
-            np.save(os.path.join(d, "tau_star_idx.npy"), np.argmax(smp.tau_star, axis=2).astype(np.uint8))
-        return dict(G=G, seed=seed, G_final=smp.G, lp_star=smp.lp_star, mean_dev=smp.meanDeviance(),
-                    iters=2 * n_iter, wall_s=time.perf_counter() - t0)
+        d = "%s_%d_%d" % (out_stub, G, seed)
+        for h in list(logging.root.handlers):            # one log_file.txt per chain, as one process per chain has
+            logging.root.removeHandler(h)
+            h.close()
+        cli.main([variant_file, "-g", str(G), "-s", str(seed), "-i", str(n_iter), "-o", d, "--device", str(device)]
+                 + list(extra_args))
+        _, gt, ht, lp, dev = open(os.path.join(d, "fit.txt")).read().strip().split(",")
+        return dict(G=G, seed=seed, G_final=int(ht), lp_star=float(lp), mean_dev=float(dev), iters=2 * n_iter,
+                    wall_s=time.perf_counter() - t0)
     return run
 
 
@@ -126,28 +119,29 @@ def main(argv=None):
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("-i", "--no_iter", type=int, default=100)
     ap.add_argument("-m", "--min_coverage", type=float, default=5.0)
+    ap.add_argument("-r", "--random_select", type=int, default=None)
     ap.add_argument("-o", "--output_stub", default="sweep")
     args = ap.parse_args(argv)
     import pandas as p
     import torch
-    from .Variant_Filter import Variant_Filter
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if "RANK" in os.environ:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     frame = p.read_csv(args.variant_file, header=0, index_col=0)
-    flt = Variant_Filter(frame, randomState=np.random.RandomState(238329), threshold=None,
-                         min_coverage=args.min_coverage)
-    counts = np.ascontiguousarray(flt.snps_filter, dtype=np.int64)
-    specs = sweep_specs(range(args.gmin, args.gmax + 1), args.reps, flt.V, flt.S)
-    recs = run_chains(specs, gibbs_chain_runner(counts, args.no_iter, local, args.output_stub), dist,
-                      device=torch.device("cuda", local) if world > 1 else None)
+    V, S = frame.shape[0], (frame.shape[1] - 1) // 4
+    specs = sweep_specs(range(args.gmin, args.gmax + 1), args.reps, V, S)
+    extra = ["-m", str(args.min_coverage)] + (["-r", str(args.random_select)] if args.random_select else [])
+    recs = run_chains(specs, gibbs_chain_runner(args.variant_file, args.no_iter, local, args.output_stub, extra), dist,
+                      device=torch.device("cuda", local) if dist is not None else None)
     if dist is None or dist.get_rank() == 0:
         write_dev_csv(args.output_stub + "_Dev.csv", recs)
         print(json.dumps(recs))
+        from . import resolvenhap                      # f2: posterior-deviance model selection over the sweep
+        resolvenhap.resolve(args.output_stub)
     if dist is not None:
         dist.destroy_process_group()
 

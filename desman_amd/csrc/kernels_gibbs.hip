@@ -492,7 +492,9 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                     ex[a] = (d == 0.0) ? 1.0 : (d < -750.0) ? 0.0 : exp(d);
                     sum += ex[a];
                 }
-                const double c0 = ex[0] / sum, c1 = ex[1] / sum + c0, c2 = ex[2] / sum + c1;
+                // inverse CDF without the three fp64 divisions: u < ex0/sum  <=>  u*sum < ex0 (sum in [1,4]);
+                // the two forms can disagree only if u lies within ~1e-16 (relative) of a CDF edge
+                const double c0 = ex[0], c1 = ex[1] + c0, c2 = ex[2] + c1;
                 double u;
                 const size_t ui = (size_t)v * G + g;
                 if (p.u_raw) {
@@ -502,7 +504,8 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                     philox4x32_10((uint32_t)ui, (uint32_t)(ui >> 32), p.iter, DSM_STREAM_TAUU, p.k0, p.k1, r);
                     u = (double)r[0] * 2.3283064365386963e-10;
                 }
-                const int tn = (u < c0) ? 0 : (u < c1) ? 1 : (u < c2) ? 2 : 3;
+                const double us = u * sum;
+                const int tn = (us < c0) ? 0 : (us < c1) ? 1 : (us < c2) ? 2 : 3;
                 l_cur = (tn == 0) ? l[0] : (tn == 1) ? l[1] : (tn == 2) ? l[2] : l[3];
                 nchg += (lig == 0) & (tn != told);
                 t = (t & ~(3ull << (2 * g))) | ((uint64_t)tn << (2 * g));

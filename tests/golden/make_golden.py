@@ -18,6 +18,7 @@ Import shims (environment only, nothing of the reference is modified):
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--cog]
 """
 import argparse
+import glob
 import os
 import sys
 import types
@@ -270,6 +271,82 @@ def gen_host_formats(out):
                         eta=eta, files=json.dumps(files), **rec)
 
 
+def build_sweep_tree(root, spec):
+    """materialise a `<stub>_<G>_<r>/` tree from arrays (shared by the generator and the test)."""
+    import pandas as p
+    stub = os.path.join(root, "sw")
+    V, S = int(spec["V"]), int(spec["S"])
+    pos = np.arange(V) * 3 + 1
+    idx = ["c%d" % (v // 7) for v in range(V)]
+    for key in [k for k in spec if k.startswith("fit_")]:
+        _, G, r = key.split("_")
+        G, r = int(G), int(r)
+        d = "%s_%d_%d" % (stub, G, r)
+        os.makedirs(d, exist_ok=True)
+        gt, ht, ll, pd = spec[key]
+        with open(os.path.join(d, "fit.txt"), "w") as f:
+            f.write("Fit,%d,%d,%f,%f\n" % (int(gt), int(ht), ll, pd))
+        tau = spec["tau_%d_%d" % (G, r)]
+        Gh = tau.shape[1]
+        for name, arr in (("Filtered_Tau_star", tau.reshape(V, Gh * 4)),
+                          ("Tau_Mean", spec["taum_%d_%d" % (G, r)].reshape(V, Gh * 4))):
+            df = p.DataFrame(arr, index=idx)
+            df['Position'] = pos
+            c = df.columns.tolist()
+            df[c[-1:] + c[:-1]].to_csv(os.path.join(d, name + ".csv"))
+        for name in ("Gamma_star", "Gamma_mean"):
+            p.DataFrame(spec["gam_%d_%d" % (G, r)], index=["S%d" % s for s in range(S)]).to_csv(os.path.join(d, name + ".csv"))
+    return stub
+
+
+def gen_resolvenhap(out):
+    """scripts/resolvenhap.py run (unmodified, via runpy) on synthetic sweep trees: stdout + the *R.csv it writes."""
+    import io
+    import json
+    import runpy
+    import tempfile
+    import contextlib
+    rng = np.random.default_rng(11)
+    cases = {}
+    for case, (gvals, reps, pdfun, drop) in enumerate([
+            (range(2, 7), 3, lambda G: 1000.0 * (0.5 ** min(G, 4)) + 3.0 * G, {(5, 1)}),
+            (range(2, 4), 2, lambda G: 500.0 / G, set()),
+            (range(1, 8), 4, lambda G: 900.0 - 100.0 * G, {(3, 0), (6, 2)})]):
+        V, S = 60, 6
+        spec = dict(V=V, S=S)
+        base = rng.integers(0, 4, size=(V, 8))
+        for G in gvals:
+            for r in range(reps):
+                ht = G - 1 if (G, r) in drop else G
+                idx = base[:, rng.permutation(G)[:ht]].copy()
+                flip = rng.random(idx.shape) < (0.02 + 0.08 * (G >= 5))
+                idx[flip] = rng.integers(0, 4, size=int(flip.sum()))
+                tau = np.zeros((V, ht, 4), dtype=np.int64)
+                np.put_along_axis(tau, idx[..., None], 1, axis=2)
+                spec["tau_%d_%d" % (G, r)] = tau
+                spec["taum_%d_%d" % (G, r)] = rng.dirichlet(np.ones(4), size=(V, ht))
+                spec["gam_%d_%d" % (G, r)] = rng.dirichlet(np.ones(ht) * 0.7, size=S)
+                spec["fit_%d_%d" % (G, r)] = np.array([G, ht, -5000.0 - G, pdfun(G) + rng.normal(0, 2.0)])
+        with tempfile.TemporaryDirectory() as d:
+            stub = build_sweep_tree(d, spec)
+            buf = io.StringIO()
+            argv = sys.argv
+            sys.argv = ["resolvenhap.py", stub]
+            try:
+                with contextlib.redirect_stdout(buf):
+                    runpy.run_path(os.path.join(REF, "scripts", "resolvenhap.py"), run_name="__main__")
+            finally:
+                sys.argv = argv
+            line = buf.getvalue().replace(d, "<ROOT>")
+            rfiles = {}
+            for f in sorted(glob.glob(os.path.join(d, "*", "*R.csv"))):
+                rfiles[os.path.relpath(f, d)] = open(f).read()
+        spec["stdout"] = line
+        spec["rfiles"] = json.dumps(rfiles)
+        cases[case] = spec
+        np.savez_compressed(os.path.join(out, "resolvenhap_%d.npz" % case), **spec)
+
+
 def gen_cog(inmft, hsnp, out):
     """Config 1 (COG0015, -g 5 -i 50, default seed): the reference CLI's numeric
     path run through the imported classes (minutes of CPU).  Records fit.txt's
@@ -323,6 +400,7 @@ def main():
         gen_gibbs_pieces(hsnp, HERE)
         gen_nmft(inmft, HERE)
         gen_host_formats(HERE)
+        gen_resolvenhap(HERE)
     if args.cog or args.only_cog:
         gen_cog(inmft, hsnp, HERE)
     print("golden fixtures written to", HERE)

@@ -156,3 +156,23 @@ def test_cli_random_select_path(tmp_path):
     assert (t.sum(axis=2) == 1).all()
     if Gf == G:
         assert _best_perm_err(np.argmax(t, axis=2), tau_true) < 0.05
+
+
+def test_gsweep_driver_and_model_selection(tmp_path, capsys):
+    """desman-sweep (chains.py) on one GPU: per-chain reference-format directories, Dev.csv, and the
+    resolvenhap heuristic picks the generating number of haplotypes on well-identified data."""
+    from desman_amd import chains
+    V, S, G = 160, 12, 3
+    counts, _, _ = synth_counts(V, S, G, seed=99)
+    freq = str(tmp_path / "syn.freq")
+    _write_freq(freq, counts)
+    stub = str(tmp_path / "sw")
+    chains.main([freq, "--gmin", "2", "--gmax", "5", "--reps", "3", "-i", "40", "-o", stub])
+    dev = open(stub + "_Dev.csv").read().strip().split("\n")
+    assert dev[0] == "H,G,LP,Dev" and len(dev) == 13
+    for g in range(2, 6):
+        for r in range(3):
+            assert os.path.exists("%s_%d_%d/Filtered_Tau_star.csv" % (stub, g, r))
+            assert os.path.exists("%s_%d_%d/log_file.txt" % (stub, g, r))
+    out = capsys.readouterr().out.strip().split("\n")[-1].split(",")
+    assert int(out[0]) >= G and int(out[1]) == G          # G strains are reproducible and abundant

@@ -26,6 +26,7 @@ _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 _vp, _i, _d = C.c_void_p, C.c_int, C.c_double
 
 # name -> (restype, argtypes); every symbol include/desman_hip.h declares
@@ -67,6 +68,7 @@ SIGNATURES = {
     "dsm_nmft_factorize": (_i, [_vp, _i, _d, _i, C.POINTER(_i), _vp]),
     "dsm_nmft_objective": (_i, [_vp, C.POINTER(_d)]),
     "dsm_nmft_get_tau": (_i, [_vp, _i64p]),
+    "dsm_lrt_step": (_i, [_i, _f64p, _i32p, _i32p, _f64p, _d, _i, _i, _f64p, _f64p, _f64p]),
     "dsm_ctx_set_timing": (_i, [_vp, _i]),
     "dsm_ctx_get_timing": (_i, [_vp, _vp, _vp]),
     "dsm_kernel_name": (C.c_char_p, [_i]),
@@ -106,6 +108,18 @@ def mt_seed_state(seed):
     st = np.empty(625, dtype=np.uint32)
     check(load().dsm_mt_seed_state(int(seed) & 0xFFFFFFFFFFFFFFFF, st))
     return st
+
+
+def lrt_step(ffreq, maxA, maxB, eta, upperP, optimise, p, device=0):
+    """one inner step of the likelihood-ratio variant filter on the GPU -> (p, MLL, BLL)."""
+    ffreq = np.ascontiguousarray(ffreq, dtype=np.float64)
+    V = ffreq.shape[0]
+    p = np.ascontiguousarray(p, dtype=np.float64).copy()
+    MLL = np.empty(V); BLL = np.empty(V)
+    check(load().dsm_lrt_step(int(device), ffreq, np.ascontiguousarray(maxA, dtype=np.int32),
+                              np.ascontiguousarray(maxB, dtype=np.int32), np.ascontiguousarray(eta, dtype=np.float64),
+                              float(upperP), int(bool(optimise)), V, p, MLL, BLL))
+    return p, MLL, BLL
 
 
 def device_count():

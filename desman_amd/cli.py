@@ -67,8 +67,12 @@ def main(argv=None):
         sys.exit()
     logging.info('Running Desman with %d samples and %d variant positions finding %d genomes.'
                  % (variant_Filter.S, variant_Filter.V, genomes))
+    variant_Filter.device = args.device
     if args.filter_variants is not None:
-        variant_Filter.get_filtered_VariantsLogRatio()          # not on the accelerated path: raises
+        logging.info('Begun filtering variants with parameters: optimise probability = %s, lr threshold = %s, min. coverage = %s, q-value threshold = %s, min. variant frequency = %s'
+                     % (args.optimiseP, args.filter_variants, args.min_coverage, args.max_qvalue, args.min_variant_freq))
+        variant_Filter.get_filtered_VariantsLogRatio()          # row f3: lrt_kernel on the GPU
+        logging.info("Completed variant filtering")
     if args.eta_file is not None:
         logging.info('Set eta error transition matrix from = %s' % args.eta_file)
         variant_Filter.eta = p.read_csv(args.eta_file, header=0, index_col=0).to_numpy()

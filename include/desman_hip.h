@@ -152,6 +152,15 @@ int dsm_nmft_objective(dsm_ctx *ctx, double *div);
 /* get_tau (:230-245) -> one-hot [V][G][4] int64                              */
 int dsm_nmft_get_tau(dsm_ctx *ctx, int64_t *tau_onehot);
 
+/* f3 (upstream of the path): one inner step of Variant_Filter.get_filtered_VariantsLogRatio
+ * (desman/Variant_Filter.py:348-356) for all V positions: BLL, the bounded-Brent minimiser of
+ * mixNLL over p in (0, upperP) when `optimise` (scipy minimize_scalar(method='bounded')
+ * semantics), and MLL at p.  Host pointers: ffreq [V][4] f64, maxA/maxB [V] int32, eta [4][4],
+ * p_inout/MLL/BLL [V].                                                        */
+int dsm_lrt_step(int device, const double *ffreq, const int32_t *maxA, const int32_t *maxB,
+                 const double *eta, double upperP, int optimise, int V, double *p_inout,
+                 double *MLL, double *BLL);
+
 /* per-kernel HIP-event timing on the context's stream (bench/roofline).      */
 #define DSM_K_STATS    0
 #define DSM_K_DIRICH   1

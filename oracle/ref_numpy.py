@@ -253,3 +253,95 @@ def nmft_get_tau(tau, G):
         best = np.where(m, t3[a], best)
         arg = np.where(m, a, arg)
     return cbind.idx_to_onehot(arg)
+
+
+# --------------------------------------------------------------------------
+# Variant_Filter likelihood-ratio filter (row f3)
+# --------------------------------------------------------------------------
+def fminbound(func, x1, x2, xatol=1e-5, maxfun=500):
+    """Bounded Brent minimiser = scipy.optimize.minimize_scalar(method='bounded'), the third-party
+    routine the reference calls at Variant_Filter.py:353 (SciPy, unpinned; restated from
+    scipy/optimize/_optimize.py:_minimize_scalar_bounded and checked against the installed SciPy
+    in tests/test_oracle_golden.py).  Returns the abscissa of the minimum."""
+    sqrt_eps = math.sqrt(2.2e-16)
+    golden_mean = 0.5 * (3.0 - math.sqrt(5.0))
+    a, b = x1, x2
+    fulc = a + golden_mean * (b - a)
+    nfc, xf = fulc, fulc
+    rat = e = 0.0
+    x = xf
+    fx = func(x)
+    num = 1
+    ffulc = fnfc = fx
+    xm = 0.5 * (a + b)
+    tol1 = sqrt_eps * abs(xf) + xatol / 3.0
+    tol2 = 2.0 * tol1
+    sgn = lambda z: (1.0 if z > 0 else -1.0 if z < 0 else 0.0) + (1.0 if z == 0 else 0.0)   # noqa: E731
+    while abs(xf - xm) > (tol2 - 0.5 * (b - a)):
+        golden = True
+        if abs(e) > tol1:
+            golden = False
+            r = (xf - nfc) * (fx - ffulc)
+            q = (xf - fulc) * (fx - fnfc)
+            pp = (xf - fulc) * q - (xf - nfc) * r
+            q = 2.0 * (q - r)
+            if q > 0.0:
+                pp = -pp
+            q = abs(q)
+            r = e
+            e = rat
+            if abs(pp) < abs(0.5 * q * r) and pp > q * (a - xf) and pp < q * (b - xf):
+                rat = (pp + 0.0) / q
+                x = xf + rat
+                if (x - a) < tol2 or (b - x) < tol2:
+                    rat = tol1 * sgn(xm - xf)
+            else:
+                golden = True
+        if golden:
+            e = a - xf if xf >= xm else b - xf
+            rat = golden_mean * e
+        x = xf + sgn(rat) * max(abs(rat), tol1)
+        fu = func(x)
+        num += 1
+        if fu <= fx:
+            if x >= xf:
+                a = xf
+            else:
+                b = xf
+            fulc, ffulc = nfc, fnfc
+            nfc, fnfc = xf, fx
+            xf, fx = x, fu
+        else:
+            if x < xf:
+                a = x
+            else:
+                b = x
+            if fu <= fnfc or nfc == xf:
+                fulc, ffulc = nfc, fnfc
+                nfc, fnfc = x, fu
+            elif fu <= ffulc or fulc == xf or fulc == nfc:
+                fulc, ffulc = x, fu
+        xm = 0.5 * (a + b)
+        tol1 = sqrt_eps * abs(xf) + xatol / 3.0
+        tol2 = 2.0 * tol1
+        if num >= maxfun:
+            break
+    return xf
+
+
+def mix_nll(pm, eta, n, m, f):
+    """mixNLL (Variant_Filter.py:38-41)."""
+    return float(np.dot(f, -np.log(pm * eta[n, :] + (1 - pm) * eta[m, :])))
+
+
+def lrt_step(ffreq, maxA, maxB, eta, upperP, optimise, p):
+    """inner loop of get_filtered_VariantsLogRatio (Variant_Filter.py:348-356) -> (p, MLL, BLL)."""
+    V = ffreq.shape[0]
+    p = np.array(p, dtype=np.float64)
+    MLL = np.zeros(V)
+    BLL = -(np.log(eta[maxA, :]) * ffreq).sum(axis=1)
+    for v in range(V):
+        if optimise:
+            p[v] = fminbound(lambda x: mix_nll(x, eta, maxA[v], maxB[v], ffreq[v]), 0.0, upperP)
+        MLL[v] = mix_nll(p[v], eta, maxA[v], maxB[v], ffreq[v])
+    return p, MLL, BLL

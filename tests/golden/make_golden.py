@@ -347,6 +347,54 @@ def gen_resolvenhap(out):
         np.savez_compressed(os.path.join(out, "resolvenhap_%d.npz" % case), **spec)
 
 
+def lrt_frame(V=260, S=6, seed=5):
+    """a .freq-style frame with ~15 % two-allele positions (the rest: sequencing errors only)."""
+    import pandas as p
+    rng = np.random.default_rng(seed)
+    data = np.zeros((V, 1 + 4 * S), dtype=np.int64)
+    data[:, 0] = np.arange(V) * 11 + 2
+    for v in range(V):
+        major = rng.integers(0, 4)
+        pr = np.full(4, 0.004); pr[major] = 1 - 0.012
+        if rng.random() < 0.15:
+            minor = (major + 1 + rng.integers(0, 3)) % 4
+            fr = rng.uniform(0.03, 0.5)
+            pr[major] -= fr; pr[minor] += fr
+        for s in range(S):
+            depth = rng.integers(2, 9) if v % 37 == 0 else rng.integers(20, 120)
+            data[v, 1 + 4 * s:5 + 4 * s] = rng.multinomial(depth, pr / pr.sum())
+    cols = ["Position"] + ["S%d-%s" % (s, b) for s in range(S) for b in "ACGT"]
+    return p.DataFrame(data, index=["g%d" % (v // 20) for v in range(V)], columns=cols)
+
+
+def gen_variant_filter_lrt(out):
+    """get_filtered_VariantsLogRatio (Variant_Filter.py:320-390) on a synthetic frame, with and without
+    the per-position optimisation, plus the statistical core on the COG0015 base-count sums."""
+    import pandas as p
+    import desman.Variant_Filter as vf
+    frame = lrt_frame()
+    rec = dict(frame_values=frame.to_numpy(), frame_index=np.array(frame.index.tolist()),
+               frame_columns=np.array(frame.columns.tolist()))
+    for tag, opt in (("opt", True), ("noopt", False)):
+        f = vf.Variant_Filter(frame, randomState=np.random.RandomState(1), optimise=opt, threshold=3.84,
+                              min_coverage=5.0, qvalue_cutoff=1.0e-3)
+        f.get_filtered_VariantsLogRatio()
+        tm = f.calc_Error_Matrix()
+        df = f.selected_variants_todf(frame)
+        rec.update({tag + "_ratio": f.ratioNLL, tag + "_pvalue": f.pvalue, tag + "_qvalue": f.qvalue,
+                    tag + "_filtered": f.filtered, tag + "_eta": f.eta, tag + "_minV": f.minV, tag + "_tran": tm,
+                    tag + "_selected": f.selected, tag + "_snps": np.ascontiguousarray(f.snps_filter),
+                    tag + "_selvar_csv": df.to_csv()})
+    cog = p.read_csv(os.path.join(REF, "data", "contig_6or16_genesL_scgCOG0015.freq"), header=0, index_col=0)
+    f = vf.Variant_Filter(cog, randomState=np.random.RandomState(1), optimise=True, threshold=3.84,
+                          min_coverage=5.0, qvalue_cutoff=1.0e-3)
+    freq = f.freq.copy()
+    f.get_filtered_VariantsLogRatio()
+    rec.update(cog_freq=freq, cog_ratio=f.ratioNLL, cog_qvalue=f.qvalue, cog_filtered=f.filtered, cog_eta=f.eta,
+               cog_nsel=int(f.NS))
+    np.savez_compressed(os.path.join(out, "variant_filter_lrt.npz"), **rec)
+
+
 def gen_cog(inmft, hsnp, out):
     """Config 1 (COG0015, -g 5 -i 50, default seed): the reference CLI's numeric
     path run through the imported classes (minutes of CPU).  Records fit.txt's
@@ -401,6 +449,7 @@ def main():
         gen_nmft(inmft, HERE)
         gen_host_formats(HERE)
         gen_resolvenhap(HERE)
+        gen_variant_filter_lrt(HERE)
     if args.cog or args.only_cog:
         gen_cog(inmft, hsnp, HERE)
     print("golden fixtures written to", HERE)

@@ -1,0 +1,53 @@
+"""Parity at BASELINE.json's full sizes (configs[2]: V=10k, S=64, G=8; configs[4]: V=50k, S=96, G=12):
+the C oracle still finishes one tau sweep / one log-likelihood in seconds, so the integer outcome is
+compared exactly; the per-read pass is checked through its size-independent invariants."""
+import numpy as np
+import pytest
+
+from desman_amd import _lib
+from desman_amd.synth import synth_counts, random_state
+from oracle import cbind
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("V,S,G", [(10000, 64, 8), (50000, 96, 12)])
+def test_full_size_sweep_loglik_and_stats_invariants(V, S, G):
+    counts, _, _ = synth_counts(V, S, G, seed=1234)
+    tau, gamma, eta = random_state(V, S, G, seed=5)
+    ctx = _lib.Context(0)
+    ctx.set_counts(counts)
+    ctx.set_state(tau, gamma, eta)
+    ctx.seed(31337, ctr_seed=42)
+    # log-likelihood / log-posterior of the whole tensor
+    ll, lp = ctx.loglik()
+    idx = cbind.onehot_to_idx(tau)
+    assert ll == pytest.approx(cbind.loglik(idx, gamma, eta, counts), rel=1e-12)
+    assert lp == pytest.approx(cbind.logpost(idx, gamma, eta, counts), rel=1e-12)
+    # one full tau sweep: bit-identical haplotypes and change count
+    ref = tau.copy()
+    n_ref = cbind.sample_tau_u(ref, gamma, eta, counts, cbind.MT19937(31337).uniform(V * G))
+    n = ctx.sample_tau()
+    got, _, _ = ctx.get_state()
+    assert n == n_ref and np.array_equal(got, ref)
+    # per-read pass: every read is assigned exactly once, observed-base totals are preserved,
+    # identical (seed, iter) -> identical sums, different iter -> different sums
+    mu, E = ctx.sample_stats(3)
+    assert int(mu.sum()) == int(counts.sum())
+    assert np.array_equal(mu.sum(axis=1), counts.sum(axis=(0, 2)).astype(np.uint64))        # reads per sample
+    assert np.array_equal(E.sum(axis=1), counts.sum(axis=(0, 1)).astype(np.uint64))         # reads per observed base
+    mu2, E2 = ctx.sample_stats(3)
+    assert np.array_equal(mu, mu2) and np.array_equal(E, E2)
+    mu3, _ = ctx.sample_stats(4)
+    assert not np.array_equal(mu, mu3)
+    # expectation check (z-test on the S x G sums against the exact conditional mean)
+    e_mu, v_mu, e_E = cbind.stats_expect(cbind.onehot_to_idx(got), gamma, eta, counts)
+    z = (mu.astype(np.float64) - e_mu) / np.sqrt(v_mu + 1e-9)
+    assert np.abs(z).max() < 5.5 and abs(z.mean()) < 0.5
+    # a few full iterations keep every trace consistent with the oracle's likelihood
+    ctx.gibbs_update(3)
+    tr = ctx.get_trace()
+    t, g, e = ctx.get_state()
+    assert tr["ll"][-1] == pytest.approx(cbind.loglik(cbind.onehot_to_idx(t), g, e, counts), rel=1e-12)
+    np.testing.assert_allclose(g.sum(axis=1), 1.0, rtol=1e-12)
+    ctx.close()

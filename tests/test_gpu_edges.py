@@ -1,0 +1,91 @@
+"""Edge cases and the error channel of the C ABI (negative codes + message instead of the
+reference's exit(1), c_sample_tau.c:200-203)."""
+import numpy as np
+import pytest
+
+from desman_amd import _lib
+from desman_amd.synth import synth_counts, random_state
+from oracle import cbind
+
+pytestmark = pytest.mark.gpu
+
+
+def test_error_paths():
+    ctx = _lib.Context(0)
+    with pytest.raises(_lib.DesmanHipError, match="no count tensor"):
+        ctx.lib.dsm_ctx_gibbs_update.restype  # noqa: B018  (keep the binding alive)
+        _lib.check(ctx.lib.dsm_ctx_gibbs_update(ctx._h, 3))
+    counts, _, _ = synth_counts(20, 4, 2, seed=1)
+    ctx.set_counts(counts)
+    with pytest.raises(_lib.DesmanHipError, match="no chain state"):
+        _lib.check(ctx.lib.dsm_ctx_gibbs_update(ctx._h, 3))
+    tau, gamma, eta = random_state(20, 4, 2, seed=1)
+    ctx.set_state(tau, gamma, eta)
+    ctx.set_tau_rng(_lib.RNG_MT19937)
+    with pytest.raises(_lib.DesmanHipError, match="not seeded"):
+        ctx.sample_tau()
+    bad = counts.copy(); bad[0, 0, 0] = -1
+    with pytest.raises(_lib.DesmanHipError, match="negative count"):
+        ctx.set_counts(bad)
+    bad = counts.copy(); bad[0, 0, 0] = 2 ** 31
+    with pytest.raises(_lib.DesmanHipError, match="negative count or depth"):
+        ctx.set_counts(bad)
+    with pytest.raises(_lib.DesmanHipError, match="DSM_MAX_S"):
+        ctx.set_counts(np.ones((2, 513, 4), dtype=np.int64))
+    ctx.set_counts(counts)
+    t33, g33, _ = random_state(20, 4, 33, seed=1)
+    with pytest.raises(_lib.DesmanHipError, match="outside 1..32"):
+        ctx.set_state(t33, g33, eta)
+    with pytest.raises(_lib.DesmanHipError):
+        _lib.Context(99)
+    ctx.close()
+
+
+def test_philox_tau_mode_is_deterministic_and_geometry_free():
+    V, S, G = 500, 16, 4
+    counts, _, _ = synth_counts(V, S, G, seed=2)
+    tau, gamma, eta = random_state(V, S, G, seed=3)
+    outs = []
+    for _ in range(2):
+        ctx = _lib.Context(0)
+        ctx.set_counts(counts); ctx.set_state(tau, gamma, eta)
+        ctx.seed(1, ctr_seed=777); ctx.set_tau_rng(_lib.RNG_PHILOX)
+        ctx.gibbs_update(5)
+        outs.append((ctx.get_state(), ctx.get_trace()))
+        ctx.close()
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0][0], outs[1][0]))
+    assert np.array_equal(outs[0][1]["ll"], outs[1][1]["ll"])          # bitwise reproducible run to run
+    # the Philox uniforms are u32 / 2^32 of Philox(seed; v*G+g, iter, 'TAUU') -- check one sweep by hand
+    ctx = _lib.Context(0)
+    ctx.set_counts(counts); ctx.set_state(tau, gamma, eta)
+    ctx.seed(1, ctr_seed=777); ctx.set_tau_rng(_lib.RNG_PHILOX)
+    n = ctx.sample_tau()
+    got, _, _ = ctx.get_state()
+    key = [777, 0]
+    u = np.array([cbind.philox4x32_10([i, 0, 0, 0x54415555], key)[0] for i in range(V * G)], dtype=np.float64) / 2 ** 32
+    ref = tau.copy()
+    assert cbind.sample_tau_u(ref, gamma, eta, counts, u) == n and np.array_equal(got, ref)
+    ctx.close()
+
+
+def test_max_sample_count_and_tiny_probabilities():
+    V, S, G = 6, 512, 3                                           # DSM_MAX_S
+    counts, _, _ = synth_counts(V, S, G, seed=4)
+    tau, gamma, eta = random_state(V, S, G, seed=5)
+    gamma[:, 0] = 2.220446049250313e-16                           # the NMFT clamp value (Init_NMFT.py:88-91)
+    gamma /= gamma.sum(axis=1, keepdims=True)
+    ctx = _lib.Context(0)
+    ctx.set_counts(counts); ctx.set_state(tau, gamma, eta); ctx.seed(8)
+    ref = tau.copy()
+    n_ref = cbind.sample_tau_u(ref, gamma, eta, counts, cbind.MT19937(8).uniform(V * G))
+    n = ctx.sample_tau()
+    got, _, _ = ctx.get_state()
+    assert n == n_ref and np.array_equal(got, ref)
+    ll, _ = ctx.loglik()
+    assert ll == pytest.approx(cbind.loglik(cbind.onehot_to_idx(got), gamma, eta, counts), rel=1e-12)
+    # an exactly-zero mixture probability with a non-zero count: -inf/NaN propagate as in the reference
+    eta0 = np.array([[1.0, 0, 0, 0], [0, 1.0, 0, 0], [0, 0, 1.0, 0], [0, 0, 0, 1.0]])
+    ctx.set_state(tau, gamma, eta0)
+    ll0, _ = ctx.loglik()
+    assert not np.isfinite(ll0)
+    ctx.close()

@@ -106,6 +106,18 @@ static int dev_alloc(T **p, size_t n)
 template <typename T>
 static void dev_free(T **p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
 
+// scratch device buffer released on every exit path (error returns included)
+template <typename T>
+struct Scratch {
+    T *p = nullptr;
+    ~Scratch() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { return dev_alloc(&p, n); }
+    operator T *() const { return p; }
+    Scratch() = default;
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+};
+
 #define TRY(x) do { int _r = (x); if (_r != DSM_OK) return _r; } while (0)
 #define BIND(c) HIP_TRY(hipSetDevice((c)->device))
 
@@ -175,7 +187,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     collect_spans(c);
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     free_traces(c);
-    dev_free(&c->cnt_vs); dev_free(&c->items); dev_free(&c->nitems); dev_free(&c->sample_order); dev_free(&c->tau);
+    dev_free(&c->cnt_vs); dev_free(&c->items); dev_free(&c->nitems); dev_free(&c->tau);
     dev_free(&c->blk_tab);
     dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
@@ -213,15 +225,14 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     TRY(dev_alloc(&c->cnt_vs, n * 4));
     TRY(dev_alloc(&c->items, n * 8));
     TRY(dev_alloc(&c->nitems, (size_t)S));
-    TRY(dev_alloc(&c->sample_order, (size_t)S));
     TRY(dev_alloc(&c->tau, (size_t)V));
     dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); c->nG = 0;
     free_traces(c);
-    int64_t *d_in = nullptr; int *d_flag = nullptr; double *d_part = nullptr;
+    Scratch<int64_t> d_in; Scratch<int> d_flag; Scratch<double> d_part;
     const int nblk = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    TRY(dev_alloc(&d_in, n * 4));
-    TRY(dev_alloc(&d_flag, 1));
-    TRY(dev_alloc(&d_part, (size_t)nblk));
+    TRY(d_in.alloc(n * 4));
+    TRY(d_flag.alloc(1));
+    TRY(d_part.alloc((size_t)nblk));
     HIP_TRY(hipMemcpyAsync(d_in, variants, n * 4 * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), c->stream));
     TRY(k_convert_counts(c, d_in, d_flag, d_part, nblk));
@@ -230,12 +241,11 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     HIP_TRY(hipMemcpyAsync(part.data(), d_part, nblk * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    dev_free(&d_in); dev_free(&d_flag); dev_free(&d_part);
     if (!flag) {
         // work list of the per-read pass: per sample, the (variant, base) pairs with a non-zero
         // count, sorted by decreasing count (ties: lower id first) -> the lanes of a wavefront run
-        // read loops of equal length; samples ordered by total depth -> heaviest workgroups first.
-        std::vector<int32_t> items(n * 8, 0), nit(S), sord(S);
+        // read loops of equal length (k_stats shares the resident workgroups among samples by depth).
+        std::vector<int32_t> items(n * 8, 0), nit(S);
         std::vector<int64_t> depth(S, 0);
         std::vector<std::pair<int32_t, int32_t>> lst;      // (count, id)
         lst.reserve((size_t)V * 4);
@@ -257,11 +267,8 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
         c->depth = depth;
         c->nitems_h = nit;
         c->blk_gmax = 0;
-        std::iota(sord.begin(), sord.end(), 0);
-        std::stable_sort(sord.begin(), sord.end(), [&](int32_t p, int32_t q) { return depth[p] > depth[q]; });
         HIP_TRY(hipMemcpyAsync(c->items, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->nitems, nit.data(), (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->sample_order, sord.data(), (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     if (flag) {
@@ -300,14 +307,13 @@ extern "C" int dsm_ctx_set_state(dsm_ctx *c, const int64_t *tau, const double *g
     HIP_TRY(hipStreamSynchronize(c->stream));
     TRY(ensure_state_buffers(c, G));
     const size_t nt = (size_t)c->V * G * 4;
-    int64_t *d_t = nullptr;
-    TRY(dev_alloc(&d_t, nt));
+    Scratch<int64_t> d_t;
+    TRY(d_t.alloc(nt));
     HIP_TRY(hipMemcpyAsync(d_t, tau, nt * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     TRY(k_pack_tau(c, d_t, c->tau, c->V, G));
     HIP_TRY(hipMemcpyAsync(c->gamma, gamma, (size_t)c->S * G * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->eta, eta, 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    dev_free(&d_t);
     c->have_state = true;
     return DSM_OK;
 }
@@ -325,12 +331,11 @@ extern "C" int dsm_ctx_set_gamma_eta(dsm_ctx *c, const double *gamma, const doub
 static int fetch_tau(dsm_ctx *c, const uint64_t *d_packed, int64_t *host_onehot)
 {
     const size_t nt = (size_t)c->V * c->G * 4;
-    int64_t *d_t = nullptr;
-    TRY(dev_alloc(&d_t, nt));
+    Scratch<int64_t> d_t;
+    TRY(d_t.alloc(nt));
     TRY(k_unpack_tau(c, d_packed, d_t, c->V, c->G));
     HIP_TRY(hipMemcpyAsync(host_onehot, d_t, nt * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    dev_free(&d_t);
     return DSM_OK;
 }
 
@@ -456,9 +461,9 @@ extern "C" int dsm_ctx_sample_tau(dsm_ctx *c, int *nchange, double *logp_out)
 {
     TRY(need(c, true, true));
     BIND(c);
-    double *d_logp = nullptr;
+    Scratch<double> d_logp;
     const size_t nl = (size_t)c->V * c->G * 4;
-    if (logp_out) TRY(dev_alloc(&d_logp, nl));
+    if (logp_out) TRY(d_logp.alloc(nl));
     const uint32_t *u = nullptr;
     TRY(fill_sweep_uniforms(c, &u));
     HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
@@ -470,7 +475,6 @@ extern "C" int dsm_ctx_sample_tau(dsm_ctx *c, int *nchange, double *logp_out)
     if (logp_out) HIP_TRY(hipMemcpyAsync(logp_out, d_logp, nl * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    dev_free(&d_logp);
     if (nchange) *nchange = n;
     return DSM_OK;
 }
@@ -498,16 +502,15 @@ extern "C" int dsm_ctx_draw_gamma_eta(dsm_ctx *c, uint32_t iter, const uint64_t 
     if (!sum_mu || !esum) { dsm_set_error("draw_gamma_eta: null sums"); return DSM_ERR_ARG; }
     BIND(c);
     const size_t sg = (size_t)c->S * c->G;
-    double *d_g = nullptr, *d_e = nullptr;
-    TRY(dev_alloc(&d_g, sg));
-    TRY(dev_alloc(&d_e, 16));
+    Scratch<double> d_g, d_e;
+    TRY(d_g.alloc(sg));
+    TRY(d_e.alloc(16));
     HIP_TRY(hipMemcpyAsync(c->sum_mu, sum_mu, sg * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->esum, esum, 16 * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     TRY(k_dirichlet(c, iter, d_g, nullptr, d_e));
     if (gamma_out) HIP_TRY(hipMemcpyAsync(gamma_out, d_g, sg * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (eta_out) HIP_TRY(hipMemcpyAsync(eta_out, d_e, 16 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    dev_free(&d_g); dev_free(&d_e);
     return DSM_OK;
 }
 
@@ -660,12 +663,11 @@ extern "C" int dsm_ctx_get_tau_sum(dsm_ctx *c, int64_t *tau_sum)
     if (!c->tau_trace || !tau_sum) { dsm_set_error("get_tau_sum: no update has run"); return DSM_ERR_STATE; }
     BIND(c);
     const size_t nt = (size_t)c->V * c->G * 4;
-    int64_t *d = nullptr;
-    TRY(dev_alloc(&d, nt));
+    Scratch<int64_t> d;
+    TRY(d.alloc(nt));
     TRY(k_tau_sum(c, c->tau_trace, c->n_trace, d));
     HIP_TRY(hipMemcpyAsync(tau_sum, d, nt * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    dev_free(&d);
     return DSM_OK;
 }
 
@@ -732,8 +734,9 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     BIND(c);
     const int G = c->nG, S = c->S;
     double *ctl = c->nstat + (size_t)G * S + 2 * G;
-    double *d_trace = nullptr;
-    TRY(dev_alloc(&d_trace, (size_t)max_iter + 1));
+    Scratch<double> d_trace;
+    TRY(d_trace.alloc((size_t)max_iter + 1));
+    struct TraceGuard { dsm_ctx *c; ~TraceGuard() { c->ndiv_trace = nullptr; } } trace_guard{c};
     HIP_TRY(hipMemsetAsync(ctl, 0, 16 * sizeof(double), c->stream));
     const int adjust = fix_gamma ? 0 : 1;
     c->ndiv_trace = d_trace;
@@ -761,8 +764,6 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
         HIP_TRY(hipMemcpyAsync(div_trace, d_trace, ((size_t)done + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    c->ndiv_trace = nullptr;
-    dev_free(&d_trace);
     return DSM_OK;
 }
 
@@ -786,14 +787,13 @@ extern "C" int dsm_nmft_get_tau(dsm_ctx *c, int64_t *tau_onehot)
     TRY(need(c, true, false));
     if (!c->ntau || !tau_onehot) { dsm_set_error("nmft_get_tau: call dsm_nmft_set first"); return DSM_ERR_STATE; }
     BIND(c);
-    uint64_t *d_p = nullptr;
-    TRY(dev_alloc(&d_p, (size_t)c->V));
+    Scratch<uint64_t> d_p;
+    TRY(d_p.alloc((size_t)c->V));
     TRY(k_nmft_get_tau(c, d_p));
     const int Gs = c->G;
     c->G = c->nG;
     int r = fetch_tau(c, d_p, tau_onehot);
     c->G = Gs;
-    dev_free(&d_p);
     return r;
 }
 

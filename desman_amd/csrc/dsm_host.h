@@ -39,7 +39,6 @@ struct dsm_ctx {
     int blk_n = 0, blk_gmax = 0;
     std::vector<int64_t> depth;     // host: total reads per sample
     std::vector<int32_t> nitems_h;  // host copy of nitems
-    int32_t *sample_order = nullptr;// [S] samples by decreasing total depth
     double ll_const = 0.0;
     // chain state
     uint64_t *tau = nullptr;        // [V] packed, 2 bits per haplotype

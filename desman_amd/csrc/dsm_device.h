@@ -29,13 +29,15 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// ---- xoshiro128++ (Blackman & Vigna): the per-cell stream of the mu/E draw
+// ---- xoshiro128+ (Blackman & Vigna): the per-item stream of the mu/E draw.  The "+" scrambler
+// (one add) is the variant recommended when only the upper bits matter: its known weakness is
+// low linear complexity of the lowest four bits, and a word is only ever compared with a 32-bit
+// threshold here, so those bits decide a draw with probability 2^-28 per comparison.
 struct Xo128 {
     uint32_t s0, s1, s2, s3;
     __device__ __forceinline__ uint32_t next()
     {
-        const uint32_t a = s0 + s3;
-        const uint32_t res = ((a << 7) | (a >> 25)) + s0;
+        const uint32_t res = s0 + s3;
         const uint32_t t = s1 << 9;
         s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;
         s2 ^= t;

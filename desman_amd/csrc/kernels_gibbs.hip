@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void mt_fill_kernel(uint32_t *__restrict__ sta
 // once at upload, sorted by decreasing count, so the 64 lanes of a wavefront
 // run read loops of (almost) equal length and the heaviest workgroups are
 // dispatched first.  Every read draws its haplotype g with probability
-// gamma[s,g]*eta[tau_vg,b]/sum from the item's xoshiro128++ stream (keyed by
+// gamma[s,g]*eta[tau_vg,b]/sum from the item's xoshiro128+ stream (keyed by
 // Philox(seed; cell, iter, base)): one 32-bit word against G-1 thresholds,
 // two VALU issues per threshold.  Only the sums sum_mu[s,g] and esum[b,a]
 // ever leave the registers.
@@ -227,7 +227,14 @@ __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ ite
             thr[g] = (g < G - 1) ? q : 0u;     // unused slots never count
             cnt[g] = 0;
         }
-        for (int i = 0; i < nb; ++i) {
+        int i = 0;
+        for (; i + 1 < nb; i += 2) {                     // two reads per trip: half the loop overhead
+            const uint32_t r0 = rng.next();
+            const uint32_t r1 = rng.next();
+#pragma unroll
+            for (int g = 0; g < GMAX - 1; ++g) { count_if_less(cnt[g], r0, thr[g]); count_if_less(cnt[g], r1, thr[g]); }
+        }
+        if (i < nb) {
             const uint32_t r = rng.next();
 #pragma unroll
             for (int g = 0; g < GMAX - 1; ++g) count_if_less(cnt[g], r, thr[g]);

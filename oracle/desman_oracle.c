@@ -424,7 +424,7 @@ void orc_nmft_get_tau(const double *tau, int V, int G, uint8_t *tau_idx)
 /* which no parallel sampler can replay.  The product instead draws, for     */
 /* every read of observed base b at (v,s), its haplotype g with probability  */
 /* gamma[s,g]*eta[tau_vg,b]/sum (the one-stage form of the same joint law,   */
-/* SURVEY App. A2) from a Philox4x32-10 / xoshiro128++ stream keyed by       */
+/* SURVEY App. A2) from a Philox4x32-10 / xoshiro128+ stream keyed by       */
 /* (seed, iteration, cell, observed base).  The restatement below lets tests check the HIP  */
 /* kernel bit-for-bit; equivalence in law to the reference's sampleMu is     */
 /* checked statistically against oracle/ref_numpy.py.                        */
@@ -452,10 +452,10 @@ static inline uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 -
 
 typedef struct { uint32_t s[4]; } orc_xo;
 
-static inline uint32_t xo_next(orc_xo *r)     /* xoshiro128++ (Blackman & Vigna) */
+static inline uint32_t xo_next(orc_xo *r)     /* xoshiro128+ (Blackman & Vigna) */
 {
     uint32_t *s = r->s;
-    uint32_t res = rotl32(s[0] + s[3], 7) + s[0];
+    uint32_t res = s[0] + s[3];
     uint32_t t = s[1] << 9;
     s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
     s[2] ^= t; s[3] = rotl32(s[3], 11);

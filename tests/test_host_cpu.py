@@ -90,8 +90,9 @@ def test_variant_filter_constructor_and_select_random():
     assert np.array_equal(flt.snps_filter, z["sel_snps"]) and np.array_equal(flt.selected, z["sel_selected"])
     assert flt.selected_indices == z["sel_indices"].tolist()
     assert np.array_equal(flt.selected_indices_original, z["sel_indices_original"])
-    with pytest.raises(NotImplementedError):
-        flt.get_filtered_VariantsLogRatio()
+    if not HAVE_GPU:                                   # the -f filter runs on the GPU only: loud failure, no fallback
+        with pytest.raises(_lib.DesmanHipError):
+            flt.get_filtered_VariantsLogRatio()
 
 
 def test_output_files_byte_identical_to_reference_writers(tmp_path):

@@ -147,7 +147,11 @@ extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
     dsm_ctx *c = new dsm_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream_rng, hipStreamNonBlocking));
+    {   // the single-workgroup MT19937 refill must not queue behind a full grid of the main stream
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&c->stream_rng, hipStreamNonBlocking, hi));
+    }
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipEventCreateWithFlags(&c->ev_u_ready[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_u_free[i], hipEventDisableTiming));
@@ -155,7 +159,7 @@ extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
     TRY(dev_alloc(&c->mt_state, 625));
     TRY(dev_alloc(&c->ll_partial, DSM_MAX_GRID));
     TRY(dev_alloc(&c->nchange, 1));
-    TRY(dev_alloc(&c->prior, DSM_MAX_S + 4));
+    TRY(dev_alloc(&c->prior, 2 * (DSM_MAX_S + 4)));
     TRY(dev_alloc(&c->scalars, 8));
     TRY(dev_alloc(&c->star, 2));
     TRY(dev_alloc(&c->eta, 16));
@@ -507,7 +511,7 @@ extern "C" int dsm_ctx_draw_gamma_eta(dsm_ctx *c, uint32_t iter, const uint64_t 
     TRY(d_e.alloc(16));
     HIP_TRY(hipMemcpyAsync(c->sum_mu, sum_mu, sg * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->esum, esum, 16 * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    TRY(k_dirichlet(c, iter, d_g, nullptr, d_e));
+    TRY(k_dirichlet(c, iter, d_g, nullptr, d_e, nullptr, c->prior, -1, 0, nullptr));
     if (gamma_out) HIP_TRY(hipMemcpyAsync(gamma_out, d_g, sg * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (eta_out) HIP_TRY(hipMemcpyAsync(eta_out, d_e, 16 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -518,17 +522,9 @@ extern "C" int dsm_ctx_draw_gamma_eta(dsm_ctx *c, uint32_t iter, const uint64_t 
 static int eval_state(dsm_ctx *c, const double *gamma, const double *eta, uint64_t *trace_slot, int star_mode)
 {
     int nb = 0;
-    TRY(k_prior(c, gamma, eta));
+    TRY(k_prior(c, gamma, eta, c->prior));
     TRY(k_tau_sweep(c, 2, gamma, eta, eta, trace_slot, nullptr, 0, &nb, nullptr));
-    // finalize with eta_new := eta so that the star copy (entry state) takes the current eta
-    double *save = c->eta_new;
-    c->eta_new = const_cast<double *>(eta);
-    const double *gsave = c->gamma;
-    c->gamma = const_cast<double *>(gamma);
-    int r = k_finalize(c, nb, -1, 0, star_mode);
-    c->eta_new = save;
-    c->gamma = const_cast<double *>(gsave);
-    return r;
+    return k_finalize(c, nb, -1, star_mode, c->prior, gamma, eta);
 }
 
 extern "C" int dsm_ctx_loglik(dsm_ctx *c, double *ll, double *lp)
@@ -573,18 +569,31 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
     HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
     // entry state: ll, lp, storeStarState(0)  (HaploSNP_Sampler.py:336-338)
     TRY(eval_state(c, c->gamma, c->eta, c->tau_trace, 1));
+    double *const P[2] = {c->prior, c->prior + (DSM_MAX_S + 4)};
+    int nb_prev = 0;
+    const uint32_t *u = nullptr, *u_next = nullptr;
+    if (n_iter > 0) TRY(fill_sweep_uniforms(c, &u));                     // uniforms of sweep 0
     for (int it = 0; it < n_iter; ++it) {
         const uint32_t ic = c->iter_ctr++;
-        const uint32_t *u = nullptr;
-        TRY(fill_sweep_uniforms(c, &u));                                 // side stream, overlaps the mu/E pass
+        // the MT19937 words of the NEXT sweep are generated on the side stream one whole iteration
+        // ahead (never beyond the last sweep: the stream position must equal the reference's)
+        u_next = nullptr;
+        if (it + 1 < n_iter) TRY(fill_sweep_uniforms(c, &u_next));
         TRY(k_stats(c, ic));                                             // sampleMu  (:341)
-        TRY(k_dirichlet(c, ic, c->gamma, c->gamma_trace + (size_t)it * sg, c->eta_new));  // sampleGamma (:342) + eta draw (:347)
-        int nb = 0;
+        // sampleGamma (:342) + the eta draw (:347: eta depends only on the E sums) + traces; the same
+        // launch finalizes iteration it-1 (ll, lp, MAP test :349-353) in one extra workgroup
+        TRY(k_dirichlet(c, ic, c->gamma, c->gamma_trace + (size_t)it * sg, c->eta_new, c->eta_trace + (size_t)it * 16,
+                        P[it & 1], it - 1, nb_prev, P[(it - 1) & 1]));
         TRY(await_sweep_uniforms(c, u));
-        TRY(k_tau_sweep(c, 3, c->gamma, c->eta, c->eta_new, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb, u));  // :345,:349
+        // tau sweep with (gamma_new, eta_old) (:345) + log-likelihood of the new state with eta_new (:349)
+        TRY(k_tau_sweep(c, 3, c->gamma, c->eta, c->eta_new, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb_prev, u));
         TRY(release_sweep_uniforms(c, u));
-        TRY(k_finalize(c, nb, it, 1, 0));                                   // :349-358
+        std::swap(c->eta, c->eta_new);                                   // eta_new becomes the chain's eta
+        u = u_next;
     }
+    if (n_iter > 0)
+        TRY(k_finalize(c, nb_prev, n_iter - 1, 0, P[(n_iter - 1) & 1], c->gamma_trace + (size_t)(n_iter - 1) * sg,
+                       c->eta_trace + (size_t)(n_iter - 1) * 16));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSM_OK;
 }
@@ -601,6 +610,7 @@ extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_st
     HIP_TRY(hipMemcpyAsync(c->gamma_in, gamma_store, (size_t)n_iter * sg * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->eta_in, eta_store, (size_t)n_iter * 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->gamma_trace, c->gamma_in, (size_t)n_iter * sg * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->eta_trace, c->eta_in, (size_t)n_iter * 16 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
     // entry: lp with (gamma_store[0], eta_store[0])  (HaploSNP_Sampler.py:386-389)
     TRY(eval_state(c, c->gamma_in, c->eta_in, c->tau_trace, 1));
@@ -609,16 +619,12 @@ extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_st
         const double *g = c->gamma_in + (size_t)it * sg, *e = c->eta_in + (size_t)it * 16;
         const uint32_t *u = nullptr;
         TRY(fill_sweep_uniforms(c, &u));
-        TRY(k_prior(c, g, e));
+        TRY(k_prior(c, g, e, c->prior));
         int nb = 0;
         TRY(await_sweep_uniforms(c, u));
         TRY(k_tau_sweep(c, 3, g, e, e, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb, u));  // :392-393
         TRY(release_sweep_uniforms(c, u));
-        double *save = c->eta_new; const double *gsave = c->gamma;
-        c->eta_new = const_cast<double *>(e); c->gamma = const_cast<double *>(g);
-        int r = k_finalize(c, nb, it, 0, 0);
-        c->eta_new = save; c->gamma = const_cast<double *>(gsave);
-        TRY(r);
+        TRY(k_finalize(c, nb, it, 0, c->prior, g, e));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSM_OK;

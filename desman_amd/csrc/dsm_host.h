@@ -62,7 +62,7 @@ struct dsm_ctx {
     // scratch
     double *ll_partial = nullptr;   // [DSM_MAX_GRID]
     int *nchange = nullptr;         // device counter
-    double *prior = nullptr;        // [S + 4] per-row Dirichlet log-prior terms of (gamma, eta)
+    double *prior = nullptr;        // [2][DSM_MAX_S + 4] per-row Dirichlet log-prior terms, by iteration parity
     double *scalars = nullptr;      // [8] misc device scalars
     double *log_tab = nullptr;      // [128][2] table of dsm_log (log_table.h)
     // traces of the last update call
@@ -107,13 +107,15 @@ int k_unpack_tau(dsm_ctx *c, const uint64_t *d_packed, int64_t *d_onehot, int V,
 int k_tau_sum(dsm_ctx *c, const uint64_t *trace, int n, int64_t *d_sum);
 int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n, hipStream_t stream);
 int k_stats(dsm_ctx *c, uint32_t iter);
-int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trace, double *eta_out);
-int k_prior(dsm_ctx *c, const double *gamma, const double *eta);
+int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trace, double *eta_out, double *eta_trace,
+                double *prior_out, int fin_it, int fin_nblocks, const double *fin_prior);
+int k_prior(dsm_ctx *c, const double *gamma, const double *eta, double *prior_out);
 // mode bit0 = sweep, bit1 = log-likelihood epilogue
 int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_sweep,
                 const double *eta_ll, uint64_t *trace_slot, double *d_logp, uint32_t iter, int *nblocks,
                 const uint32_t *u_raw);
-int k_finalize(dsm_ctx *c, int nblocks, int it, int commit_eta, int star_mode);
+int k_finalize(dsm_ctx *c, int nblocks, int it, int star_mode, const double *prior, const double *gamma_src,
+               const double *eta_src);
 
 // ---- launchers (kernels_nmft.hip)
 int k_nmft_freq(dsm_ctx *c);

@@ -275,6 +275,65 @@ __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ ite
 }
 
 // =====================================================================
+// A5/A6: finalize one iteration: fixed-order reduction of the per-workgroup LL
+// partials and of the Dirichlet log-prior terms, lp, MAP tracking, traces.
+// it < 0: no trace slot (entry state / plain evaluation).  Runs either as its
+// own single-workgroup kernel or as one extra workgroup of the NEXT iteration's
+// dirichlet launch (it only needs data that launch order already guarantees).
+// =====================================================================
+struct FinalParams {
+    const double *ll_partial; int nblocks;
+    double ll_const, tau_prior;
+    const double *prior; int S;      // [S + 4] per-row Dirichlet log-prior terms of the finalized state
+    int *nchange;
+    int it;
+    double *ll_trace, *lp_trace; int *nchange_trace;
+    double *star;                 // {lp_star, slot}
+    const double *gamma_src; double *gamma_star; int SG;   // gamma / eta of the finalized state
+    const double *eta_src; double *eta_star;
+    int star_mode;                // 0 = keep the better lp, 1 = force (entry state), 2 = never
+    double *scalars;              // [0]=ll [1]=lp of this evaluation
+};
+
+__device__ void finalize_body(const FinalParams &p, double *red, double *redp, int *flag, int tid, int nthr)
+{
+    double a = 0.0, b = 0.0;
+    for (int i = tid; i < p.nblocks; i += nthr) a += p.ll_partial[i];
+    for (int i = tid; i < p.S + 4; i += nthr) b += p.prior[i];
+    red[tid] = a; redp[tid] = b;
+    __syncthreads();
+    for (int o = nthr / 2; o >= 1; o >>= 1) {
+        if (tid < o) { red[tid] += red[tid + o]; redp[tid] += redp[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double ll = p.ll_const + red[0];
+        const double lp = ll + redp[0] + p.tau_prior;
+        p.scalars[0] = ll; p.scalars[1] = lp;
+        const int nch = *p.nchange;
+        *p.nchange = 0;
+        if (p.it >= 0) { p.ll_trace[p.it] = ll; p.lp_trace[p.it] = lp; p.nchange_trace[p.it] = nch; }
+        int f = 0;
+        if (p.star_mode == 1 || (p.star_mode == 0 && lp > p.star[0])) { p.star[0] = lp; p.star[1] = (double)(p.it + 1); f = 1; }
+        *flag = f;
+    }
+    __syncthreads();
+    if (*flag) {
+        for (int i = tid; i < p.SG; i += nthr) p.gamma_star[i] = p.gamma_src[i];
+        if (tid < 16) p.eta_star[tid] = p.eta_src[tid];
+    }
+}
+
+// NB the reduction tree depends on the workgroup size, so one chain must always finalize with the same
+// size to stay bitwise reproducible: both users below run it with 256 threads.
+__global__ __launch_bounds__(256) void finalize_kernel(FinalParams p)
+{
+    __shared__ double red[256], redp[256];
+    __shared__ int flag;
+    finalize_body(p, red, redp, &flag, threadIdx.x, 256);
+}
+
+// =====================================================================
 // A3/A4: Dirichlet draws from the sums, one workgroup.
 // gamma[s,:] ~ Dir(alpha + sum_mu[s,:]); clamp < eps -> eps; renormalise
 // eta[a,:]   ~ Dir(delta + esum[:,a])
@@ -310,18 +369,26 @@ __device__ double gamma_variate(double shape, uint32_t idx, uint32_t iter, uint3
     return res;
 }
 
-// One 64-lane workgroup per row (S gamma rows + 4 eta rows): lane g draws variate g, lane 0
-// normalises the row and writes its log-prior term to rowprior[row] (summed by finalize in a
+// One workgroup per row (S gamma rows + 4 eta rows; its first wavefront does the work): lane g
+// draws variate g, the row is normalised lane-parallel and writes its log-prior term to rowprior[row] (summed by finalize in a
 // fixed order).  Rows are independent, so the launch fills S+4 CUs instead of one.
-__global__ __launch_bounds__(64) void dirichlet_kernel(unsigned long long *__restrict__ sum_mu,
+__global__ __launch_bounds__(256) void dirichlet_kernel(unsigned long long *__restrict__ sum_mu,
                                                        unsigned long long *__restrict__ esum, int S, int G,
                                                        double alpha, double delta, double epsilon,
                                                        double lgc_gamma, double lgc_eta, uint32_t k0,
                                                        uint32_t k1, uint32_t iter, int zero_after,
                                                        double *__restrict__ gamma_out,
                                                        double *__restrict__ gamma_trace,
-                                                       double *__restrict__ eta_out, double *__restrict__ rowprior)
+                                                       double *__restrict__ eta_out, double *__restrict__ eta_trace,
+                                                       double *__restrict__ rowprior, int do_fin, FinalParams fin)
 {
+    if (do_fin && (int)blockIdx.x == S + 4) {            // extra workgroup: finalize the PREVIOUS iteration
+        __shared__ double red[256], redp[256];
+        __shared__ int flag;
+        finalize_body(fin, red, redp, &flag, threadIdx.x, 256);
+        return;
+    }
+    if (threadIdx.x >= 64) return;                       // a row needs one wavefront (no workgroup barriers below)
     const int row = blockIdx.x, lane = threadIdx.x;
     const bool is_gamma = row < S;
     const int n = is_gamma ? G : 4;
@@ -346,7 +413,7 @@ __global__ __launch_bounds__(64) void dirichlet_kernel(unsigned long long *__res
     if (lane == 0) rowprior[row] = (is_gamma ? lgc_gamma : lgc_eta) + lsum;
     if (lane < n) {
         if (is_gamma) { gamma_out[row * G + lane] = x; if (gamma_trace) gamma_trace[row * G + lane] = x; }
-        else eta_out[(row - S) * 4 + lane] = x;
+        else { eta_out[(row - S) * 4 + lane] = x; if (eta_trace) eta_trace[(row - S) * 4 + lane] = x; }
     }
 }
 
@@ -548,62 +615,6 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
 }
 
 // =====================================================================
-// A5/A6: finalize one iteration (single workgroup): ll, lp, MAP tracking,
-// traces, eta commit.  it < 0: no trace slot (entry state / plain evaluation).
-// =====================================================================
-struct FinalParams {
-    const double *ll_partial; int nblocks;
-    double ll_const, tau_prior;
-    const double *prior; int S;      // [S + 4] per-row Dirichlet log-prior terms
-    int *nchange;
-    int it;
-    double *ll_trace, *lp_trace; int *nchange_trace;
-    double *star;                 // {lp_star, slot}
-    const double *gamma; double *gamma_star; int SG;
-    double *eta; const double *eta_new; double *eta_star; double *eta_trace;
-    int commit_eta;
-    int star_mode;                // 0 = keep the better lp, 1 = force (entry state), 2 = never
-    double *scalars;              // [0]=ll [1]=lp of this evaluation
-};
-
-__global__ __launch_bounds__(256) void finalize_kernel(FinalParams p)
-{
-    __shared__ double red[256], redp[256];
-    __shared__ int flag;
-    const int tid = threadIdx.x;
-    double a = 0.0, b = 0.0;
-    for (int i = tid; i < p.nblocks; i += 256) a += p.ll_partial[i];
-    for (int i = tid; i < p.S + 4; i += 256) b += p.prior[i];        // Dirichlet log-prior terms, same fixed-order tree
-    red[tid] = a; redp[tid] = b;
-    __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) {
-        if (tid < o) { red[tid] += red[tid + o]; redp[tid] += redp[tid + o]; }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const double ll = p.ll_const + red[0];
-        const double lp = ll + redp[0] + p.tau_prior;
-        p.scalars[0] = ll; p.scalars[1] = lp;
-        const int nch = *p.nchange;
-        *p.nchange = 0;
-        if (p.it >= 0) { p.ll_trace[p.it] = ll; p.lp_trace[p.it] = lp; p.nchange_trace[p.it] = nch; }
-        int f = 0;
-        if (p.star_mode == 1 || (p.star_mode == 0 && lp > p.star[0])) { p.star[0] = lp; p.star[1] = (double)(p.it + 1); f = 1; }
-        flag = f;
-    }
-    __syncthreads();
-    if (flag) {
-        for (int i = tid; i < p.SG; i += 256) p.gamma_star[i] = p.gamma[i];
-        if (tid < 16) p.eta_star[tid] = p.eta_new[tid];
-    }
-    if (tid < 16) {
-        const double e = p.eta_new[tid];
-        if (p.commit_eta) p.eta[tid] = e;
-        if (p.eta_trace && p.it >= 0) p.eta_trace[(size_t)p.it * 16 + tid] = e;
-    }
-}
-
-// =====================================================================
 // host launchers
 // =====================================================================
 int k_convert_counts(dsm_ctx *c, const int64_t *d_in, int *d_flag, double *d_partial, int nblk)
@@ -710,25 +721,47 @@ static void dirichlet_consts(const dsm_ctx *c, double *lgc_gamma, double *lgc_et
     *lgc_eta = lgamma(c->delta * 4) - 4 * lgamma(c->delta);
 }
 
-int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trace, double *eta_out)
+static FinalParams make_final(dsm_ctx *c, int nblocks, int it, int star_mode, const double *prior, const double *gamma_src,
+                              const double *eta_src)
+{
+    FinalParams p;
+    p.ll_partial = c->ll_partial; p.nblocks = nblocks;
+    p.ll_const = c->ll_const;
+    p.tau_prior = (double)c->V * (double)c->G * log(1.0 / 4.0);     // HaploSNP_Sampler.py:457
+    p.prior = prior; p.S = c->S; p.nchange = c->nchange; p.it = it;
+    p.ll_trace = c->ll_trace; p.lp_trace = c->lp_trace; p.nchange_trace = c->nchange_trace;
+    p.star = c->star; p.gamma_src = gamma_src; p.gamma_star = c->gamma_star; p.SG = c->S * c->G;
+    p.eta_src = eta_src; p.eta_star = c->eta_star;
+    p.star_mode = star_mode; p.scalars = c->scalars;
+    return p;
+}
+
+// fin_it >= 0: the launch also finalizes iteration fin_it (traces of that iteration are its gamma/eta source)
+int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trace, double *eta_out, double *eta_trace,
+                double *prior_out, int fin_it, int fin_nblocks, const double *fin_prior)
 {
     KTimer tm(c, DSM_K_DIRICH);
     double lg, le;
     dirichlet_consts(c, &lg, &le);
     const uint32_t k0 = (uint32_t)c->ctr_seed, k1 = (uint32_t)(c->ctr_seed >> 32);
-    hipLaunchKernelGGL(dirichlet_kernel, dim3(c->S + 4), dim3(64), 0, c->stream, c->sum_mu, c->esum, c->S, c->G,
-                       c->alpha, c->delta, c->epsilon, lg, le, k0, k1, iter, 1, gamma_out, gamma_trace, eta_out,
-                       c->prior);
+    const int do_fin = fin_it >= 0 ? 1 : 0;
+    FinalParams fin = {};
+    if (do_fin)
+        fin = make_final(c, fin_nblocks, fin_it, 0, fin_prior, c->gamma_trace + (size_t)fin_it * c->S * c->G,
+                         c->eta_trace + (size_t)fin_it * 16);
+    hipLaunchKernelGGL(dirichlet_kernel, dim3(c->S + 4 + do_fin), dim3(256), 0, c->stream, c->sum_mu, c->esum, c->S, c->G,
+                       c->alpha, c->delta, c->epsilon, lg, le, k0, k1, iter, 1, gamma_out, gamma_trace, eta_out, eta_trace,
+                       prior_out, do_fin, fin);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }
 
-int k_prior(dsm_ctx *c, const double *gamma, const double *eta)
+int k_prior(dsm_ctx *c, const double *gamma, const double *eta, double *prior_out)
 {
     double lg, le;
     dirichlet_consts(c, &lg, &le);
     hipLaunchKernelGGL(prior_kernel, dim3(1), dim3(256), 0, c->stream, gamma, eta, c->S, c->G, c->alpha, c->delta, lg,
-                       le, c->prior);
+                       le, prior_out);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }
@@ -777,18 +810,11 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
     return DSM_OK;
 }
 
-int k_finalize(dsm_ctx *c, int nblocks, int it, int commit_eta, int star_mode)
+int k_finalize(dsm_ctx *c, int nblocks, int it, int star_mode, const double *prior, const double *gamma_src,
+               const double *eta_src)
 {
     KTimer tm(c, DSM_K_FINAL);
-    FinalParams p;
-    p.ll_partial = c->ll_partial; p.nblocks = nblocks;
-    p.ll_const = c->ll_const;
-    p.tau_prior = (double)c->V * (double)c->G * log(1.0 / 4.0);     // HaploSNP_Sampler.py:457
-    p.prior = c->prior; p.S = c->S; p.nchange = c->nchange; p.it = it;
-    p.ll_trace = c->ll_trace; p.lp_trace = c->lp_trace; p.nchange_trace = c->nchange_trace;
-    p.star = c->star; p.gamma = c->gamma; p.gamma_star = c->gamma_star; p.SG = c->S * c->G;
-    p.eta = c->eta; p.eta_new = c->eta_new; p.eta_star = c->eta_star; p.eta_trace = c->eta_trace;
-    p.commit_eta = commit_eta; p.star_mode = star_mode; p.scalars = c->scalars;
+    const FinalParams p = make_final(c, nblocks, it, star_mode, prior, gamma_src, eta_src);
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, p);
     HIP_TRY(hipGetLastError());
     return DSM_OK;

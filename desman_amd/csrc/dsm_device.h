@@ -99,9 +99,12 @@ __device__ __forceinline__ bool dsm_log_ok(double x)
 {
     return ((uint32_t)__double2hiint(x) - 0x00100000u) < 0x7fe00000u;
 }
+// cold path (zero / subnormal / inf / NaN arguments): kept out of line so that libm's log does not
+// inflate the register allocation of the hot loops
+__device__ __attribute__((noinline)) double dsm_log_slow(double x) { return log(x); }
 __device__ __forceinline__ double dsm_log(double x, const double2 *__restrict__ tab)
 {
-    if (__builtin_expect(!dsm_log_ok(x), 0)) return log(x);
+    if (__builtin_expect(!dsm_log_ok(x), 0)) return dsm_log_slow(x);
     return dsm_log_core(x, tab);
 }
 

@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                                 for (int b = 0; b < 4; ++b) acc = fma(xf[j][b], dsm_log_core(P[b], ltab), acc);
                             } else {
 #pragma unroll
-                                for (int b = 0; b < 4; ++b) acc = fma(xf[j][b], log(P[b]), acc);
+                                for (int b = 0; b < 4; ++b) acc = fma(xf[j][b], dsm_log_slow(P[b]), acc);
                             }
                         }
                     }

@@ -196,7 +196,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
     dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->prior); dev_free(&c->scalars); dev_free(&c->star);
-    dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam);
+    dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); dev_free(&c->ngam_raw);
     dev_free(&c->npart); dev_free(&c->nstat);
     for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ev_u_ready[i]); (void)hipEventDestroy(c->ev_u_free[i]); }
     (void)hipStreamDestroy(c->stream_rng);
@@ -230,7 +230,7 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     TRY(dev_alloc(&c->items, n * 8));
     TRY(dev_alloc(&c->nitems, (size_t)S));
     TRY(dev_alloc(&c->tau, (size_t)V));
-    dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); c->nG = 0;
+    dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); dev_free(&c->ngam_raw); c->nG = 0;
     free_traces(c);
     Scratch<int64_t> d_in; Scratch<int> d_flag; Scratch<double> d_part;
     const int nblk = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
@@ -698,6 +698,7 @@ extern "C" int dsm_nmft_set(dsm_ctx *c, const double *tau, const double *gamma, 
     c->nmft_blocks = nmft_grid(c);
     TRY(dev_alloc(&c->ntau, (size_t)V * 4 * G));
     TRY(dev_alloc(&c->ngam, (size_t)G * S));
+    TRY(dev_alloc(&c->ngam_raw, (size_t)G * S));
     TRY(dev_alloc(&c->npart, (size_t)c->nmft_blocks * ((size_t)G * S + G + 1)));
     TRY(dev_alloc(&c->nstat, (size_t)G * S + 2 * G + 16));
     // reference layout tau[v + a*V][g] -> device layout [v][a][g]
@@ -707,6 +708,7 @@ extern "C" int dsm_nmft_set(dsm_ctx *c, const double *tau, const double *gamma, 
             memcpy(&t[((size_t)v * 4 + a) * G], &tau[((size_t)a * V + v) * G], sizeof(double) * G);
     HIP_TRY(hipMemcpyAsync(c->ntau, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->ngam, gamma, (size_t)G * S * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ngam_raw, gamma, (size_t)G * S * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSM_OK;
 }

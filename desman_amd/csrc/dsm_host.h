@@ -80,7 +80,8 @@ struct dsm_ctx {
     // NMFT
     double *F = nullptr;            // [V][4][S]
     double *ntau = nullptr;         // [V][4][G]
-    double *ngam = nullptr;         // [G][S]
+    double *ngam = nullptr;         // [G][S] (after _adjustment)
+    double *ngam_raw = nullptr;     // [G][S] normalised gamma of the running update, before _adjustment
     double *npart = nullptr;        // per-block partials
     double *nstat = nullptr;        // reduced statistics + control words
     double *ndiv_trace = nullptr;   // objective after every update of the running factorize (or null)

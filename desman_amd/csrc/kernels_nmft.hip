@@ -9,7 +9,8 @@
 //             tau^T.Q and H1 = colsum(tau), reduced per workgroup (fixed order)
 //   gamma   : cross-workgroup reduction, convergence test of the factorize loop
 //             (:106) ON THE DEVICE (no host sync per iteration), gamma update (:163-166)
-//   pass B  : R' = tau.gamma_new, Q' = F (/) R', tau *= (Q'.gamma^T) (/) rowsum(gamma),
+//   pass B  : R' = tau.gamma_new (the normalised gamma BEFORE _adjustment, as in the reference),
+//             Q' = F (/) R', tau *= (Q'.gamma^T) (/) rowsum(gamma),
 //             per-(v,g) renormalisation over the four bases (:170-181), _adjustment (:88-91)
 #include "dsm_device.h"
 #include "dsm_host.h"
@@ -170,8 +171,8 @@ __global__ __launch_bounds__(256) void nmft_reduce_kernel(const double *__restri
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void nmft_gamma_kernel(const double *__restrict__ stat, int S, int G, int it,
                                                           int max_iter, double min_change, int fix_gamma, int adjust,
-                                                          double *__restrict__ gam, double *__restrict__ ctl,
-                                                          double *__restrict__ div_trace)
+                                                          double *__restrict__ gam, double *__restrict__ gam_raw,
+                                                          double *__restrict__ ctl, double *__restrict__ div_trace)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_g[];
     double *val = reinterpret_cast<double *>(smem_g);          // [G][SC] one chunk of sample columns
@@ -204,7 +205,8 @@ __global__ __launch_bounds__(1024) void nmft_gamma_kernel(const double *__restri
                 for (int k = 0; k < G; ++k) tot += val[k * SC + tid % SC];   // :165
                 v = v / tot;                                                 // :166
             }
-            if (adjust && v < DSM_EPS) v = DSM_EPS;                          // :91
+            gam_raw[(size_t)g * S + s] = v;                                  // the tau update of this iteration sees it unclamped
+            if (adjust && v < DSM_EPS) v = DSM_EPS;                          // _adjustment follows the whole div_update (:88-91,:108)
             gam[(size_t)g * S + s] = v;
         }
         __syncthreads();
@@ -354,7 +356,7 @@ int k_nmft_gamma(dsm_ctx *c, int it, int max_iter, double min_change, int fix_ga
     hipLaunchKernelGGL(nmft_reduce_kernel, dim3((nout + 3) / 4), dim3(256), 0, c->stream, c->npart, c->nmft_blocks, nout,
                        NMFT_CTL(c), c->nstat);
     hipLaunchKernelGGL(nmft_gamma_kernel, dim3(1), dim3(1024), (size_t)1024 * sizeof(double), c->stream, c->nstat, c->S,
-                       c->nG, it, max_iter, min_change, fix_gamma, adjust, c->ngam, NMFT_CTL(c), c->ndiv_trace);
+                       c->nG, it, max_iter, min_change, fix_gamma, adjust, c->ngam, c->ngam_raw, NMFT_CTL(c), c->ndiv_trace);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }
@@ -370,7 +372,7 @@ int k_nmft_pass_b(dsm_ctx *c, int adjust)
     if (sh > 160 * 1024) { dsm_set_error("NMFT tile (%zu B) exceeds LDS", sh); return DSM_ERR_UNSUPPORTED; }
     int grid = (c->V + VT - 1) / VT;
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(nmft_pass_b_kernel, dim3(grid), dim3(256), sh, c->stream, c->F, c->ntau, c->ngam, c->V, S, G, VT,
+    hipLaunchKernelGGL(nmft_pass_b_kernel, dim3(grid), dim3(256), sh, c->stream, c->F, c->ntau, c->ngam_raw, c->V, S, G, VT,
                        adjust, NMFT_CTL(c));
     HIP_TRY(hipGetLastError());
     return DSM_OK;

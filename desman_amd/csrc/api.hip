@@ -699,7 +699,7 @@ extern "C" int dsm_nmft_set(dsm_ctx *c, const double *tau, const double *gamma, 
     TRY(dev_alloc(&c->ntau, (size_t)V * 4 * G));
     TRY(dev_alloc(&c->ngam, (size_t)G * S));
     TRY(dev_alloc(&c->ngam_raw, (size_t)G * S));
-    TRY(dev_alloc(&c->npart, (size_t)c->nmft_blocks * ((size_t)G * S + G + 1)));
+    TRY(dev_alloc(&c->npart, (size_t)std::max(c->nmft_blocks, nmft_wave_grid(c)) * ((size_t)G * S + G + 1)));
     TRY(dev_alloc(&c->nstat, (size_t)G * S + 2 * G + 16));
     // reference layout tau[v + a*V][g] -> device layout [v][a][g]
     std::vector<double> t((size_t)V * 4 * G);
@@ -753,14 +753,17 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     const int BATCH = 64;
     int it = 0;
     double h[5] = {0, 0, 0, 0, 0};
+    const bool wave = nmft_use_wave(c);
+    // one-pass path: statistics of the initial state, then every update launch also produces the
+    // statistics of the next iteration; two-pass path (large S*G): pass A + pass B per iteration
+    if (wave) TRY(k_nmft_wave(c, adjust, 0));
     while (true) {
         const int hi = (it + BATCH < max_iter) ? it + BATCH : max_iter;
         for (; it <= hi; ++it) {
-            // pass A on the current state gives div_it and the gamma numerators; the control
-            // kernel decides (on device) whether update `it` runs at all.
-            TRY(k_nmft_pass_a(c));
+            if (!wave) TRY(k_nmft_pass_a(c));
+            // the control kernel decides ON THE DEVICE whether update `it` runs at all (Init_NMFT.py:106)
             TRY(k_nmft_gamma(c, it, max_iter, min_change, fix_gamma, adjust));      // also records div_trace[it]
-            if (it < max_iter) TRY(k_nmft_pass_b(c, adjust));
+            if (it < max_iter) TRY(wave ? k_nmft_wave(c, adjust, 1) : k_nmft_pass_b(c, adjust));
         }
         HIP_TRY(hipMemcpyAsync(h, ctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -783,7 +786,7 @@ extern "C" int dsm_nmft_objective(dsm_ctx *c, double *div)
     const int G = c->nG, S = c->S;
     double *ctl = c->nstat + (size_t)G * S + 2 * G;
     HIP_TRY(hipMemsetAsync(ctl, 0, 16 * sizeof(double), c->stream));
-    TRY(k_nmft_pass_a(c));
+    TRY(nmft_use_wave(c) ? k_nmft_wave(c, 0, 0) : k_nmft_pass_a(c));
     TRY(k_nmft_gamma(c, 0, 0, 0.0, 1, 0));     // max_iter = 0: reduce + record div only
     HIP_TRY(hipMemcpyAsync(div, ctl, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -82,6 +82,7 @@ struct dsm_ctx {
     double *ntau = nullptr;         // [V][4][G]
     double *ngam = nullptr;         // [G][S] (after _adjustment)
     double *ngam_raw = nullptr;     // [G][S] normalised gamma of the running update, before _adjustment
+    int npart_cols = 0;             // workgroup partials currently held by npart
     double *npart = nullptr;        // per-block partials
     double *nstat = nullptr;        // reduced statistics + control words
     double *ndiv_trace = nullptr;   // objective after every update of the running factorize (or null)
@@ -126,3 +127,6 @@ int k_nmft_gamma(dsm_ctx *c, int it, int max_iter, double min_change, int fix_ga
 int k_nmft_pass_b(dsm_ctx *c, int adjust);
 int k_nmft_get_tau(dsm_ctx *c, uint64_t *d_packed);
 int nmft_grid(dsm_ctx *c);
+bool nmft_use_wave(const dsm_ctx *c);
+int nmft_wave_grid(const dsm_ctx *c);
+int k_nmft_wave(dsm_ctx *c, int adjust, int do_update);

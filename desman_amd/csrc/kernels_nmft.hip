@@ -280,6 +280,243 @@ __global__ __launch_bounds__(256) void nmft_pass_b_kernel(const double *__restri
     }
 }
 
+// ---------------------------------------------------------------------------
+// nmft_wave_kernel: one update in ONE pass over F, without workgroup barriers in the loop.
+// A wavefront owns a variant (its 4 rows of F and tau); lanes = samples (NSL per lane).
+//   1  R = tau.gamma_raw per lane (tau rows read as LDS broadcasts), Q' = F (/) R
+//   2  num[r][g] = sum_s Q'[r][s] gamma_raw[g][s]: 4 x 8 per-lane products per g-chunk, summed over
+//      the wavefront by a transposing butterfly that leaves ONE (r,g) total per lane
+//   3  that lane updates tau[r][g] (:171-172); the four bases of a (v,g) sit in one quad, so the
+//      renormalisation (:174-181) is two DPP exchanges; _adjustment (:88-91); tau -> HBM and LDS
+//   4  R2 = tau_new.gamma, objective terms (:152-156), Q = F (/) R2
+//   5  gamma numerators of the NEXT iteration accumulate in per-lane registers: num[g] += tau_new[r][g] Q[r]
+// do_update = 0 runs 4-5 only (statistics of the current state: the first iteration, div_objective).
+// gamma_raw / gamma: the running update's normalised gamma before / after _adjustment.
+// Partials are written transposed, [G*S numerators][G H1][1 objective] x workgroups.
+// ---------------------------------------------------------------------------
+template <int NV, int CNT, int OFF>
+__device__ __forceinline__ void transpose_reduce_step(double (&v)[NV], int lane)
+{
+    if constexpr (OFF < 64) {
+        if constexpr (CNT > 1) {
+            constexpr int H = CNT / 2;
+            const bool up = lane & OFF;                 // this lane keeps the upper half
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                const double keep = up ? v[i + H] : v[i];
+                const double send = up ? v[i] : v[i + H];
+                double got;
+                if constexpr (OFF == 1) got = dpp_mov<DSM_DPP_XOR1>(send);
+                else if constexpr (OFF == 2) got = dpp_mov<DSM_DPP_XOR2>(send);
+                else got = __shfl_xor(send, OFF, 64);
+                v[i] = keep + got;
+            }
+            transpose_reduce_step<NV, H, OFF * 2>(v, lane);
+        } else {
+            v[0] += __shfl_xor(v[0], OFF, 64);
+            transpose_reduce_step<NV, 1, OFF * 2>(v, lane);
+        }
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ double wave_transpose_reduce(double (&v)[NV])
+{
+    transpose_reduce_step<NV, NV, 1>(v, __lane_id());
+    return v[0];
+}
+
+// index (within the NV values) that wave_transpose_reduce leaves on `lane`
+template <int NV>
+__device__ __forceinline__ int transpose_index(int lane)
+{
+    int idx = 0, h = NV / 2;
+#pragma unroll
+    for (int off = 1; off < 64 && h >= 1; off <<= 1, h >>= 1) idx += (lane & off) ? h : 0;
+    return idx;
+}
+
+template <int NSL, int GMAX>
+__global__ __launch_bounds__(256) void nmft_wave_kernel(const double *__restrict__ F, double *__restrict__ tau,
+                                                        const double *__restrict__ gam_raw,
+                                                        const double *__restrict__ gam, int V, int S, int G,
+                                                        int adjust, int do_update, const double *__restrict__ ctl,
+                                                        const double *__restrict__ log_tab, double *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_w[];
+    if (ctl[2] != 0.0) return;
+    constexpr int SPAD = 64 * NSL;
+    constexpr int GCH = GMAX < 8 ? GMAX : 8;             // haplotypes per reduction chunk
+    constexpr int NV = 4 * GCH;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nblk = gridDim.x;
+    double2 *ltab = reinterpret_cast<double2 *>(smem_w);                       // [128]
+    double *gr = reinterpret_cast<double *>(smem_w) + 2 * DSM_LOG_TAB_N;        // [GMAX][SPAD] gamma_raw
+    double *gs = gr + GMAX * SPAD;                                              // [GMAX][SPAD] gamma
+    double *t1 = gs + GMAX * SPAD;                                              // [GMAX] rowsum(gamma_raw)
+    double *told = t1 + GMAX + wv * (8 * GMAX);                                 // per wavefront [4][GMAX]
+    double *tnew = told + 4 * GMAX;                                             // per wavefront [4][GMAX]
+    double *red = t1 + GMAX + 4 * (8 * GMAX);                                   // [4][GMAX + 2][SPAD]
+    if (tid < DSM_LOG_TAB_N) ltab[tid] = reinterpret_cast<const double2 *>(log_tab)[tid];
+    for (int i = tid; i < GMAX * SPAD; i += 256) {
+        const int g = i / SPAD, s = i % SPAD;
+        const bool in = g < G && s < S;
+        gr[i] = in ? gam_raw[(size_t)g * S + s] : 0.0;
+        gs[i] = in ? gam[(size_t)g * S + s] : 0.0;
+    }
+    __syncthreads();
+    if (tid < GMAX) {
+        double a = 0.0;
+        for (int s = 0; s < S; ++s) a += gr[tid * SPAD + s];     // gamma.sum(1)  (:170)
+        t1[tid] = a;
+    }
+    __syncthreads();
+
+    double num[NSL][GMAX];
+#pragma unroll
+    for (int j = 0; j < NSL; ++j)
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) num[j][g] = 0.0;
+    double obj = 0.0, h1 = 0.0;
+    const int myidx = transpose_index<NV>(lane);         // (r, gg) this lane owns after the reduction
+    const int my_r = myidx / GCH, my_gg = myidx % GCH;
+
+    // software prefetch: the F rows and the tau rows of the wavefront's NEXT variant are requested
+    // while the current one is processed (a wavefront handles only a handful of variants, so the
+    // load latency would otherwise be exposed once per variant)
+    double f_nx[NSL][4];
+    double t_nx[(4 * GMAX + 63) / 64];
+    auto prefetch = [&](int v) {
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            const int s = lane + 64 * j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f_nx[j][r] = (v < V && s < S) ? F[((size_t)v * 4 + r) * S + s] : 1.0;
+        }
+#pragma unroll
+        for (int k = 0; k < (4 * GMAX + 63) / 64; ++k) {
+            const int i = lane + 64 * k, r = i / GMAX, g = i % GMAX;
+            t_nx[k] = (v < V && i < 4 * GMAX && g < G) ? tau[((size_t)v * 4 + r) * G + g] : 0.0;
+        }
+    };
+    prefetch(blockIdx.x * 4 + wv);
+    for (int v = blockIdx.x * 4 + wv; v < V; v += nblk * 4) {
+        // tau rows of the variant -> this wavefront's LDS scratch (uniform reads afterwards)
+#pragma unroll
+        for (int k = 0; k < (4 * GMAX + 63) / 64; ++k) {
+            const int i = lane + 64 * k;
+            if (i < 4 * GMAX) { told[i] = t_nx[k]; if (!do_update) tnew[i] = t_nx[k]; }
+        }
+        double f[NSL][4];
+        bool live[NSL];
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            live[j] = lane + 64 * j < S;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f[j][r] = f_nx[j][r];
+        }
+        prefetch(v + nblk * 4);
+        if (do_update) {
+            double q[NSL][4];
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) {
+                double R[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int g = 0; g < G; ++g) {
+                    const double gm = gr[g * SPAD + lane + 64 * j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) R[r] = fma(told[r * GMAX + g], gm, R[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q[j][r] = live[j] ? nzd(f[j][r]) / nzd(R[r]) : 0.0;
+            }
+            for (int g0 = 0; g0 < G; g0 += GCH) {
+                double val[NV];
+#pragma unroll
+                for (int gg = 0; gg < GCH; ++gg) {
+                    double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int j = 0; j < NSL; ++j) {
+                        const double gm = gr[(g0 + gg) * SPAD + lane + 64 * j];   // rows >= G are zero
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a[r] = fma(q[j][r], gm, a[r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) val[r * GCH + gg] = a[r];
+                }
+                const double tot_rg = wave_transpose_reduce<NV>(val);             // num[my_r][g0 + my_gg]
+                const int g = g0 + my_gg;
+                const bool ok = g < G;
+                double tn = 0.0;
+                if (ok) tn = told[my_r * GMAX + g] * (nzd(tot_rg) / nzd(t1[g]));  // :171-172
+                // the four bases of (v,g) live in one quad: sum over a in the reference's order
+                const double t_a0 = dpp_mov<0x00>(tn), t_a1 = dpp_mov<0xAA>(tn);  // lanes with (b0,b1) = (0,0) / (0,1) -> r = 0 / 1
+                const double t_a2 = dpp_mov<0x55>(tn), t_a3 = dpp_mov<0xFF>(tn);  //                    (1,0) / (1,1) -> r = 2 / 3
+                const double tot = ((t_a0 + t_a1) + t_a2) + t_a3;                 // :176-178
+                if (ok) {
+                    double x = tn / tot;                                          // :180-181
+                    if (adjust && x < DSM_EPS) x = DSM_EPS;                       // :88-91
+                    if (lane < 32) tau[((size_t)v * 4 + my_r) * G + g] = x;
+                    tnew[my_r * GMAX + g] = x;
+                }
+            }
+        }
+        // statistics of the (new) state for the next iteration
+        h1 += (lane < 4 * GMAX) ? tnew[lane] : 0.0;          // GMAX <= 16: one (r,g) column per lane
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            double R[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int g = 0; g < G; ++g) {
+                const double gm = gs[g * SPAD + lane + 64 * j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) R[r] = fma(tnew[r * GMAX + g], gm, R[r]);
+            }
+            double q2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double pa = R[r] < DSM_EPS ? DSM_EPS : R[r];
+                const double ratio = nzd(f[j][r]) / pa;
+                q2[r] = live[j] ? ((R[r] < DSM_EPS) ? nzd(f[j][r]) / nzd(R[r]) : ratio) : 0.0;
+                if (live[j]) obj += f[j][r] * dsm_log(ratio, ltab) - f[j][r] + pa;
+            }
+#pragma unroll
+            for (int g = 0; g < GMAX; ++g) {
+                if (g < G) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) num[j][g] = fma(tnew[r * GMAX + g], q2[r], num[j][g]);
+                }
+            }
+        }
+    }
+    // workgroup reduction over the 4 wavefronts (fixed order) -> transposed partials
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NSL; ++j)
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) red[((size_t)wv * (GMAX + 2) + g) * SPAD + lane + 64 * j] = num[j][g];
+    red[((size_t)wv * (GMAX + 2) + GMAX) * SPAD + lane] = obj;
+    // H1: lane i holds the (r = i / GMAX, g = i % GMAX) column sums
+    red[((size_t)wv * (GMAX + 2) + GMAX + 1) * SPAD + lane] = (lane < 4 * GMAX) ? h1 : 0.0;
+    __syncthreads();
+    for (int i = tid; i < G * S; i += 256) {
+        const int g = i / S, s = i % S;
+        double a = 0.0;
+        for (int k = 0; k < 4; ++k) a += red[((size_t)k * (GMAX + 2) + g) * SPAD + s];
+        partial[(size_t)i * nblk + blockIdx.x] = a;
+    }
+    if (tid < G) {
+        double a = 0.0;
+        for (int k = 0; k < 4; ++k)
+            for (int r = 0; r < 4; ++r) a += red[((size_t)k * (GMAX + 2) + GMAX + 1) * SPAD + r * GMAX + tid];
+        partial[((size_t)G * S + tid) * nblk + blockIdx.x] = a;
+    }
+    if (tid == 64) {
+        double a = 0.0;
+        for (int k = 0; k < 4; ++k)
+            for (int l = 0; l < 64; ++l) a += red[((size_t)k * (GMAX + 2) + GMAX) * SPAD + l];
+        partial[((size_t)G * S + G) * nblk + blockIdx.x] = a;
+    }
+}
+
 // get_tau (Init_NMFT.py:230-245): strict '>' against a running max from 0.0
 __global__ void nmft_get_tau_kernel(const double *__restrict__ tau, int V, int G, uint64_t *__restrict__ packed)
 {
@@ -346,6 +583,7 @@ int k_nmft_pass_a(dsm_ctx *c)
     else LAUNCH_A(32, 256);
 #undef LAUNCH_A
     HIP_TRY(hipGetLastError());
+    c->npart_cols = c->nmft_blocks;
     return DSM_OK;
 }
 
@@ -353,7 +591,7 @@ int k_nmft_gamma(dsm_ctx *c, int it, int max_iter, double min_change, int fix_ga
 {
     KTimer tm(c, DSM_K_NMFT_G);
     const int nout = c->nG * c->S + c->nG + 1;
-    hipLaunchKernelGGL(nmft_reduce_kernel, dim3((nout + 3) / 4), dim3(256), 0, c->stream, c->npart, c->nmft_blocks, nout,
+    hipLaunchKernelGGL(nmft_reduce_kernel, dim3((nout + 3) / 4), dim3(256), 0, c->stream, c->npart, c->npart_cols, nout,
                        NMFT_CTL(c), c->nstat);
     hipLaunchKernelGGL(nmft_gamma_kernel, dim3(1), dim3(1024), (size_t)1024 * sizeof(double), c->stream, c->nstat, c->S,
                        c->nG, it, max_iter, min_change, fix_gamma, adjust, c->ngam, c->ngam_raw, NMFT_CTL(c), c->ndiv_trace);
@@ -375,6 +613,49 @@ int k_nmft_pass_b(dsm_ctx *c, int adjust)
     hipLaunchKernelGGL(nmft_pass_b_kernel, dim3(grid), dim3(256), sh, c->stream, c->F, c->ntau, c->ngam_raw, c->V, S, G, VT,
                        adjust, NMFT_CTL(c));
     HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}
+
+// which (NSL, GMAX) the one-pass wavefront kernel is compiled for (per-lane accumulators NSL*GMAX <= 32)
+static bool wave_shape(const dsm_ctx *c, int *nsl, int *gmax)
+{
+    const int need = (c->S + 63) / 64;
+    *nsl = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
+    *gmax = c->nG <= 4 ? 4 : c->nG <= 8 ? 8 : c->nG <= 16 ? 16 : 32;
+    return need <= 8 && (*nsl) * (*gmax) <= 32 && (*gmax) <= 16;
+}
+
+bool nmft_use_wave(const dsm_ctx *c) { int a, b; return wave_shape(c, &a, &b); }
+
+int nmft_wave_grid(const dsm_ctx *c)
+{
+    int g = (c->V + 3) / 4;
+    if (g > 768) g = 768;                     // ~3 wavefronts per SIMD (the kernel's register occupancy)
+    return g < 1 ? 1 : g;
+}
+
+template <int NSL, int GMAX>
+static void launch_wave(dsm_ctx *c, int adjust, int do_update, int grid)
+{
+    const size_t sh = (2 * DSM_LOG_TAB_N + 2 * (size_t)GMAX * 64 * NSL + GMAX + 4 * 8 * GMAX +
+                       4 * (size_t)(GMAX + 2) * 64 * NSL) * sizeof(double);
+    hipLaunchKernelGGL((nmft_wave_kernel<NSL, GMAX>), dim3(grid), dim3(256), sh, c->stream, c->F, c->ntau, c->ngam_raw,
+                       c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart);
+}
+
+// do_update = 1: tau half of the running update + statistics of the next; 0: statistics only
+int k_nmft_wave(dsm_ctx *c, int adjust, int do_update)
+{
+    KTimer tm(c, do_update ? DSM_K_NMFT_B : DSM_K_NMFT_A);
+    int nsl, gmax;
+    if (!wave_shape(c, &nsl, &gmax)) { dsm_set_error("nmft_wave: unsupported shape"); return DSM_ERR_UNSUPPORTED; }
+    const int grid = nmft_wave_grid(c);
+#define WCASE(N, GM) if (nsl == N && gmax == GM) launch_wave<N, GM>(c, adjust, do_update, grid)
+    WCASE(1, 4); WCASE(1, 8); WCASE(1, 16); WCASE(2, 4); WCASE(2, 8); WCASE(2, 16); WCASE(4, 4); WCASE(4, 8);
+    WCASE(8, 4);
+#undef WCASE
+    HIP_TRY(hipGetLastError());
+    c->npart_cols = grid;
     return DSM_OK;
 }
 

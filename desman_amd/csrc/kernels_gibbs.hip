@@ -663,12 +663,19 @@ int k_stats(dsm_ctx *c, uint32_t iter)
 {
     KTimer tm(c, DSM_K_STATS);
     if (c->max_items == 0) return DSM_OK;
-    const int gm = c->G <= 4 ? 4 : c->G <= 8 ? 8 : c->G <= 16 ? 16 : 32;
+    // the per-read loop issues two instructions per threshold slot: instantiate it for the exact
+    // haplotype count (every G up to 8, then in steps of 2 and 4) instead of padding to a power of two
+    static const int sizes[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32};
+    int gm = 32;
+    for (int z : sizes) if (c->G <= z) { gm = z; break; }
+    const void *fn = nullptr;
+#define STATS_FN(GM) if (gm == GM) fn = (const void *)stats_kernel<GM>
+    STATS_FN(1); STATS_FN(2); STATS_FN(3); STATS_FN(4); STATS_FN(5); STATS_FN(6); STATS_FN(7); STATS_FN(8);
+    STATS_FN(10); STATS_FN(12); STATS_FN(14); STATS_FN(16); STATS_FN(20); STATS_FN(24); STATS_FN(28); STATS_FN(32);
+#undef STATS_FN
     if (c->blk_gmax != gm) {
         // size the grid to exactly the resident workgroups and share them among the samples by depth
         int occ = 0;
-        const void *fn = gm == 4 ? (const void *)stats_kernel<4> : gm == 8 ? (const void *)stats_kernel<8>
-                       : gm == 16 ? (const void *)stats_kernel<16> : (const void *)stats_kernel<32>;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, 0));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, c->device));
@@ -706,10 +713,11 @@ int k_stats(dsm_ctx *c, uint32_t iter)
     hipLaunchKernelGGL(stats_kernel<GM>, grid, block, 0, c->stream, reinterpret_cast<const int2 *>(c->items), \
                        c->nitems, c->blk_tab, c->tau, c->gamma, c->eta,                                       \
                        c->V, c->S, c->G, k0, k1, iter, c->sum_mu, c->esum)
-    if (gm == 4) LAUNCH_STATS(4);
-    else if (gm == 8) LAUNCH_STATS(8);
-    else if (gm == 16) LAUNCH_STATS(16);
-    else LAUNCH_STATS(32);
+#define STATS_CASE(GM) if (gm == GM) LAUNCH_STATS(GM)
+    STATS_CASE(1); STATS_CASE(2); STATS_CASE(3); STATS_CASE(4); STATS_CASE(5); STATS_CASE(6); STATS_CASE(7);
+    STATS_CASE(8); STATS_CASE(10); STATS_CASE(12); STATS_CASE(14); STATS_CASE(16); STATS_CASE(20); STATS_CASE(24);
+    STATS_CASE(28); STATS_CASE(32);
+#undef STATS_CASE
 #undef LAUNCH_STATS
     HIP_TRY(hipGetLastError());
     return DSM_OK;

@@ -102,9 +102,9 @@ int dsm_ctx_set_mt_state(dsm_ctx *ctx, const uint32_t *state625);
 /* fill `state625` from a seed exactly as gsl_rng_set(mt19937, seed) would. */
 int dsm_mt_seed_state(unsigned long seed, uint32_t *state625);
 
-/* A1: one tau sweep on the resident state (c_sample_tau.c:95-204);
- * gamma/eta may be NULL (use resident) or host overrides.  logp_out (optional,
- * host, [V][G][4]) receives the un-normalised conditional log-probabilities. */
+/* A1: one tau sweep on the resident state (c_sample_tau.c:95-204) with the
+ * resident gamma / eta (see dsm_ctx_set_gamma_eta).  logp_out (optional, host,
+ * [V][G][4]) receives the un-normalised conditional log-probabilities.       */
 int dsm_ctx_sample_tau(dsm_ctx *ctx, int *nchange, double *logp_out);
 
 /* A2: one draw of the auxiliary-count sums (HaploSNP_Sampler.py:284-309 via

@@ -348,3 +348,36 @@ def test_nmft_vs_oracle(ctx, V, S, G):
     np.testing.assert_allclose(t, tc, rtol=1e-6, atol=1e-12)
     np.testing.assert_allclose(g, gc, rtol=1e-6, atol=1e-12)
     assert np.array_equal(ctx.nmft_get_tau(), cbind.idx_to_onehot(cbind.nmft_get_tau(tc, G)))
+
+
+def test_chain_posterior_matches_reference_sampler_in_law(ctx):
+    """T1 parity at chain level: the HIP chain (counter-based mu/E, gamma, eta draws) and the oracle's
+    RandomState-exact restatement of the reference's update() target the same posterior: posterior means of
+    gamma, eta and the deviance agree within Monte-Carlo error when both start from the generating state."""
+    V, S, G = 60, 8, 3
+    counts, tau_true, gamma_true = synth_counts(V, S, G, seed=202)
+    tau0 = cbind.idx_to_onehot(tau_true)
+    eta0 = 0.96 * np.eye(4) + 0.01
+    # reference law: python-level loops with numpy's RandomState + the C tau sweep
+    rs = np.random.RandomState(11)
+    cbind.initRNG(); cbind.setRNG(11)
+    burn = rn.gibbs_update(rs, tau0, gamma_true, eta0, counts, 30, cbind.sample_tau)
+    ref = rn.gibbs_update(rs, burn["tau"], burn["gamma"], burn["eta"], counts, 160, cbind.sample_tau)
+    cbind.freeRNG()
+    # HIP chain
+    _load(ctx, counts, tau0, np.ascontiguousarray(gamma_true), eta0, mt_seed=12)
+    ctx.gibbs_update(200)
+    ctx.gibbs_update(3000)
+    tr = ctx.get_trace()
+    g_ref, g_hip = ref["trace"]["gamma"], tr["gamma"]
+    se = np.sqrt(g_ref.var(axis=0) / 40.0 + g_hip.var(axis=0) / 300.0) + 2e-3     # autocorrelation-padded
+    assert (np.abs(g_ref.mean(axis=0) - g_hip.mean(axis=0)) < 5.0 * se).all()
+    e_ref, e_hip = ref["trace"]["eta"], tr["eta"]
+    se_e = np.sqrt(e_ref.var(axis=0) / 40.0 + e_hip.var(axis=0) / 300.0) + 1e-3
+    assert (np.abs(e_ref.mean(axis=0) - e_hip.mean(axis=0)) < 5.0 * se_e).all()
+    dev_ref, dev_hip = -2 * ref["trace"]["ll"], -2 * tr["ll"]
+    se_d = np.sqrt(dev_ref.var() / 40.0 + dev_hip.var() / 300.0)
+    assert abs(dev_ref.mean() - dev_hip.mean()) < 5.0 * se_d + 1.0
+    # and the haplotypes both chains settle on are the generating ones
+    assert (np.argmax(ctx.get_star()["tau"], axis=2) != tau_true).mean() < 0.05
+    assert (np.argmax(ref["star"]["tau"], axis=2) != tau_true).mean() < 0.05

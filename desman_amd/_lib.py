@@ -160,8 +160,15 @@ class Context:
         v = np.ascontiguousarray(variants, dtype=np.int64)
         if v.ndim != 3 or v.shape[2] != 4:
             raise ValueError("variants must be [V,S,4]")
+        # re-uploading (and re-sorting the per-read work list) is skipped when the very same tensor is
+        # already resident -- Init_NMFT and HaploSNP_Sampler of one run share a context
+        token = (v.shape, int(v.sum()), int((v * (np.arange(v.size, dtype=np.int64).reshape(v.shape) % 1021 + 1)).sum()))
+        if getattr(self, "_counts_token", None) == token:
+            return
         check(self.lib.dsm_ctx_set_counts(self._h, v, v.shape[0], v.shape[1]))
         self.V, self.S = v.shape[0], v.shape[1]
+        self.G = 0
+        self._counts_token = token
 
     def set_state(self, tau, gamma, eta):
         tau = np.ascontiguousarray(tau, dtype=np.int64)

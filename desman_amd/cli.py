@@ -95,7 +95,7 @@ def main(argv=None):
     init_NMFT.factorize()
 
     haplo_SNP = hsnp.HaploSNP_Sampler(variant_Filter.snps_filter, genomes, prng, max_iter=no_iter,
-                                      device=args.device)
+                                      device=args.device, ctx=init_NMFT._ctx)      # same resident count tensor
     haplo_SNP.tau = np.copy(init_NMFT.get_tau(), order='C')
     haplo_SNP.updateTauIndices()
     haplo_SNP.gamma = np.copy(init_NMFT.get_gamma(), order='C')
@@ -125,7 +125,7 @@ def main(argv=None):
         logging.info('Perform NTF initialisation on not selected SNPs fixed gamma')
         init_NMFT_NS.factorize_tau()
         haplo_SNP_NS = hsnp.HaploSNP_Sampler(snps_notselected, haplo_SNP.G, haplo_SNP.randomState,
-                                             max_iter=no_iter, device=args.device)
+                                             max_iter=no_iter, device=args.device, ctx=init_NMFT_NS._ctx)
         haplo_SNP_NS.tau = init_NMFT_NS.get_tau()
         haplo_SNP_NS.updateTauIndices()
         haplo_SNP_NS.gamma_star = np.copy(haplo_SNP.gammaMean(), order='C')

@@ -13,8 +13,6 @@ import numpy as np
 from . import _lib
 from . import sampletau as _sampletau
 
-_chain_counter = [0]
-
 
 class HaploSNP_Sampler:
 
@@ -48,8 +46,6 @@ class HaploSNP_Sampler:
         self._ctx = ctx if ctx is not None else _lib.Context(device)
         self._ctx.set_counts(self.variants)
         self._ctx.set_priors(alpha_constant, delta_constant, epsilon)
-        _chain_counter[0] += 1
-        self._chain_id = _chain_counter[0]
         self._tau_sum = None
         self._have_trace = False
         self._keyed = False
@@ -69,7 +65,9 @@ class HaploSNP_Sampler:
         st = _sampletau.getRNGState()          # raises if initRNG()/setRNG() were not called
         if not self._keyed:
             # key the counter-based streams (mu/E, gamma, eta) once per sampler object
-            key = ((int(st[0]) << 32) ^ int(st[1]) ^ (0x9E3779B97F4A7C15 * self._chain_id)) & 0xFFFFFFFFFFFFFFFF
+            # a function of the stream position only: deterministic whatever else runs in the process
+            key = ((int(st[0]) << 32) ^ int(st[1]) ^ (int(st[2]) << 16) ^ (0x9E3779B97F4A7C15 * (int(st[624]) + 1))) \
+                & 0xFFFFFFFFFFFFFFFF
             self._ctx.seed(1, ctr_seed=key)
             self._keyed = True
         self._ctx.set_mt_state(st)

@@ -48,21 +48,31 @@ def sweep_specs(g_values, n_reps, V, S):
     return specs
 
 
-def run_chains(specs, run_fn, dist=None, device=None):
+def run_chains(specs, run_fn, dist=None, device=None, concurrency=1):
     """Run `run_fn(spec) -> dict(REC_FIELDS...)` for this rank's share of `specs` and gather
     every chain's record on all ranks.  `dist` = an initialised torch.distributed module
-    (or None for a single process).  Returns the records sorted by chain id."""
+    (or None for a single process).  `concurrency` chains of a rank run at the same time in
+    threads (each on its own context / HIP streams; ctypes releases the GIL while a launch
+    sequence is in flight): small-V chains are latency-bound, so several of them share a GPU
+    well.  Returns the records sorted by chain id."""
     import torch
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     bins = lpt_assign([s["cost"] for s in specs], world)
-    mine = []
-    for cid in bins[rank]:
+
+    def one(cid):
         t0 = time.perf_counter()
         rec = dict(run_fn(specs[cid]))
         rec.setdefault("wall_s", time.perf_counter() - t0)
         rec["chain"] = cid
-        mine.append([float(rec[k]) for k in REC_FIELDS])
+        return [float(rec[k]) for k in REC_FIELDS]
+
+    if concurrency > 1 and len(bins[rank]) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=concurrency) as pool:
+            mine = list(pool.map(one, bins[rank]))           # LPT order: longest chains start first
+    else:
+        mine = [one(cid) for cid in bins[rank]]
     width = max(len(b) for b in bins) if specs else 0
     buf = np.full((max(width, 1), len(REC_FIELDS)), np.nan)
     if mine:
@@ -79,23 +89,63 @@ def run_chains(specs, run_fn, dist=None, device=None):
     return [dict(zip(REC_FIELDS, r.tolist())) for r in rows]
 
 
+class _ThreadLogRouter(__import__("logging").Handler):
+    """routes log records to the log_file.txt of the chain the emitting thread is running (the
+    reference has one process, hence one log file, per chain)."""
+
+    def __init__(self):
+        super().__init__()
+        import threading
+        self._files, self._lock = {}, threading.Lock()
+        self.setFormatter(__import__("logging").Formatter('%(asctime)s:%(levelname)s:%(name)s:%(message)s'))
+
+    def open(self, path):
+        import threading
+        with self._lock:
+            self._files[threading.get_ident()] = open(path, "w")
+
+    def close_current(self):
+        import threading
+        with self._lock:
+            f = self._files.pop(threading.get_ident(), None)
+        if f:
+            f.close()
+
+    def emit(self, record):
+        f = self._files.get(record.thread)
+        if f is not None:
+            f.write(self.format(record) + "\n")
+            f.flush()
+
+
 def gibbs_chain_runner(variant_file, n_iter, device, out_stub, extra_args=()):
     """run_fn for real chains on one GPU: the whole `desman` run for (G, seed) -- NMFT init,
     burn-in, removeDegenerate, sampling, all output files -- into `<stub>_<G>_<seed>/`, the
-    directory layout scripts/runDesman.sh:15-21 produces and scripts/resolvenhap.py reads."""
+    directory layout scripts/runDesman.sh:15-21 produces and scripts/resolvenhap.py reads.
+    Thread-safe: every chain has its own context, its own logical GSL stream and its own log file."""
     import logging
 
-    from . import cli
+    from . import _lib, cli, sampletau
+
+    _lib.load()                                           # before any worker thread
+    router = _ThreadLogRouter()
+    for h in list(logging.root.handlers):
+        logging.root.removeHandler(h)
+    logging.root.addHandler(router)
+    logging.root.setLevel(logging.INFO)
 
     def run(spec):
         t0 = time.perf_counter()
         G, seed = spec["G"], spec["seed"]
         d = "%s_%d_%d" % (out_stub, G, seed)
-        for h in list(logging.root.handlers):            # one log_file.txt per chain, as one process per chain has
-            logging.root.removeHandler(h)
-            h.close()
-        cli.main([variant_file, "-g", str(G), "-s", str(seed), "-i", str(n_iter), "-o", d, "--device", str(device)]
-                 + list(extra_args))
+        os.makedirs(d, exist_ok=True)
+        sampletau.use_thread_local_rng(True)
+        router.open(os.path.join(d, "log_file.txt"))
+        try:
+            cli.main([variant_file, "-g", str(G), "-s", str(seed), "-i", str(n_iter), "-o", d, "--device", str(device)]
+                     + list(extra_args))
+        finally:
+            router.close_current()
         _, gt, ht, lp, dev = open(os.path.join(d, "fit.txt")).read().strip().split(",")
         return dict(G=G, seed=seed, G_final=int(ht), lp_star=float(lp), mean_dev=float(dev), iters=2 * n_iter,
                     wall_s=time.perf_counter() - t0)
@@ -121,6 +171,7 @@ def main(argv=None):
     ap.add_argument("-m", "--min_coverage", type=float, default=5.0)
     ap.add_argument("-r", "--random_select", type=int, default=None)
     ap.add_argument("-o", "--output_stub", default="sweep")
+    ap.add_argument("-c", "--concurrency", type=int, default=4, help="chains running at the same time per GPU")
     args = ap.parse_args(argv)
     import pandas as p
     import torch
@@ -136,7 +187,7 @@ def main(argv=None):
     specs = sweep_specs(range(args.gmin, args.gmax + 1), args.reps, V, S)
     extra = ["-m", str(args.min_coverage)] + (["-r", str(args.random_select)] if args.random_select else [])
     recs = run_chains(specs, gibbs_chain_runner(args.variant_file, args.no_iter, local, args.output_stub, extra), dist,
-                      device=torch.device("cuda", local) if dist is not None else None)
+                      device=torch.device("cuda", local) if dist is not None else None, concurrency=args.concurrency)
     if dist is None or dist.get_rank() == 0:
         write_dev_csv(args.output_stub + "_Dev.csv", recs)
         print(json.dumps(recs))

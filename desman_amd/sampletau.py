@@ -8,13 +8,32 @@ it from reference-style code:  ``import desman_amd.sampletau as sampletau`` or
 
 There is no CPU fallback: a missing library or GPU raises DesmanHipError.
 """
+import threading
+
 import numpy as np
 
 from . import _lib
 
+# A thread that calls use_thread_local_rng() gets its own logical GSL stream (a host copy of the 625-word
+# MT19937 state) instead of the process-global one of the C shim: several chains can then run
+# concurrently in one process (desman_amd.chains), each continuing its own stream across its samplers.
+_tls = threading.local()
+
+
+def use_thread_local_rng(on=True):
+    _tls.enabled = bool(on)
+    _tls.state = None
+
+
+def _local():
+    return getattr(_tls, "enabled", False)
+
 
 def initRNG():
     """c_initRNG (sampletau.pyx:23-24): allocate the global MT19937 stream."""
+    if _local():
+        _tls.state = _lib.mt_seed_state(0)
+        return
     _lib.check(_lib.load().dsm_initRNG())
 
 
@@ -22,11 +41,19 @@ def setRNG(seed):
     """c_setRNG (sampletau.pyx:28-29): `int seed` -> unsigned long."""
     if not isinstance(seed, (int, np.integer)):
         raise TypeError("an integer is required")
+    if _local():
+        if _tls.state is None:
+            raise _lib.DesmanHipError("setRNG before initRNG")
+        _tls.state = _lib.mt_seed_state(seed)
+        return
     _lib.check(_lib.load().dsm_setRNG(int(seed) & 0xFFFFFFFFFFFFFFFF))
 
 
 def freeRNG():
     """c_freeRNG (sampletau.pyx:33-34)."""
+    if _local():
+        _tls.state = None
+        return
     _lib.check(_lib.load().dsm_freeRNG())
 
 
@@ -69,6 +96,10 @@ def sample_tau(tau, pi, eta, variants):
 
 def getRNGState():
     """(extension) the 625-word state of the global MT19937 stream."""
+    if _local():
+        if _tls.state is None:
+            raise _lib.DesmanHipError("getRNGState: RNG not initialised")
+        return _tls.state.copy()
     st = np.empty(625, dtype=np.uint32)
     _lib.check(_lib.load().dsm_getRNG_state(st))
     return st
@@ -76,4 +107,7 @@ def getRNGState():
 
 def setRNGState(state):
     """(extension) restore the global MT19937 stream."""
+    if _local():
+        _tls.state = np.ascontiguousarray(state, dtype=np.uint32).copy()
+        return
     _lib.check(_lib.load().dsm_setRNG_state(np.ascontiguousarray(state, dtype=np.uint32)))

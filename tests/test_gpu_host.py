@@ -176,3 +176,11 @@ def test_gsweep_driver_and_model_selection(tmp_path, capsys):
             assert os.path.exists("%s_%d_%d/log_file.txt" % (stub, g, r))
     out = capsys.readouterr().out.strip().split("\n")[-1].split(",")
     assert int(out[0]) >= G and int(out[1]) == G          # G strains are reproducible and abundant
+    # chains are independent of how many run at the same time: sequential == 4-way concurrent, file for file
+    stub1 = str(tmp_path / "seq")
+    chains.main([freq, "--gmin", "2", "--gmax", "5", "--reps", "3", "-i", "40", "-o", stub1, "-c", "1"])
+    for g in range(2, 6):
+        for r in range(3):
+            for f in ("fit.txt", "Filtered_Tau_star.csv", "Gamma_mean.csv", "Eta_star.csv"):
+                assert open("%s_%d_%d/%s" % (stub, g, r, f)).read() == open("%s_%d_%d/%s" % (stub1, g, r, f)).read()
+            assert "Gibbs Iter" in open("%s_%d_%d/log_file.txt" % (stub, g, r)).read()

@@ -167,9 +167,9 @@ __global__ __launch_bounds__(256) void nmft_reduce_kernel(const double *__restri
 // ---------------------------------------------------------------------------
 // gamma / control kernel (one workgroup): the stop test of the factorize loop
 // (Init_NMFT.py:106) on the device, then the gamma update (:163-168).
-// ctl: [0] div  [2] done  [3] updates run  [4 + (it&1)] div of iteration it.
+// ctl: [0] div  [2] done  [3] updates run  [4 + (it&1)] div of iteration it  [6] iteration counter.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void nmft_gamma_kernel(const double *__restrict__ stat, int S, int G, int it,
+__global__ __launch_bounds__(1024) void nmft_gamma_kernel(const double *__restrict__ stat, int S, int G,
                                                           int max_iter, double min_change, int fix_gamma, int adjust,
                                                           double *__restrict__ gam, double *__restrict__ gam_raw,
                                                           double *__restrict__ ctl, double *__restrict__ div_trace)
@@ -180,6 +180,10 @@ __global__ __launch_bounds__(1024) void nmft_gamma_kernel(const double *__restri
     if (ctl[2] != 0.0) return;
     const int tid = threadIdx.x;
     if (tid == 0) {
+        // the iteration index is a device word, so every iteration is the SAME launch and a batch of
+        // iterations can be replayed as one hipGraph
+        const int it = (int)ctl[6];
+        ctl[6] = (double)(it + 1);
         const double div = stat[(size_t)G * S + G];
         const double prev = (it == 0) ? 0.0 : ctl[4 + ((it - 1) & 1)];
         go = (it < max_iter) && (fabs(prev - div) > min_change);         // Init_NMFT.py:106
@@ -587,14 +591,14 @@ int k_nmft_pass_a(dsm_ctx *c)
     return DSM_OK;
 }
 
-int k_nmft_gamma(dsm_ctx *c, int it, int max_iter, double min_change, int fix_gamma, int adjust)
+int k_nmft_gamma(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int adjust)
 {
     KTimer tm(c, DSM_K_NMFT_G);
     const int nout = c->nG * c->S + c->nG + 1;
     hipLaunchKernelGGL(nmft_reduce_kernel, dim3((nout + 3) / 4), dim3(256), 0, c->stream, c->npart, c->npart_cols, nout,
                        NMFT_CTL(c), c->nstat);
     hipLaunchKernelGGL(nmft_gamma_kernel, dim3(1), dim3(1024), (size_t)1024 * sizeof(double), c->stream, c->nstat, c->S,
-                       c->nG, it, max_iter, min_change, fix_gamma, adjust, c->ngam, c->ngam_raw, NMFT_CTL(c), c->ndiv_trace);
+                       c->nG, max_iter, min_change, fix_gamma, adjust, c->ngam, c->ngam_raw, NMFT_CTL(c), c->ndiv_trace);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }

@@ -69,6 +69,7 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1):
 
     if concurrency > 1 and len(bins[rank]) > 1:
         from concurrent.futures import ThreadPoolExecutor
+        os.environ.setdefault("DESMAN_HIP_NMFT_GRAPH", "1")      # replayed NMFT batches: see api.hip (dsm_nmft_factorize)
         with ThreadPoolExecutor(max_workers=concurrency) as pool:
             mine = list(pool.map(one, bins[rank]))           # LPT order: longest chains start first
     else:

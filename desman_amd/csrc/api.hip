@@ -758,10 +758,11 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     if (wave) TRY(k_nmft_wave(c, adjust, 0));
     // One iteration = the same 2-3 launches every time (the iteration index and the stop flag live in
     // device memory), so BATCH iterations can be captured once into a hipGraph and replayed.  Measured on
-    // MI355X / ROCm 7.2: a replayed kernel node costs more than a stream-ordered launch when the kernels are
-    // long (V=10k: 70 vs 40 us per iteration), while for small V -- the `-r 1000` subsample every shipped
-    // workflow uses -- replay takes the host out of the loop and lets several chains share the GPU
-    // (35-chain sweep at V=1000: 2.6 s eager -> 2.2 s).  Hence graphs for small tensors only.
+    // MI355X / ROCm 7.2: a replayed kernel node costs ~10 us, more than a stream-ordered launch (V=10k: 70 vs
+    // 40 us per iteration; V=1k: 48 vs 25), so a single chain runs eagerly.  Replay pays when several chains
+    // share the GPU from different host threads -- the `-r 1000` sweeps every shipped workflow runs -- because
+    // it takes the host (and the runtime's launch lock) out of the loop: 35-chain sweep at V=1000, 4 chains at a
+    // time: 4.2 s eager -> 2.2 s replayed.  desman_amd.chains opts in through DESMAN_HIP_NMFT_GRAPH=1.
     // (Timing mode records events per launch -> eager.)
     auto enqueue_iteration = [&]() -> int {
         if (!wave) TRY(k_nmft_pass_a(c));
@@ -773,7 +774,8 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     struct GraphGuard { hipGraph_t &g; hipGraphExec_t &e; ~GraphGuard() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); } } gg{graph, gexec};
-    const bool use_graph = !c->timing && max_iter >= BATCH && (size_t)c->V * c->S <= 131072;
+    const char *genv = getenv("DESMAN_HIP_NMFT_GRAPH");
+    const bool use_graph = genv && genv[0] == '1' && !c->timing && max_iter >= BATCH && (size_t)c->V * c->S <= 131072;
     if (use_graph) {
         HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         int rc = DSM_OK;

@@ -147,6 +147,7 @@ def gibbs_chain_runner(variant_file, n_iter, device, out_stub, extra_args=()):
                      + list(extra_args))
         finally:
             router.close_current()
+            sampletau.use_thread_local_rng(False)         # the calling thread gets the process-global stream back
         _, gt, ht, lp, dev = open(os.path.join(d, "fit.txt")).read().strip().split(",")
         return dict(G=G, seed=seed, G_final=int(ht), lp_star=float(lp), mean_dev=float(dev), iters=2 * n_iter,
                     wall_s=time.perf_counter() - t0)

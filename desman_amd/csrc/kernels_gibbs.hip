@@ -101,47 +101,60 @@ __global__ void tau_sum_kernel(const uint64_t *__restrict__ trace, int n, int V,
 // A refill of the 624-word state has only three dependent phases
 // ([0,227) [227,454) [454,624)), each fully lane-parallel.
 // =====================================================================
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y)
+{
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+// The state is double-buffered in LDS (old block / new block), so a phase has no read-after-write
+// hazard inside itself and needs ONE barrier (3 per 624 words instead of 6); the tempered output of
+// a word is stored by the lane that just produced it (no separate output pass).
 __global__ __launch_bounds__(256) void mt_fill_kernel(uint32_t *__restrict__ state, uint32_t *__restrict__ out,
                                                       size_t n)
 {
-    __shared__ uint32_t mt[624];
+    __shared__ uint32_t buf[2][624];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 624; i += 256) mt[i] = state[i];
+    int cur = 0;
+    for (int i = tid; i < 624; i += 256) buf[0][i] = state[i];
     int pos = (int)state[624];
     __syncthreads();
     size_t done = 0;
-    while (done < n) {
-        if (pos >= 624) {
-            const int lo[3] = {0, 227, 454}, hi[3] = {227, 454, 624};
-#pragma unroll
-            for (int ph = 0; ph < 3; ++ph) {
-                const int i = lo[ph] + tid;
-                uint32_t val = 0;
-                if (i < hi[ph]) {
-                    const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
-                    val = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-                }
-                __syncthreads();
-                if (i < hi[ph]) mt[i] = val;
-                __syncthreads();
-            }
-            pos = 0;
-        }
-        const size_t left = n - done;
-        const int chunk = (left < (size_t)(624 - pos)) ? (int)left : (624 - pos);
-        for (int i = tid; i < chunk; i += 256) {
-            uint32_t y = mt[pos + i];
-            y ^= y >> 11;
-            y ^= (y << 7) & 0x9d2c5680u;
-            y ^= (y << 15) & 0xefc60000u;
-            y ^= y >> 18;
-            out[done + i] = y;
-        }
-        pos += chunk;
-        done += chunk;
-        __syncthreads();
+    // words still unread in the resident block
+    if (pos < 624) {
+        const size_t take = (n < (size_t)(624 - pos)) ? n : (size_t)(624 - pos);
+        for (int i = tid; i < (int)take; i += 256) out[i] = mt_temper(buf[0][pos + i]);
+        pos += (int)take;
+        done = take;
     }
-    for (int i = tid; i < 624; i += 256) state[i] = mt[i];
+    while (done < n) {
+        const uint32_t *o = buf[cur];
+        uint32_t *w = buf[cur ^ 1];
+        const size_t left = n - done;
+        const int lo[3] = {0, 227, 454}, hi[3] = {227, 454, 624};
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) {
+            const int i = lo[ph] + tid;
+            if (i < hi[ph]) {
+                // word i+1 = 624 is the new block's word 0; words i+397 >= 624 are new words i-227
+                const uint32_t nxt = (i + 1 < 624) ? o[i + 1] : w[0];
+                const uint32_t far = (i + 397 < 624) ? o[i + 397] : w[i - 227];
+                const uint32_t y = (o[i] & 0x80000000u) | (nxt & 0x7fffffffu);
+                const uint32_t val = far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                w[i] = val;
+                if ((size_t)i < left) out[done + i] = mt_temper(val);
+            }
+            __syncthreads();
+        }
+        cur ^= 1;
+        const size_t take = (left < 624) ? left : 624;
+        pos = (int)take;
+        done += take;
+    }
+    for (int i = tid; i < 624; i += 256) state[i] = buf[cur][i];
     if (tid == 0) state[624] = (uint32_t)pos;
 }
 

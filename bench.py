@@ -45,7 +45,10 @@ def cpu_baseline(S, G, budget_s=20.0):
     return dict(value=Vs * S * its / dt, unit="V*S updates/s", cores=1, kind="port",
                 sample="%d full Gibbs iterations of oracle/ref_numpy.gibbs_update (+ C tau sweep) on a V=%d slice "
                        "of the same S=%d, G=%d workload, 1 thread, %.1f s" % (its, Vs, S, G, dt),
-                cpu=_cpu_model())
+                cpu=_cpu_model(),
+                # measured once in the development container (where /root/reference exists): the imported
+                # reference's update() on this same V=400 slice took 2.97 s/iteration, the port 1.83 s
+                calibration_reference_over_port=1.62)
 
 
 def _cpu_model():

@@ -1,15 +1,22 @@
-"""Writers for DESMAN's output files (desman/Output_Results.py) -- the on-disk
-contract of the drop-in CLI: same file names, same CSV layouts."""
+"""Result files of a `desman` run -- the on-disk half of the drop-in contract.
+
+Same class / method names as desman/Output_Results.py (the driver and downstream scripts call them) and
+byte-identical files (tests/test_host_cpu.py compares against files the reference class wrote); inside,
+everything goes through two small helpers: one for haplotype tables (Position first, then 4 columns per
+haplotype), one for per-sample abundance tables.
+"""
 import logging
 import os
 import sys
 
 import numpy as np
-import pandas as p
+import pandas as pd
+
+LOG_FORMAT = '%(asctime)s:%(levelname)s:%(name)s:%(message)s'
 
 
-def rchop(s, ending):
-    return s[:-len(ending)] if s.endswith(ending) else s
+def rchop(text, suffix):
+    return text[:-len(suffix)] if text.endswith(suffix) else text
 
 
 class Output_Results:
@@ -17,12 +24,13 @@ class Output_Results:
     def __init__(self, outputDir):
         self.outputDir = outputDir
         os.makedirs(outputDir, exist_ok=True)
-        self.log_file_name = self.outputDir + "/log_file.txt"
-        logging.basicConfig(filename=self.log_file_name, level=logging.INFO, filemode='w',
-                            format='%(asctime)s:%(levelname)s:%(name)s:%(message)s')
-        logging.info("Results created in {0}".format(os.path.abspath(self.outputDir)))
+        self.log_file_name = outputDir + "/log_file.txt"
+        logging.basicConfig(filename=self.log_file_name, level=logging.INFO, filemode='w', format=LOG_FORMAT)
+        here = os.path.abspath(self.outputDir)
+        logging.info("Results created in {0}".format(here))
         print("Up and running. Check {0} for progress".format(os.path.abspath(self.log_file_name)), file=sys.stderr)
 
+    # ---- wiring
     def set_Variants(self, variants):
         self.variants = variants
         self.contig_names = variants.index.tolist()
@@ -30,84 +38,90 @@ class Output_Results:
 
     def set_Variant_Filter(self, variantFilter):
         self.variantFilter = variantFilter
-        sel = variantFilter.selected_indices
-        self.filtered_contig_names = [self.contig_names[i] for i in sel]
-        self.filtered_position = [self.position.iloc[i] for i in sel]
+        keep = variantFilter.selected_indices
+        self.filtered_contig_names = [self.contig_names[i] for i in keep]
+        self.filtered_position = [self.position.iloc[i] for i in keep]
 
-    def _fit(self, name, haplo_SNP, genomes):
-        with open(self.outputDir + "/" + name, "w") as f:
-            f.write("Fit,%d,%d,%f,%f\n" % (genomes, haplo_SNP.G, haplo_SNP.lp_star, haplo_SNP.meanDeviance()))
+    def _path(self, name):
+        return self.outputDir + "/" + name
+
+    # ---- fit statistics: Fit,<G requested>,<G kept>,<lp*>,<mean deviance>
+    def _write_fit(self, name, sampler, requested):
+        line = "Fit,%d,%d,%f,%f\n" % (requested, sampler.G, sampler.lp_star, sampler.meanDeviance())
+        with open(self._path(name), "w") as fh:
+            fh.write(line)
 
     def set_haplo_SNP(self, haplo_SNP, genomes):
         self.haplo_SNP = haplo_SNP
-        self._fit("fit.txt", haplo_SNP, genomes)
-        logging.info("Wrote fit stats")
+        self._write_fit("fit.txt", haplo_SNP, genomes)
+        logging.info("fit.txt written")
 
     def outPredFit(self, haplo_SNP, genomes):
-        self._fit("fitP.txt", haplo_SNP, genomes)
-        logging.info("Wrote pred fit stats")
+        self._write_fit("fitP.txt", haplo_SNP, genomes)
+        logging.info("fitP.txt written")
 
-    @staticmethod
-    def _position_first(values, index, position):
-        df = p.DataFrame(values, index=index)
-        df['Position'] = position
-        cols = df.columns.tolist()
-        return df[cols[-1:] + cols[:-1]]
-
-    def _tau_csv(self, name, tau):
-        flat = np.reshape(tau, (self.haplo_SNP.V, self.haplo_SNP.G * 4))
-        self._position_first(flat, self.filtered_contig_names, self.filtered_position).to_csv(self.outputDir + "/" + name)
+    # ---- haplotype tables
+    def _haplotype_table(self, name, values, names, positions):
+        """rows = positions, first column Position, then the flattened [G][4] block."""
+        flat = np.reshape(values, (values.shape[0], -1))
+        frame = pd.DataFrame(flat, index=names)
+        frame['Position'] = positions
+        order = frame.columns.tolist()
+        frame[order[-1:] + order[:-1]].to_csv(self._path(name))
 
     def output_Filtered_Tau(self, tau):
-        self._tau_csv("Filtered_Tau_star.csv", tau)
-        logging.info("Wrote filtered tau star haplotype predictions")
+        self._haplotype_table("Filtered_Tau_star.csv", np.reshape(tau, (self.haplo_SNP.V, self.haplo_SNP.G, 4)),
+                              self.filtered_contig_names, self.filtered_position)
+        logging.info("Filtered_Tau_star.csv written")
 
     def output_Tau_Mean(self, tauProb):
-        self._tau_csv("Tau_Mean.csv", tauProb)
-        logging.info("Wrote probabilistic tau haplotype predictions")
+        self._haplotype_table("Tau_Mean.csv", np.reshape(tauProb, (self.haplo_SNP.V, self.haplo_SNP.G, 4)),
+                              self.filtered_contig_names, self.filtered_position)
+        logging.info("Tau_Mean.csv written")
 
     def output_collated_Tau(self, haplo_SNP_NS, full_variants):
-        VS = haplo_SNP_NS.V + self.haplo_SNP.V
+        """-r: fitted and assigned positions merged back into input order."""
+        total = haplo_SNP_NS.V + self.haplo_SNP.V
         G = self.haplo_SNP.G
-        sel = np.asarray(self.variantFilter.selected[:VS], dtype=bool)
-        star = np.zeros((VS, G, 4), dtype=np.int64)
-        mean = np.zeros((VS, G, 4))
-        star[sel] = self.haplo_SNP.tau_star
-        star[~sel] = haplo_SNP_NS.tau_star
-        mean[sel] = self.haplo_SNP.probabilisticTau()
-        mean[~sel] = haplo_SNP_NS.probabilisticTau()
-        names = full_variants.index.tolist()
-        pos = full_variants['Position']
-        orig = self.variantFilter.selected_indices_original
-        o_names = [names[i] for i in orig]
-        o_pos = [pos.iloc[i] for i in orig]
-        self._position_first(star.reshape(VS, G * 4), o_names, o_pos).to_csv(self.outputDir + "/Collated_Tau_star.csv")
-        logging.info("Wrote all tau haplotype predictions")
-        self._position_first(mean.reshape(VS, G * 4), o_names, o_pos).to_csv(self.outputDir + "/Collated_Tau_mean.csv")
-        logging.info("Wrote all probabilistic tau haplotype predictions")
+        fitted = np.asarray(self.variantFilter.selected[:total], dtype=bool)
+        star = np.zeros((total, G, 4), dtype=np.int64)
+        prob = np.zeros((total, G, 4))
+        star[fitted], star[~fitted] = self.haplo_SNP.tau_star, haplo_SNP_NS.tau_star
+        prob[fitted], prob[~fitted] = self.haplo_SNP.probabilisticTau(), haplo_SNP_NS.probabilisticTau()
+        all_names = full_variants.index.tolist()
+        all_pos = full_variants['Position']
+        rows = self.variantFilter.selected_indices_original
+        names = [all_names[i] for i in rows]
+        positions = [all_pos.iloc[i] for i in rows]
+        self._haplotype_table("Collated_Tau_star.csv", star, names, positions)
+        self._haplotype_table("Collated_Tau_mean.csv", prob, names, positions)
+        logging.info("Collated_Tau_star.csv / Collated_Tau_mean.csv written")
 
-    def _sample_names(self):
+    # ---- abundance and error tables
+    def _kept_sample_names(self):
         cols = self.variants.columns.values.tolist()
-        n0 = (len(cols) - 1) // 4
-        names = [rchop(cols[i], '-A') for i in range(1, n0 * 4, 4)]
-        return [names[i] for i in self.variantFilter.sample_indices]
+        n_samples = (len(cols) - 1) // 4
+        every = [rchop(cols[1 + 4 * k], '-A') for k in range(n_samples)]
+        return [every[k] for k in self.variantFilter.sample_indices]
 
-    def output_Gamma_Mean(self, gamma):
-        p.DataFrame(gamma, index=self._sample_names()).to_csv(self.outputDir + "/Gamma_mean.csv")
-        logging.info("Wrote mean gamma haplotype relative frequencies")
+    def _abundance_table(self, name, gamma):
+        pd.DataFrame(gamma, index=self._kept_sample_names()).to_csv(self._path(name))
+        logging.info(name + " written")
 
     def output_Gamma(self, gamma):
-        p.DataFrame(gamma, index=self._sample_names()).to_csv(self.outputDir + "/Gamma_star.csv")
-        logging.info("Wrote gamma haplotype relative frequencies")
+        self._abundance_table("Gamma_star.csv", gamma)
+
+    def output_Gamma_Mean(self, gamma):
+        self._abundance_table("Gamma_mean.csv", gamma)
 
     def output_Eta(self, eta):
-        p.DataFrame(eta).to_csv(self.outputDir + "/Eta_star.csv")
-        logging.info("Wrote transition error matrix")
+        pd.DataFrame(eta).to_csv(self._path("Eta_star.csv"))
+        logging.info("Eta_star.csv written")
 
     def output_Eta_Mean(self, eta):
-        p.DataFrame(eta).to_csv(self.outputDir + "/Eta_mean.csv")
-        logging.info("Wrote transition error matrix")
+        pd.DataFrame(eta).to_csv(self._path("Eta_mean.csv"))
+        logging.info("Eta_mean.csv written")
 
     def output_Selected_Variants(self):
-        self.variants[self.variantFilter.selected].to_csv(self.outputDir + "/Selected_variants.csv")
-        logging.info("Wrote selected variants")
+        self.variants[self.variantFilter.selected].to_csv(self._path("Selected_variants.csv"))
+        logging.info("Selected_variants.csv written")

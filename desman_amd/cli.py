@@ -1,149 +1,156 @@
-"""`desman` command line: the flags, defaults, quirks and output files of the
-reference's bin/desman (:21-242), driving the device-resident classes."""
+"""`desman` command line on the device-resident classes.
+
+Drop-in contract (reference: bin/desman:21-242): the same flags with the same defaults and quirks, and the
+same output files.  The driver itself is organised differently: a flag table, then four
+stages -- load, fit, report, assign-the-rest.
+"""
 import argparse
 import logging
 import sys
 
 import numpy as np
-import pandas as p
+import pandas as pd
 from numpy.random import RandomState
 
-from . import HaploSNP_Sampler as hsnp
-from . import Init_NMFT as inmft
-from . import Output_Results as outr
-from . import Variant_Filter as vf
 from . import sampletau
+from .HaploSNP_Sampler import HaploSNP_Sampler
+from .Init_NMFT import Init_NMFT
+from .Output_Results import Output_Results
+from .Variant_Filter import Variant_Filter
+
+POSITION_SELECT_SEED = 238329          # fixed seed of the -r position draw (bin/desman:85-86)
+
+# (short, long, kwargs) -- defaults and nargs/const quirks as in bin/desman:25-59
+_FLAGS = [
+    ('-g', '--genomes', dict(type=int, required=True, help="number of haplotypes to infer")),
+    ('-f', '--filter_variants', dict(nargs='?', const=3.84, type=float,
+                                     help="likelihood-ratio variant filter; optional chi2 threshold (3.84)")),
+    ('-r', '--random_select', dict(nargs='?', const=1e3, type=int,
+                                   help="fit on this many random positions (1000), then assign the others")),
+    ('-e', '--eta_file', dict(type=open, help="CSV with the initial 4x4 error matrix")),
+    ('-a', '--assign_file', dict(type=open, help="(dead upstream) extra positions to assign")),
+    ('-o', '--output_dir', dict(type=str, default="output", help="directory for all result files")),
+    ('-p', '--optimiseP', dict(default=True, type=bool, help="optimise the mixture proportion in the filter")),
+    ('-i', '--no_iter', dict(nargs='?', const=250, type=int, help="Gibbs iterations per phase")),
+    ('-m', '--min_coverage', dict(type=float, default=5.0, help="drop samples whose mean depth is not above this")),
+    ('-q', '--max_qvalue', dict(default=1.0e-3, type=float, help="q-value cut of the variant filter")),
+    ('-s', '--random_seed', dict(default=23724839, type=int, help="seed of both sampler RNG streams")),
+    ('-v', '--min_variant_freq', dict(nargs='?', const=0.01, type=float, help="minimum variant frequency (0.01)")),
+]
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(prog="desman")
-    parser.add_argument("variant_file", help="input SNP frequencies")
-    parser.add_argument('-g', '--genomes', type=int, required=True, help="specify the haplotype number")
-    parser.add_argument('-f', '--filter_variants', nargs='?', const=3.84, type=float,
-                        help='filters variants by negative binomial loge likelihood defaults to 3.84')
-    parser.add_argument('-r', '--random_select', nargs='?', const=1e3, type=int,
-                        help="selects subset of variants passing filter to build model and assigns others")
-    parser.add_argument('-e', '--eta_file', type=open, help="reads initial eta matrix from file")
-    parser.add_argument('-a', '--assign_file', type=open,
-                        help="calculates haplotype profiles for these SNPs using fitted gamma, eta values")
-    parser.add_argument('-o', '--output_dir', type=str, default="output",
-                        help="string specifying output directory and file stubs")
-    parser.add_argument('-p', '--optimiseP', default=True, type=bool,
-                        help="optimise proportions in likelihood ratio test")
-    parser.add_argument('-i', '--no_iter', nargs='?', const=250, type=int,
-                        help='Number of iterations of Gibbs sampler')
-    parser.add_argument('-m', '--min_coverage', type=float, default=5.0,
-                        help='minimum coverage for sample to be included')
-    parser.add_argument('-q', '--max_qvalue', default=1.0e-3, type=float,
-                        help="specifies q value cut-off for variant detection defaults 1.0e-3")
-    parser.add_argument('-s', '--random_seed', default=23724839, type=int,
-                        help="specifies seed for numpy random number generator defaults to 23724839 applied after random filtering")
-    parser.add_argument('-v', '--min_variant_freq', nargs='?', const=0.01, type=float,
-                        help="specifies minimum variant frequency defaults 0.01")
-    # extensions (not in the reference)
-    parser.add_argument('--device', type=int, default=0, help="GPU ordinal (extension)")
-    return parser
+    ap = argparse.ArgumentParser(prog="desman", description="strain haplotypes and abundances from base counts (MI355X)")
+    ap.add_argument("variant_file", help="base-count table: Contig,Position,<sample>-A,-C,-G,-T,...")
+    for short, long_, kw in _FLAGS:
+        ap.add_argument(short, long_, **kw)
+    ap.add_argument('--device', type=int, default=0, help="GPU ordinal (extension)")
+    return ap
+
+
+def _load(opts, report):
+    """CSV -> count tensor, sample filter, optional variant filter / eta file / position subsample."""
+    logging.info('position-selection RNG seeded with %d' % POSITION_SELECT_SEED)
+    table = pd.read_csv(opts.variant_file, header=0, index_col=0)
+    flt = Variant_Filter(table, randomState=RandomState(POSITION_SELECT_SEED), optimise=opts.optimiseP,
+                         threshold=opts.filter_variants, min_coverage=opts.min_coverage, qvalue_cutoff=opts.max_qvalue)
+    flt.device = opts.device
+    if flt.S < 1 or flt.V < 1:
+        logging.error('nothing to do: %d samples above the coverage cut, %d positions' % (flt.S, flt.V))
+        sys.exit()
+    logging.info('%d samples, %d positions, %d haplotypes requested' % (flt.S, flt.V, opts.genomes))
+    if opts.filter_variants is not None:
+        logging.info('variant filter: optimise=%s threshold=%s min_coverage=%s q<=%s min_freq=%s'
+                     % (opts.optimiseP, opts.filter_variants, opts.min_coverage, opts.max_qvalue, opts.min_variant_freq))
+        flt.get_filtered_VariantsLogRatio()                       # lrt_kernel on the GPU
+        logging.info('variant filter kept %d positions' % flt.NS)
+    if opts.eta_file is not None:
+        logging.info('initial error matrix read from %s' % opts.eta_file)
+        flt.eta = pd.read_csv(opts.eta_file, header=0, index_col=0).to_numpy()
+    subsample = opts.random_select
+    if subsample is not None:
+        if subsample < flt.V:
+            logging.info('fitting on %d random positions' % subsample)
+            flt.select_Random(subsample)
+        else:
+            logging.info('only %d positions: the -r subsample of %d is ignored' % (flt.V, subsample))
+            subsample = None
+    return table, flt, subsample
+
+
+def _fit(opts, flt):
+    """NMF-tensor initialisation, burn-in, degenerate-haplotype merge, sampling (bin/desman:129-153)."""
+    logging.info('sampler seed %d', opts.random_seed)
+    rng = RandomState(opts.random_seed)
+    sampletau.initRNG()
+    sampletau.setRNG(opts.random_seed)
+    nmft = Init_NMFT(flt.snps_filter, opts.genomes, rng, device=opts.device)
+    logging.info('NMF-tensor initialisation')
+    nmft.factorize()
+    chain = HaploSNP_Sampler(flt.snps_filter, opts.genomes, rng, max_iter=opts.no_iter, device=opts.device,
+                             ctx=nmft._ctx)                        # same resident count tensor
+    chain.tau = np.copy(nmft.get_tau(), order='C')
+    chain.updateTauIndices()
+    chain.gamma = np.copy(nmft.get_gamma(), order='C')
+    chain.eta = np.copy(flt.eta, order='C')
+    logging.info('Gibbs burn-in')
+    chain.update()
+    chain.removeDegenerate()
+    logging.info('Gibbs sampling')
+    chain.update()
+    return chain
+
+
+def _report(report, table, flt, chain, requested):
+    report.set_Variants(table)
+    report.set_Variant_Filter(flt)
+    report.set_haplo_SNP(chain, requested)
+    report.output_Filtered_Tau(chain.tau_star)
+    report.output_Tau_Mean(chain.tauMean())
+    report.output_Gamma(chain.gamma_star)
+    report.output_Gamma_Mean(chain.gammaMean())
+    report.output_Eta(chain.eta_star)
+    report.output_Eta_Mean(chain.etaMean())
+    report.output_Selected_Variants()
+
+
+def _assign_rest(opts, report, table, flt, chain):
+    """-r: haplotypes of the positions left out of the fit, with tau-only sweeps driven by the fitted
+    chain's gamma / eta traces (bin/desman:181-206)."""
+    rest = flt.snps_filter_original[~np.asarray(flt.selected, dtype=bool), :]
+    nmft = Init_NMFT(rest, chain.G, chain.randomState, device=opts.device)
+    nmft.gamma = np.transpose(chain.gamma)
+    logging.info('NMF-tensor initialisation of the %d remaining positions (gamma fixed)' % rest.shape[0])
+    nmft.factorize_tau()
+    other = HaploSNP_Sampler(rest, chain.G, chain.randomState, max_iter=opts.no_iter, device=opts.device, ctx=nmft._ctx)
+    other.tau = nmft.get_tau()
+    other.updateTauIndices()
+    other.gamma_star = np.copy(chain.gammaMean(), order='C')
+    other.eta_star = np.copy(chain.etaMean(), order='C')
+    other.gamma_store = np.copy(chain.gamma_store, order='C')
+    other.eta_store = np.copy(chain.eta_store, order='C')
+    for phase in ('burn-in', 'sampling'):
+        logging.info('tau-only %s' % phase)
+        other.updateTau()
+    report.outPredFit(other, opts.genomes)
+    report.output_collated_Tau(other, table)
 
 
 def main(argv=None):
-    args = build_parser().parse_args(argv)
-    genomes = args.genomes
-    if genomes < 0:
-        logging.error('Only positive haplotype number valid not  %d. Exiting!' % genomes)
+    opts = build_parser().parse_args(argv)
+    if opts.genomes < 0:
+        logging.error('the haplotype number must be positive, got %d' % opts.genomes)
         sys.exit(-1)
-    no_iter = args.no_iter
-    random_select = args.random_select
-
-    output_Results = outr.Output_Results(args.output_dir)
-    logging.info('Set fixed seed for random position selection = 238329')
-    prng = RandomState(238329)
-    variants = p.read_csv(args.variant_file, header=0, index_col=0)
-    variant_Filter = vf.Variant_Filter(variants, randomState=prng, optimise=args.optimiseP,
-                                       threshold=args.filter_variants, min_coverage=args.min_coverage,
-                                       qvalue_cutoff=args.max_qvalue)
-    if variant_Filter.S < 1 or variant_Filter.V < 1:
-        logging.error('Not enough samples with minimum coverage %d or variant positions %d. Exiting!'
-                      % (variant_Filter.S, variant_Filter.V))
-        sys.exit()
-    logging.info('Running Desman with %d samples and %d variant positions finding %d genomes.'
-                 % (variant_Filter.S, variant_Filter.V, genomes))
-    variant_Filter.device = args.device
-    if args.filter_variants is not None:
-        logging.info('Begun filtering variants with parameters: optimise probability = %s, lr threshold = %s, min. coverage = %s, q-value threshold = %s, min. variant frequency = %s'
-                     % (args.optimiseP, args.filter_variants, args.min_coverage, args.max_qvalue, args.min_variant_freq))
-        variant_Filter.get_filtered_VariantsLogRatio()          # row f3: lrt_kernel on the GPU
-        logging.info("Completed variant filtering")
-    if args.eta_file is not None:
-        logging.info('Set eta error transition matrix from = %s' % args.eta_file)
-        variant_Filter.eta = p.read_csv(args.eta_file, header=0, index_col=0).to_numpy()
-    if random_select is not None:
-        if random_select < variant_Filter.V:
-            logging.info('Selected %d random variant positions to infer haplotypes from' % random_select)
-            variant_Filter.select_Random(random_select)
-        else:
-            logging.info('Not enough variable positions for random selection %d >= %d using all'
-                         % (random_select, variant_Filter.V))
-            random_select = None
-
-    logging.info('Set second adjustable random seed = %d', args.random_seed)
-    prng = RandomState(args.random_seed)
-    sampletau.initRNG()
-    sampletau.setRNG(args.random_seed)
-
-    init_NMFT = inmft.Init_NMFT(variant_Filter.snps_filter, genomes, prng, device=args.device)
-    logging.info('Perform NTF initialisation')
-    init_NMFT.factorize()
-
-    haplo_SNP = hsnp.HaploSNP_Sampler(variant_Filter.snps_filter, genomes, prng, max_iter=no_iter,
-                                      device=args.device, ctx=init_NMFT._ctx)      # same resident count tensor
-    haplo_SNP.tau = np.copy(init_NMFT.get_tau(), order='C')
-    haplo_SNP.updateTauIndices()
-    haplo_SNP.gamma = np.copy(init_NMFT.get_gamma(), order='C')
-    haplo_SNP.eta = np.copy(variant_Filter.eta, order='C')
-
-    logging.info('Start Gibbs sampler burn-in phase')
-    haplo_SNP.update()
-    haplo_SNP.removeDegenerate()
-    logging.info('Start Gibbs sampler sampling phase')
-    haplo_SNP.update()
-
-    output_Results.set_Variants(variants)
-    output_Results.set_Variant_Filter(variant_Filter)
-    output_Results.set_haplo_SNP(haplo_SNP, genomes)
-    output_Results.output_Filtered_Tau(haplo_SNP.tau_star)
-    output_Results.output_Tau_Mean(haplo_SNP.tauMean())
-    output_Results.output_Gamma(haplo_SNP.gamma_star)
-    output_Results.output_Gamma_Mean(haplo_SNP.gammaMean())
-    output_Results.output_Eta(haplo_SNP.eta_star)
-    output_Results.output_Eta_Mean(haplo_SNP.etaMean())
-    output_Results.output_Selected_Variants()
-
-    if random_select is not None:
-        snps_notselected = variant_Filter.snps_filter_original[variant_Filter.selected != True, :]   # noqa: E712
-        init_NMFT_NS = inmft.Init_NMFT(snps_notselected, haplo_SNP.G, haplo_SNP.randomState, device=args.device)
-        init_NMFT_NS.gamma = np.transpose(haplo_SNP.gamma)
-        logging.info('Perform NTF initialisation on not selected SNPs fixed gamma')
-        init_NMFT_NS.factorize_tau()
-        haplo_SNP_NS = hsnp.HaploSNP_Sampler(snps_notselected, haplo_SNP.G, haplo_SNP.randomState,
-                                             max_iter=no_iter, device=args.device, ctx=init_NMFT_NS._ctx)
-        haplo_SNP_NS.tau = init_NMFT_NS.get_tau()
-        haplo_SNP_NS.updateTauIndices()
-        haplo_SNP_NS.gamma_star = np.copy(haplo_SNP.gammaMean(), order='C')
-        haplo_SNP_NS.eta_star = np.copy(haplo_SNP.etaMean(), order='C')
-        haplo_SNP_NS.gamma_store = np.copy(haplo_SNP.gamma_store, order='C')
-        haplo_SNP_NS.eta_store = np.copy(haplo_SNP.eta_store, order='C')
-        logging.info('Start Gibbs sampler burn-in phase')
-        haplo_SNP_NS.updateTau()
-        logging.info('Start Gibbs sampler sampling phase')
-        haplo_SNP_NS.updateTau()
-        output_Results.outPredFit(haplo_SNP_NS, genomes)
-        output_Results.output_collated_Tau(haplo_SNP_NS, variants)
-
-    if args.assign_file is not None:
-        # the reference stops in ipdb.set_trace() here (bin/desman:213-214): the path is dead upstream
-        logging.error('-a/--assign_file is not supported (dead in the reference: ipdb breakpoint)')
+    report = Output_Results(opts.output_dir)
+    table, flt, subsample = _load(opts, report)
+    chain = _fit(opts, flt)
+    _report(report, table, flt, chain, opts.genomes)
+    if subsample is not None:
+        _assign_rest(opts, report, table, flt, chain)
+    if opts.assign_file is not None:
+        # upstream this branch stops in ipdb.set_trace() (bin/desman:213-214): there is nothing to mirror
+        logging.error('-a/--assign_file is not supported (dead in the reference)')
         sys.exit('desman: -a/--assign_file is not supported')
-
     sampletau.freeRNG()
 
 

@@ -382,3 +382,35 @@ def test_chain_posterior_matches_reference_sampler_in_law(ctx):
     # and the haplotypes both chains settle on are the generating ones
     assert (np.argmax(ctx.get_star()["tau"], axis=2) != tau_true).mean() < 0.05
     assert (np.argmax(ref["star"]["tau"], axis=2) != tau_true).mean() < 0.05
+
+
+def test_per_read_draws_have_multinomial_mean_and_variance(ctx):
+    """distributional check of the xoshiro128+/Philox per-read draws beyond the mean: over many
+    iterations the per-haplotype totals of one deep cell have the multinomial variance n p (1-p) and
+    the right pairwise covariance -n p_g p_h (correlated or biased words would inflate / deflate them)."""
+    V, S, G = 4, 2, 4
+    counts = np.zeros((V, S, 4), dtype=np.int64)
+    counts[0, 0, 0] = 20000                                     # one deep item dominates; the others stay small
+    counts[1:, :, :] = 3
+    tau, gamma, eta = random_state(V, S, G, seed=9)
+    gamma[0] = [0.4, 0.3, 0.2, 0.1]
+    _load(ctx, counts, tau, gamma, eta)
+    ctx.seed(1, ctr_seed=2024)
+    n_it = 1500
+    draws = np.zeros((n_it, G))
+    small = counts[:, 0, :].sum() - 20000
+    for it in range(n_it):
+        mu, _ = ctx.sample_stats(it)
+        draws[it] = mu[0]
+    idx = np.argmax(tau[0], axis=1)
+    w = gamma[0] * eta[idx, 0]
+    p_ = w / w.sum()
+    n = 20000
+    mean = draws.mean(axis=0)
+    assert np.abs(mean - n * p_).max() < 5 * np.sqrt(n * 0.25 / n_it) + small
+    var = draws.var(axis=0, ddof=1)
+    want = n * p_ * (1 - p_)
+    # sampling error of a variance estimate ~ want * sqrt(2 / n_it); the small items add at most `small`
+    assert (np.abs(var - want) < 6 * want * np.sqrt(2.0 / n_it) + 2 * small).all()
+    cov01 = np.cov(draws[:, 0], draws[:, 1])[0, 1]
+    assert abs(cov01 + n * p_[0] * p_[1]) < 6 * np.sqrt(want[0] * want[1] / n_it) + 2 * small

@@ -160,3 +160,60 @@ __device__ __forceinline__ void group_allreduce_sum4(double &v0, double &v1, dou
         v3 = __shfl(k, base + 3, 64);
     }
 }
+
+// ---- transposing butterfly: every lane brings NV values; afterwards lane l holds, in v[0], the
+// wavefront total of value transpose_index<NV>(l).  Each exchange step halves the values a lane
+// carries (it keeps the half selected by one lane-id bit and sends the other half to its partner),
+// so NV + log2(64/NV)... exchanges replace 6*NV; the first two steps are DPP quad permutes.
+template <typename T, int CTRL>
+__device__ __forceinline__ T dpp_mov_t(T x)
+{
+    if constexpr (sizeof(T) == 8) {
+        const double d = dpp_mov<CTRL>(__builtin_bit_cast(double, x));
+        return __builtin_bit_cast(T, d);
+    } else {
+        return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+    }
+}
+
+template <typename T, int NV, int CNT, int OFF>
+__device__ __forceinline__ void transpose_reduce_step(T (&v)[NV], int lane)
+{
+    if constexpr (OFF < 64) {
+        if constexpr (CNT > 1) {
+            constexpr int H = CNT / 2;
+            const bool up = lane & OFF;                 // this lane keeps the upper half
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                const T keep = up ? v[i + H] : v[i];
+                const T send = up ? v[i] : v[i + H];
+                T got;
+                if constexpr (OFF == 1) got = dpp_mov_t<T, DSM_DPP_XOR1>(send);
+                else if constexpr (OFF == 2) got = dpp_mov_t<T, DSM_DPP_XOR2>(send);
+                else got = __shfl_xor(send, OFF, 64);
+                v[i] = keep + got;
+            }
+            transpose_reduce_step<T, NV, H, OFF * 2>(v, lane);
+        } else {
+            v[0] += __shfl_xor(v[0], OFF, 64);
+            transpose_reduce_step<T, NV, 1, OFF * 2>(v, lane);
+        }
+    }
+}
+
+template <int NV, typename T>
+__device__ __forceinline__ T wave_transpose_reduce(T (&v)[NV])
+{
+    transpose_reduce_step<T, NV, NV, 1>(v, __lane_id());
+    return v[0];
+}
+
+// index (within the NV values) that wave_transpose_reduce leaves on `lane`
+template <int NV>
+__device__ __forceinline__ int transpose_index(int lane)
+{
+    int idx = 0, h = NV / 2;
+#pragma unroll
+    for (int off = 1; off < 64 && h >= 1; off <<= 1, h >>= 1) idx += (lane & off) ? h : 0;
+    return idx;
+}

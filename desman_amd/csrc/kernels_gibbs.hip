@@ -270,17 +270,18 @@ __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ ite
 #pragma unroll
             for (int a = 0; a < 4; ++a) e[bb * 4 + a] += (b == bb) ? e4[a] : 0u;
     }
-    // wavefront reduce -> LDS -> one global atomic per workgroup and counter
-    const int lane = tid & 63;
+    // wavefront reduce -> LDS -> one global atomic per workgroup and counter.  The GMAX + 16 counters go
+    // through one transposing butterfly (lane l ends up with the wavefront total of counter
+    // transpose_index(l)), so a wavefront issues NV exchanges and ONE LDS atomic instead of 6 per counter.
+    {
+        constexpr int NV = (GMAX + 16 <= 32) ? 32 : 64;
+        const int lane = tid & 63;
+        uint32_t v[NV];
 #pragma unroll
-    for (int g = 0; g < GMAX; ++g) {
-        const unsigned tot = group_allreduce_sum_u32<64>(mu[g]);
-        if (lane == 0 && g < G && tot) atomicAdd(&acc[g], (unsigned long long)tot);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const unsigned tot = group_allreduce_sum_u32<64>(e[i]);
-        if (lane == 0 && tot) atomicAdd(&acc[GMAX + i], (unsigned long long)tot);
+        for (int i = 0; i < NV; ++i) v[i] = (i < GMAX) ? mu[i < GMAX ? i : 0] : (i < GMAX + 16 ? e[(i - GMAX) & 15] : 0u);
+        const uint32_t tot = wave_transpose_reduce<NV>(v);
+        const int idx = transpose_index<NV>(lane);
+        if (lane < NV && idx < GMAX + 16 && tot) atomicAdd(&acc[idx], (unsigned long long)tot);
     }
     __syncthreads();
     if (tid < G) { if (acc[tid]) atomicAdd(&sum_mu[(size_t)s * G + tid], acc[tid]); }

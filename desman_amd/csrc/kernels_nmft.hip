@@ -298,48 +298,6 @@ __global__ __launch_bounds__(256) void nmft_pass_b_kernel(const double *__restri
 // gamma_raw / gamma: the running update's normalised gamma before / after _adjustment.
 // Partials are written transposed, [G*S numerators][G H1][1 objective] x workgroups.
 // ---------------------------------------------------------------------------
-template <int NV, int CNT, int OFF>
-__device__ __forceinline__ void transpose_reduce_step(double (&v)[NV], int lane)
-{
-    if constexpr (OFF < 64) {
-        if constexpr (CNT > 1) {
-            constexpr int H = CNT / 2;
-            const bool up = lane & OFF;                 // this lane keeps the upper half
-#pragma unroll
-            for (int i = 0; i < H; ++i) {
-                const double keep = up ? v[i + H] : v[i];
-                const double send = up ? v[i] : v[i + H];
-                double got;
-                if constexpr (OFF == 1) got = dpp_mov<DSM_DPP_XOR1>(send);
-                else if constexpr (OFF == 2) got = dpp_mov<DSM_DPP_XOR2>(send);
-                else got = __shfl_xor(send, OFF, 64);
-                v[i] = keep + got;
-            }
-            transpose_reduce_step<NV, H, OFF * 2>(v, lane);
-        } else {
-            v[0] += __shfl_xor(v[0], OFF, 64);
-            transpose_reduce_step<NV, 1, OFF * 2>(v, lane);
-        }
-    }
-}
-
-template <int NV>
-__device__ __forceinline__ double wave_transpose_reduce(double (&v)[NV])
-{
-    transpose_reduce_step<NV, NV, 1>(v, __lane_id());
-    return v[0];
-}
-
-// index (within the NV values) that wave_transpose_reduce leaves on `lane`
-template <int NV>
-__device__ __forceinline__ int transpose_index(int lane)
-{
-    int idx = 0, h = NV / 2;
-#pragma unroll
-    for (int off = 1; off < 64 && h >= 1; off <<= 1, h >>= 1) idx += (lane & off) ? h : 0;
-    return idx;
-}
-
 template <int NSL, int GMAX>
 __global__ __launch_bounds__(256) void nmft_wave_kernel(const double *__restrict__ F, double *__restrict__ tau,
                                                         const double *__restrict__ gam_raw,

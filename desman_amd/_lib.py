@@ -69,6 +69,24 @@ SIGNATURES = {
     "dsm_nmft_objective": (_i, [_vp, C.POINTER(_d)]),
     "dsm_nmft_get_tau": (_i, [_vp, _i64p]),
     "dsm_lrt_step": (_i, [_i, _f64p, _i32p, _i32p, _f64p, _d, _i, _i, _f64p, _f64p, _f64p]),
+    "dsm_genes_create": (_i, [C.POINTER(_vp), _i]),
+    "dsm_genes_destroy": (_i, [_vp]),
+    "dsm_genes_set_data": (_i, [_vp, _vp, _i, _i, _i, _i32p, _f64p]),
+    "dsm_genes_set_model": (_i, [_vp, _f64p, _f64p, _f64p, _i, _i, _f64p, _f64p, _f64p]),
+    "dsm_genes_set_state": (_i, [_vp, _vp, _vp]),
+    "dsm_genes_get_state": (_i, [_vp, _vp, _vp]),
+    "dsm_genes_seed": (_i, [_vp, C.c_ulong, C.c_uint64]),
+    "dsm_genes_get_mt_state": (_i, [_vp, _u32p]),
+    "dsm_genes_set_mt_state": (_i, [_vp, _u32p]),
+    "dsm_genes_nmft_tau": (_i, [_vp, _vp, _f64p, _i, _d, _vp]),
+    "dsm_genes_sweep_all": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "dsm_genes_step_candidates": (_i, [_vp, _i, _i, _f64p, _vp]),
+    "dsm_genes_step_choose": (_i, [_vp, _i, _i, _i]),
+    "dsm_genes_update": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "dsm_genes_loglik": (_i, [_vp, _vp]),
+    "dsm_genes_get_star": (_i, [_vp, _vp, _vp]),
+    "dsm_genes_set_star": (_i, [_vp, _vp, _vp]),
+    "dsm_kl_assign": (_i, [_i, _f64p, _f64p, _f64p, _i, _i, _i, _i, _d, C.POINTER(_i), C.POINTER(_d)]),
     "dsm_ctx_set_timing": (_i, [_vp, _i]),
     "dsm_ctx_get_timing": (_i, [_vp, _vp, _vp]),
     "dsm_kernel_name": (C.c_char_p, [_i]),
@@ -310,3 +328,127 @@ class Context:
         ms = np.zeros(len(K_NAMES)); n = np.zeros(len(K_NAMES), dtype=np.int64)
         check(self.lib.dsm_ctx_get_timing(self._h, _ptr(ms), _ptr(n)))
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(K_NAMES)}
+
+
+def kl_assign(cov, delta, eta, max_iter=10000, min_change=1.0e-4, device=0):
+    """GeneAssign.KLAssign.factorize on the GPU: returns (eta [C,G], n_updates, divergence)."""
+    cov = np.ascontiguousarray(cov, dtype=np.float64)
+    delta = np.ascontiguousarray(delta, dtype=np.float64)
+    eta = np.ascontiguousarray(eta, dtype=np.float64).copy()
+    n, div = C.c_int(0), C.c_double(0.0)
+    check(load().dsm_kl_assign(int(device), cov, delta, eta, cov.shape[0], cov.shape[1], delta.shape[1], int(max_iter),
+                               float(min_change), C.byref(n), C.byref(div)))
+    return eta, n.value, div.value
+
+
+class Genes:
+    """Device-resident accessory-gene sampler state (dsm_genes): all genes' variant rows in one tensor."""
+
+    def __init__(self, device=0):
+        self._h = _vp()
+        check(load().dsm_genes_create(C.byref(self._h), int(device)))
+        self.C = self.S = self.G = self.Vtot = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            load().dsm_genes_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_data(self, variants, gene_off, cov):
+        cov = np.ascontiguousarray(cov, dtype=np.float64)
+        gene_off = np.ascontiguousarray(gene_off, dtype=np.int32)
+        self.C, self.S = cov.shape
+        self.Vtot = int(gene_off[-1])
+        if self.Vtot:
+            variants = np.ascontiguousarray(variants, dtype=np.int64)
+            assert variants.shape == (self.Vtot, self.S, 4), variants.shape
+        else:
+            variants = None
+        self.gene_off = gene_off
+        check(load().dsm_genes_set_data(self._h, _ptr(variants), self.Vtot, self.S, self.C, gene_off, cov))
+
+    def set_model(self, gamma, epsilon, delta_gs, max_eta, eta_log_prior, cov_const, mult_const):
+        gamma = np.ascontiguousarray(gamma, dtype=np.float64)
+        self.G = gamma.shape[1]
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        check(load().dsm_genes_set_model(self._h, gamma, f(epsilon), f(delta_gs), self.G, int(max_eta), f(eta_log_prior),
+                                         f(cov_const), f(mult_const)))
+
+    def set_state(self, eta=None, tau=None):
+        eta = None if eta is None else np.ascontiguousarray(eta, dtype=np.int32)
+        tau = None if tau is None else np.ascontiguousarray(tau, dtype=np.int64)
+        check(load().dsm_genes_set_state(self._h, _ptr(eta), _ptr(tau)))
+
+    def get_state(self, want_tau=True):
+        eta = np.empty((self.C, self.G), dtype=np.int32)
+        tau = np.zeros((self.Vtot, self.G, 4), dtype=np.int64) if want_tau else None
+        check(load().dsm_genes_get_state(self._h, _ptr(eta), _ptr(tau)))
+        return eta, tau
+
+    def seed(self, mt_seed, ctr_seed=0x13198A2E03707344):
+        check(load().dsm_genes_seed(self._h, int(mt_seed), int(ctr_seed)))
+
+    def get_mt_state(self):
+        st = np.empty(625, dtype=np.uint32)
+        check(load().dsm_genes_get_mt_state(self._h, st))
+        return st
+
+    def set_mt_state(self, st):
+        check(load().dsm_genes_set_mt_state(self._h, np.ascontiguousarray(st, dtype=np.uint32)))
+
+    def _mask(self, eta_mask):
+        return None if eta_mask is None else np.ascontiguousarray(eta_mask, dtype=np.int32)
+
+    def nmft_tau(self, tau_init, eta_mask=None, max_iter=5000, min_change=1.0e-5):
+        """tau_init [Vtot,4,G]; returns the per-gene update counts (-1 = gene skipped)."""
+        tau_init = np.ascontiguousarray(tau_init, dtype=np.float64)
+        n = np.empty(self.C, dtype=np.int32)
+        m = self._mask(eta_mask)
+        check(load().dsm_genes_nmft_tau(self._h, _ptr(m), tau_init, int(max_iter), float(min_change), _ptr(n)))
+        return n
+
+    def sweep_all(self, eta_mask=None, sweep=True, want_v_ll=False):
+        nch = np.empty(self.C, dtype=np.int32)
+        lv = np.empty(self.C)
+        vll = np.empty(self.Vtot) if want_v_ll else None
+        m = self._mask(eta_mask)
+        check(load().dsm_genes_sweep_all(self._h, _ptr(m), int(bool(sweep)), _ptr(nch), _ptr(lv), _ptr(vll)))
+        return nch, lv, vll
+
+    def step_candidates(self, c, g):
+        lv = np.empty(2)
+        sw = np.empty(2, dtype=np.int32)
+        check(load().dsm_genes_step_candidates(self._h, int(c), int(g), lv, _ptr(sw)))
+        return lv, sw
+
+    def step_choose(self, c, g, value):
+        check(load().dsm_genes_step_choose(self._h, int(c), int(g), int(value)))
+
+    def update(self, n_iter, reset_star=True, u_tau_ext=None, u_eta_ext=None):
+        store = np.empty((n_iter, self.C, self.G), dtype=np.int32)
+        trace = np.empty((n_iter, self.C))
+        ut = None if u_tau_ext is None else np.ascontiguousarray(u_tau_ext, dtype=np.uint32)
+        ue = None if u_eta_ext is None else np.ascontiguousarray(u_eta_ext, dtype=np.float64)
+        check(load().dsm_genes_update(self._h, int(n_iter), int(bool(reset_star)), _ptr(store), _ptr(trace), _ptr(ut), _ptr(ue)))
+        return store, trace
+
+    def loglik(self):
+        ll = np.empty(self.C)
+        check(load().dsm_genes_loglik(self._h, _ptr(ll)))
+        return ll
+
+    def get_star(self):
+        es = np.empty((self.C, self.G), dtype=np.int32)
+        ls = np.empty(self.C)
+        check(load().dsm_genes_get_star(self._h, _ptr(es), _ptr(ls)))
+        return es, ls
+
+    def set_star(self, eta_star, gene_llstar):
+        check(load().dsm_genes_set_star(self._h, _ptr(np.ascontiguousarray(eta_star, dtype=np.int32)),
+                                        _ptr(np.ascontiguousarray(gene_llstar, dtype=np.float64))))

@@ -161,6 +161,70 @@ int dsm_lrt_step(int device, const double *ffreq, const int32_t *maxA, const int
                  const double *eta, double upperP, int optimise, int V, double *p_inout,
                  double *MLL, double *BLL);
 
+/* ------------------------------------------------------------------------ */
+/* f4: accessory-gene assignment (desman/Eta_Sampler.py, desman/GeneAssign.py) */
+/* C genes, gene c owns the rows gene_off[c]..gene_off[c+1]-1 of one           */
+/* concatenated [Vtot][S][4] count tensor; eta[c][g] in {0..max_eta-1} is the  */
+/* copy number of gene c in haplotype g.  All tau sweeps are the A1 sweep with */
+/* the gene's masked, re-normalised gamma (Eta_Sampler.maskGamma :147-157).    */
+/* ------------------------------------------------------------------------ */
+typedef struct dsm_genes dsm_genes;
+#define DSM_MAX_ETA 8
+
+int dsm_genes_create(dsm_genes **out, int device);
+int dsm_genes_destroy(dsm_genes *gs);
+/* variants may be NULL when Vtot == 0 (GeneAssign without -v).  cov [C][S].   */
+int dsm_genes_set_data(dsm_genes *gs, const int64_t *variants, int Vtot, int S, int C,
+                       const int32_t *gene_off /*[C+1]*/, const double *cov);
+/* gamma [S][G] (unmasked), epsilon [4][4], delta [G][S] (Eta_Sampler.__init__:47),
+ * eta_log_prior [max_eta] (:139-145); cov_const[c] = -sum_s lgamma(cov+1) and
+ * mult_const[c] = sum_{v,s} (lgamma(n+1) - sum_b lgamma(x_b+1)) are the data-only
+ * constants of log_Poisson (:34-39) and log_multinomial_pdf (:27-32).         */
+int dsm_genes_set_model(dsm_genes *gs, const double *gamma, const double *epsilon,
+                        const double *delta, int G, int max_eta, const double *eta_log_prior,
+                        const double *cov_const, const double *mult_const);
+/* eta [C][G]; tau one-hot [Vtot][G][4] (either may be NULL = keep)            */
+int dsm_genes_set_state(dsm_genes *gs, const int32_t *eta, const int64_t *tau);
+int dsm_genes_get_state(dsm_genes *gs, int32_t *eta, int64_t *tau);
+/* GSL-compatible MT19937 stream of the tau draws (shared semantics with dsm_setRNG) and the
+ * Philox key of the batched sampler                                           */
+int dsm_genes_seed(dsm_genes *gs, unsigned long mt_seed, uint64_t ctr_seed);
+int dsm_genes_get_mt_state(dsm_genes *gs, uint32_t *state625);
+int dsm_genes_set_mt_state(dsm_genes *gs, const uint32_t *state625);
+
+/* Init_NMFT.factorize_tau per gene with the masked gamma (Eta_Sampler.__init__:128-134,
+ * calcTauStar:419-426): tau_init [Vtot][4][G] f64 holds each gene's random start
+ * (Init_NMFT.random_initialize_tau), genes without variants or with an all-zero mask row are
+ * skipped; the arg-max (get_tau) becomes the resident tau.  n_iter [C] (optional).           */
+int dsm_genes_nmft_tau(dsm_genes *gs, const int32_t *eta_mask /*[C][G] or NULL = resident*/,
+                       const double *tau_init, int max_iter, double min_change, int32_t *n_iter);
+/* Eta_Sampler.sampleTauC over all genes with variants and a non-empty mask, in gene order on
+ * the GSL stream (:135, calcTauStar:437): nchange [C], logvar [C] = sum x log p after the
+ * sweep, v_ll [Vtot] the same per variant (any may be NULL).  sweep = 0: evaluate only.       */
+int dsm_genes_sweep_all(dsm_genes *gs, const int32_t *eta_mask, int sweep, int32_t *nchange,
+                        double *logvar, double *v_ll);
+/* reference-order single step (Eta_Sampler.update:226-262): the two candidate sweeps
+ * eta[c][g] = 0 / 1 of gene c (GSL stream: candidate 0 first, only if it keeps a haplotype),
+ * logvar[2], swept[2]; then dsm_genes_step_choose commits the value drawn by the caller.      */
+int dsm_genes_step_candidates(dsm_genes *gs, int c, int g, double *logvar, int *swept);
+int dsm_genes_step_choose(dsm_genes *gs, int c, int g, int eta_value);
+/* batched Gibbs: n_iter iterations of Eta_Sampler.update for all genes at once with
+ * counter-based draws; eta_store [n_iter][C][G], gene_ll_trace [n_iter][C] (optional).
+ * u_tau_ext [n_iter][G][2][Vtot*G] raw 32-bit words and u_eta_ext [n_iter][C][G] uniforms
+ * replace the Philox draws when given (parity tests).  reset_star != 0: star := entry state
+ * (update:216-219).                                                                          */
+int dsm_genes_update(dsm_genes *gs, int n_iter, int reset_star, int32_t *eta_store,
+                     double *gene_ll_trace, const uint32_t *u_tau_ext, const double *u_eta_ext);
+/* Eta_Sampler.logLikelihood (:182-202) per gene for the resident state                        */
+int dsm_genes_loglik(dsm_genes *gs, double *gene_ll);
+int dsm_genes_get_star(dsm_genes *gs, int32_t *eta_star, double *gene_llstar);
+int dsm_genes_set_star(dsm_genes *gs, const int32_t *eta_star, const double *gene_llstar);
+
+/* GeneAssign.KLAssign.factorize (GeneAssign.py:85-120): eta [C][G] in/out (start values drawn by
+ * the caller), cov [C][S], delta [S][G]; *n_done updates, *div final divergence.               */
+int dsm_kl_assign(int device, const double *cov, const double *delta, double *eta, int C, int S,
+                  int G, int max_iter, double min_change, int *n_done, double *div);
+
 /* per-kernel HIP-event timing on the context's stream (bench/roofline).      */
 #define DSM_K_STATS    0
 #define DSM_K_DIRICH   1

@@ -435,12 +435,111 @@ def gen_cog(inmft, hsnp, out):
     print("fit.txt = Fit,%d,%d,%f,%f" % (G, smp.G, smp.lp_star, smp.meanDeviance()))
 
 
+
+def gen_gene_assign(out, name="gene_assign", C=7, S=8, G=3, synth_kw=None):
+    """desman/GeneAssign.py + desman/Eta_Sampler.py on a synth_genes() data set, twice: through the imported
+    classes in main()'s order (intermediate states) and through main() itself (the CSV files it writes).
+    The reference needs the pre-1.24 numpy aliases np.int / np.float; they are added to the numpy namespace
+    of THIS process only.  tau sweeps = oracle C restatement (GSL-compatible MT19937)."""
+    import io
+    import logging
+    import tempfile
+    import pandas as p
+    from desman_amd.synth import synth_genes, write_gene_inputs
+    np.int, np.float = int, float
+    import desman.Eta_Sampler as es
+    import desman.GeneAssign as ga
+
+    seed, iters, tau_iter = 4711, 4, 3
+    synth_kw = dict(synth_kw or {})
+    d = synth_genes(C, S, G, seed=77, **synth_kw)
+    rec = dict(C=C, S=S, G=G, seed=seed, iters=iters, tau_iter=tau_iter, synth_seed=77,
+               synth_kw=np.array(repr(sorted(synth_kw.items()))))
+
+    class Grab(logging.Handler):
+        def __init__(self):
+            super().__init__()
+            self.lines = []
+
+        def emit(self, r):
+            self.lines.append(r.getMessage())
+
+    grab = Grab()
+    logging.getLogger().addHandler(grab)
+    logging.getLogger().setLevel(logging.INFO)
+    with tempfile.TemporaryDirectory() as td:
+        paths = write_gene_inputs(d, td)
+        scg = p.read_csv(paths[0], header=0, index_col=0)
+        gam = p.read_csv(paths[1], header=0, index_col=0)
+        cov = p.read_csv(paths[2], header=0, index_col=0)
+        eps = p.read_csv(paths[3], header=0, index_col=0).to_numpy()
+        var = p.read_csv(paths[4], header=0, index_col=0)
+        names = sorted(set(gam.index.values) & set(scg.index.values) & set(cov.columns.values))
+        scg, gam = scg.reindex(names), gam.reindex(names)
+        gm = gam.to_numpy()
+        gm = gm / gm.sum(axis=1)[:, np.newaxis]
+        delta = np.multiply(gm, scg['mean'].to_numpy()[:, np.newaxis])
+        cov = cov[names]
+        prng = np.random.RandomState(seed)
+        cbind.initRNG(); cbind.setRNG(seed)
+        kl = ga.KLAssign(prng, cov.to_numpy(), delta)
+        kl.factorize()
+        rec['kl_eta'] = kl.eta.copy()
+        rec['kl_div'] = kl.div_objective()
+        etaD = np.rint(kl.eta)
+        smp = es.Eta_Sampler(prng, var[ga.expand_sample_names(names)], cov, gm, delta, scg['sd'].to_numpy(), eps, etaD,
+                             max_iter=iters, max_eta=2, max_var=int(1e10), tau_iter=tau_iter)
+        cat = lambda dd: np.concatenate([dd[g] for g in smp.genes if smp.gene_V[g] > 0]).astype(np.int8)
+        rec['eta_init'] = smp.eta.copy()
+        rec['tau_init'] = cat(smp.gene_tau)
+        rec['eta_log_prior'] = smp.eta_log_prior.copy()
+        for rnd in (1, 2):
+            grab.lines = []
+            smp.update()
+            rec['eta_store_%d' % rnd] = smp.eta_store.copy()
+            rec['eta_star_%d' % rnd] = smp.eta_star.copy()
+            rec['gene_ll_%d' % rnd] = smp.gene_ll.copy()
+            rec['gene_llstar_%d' % rnd] = smp.gene_llstar.copy()
+            rec['ll_%d' % rnd] = smp.ll
+            rec['tau_%d' % rnd] = cat(smp.gene_tau)
+            rec['ll_log_%d' % rnd] = np.array([float(l.split('nll = ')[1]) for l in grab.lines if l.startswith('Gibbs Iter')])
+        smp.restoreFullVariants()
+        smp.calcTauStar(smp.eta_star)
+        tau_star, tau_mean, pos, contig_index = smp.getTauStar(var)
+        rec['tau_star'] = tau_star.astype(np.int8)
+        rec['tau_mean_trunc'] = tau_mean.astype(np.int8)          # the reference stores the mean in an int array
+        rec['tau_star_ll'] = np.concatenate([smp.gene_ll_tau_star[g] for g in smp.genes])
+        rec['tau_store'] = np.concatenate([smp.gene_tau_store[g] for g in smp.genes], axis=1).astype(np.int8)
+        rec['pos'] = pos
+        rec['contig_index'] = np.array(contig_index)
+        # the same run through main(): output files
+        logging.getLogger().removeHandler(grab)
+        stub = os.path.join(td, "ga")
+        argv = sys.argv
+        sys.argv = ["GeneAssign.py", paths[0], paths[1], paths[2], paths[3], "-s", str(seed), "-i", str(iters),
+                    "-o", stub, "-v", paths[4], "--assign_tau"]
+        try:
+            ga.main(sys.argv[1:])
+        finally:
+            sys.argv = argv
+        for suffix in ("etaD_df.csv", "etaS_df.csv", "etaM_df.csv", "eta_df.csv", "_tau_star.csv", "_tau_mean.csv"):
+            with open(stub + suffix) as fh:
+                rec['file_' + suffix.replace('.csv', '').strip('_')] = np.array(fh.read())
+    np.savez_compressed(os.path.join(out, name + ".npz"), **rec)
+    print(name, "eta_star", rec['eta_star_2'].tolist(), "ll", rec['ll_2'])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cog", action="store_true", help="also run config 1 (several minutes)")
     ap.add_argument("--only-cog", action="store_true")
+    ap.add_argument("--only-genes", action="store_true")
     args = ap.parse_args()
     inmft, hsnp, du = import_reference()
+    if args.only_genes:
+        gen_gene_assign(HERE)
+        gen_gene_assign(HERE, "gene_assign_lowcov", C=9, S=6, G=4, synth_kw=dict(mean_lo=0.4, mean_hi=2.5, vmax=6))
+        return
     if not args.only_cog:
         gen_tau_sweep(hsnp, HERE)
         gen_loglik(hsnp, HERE)
@@ -450,6 +549,8 @@ def main():
         gen_host_formats(HERE)
         gen_resolvenhap(HERE)
         gen_variant_filter_lrt(HERE)
+        gen_gene_assign(HERE)
+        gen_gene_assign(HERE, "gene_assign_lowcov", C=9, S=6, G=4, synth_kw=dict(mean_lo=0.4, mean_hi=2.5, vmax=6))
     if args.cog or args.only_cog:
         gen_cog(inmft, hsnp, HERE)
     print("golden fixtures written to", HERE)

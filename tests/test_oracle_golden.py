@@ -184,3 +184,82 @@ def test_counter_sampler_spec_matches_expectation():
     z = (acc_mu / n - e_mu) / np.sqrt(v_mu / n + 1e-12)
     assert np.abs(z).max() < 4.5
     np.testing.assert_allclose(acc_E / n, e_E, rtol=0.02, atol=3.0)
+
+
+# ---------------------------------------------------------------- f4: accessory genes
+@pytest.mark.parametrize("name", ["gene_assign", "gene_assign_lowcov"])
+def test_gene_oracle_reproduces_reference_run(name):
+    """oracle/ref_genes.py driven in GeneAssign.main's order reproduces the imported reference classes:
+    KL start, per-gene NMFT + first sweep, two update() rounds (copy numbers, tau, per-gene ll), calcTauStar."""
+    from oracle import ref_genes as rg
+    from _genes_util import load_case, split
+    k = load_case(name)
+    z, C, G = k['z'], k['C'], k['G']
+    rs = np.random.RandomState(k['seed'])
+    cbind.initRNG(); cbind.setRNG(k['seed'])
+    eta0 = rs.uniform(0, 1.0, (C, G))                                  # KLAssign.random_initialize
+    kl_eta, n_kl, kl_div = rg.kl_assign(k['cov'], k['delta'], eta0)
+    np.testing.assert_allclose(kl_eta, z['kl_eta'], rtol=1e-9, atol=1e-12)
+    assert abs(kl_div - float(z['kl_div'])) < 1e-8
+    eta = np.rint(kl_eta)
+    eta[eta > 1.0] = 1.0                                              # Eta_Sampler.__init__:121-122 (max_eta = 2)
+    np.testing.assert_array_equal(eta, z['eta_init'])
+    eta = eta.astype(np.int64)
+    prior = rg.eta_log_prior(2, 0.01)
+    np.testing.assert_allclose(prior, z['eta_log_prior'], rtol=0, atol=1e-15)
+    taus = []
+    for c in range(C):                                               # __init__:126-135
+        x = k['variants'][c]
+        if x.shape[0] == 0:
+            taus.append(np.zeros((0, G, 4), dtype=np.int64)); continue
+        gr = rg.mask_gamma(k['gamma'], eta[c])
+        t, _ = rg.gene_nmft_tau(rs, x, gr, G)
+        cbind.sample_tau(t, np.ascontiguousarray(gr), k['eps'], x)
+        taus.append(t)
+    np.testing.assert_array_equal(np.concatenate(taus), z['tau_init'])
+    eta_star = np.zeros_like(eta); llstar = np.zeros(C)
+    for rnd in (1, 2):
+        store, trace, gene_ll = rg.eta_update_reference_order(rs, eta, taus, k['variants'], k['cov'], k['gamma'], k['eps'],
+                                                              k['delta_gs'], prior, k['iters'], eta_star, llstar)
+        np.testing.assert_array_equal(store, z['eta_store_%d' % rnd])
+        np.testing.assert_array_equal(eta_star, z['eta_star_%d' % rnd])
+        np.testing.assert_array_equal(np.concatenate(taus), z['tau_%d' % rnd])
+        np.testing.assert_allclose(gene_ll, z['gene_ll_%d' % rnd], rtol=1e-11)
+        np.testing.assert_allclose(llstar, z['gene_llstar_%d' % rnd], rtol=1e-11)
+        np.testing.assert_allclose(trace, z['ll_log_%d' % rnd], atol=2e-6)      # the log line prints 6 decimals
+    stars, lls, stores = rg.calc_tau_star(rs, eta, eta_star, k['variants'], k['gamma'], k['eps'], k['tau_iter'], G)
+    np.testing.assert_array_equal(np.concatenate(stars), z['tau_star'])
+    np.testing.assert_array_equal(np.concatenate(stores, axis=1), z['tau_store'])
+    ref_ll = z['tau_star_ll']
+    mine = np.concatenate(lls)
+    live = ref_ll > -1e300
+    np.testing.assert_array_equal(live, mine > -1e300)
+    np.testing.assert_allclose(mine[live], ref_ll[live], rtol=1e-11)
+
+
+def test_masked_row_sum_order_is_numpys():
+    """the device and the oracle re-normalise the masked gamma with numpy's add.reduce order (sequential below
+    8 haplotypes, 8 running sums above): restated here and compared with ndarray.sum bit for bit."""
+    def row_sum(a):
+        n = len(a)
+        if n < 8:
+            r = 0.0
+            for x in a:
+                r += x
+            return r
+        r = [a[j] for j in range(8)]
+        i = 8
+        while i < n - (n % 8):
+            for j in range(8):
+                r[j] += a[i + j]
+            i += 8
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        while i < n:
+            res += a[i]
+            i += 1
+        return res
+    rng = np.random.default_rng(5)
+    for G in range(1, 33):
+        A = rng.random((9, G)) * rng.random((9, 1))
+        A[:, rng.random(G) < 0.3] = 0.0
+        np.testing.assert_array_equal(A.sum(axis=1), np.array([row_sum(list(r)) for r in A]))

@@ -119,7 +119,7 @@ __global__ void gene_unpack_kernel(const uint64_t *t0, const uint64_t *t1, const
 struct GeneSweepParams {
     const int32_t *cnt_vs;      // [Vtot][S][4]
     const int32_t *gene_off;    // [C+1]
-    const int32_t *blk_tab;     // [nblk][2] {gene, first variant row}
+    const int32_t *task_tab;    // [ntask][2] {gene, first variant row}: <= GENE_VPG rows of one gene
     uint64_t *tau[3];
     const int32_t *cur;         // [C]
     const int32_t *eta;         // [C][G] mask source
@@ -127,59 +127,57 @@ struct GeneSweepParams {
     const double *log_tab;
     const uint32_t *u_raw;      // raw 32-bit words (GSL stream or test vectors); null -> Philox
     const int64_t *u_off;       // [C][2] first word of (gene, candidate) in u_raw
-    double *ll_partial;         // [2][nblk]
+    double *v_ll;               // [2][Vtot] x log p of every variant after the sweep
     int32_t *nchange;           // [C][2]
-    double *v_ll;               // [Vtot] or null
-    int S, G, nblk, blk_base, step_g;
+    int S, G, Vtot, task_base, task_end, step_g;
     uint32_t k0, k1, iter;
 };
 
-// block (blk_base + blockIdx.x) of the table, candidate blockIdx.y.  step_g >= 0: copy-number step of
-// haplotype step_g, candidate k forces mask bit step_g to k and writes tau to buffer (cur+1+k)%3;
-// step_g < 0: the gene's own mask, in place.
+// One lane group (LPV lanes; lane = sample, NSL samples per lane) per task, candidate blockIdx.y.  Genes are
+// small (a handful of variant rows), so the masked gamma is built per GROUP, not per workgroup: every lane
+// only ever reads the gamma column of its own samples, so it re-normalises those itself (no barrier) into the
+// group's LDS tile.  step_g >= 0: copy-number step of haplotype step_g, candidate k forces mask bit step_g to k
+// and writes tau to buffer (cur+1+k)%3; step_g < 0: the gene's own mask, in place.
 template <int LPV, int NSL, bool SWEEP>
 __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_g[];
     constexpr int SP = LPV * NSL;
-    constexpr int GPB = 256 / LPV;
-    double *gT = reinterpret_cast<double *>(smem_g);     // [G][SP] masked, re-normalised, transposed
-    double *rs = gT + (size_t)p.G * SP;                  // [SP] row sums
-    double *eS = rs + SP;                                // [16]
-    double *red = eS + 16;                               // [4]
-    int *redi = reinterpret_cast<int *>(red + 4);        // [4] (+4 pad)
-    double2 *ltab = reinterpret_cast<double2 *>(red + 6);// [128]
+    const int GPB = blockDim.x / LPV;
+    double2 *ltab = reinterpret_cast<double2 *>(smem_g);                 // [128]
+    double *eS = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);       // [16]
     const int tid = threadIdx.x, G = p.G, S = p.S;
-    const int b = p.blk_base + blockIdx.x, k = blockIdx.y;
-    const int c = p.blk_tab[2 * b], vfirst = p.blk_tab[2 * b + 1];
+    const int grp = tid / LPV, lig = tid % LPV, k = blockIdx.y;
+    double *gT = eS + 16 + (size_t)grp * G * SP;                         // [G][SP] of this group
+    for (int i = tid; i < DSM_LOG_TAB_N; i += blockDim.x) ltab[i] = reinterpret_cast<const double2 *>(p.log_tab)[i];
+    if (tid < 16) eS[tid] = p.eps[tid];
+    __syncthreads();
+    const int task = p.task_base + blockIdx.x * GPB + grp;
+    if (task >= p.task_end) return;
+    const int c = p.task_tab[2 * task], vfirst = p.task_tab[2 * task + 1];
     const int g0 = p.gene_off[c], g1 = p.gene_off[c + 1];
-    const int vend = (vfirst + GPB * GENE_VPG < g1) ? vfirst + GPB * GENE_VPG : g1;
+    const int vend = (vfirst + GENE_VPG < g1) ? vfirst + GENE_VPG : g1;
     uint32_t mask = 0;
     for (int h = 0; h < G; ++h) mask |= (uint32_t)(p.eta[(size_t)c * G + h] > 0) << h;
     if (p.step_g >= 0) mask = (mask & ~(1u << p.step_g)) | ((uint32_t)k << p.step_g);
-    if (mask == 0u) {                                    // no haplotype carries the gene: nothing to sweep
-        if (tid == 0) p.ll_partial[(size_t)k * p.nblk + b] = 0.0;
-        return;
-    }
+    if (mask == 0u) return;                                              // no haplotype carries the gene: nothing to sweep
     const int src = p.cur[c];
     const int dst = (p.step_g >= 0) ? (src + 1 + k) % 3 : src;
     const uint64_t *tsrc = p.tau[src];
     uint64_t *tdst = p.tau[dst];
-
-    if (tid < DSM_LOG_TAB_N) ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
-    if (tid < 16) eS[tid] = p.eps[tid];
-    for (int s = tid; s < SP; s += 256) rs[s] = (s < S) ? masked_row_sum(p.gamma + (size_t)s * G, G, mask) : 1.0;
-    __syncthreads();
-    for (int i = tid; i < G * SP; i += 256) {
-        const int g = i / SP, s = i % SP;
-        gT[i] = (s < S) ? (((mask >> g) & 1u) ? p.gamma[(size_t)s * G + g] : 0.0) / rs[s] : 1.0;   // pad: p > 0, count = 0
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+        const int s = lig + j * LPV;
+        if (s < S) {
+            const double rsum = masked_row_sum(p.gamma + (size_t)s * G, G, mask);
+            for (int g = 0; g < G; ++g) gT[g * SP + s] = (((mask >> g) & 1u) ? p.gamma[(size_t)s * G + g] : 0.0) / rsum;
+        } else {
+            for (int g = 0; g < G; ++g) gT[g * SP + s] = 1.0;            // pad: p > 0, count = 0
+        }
     }
-    __syncthreads();
 
-    const int grp = tid / LPV, lig = tid % LPV;
-    double ll_acc = 0.0;
     int nchg = 0;
-    for (int v = vfirst + grp; v < vend; v += GPB) {
+    for (int v = vfirst; v < vend; ++v) {
         uint64_t t = tsrc[v];
         int xi[NSL][4];
         double xf[NSL][4];
@@ -194,13 +192,33 @@ __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
         }
         if (SWEEP) {
             for (int g = 0; g < G; ++g) {
+                const int told = (int)((t >> (2 * g)) & 3);
+                double u;
+                if (p.u_raw) {
+                    u = (double)p.u_raw[p.u_off[(size_t)c * 2 + k] + (size_t)(v - g0) * G + g] * 2.3283064365386963e-10;
+                } else {
+                    const size_t ui = (size_t)v * G + g;
+                    uint32_t r[4];
+                    philox4x32_10((uint32_t)ui, (uint32_t)(ui >> 32), p.iter,
+                                  DSM_STREAM_GENE + (uint32_t)((p.step_g + 1) * 2 + k), p.k0, p.k1, r);
+                    u = (double)r[0] * 2.3283064365386963e-10;
+                }
+                if (!((mask >> g) & 1u)) {
+                    // a haplotype without the gene has gamma = 0: the four candidates are the same mixture, their
+                    // log-probabilities are equal bit for bit, so the draw is uniform: ex = {1,1,1,1}, sum = 4
+                    const double us = u * 4.0;
+                    const int tn = (us < 1.0) ? 0 : (us < 2.0) ? 1 : (us < 3.0) ? 2 : 3;
+                    nchg += (lig == 0) & (tn != told);
+                    t = (t & ~(3ull << (2 * g))) | ((uint64_t)tn << (2 * g));
+                    continue;
+                }
                 double st[NSL][4];
 #pragma unroll
                 for (int j = 0; j < NSL; ++j)
 #pragma unroll
                     for (int bb = 0; bb < 4; ++bb) st[j][bb] = 0.0;
                 for (int h = 0; h < G; ++h) {            // rest mixture, h ascending (c_sample_tau.c:136-150)
-                    if (h == g) continue;
+                    if (h == g || !((mask >> h) & 1u)) continue;     // gamma = 0 adds exactly nothing
                     const double *er = eS + (int)((t >> (2 * h)) & 3) * 4;
                     const double e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
 #pragma unroll
@@ -215,7 +233,6 @@ __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
                 double gg[NSL];
 #pragma unroll
                 for (int j = 0; j < NSL; ++j) gg[j] = gT[g * SP + lig + j * LPV];
-                const int told = (int)((t >> (2 * g)) & 3);
                 double l[4];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
@@ -249,16 +266,6 @@ __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
                     sum += ex[a];
                 }
                 const double c0 = ex[0], c1 = ex[1] + c0, c2 = ex[2] + c1;
-                double u;
-                if (p.u_raw) {
-                    u = (double)p.u_raw[p.u_off[(size_t)c * 2 + k] + (size_t)(v - g0) * G + g] * 2.3283064365386963e-10;
-                } else {
-                    const size_t ui = (size_t)v * G + g;
-                    uint32_t r[4];
-                    philox4x32_10((uint32_t)ui, (uint32_t)(ui >> 32), p.iter,
-                                  DSM_STREAM_GENE + (uint32_t)((p.step_g + 1) * 2 + k), p.k0, p.k1, r);
-                    u = (double)r[0] * 2.3283064365386963e-10;
-                }
                 const double us = u * sum;
                 const int tn = (us < c0) ? 0 : (us < c1) ? 1 : (us < c2) ? 2 : 3;
                 nchg += (lig == 0) & (tn != told);
@@ -272,6 +279,7 @@ __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
         for (int j = 0; j < NSL; ++j) {
             double P[4] = {0.0, 0.0, 0.0, 0.0};
             for (int g = 0; g < G; ++g) {
+                if (!((mask >> g) & 1u)) continue;
                 const double *er = eS + (int)((t >> (2 * g)) & 3) * 4;
                 const double gm = gT[g * SP + lig + j * LPV];
 #pragma unroll
@@ -280,40 +288,29 @@ __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) vacc = fma((double)xi[j][bb], dsm_log(P[bb], ltab), vacc);
         }
-        if (p.v_ll) {
-            const double tot = group_allreduce_sum<LPV>(vacc);
-            if (lig == 0) p.v_ll[v] = tot;
-        }
-        ll_acc += vacc;
+        const double tot = group_allreduce_sum<LPV>(vacc);
+        if (lig == 0) p.v_ll[(size_t)k * p.Vtot + v] = tot;
     }
-    const double wsum = group_allreduce_sum<64>(ll_acc);
-    const int wn = (int)group_allreduce_sum_u32<64>((unsigned)nchg);
-    if ((tid & 63) == 0) { red[tid >> 6] = wsum; redi[tid >> 6] = wn; }
-    __syncthreads();
-    if (tid == 0) {
-        p.ll_partial[(size_t)k * p.nblk + b] = ((red[0] + red[1]) + red[2]) + red[3];
-        const int tot = redi[0] + redi[1] + redi[2] + redi[3];
-        if (SWEEP && tot) atomicAdd(&p.nchange[c * 2 + k], tot);
-    }
+    if (SWEEP && lig == 0 && nchg) atomicAdd(&p.nchange[c * 2 + k], nchg);
 }
 
 // =====================================================================
 // copy-number step for every gene (one wavefront per gene)
 // =====================================================================
 struct GeneChooseParams {
-    const int32_t *gene_off, *blk_off;   // [C+1] each
+    const int32_t *gene_off;             // [C+1]
     int32_t *eta, *cur;
     const double *cov, *delta;           // [C][S], [G][S]
     const double *prior;                 // [max_eta]
     const double *cov_const, *mult_const;
-    const double *ll_partial;            // [2][nblk]
+    const double *v_ll;                  // [2][Vtot] per-variant x log p of the two candidates
     double *lv_keep;                     // [C] x log p of the kept configuration
     double *gene_ll, *gene_llstar;
     int32_t *eta_star;
     int32_t *eta_store;                  // slot of this iteration or null
     double *gene_ll_trace;               // slot of this iteration or null
     const double *u_ext;                 // [C][G] uniforms of this iteration or null
-    int C, S, G, max_eta, nblk;
+    int C, S, G, max_eta, Vtot;
     int step_g;                          // >= 0: draw eta[., step_g]; < 0: evaluate only (x log p in partial slot 0)
     int finish;                          // compute gene_ll (+ MAP bookkeeping, stores)
     int reset_star;                      // star := this state
@@ -331,10 +328,14 @@ __global__ __launch_bounds__(256) void gene_choose_kernel(GeneChooseParams p)
     const int G = p.G, S = p.S, g = p.step_g;
     const int Vc = p.gene_off[c + 1] - p.gene_off[c];
     int32_t *eta = p.eta + (size_t)c * G;
-    // x log p of the candidates: workgroup partials in table order (fixed order -> deterministic)
+    // x log p of the candidates: the gene's per-variant values, lane-strided then a fixed butterfly
+    // (the order depends only on the gene's size -> deterministic)
     double lv[2] = {0.0, 0.0};
-    for (int k = 0; k < (g >= 0 ? 2 : 1); ++k)
-        for (int b = p.blk_off[c]; b < p.blk_off[c + 1]; ++b) lv[k] += p.ll_partial[(size_t)k * p.nblk + b];
+    for (int k = 0; k < (g >= 0 ? 2 : 1); ++k) {
+        double a = 0.0;
+        for (int v = p.gene_off[c] + lane; v < p.gene_off[c + 1]; v += 64) a += p.v_ll[(size_t)k * p.Vtot + v];
+        lv[k] = group_allreduce_sum<64>(a);
+    }
     double kept = (g >= 0) ? 0.0 : lv[0];
     int pick = 0;
     if (g >= 0) {
@@ -659,12 +660,12 @@ struct dsm_genes {
     dsm_ctx *base = nullptr;        // stream, MT19937 state, log table
     int device = 0;
     int Vtot = 0, S = 0, C = 0, G = 0, max_eta = 2;
-    int LPV = 64, NSL = 1, nblk = 0;
+    int LPV = 64, NSL = 1, ntask = 0, block = 256;
     bool have_data = false, have_model = false, have_state = false;
-    std::vector<int32_t> gene_off_h, blk_off_h, eta_h;
-    DBuf<int32_t> cnt_vs, gene_off, gene_of, blk_tab, blk_off, eta, cur, eta_star, nchange, n_iter;
+    std::vector<int32_t> gene_off_h, task_off_h, eta_h;
+    DBuf<int32_t> cnt_vs, gene_off, gene_of, task_tab, eta, cur, eta_star, nchange, n_iter;
     DBuf<uint64_t> tau0, tau1, tau2;
-    DBuf<double> cov, gamma, eps, delta, prior, cov_const, mult_const, ll_partial, lv_keep, gene_ll, gene_llstar, v_ll;
+    DBuf<double> cov, gamma, eps, delta, prior, cov_const, mult_const, lv_keep, gene_ll, gene_llstar, v_ll;
     DBuf<int64_t> u_off;
     DBuf<uint32_t> u_raw;
     uint64_t ctr_seed = 0x13198A2E03707344ull;
@@ -732,19 +733,17 @@ extern "C" int dsm_genes_set_data(dsm_genes *gs, const int64_t *variants, int Vt
     gs->Vtot = Vtot; gs->S = S; gs->C = C;
     pick_tile(S, &gs->LPV, &gs->NSL);
     gs->gene_off_h.assign(gene_off, gene_off + C + 1);
-    // workgroup table: GENE_VPG passes of 256/LPV lane groups per workgroup
-    const int vpb = (256 / gs->LPV) * GENE_VPG;
+    // task table: <= GENE_VPG consecutive variant rows of one gene per lane group
     std::vector<int32_t> tab, gof((size_t)(Vtot ? Vtot : 1));
-    gs->blk_off_h.assign(C + 1, 0);
+    gs->task_off_h.assign(C + 1, 0);
     for (int c = 0; c < C; ++c) {
-        for (int v = gene_off[c]; v < gene_off[c + 1]; v += vpb) { tab.push_back(c); tab.push_back(v); }
+        for (int v = gene_off[c]; v < gene_off[c + 1]; v += GENE_VPG) { tab.push_back(c); tab.push_back(v); }
         for (int v = gene_off[c]; v < gene_off[c + 1]; ++v) gof[v] = c;
-        gs->blk_off_h[c + 1] = (int32_t)(tab.size() / 2);
+        gs->task_off_h[c + 1] = (int32_t)(tab.size() / 2);
     }
-    gs->nblk = (int)(tab.size() / 2);
+    gs->ntask = (int)(tab.size() / 2);
     TRY(gs->gene_off.resize(C + 1));
-    TRY(gs->blk_off.resize(C + 1));
-    TRY(gs->blk_tab.resize(tab.size()));
+    TRY(gs->task_tab.resize(tab.size()));
     TRY(gs->gene_of.resize(gof.size()));
     TRY(gs->cov.resize((size_t)C * S));
     TRY(gs->cnt_vs.resize((size_t)Vtot * S * 4));
@@ -752,17 +751,15 @@ extern "C" int dsm_genes_set_data(dsm_genes *gs, const int64_t *variants, int Vt
     TRY(gs->cur.resize(C));
     TRY(gs->nchange.resize((size_t)C * 2));
     TRY(gs->n_iter.resize(C));
-    TRY(gs->ll_partial.resize((size_t)2 * (gs->nblk ? gs->nblk : 1)));
     TRY(gs->lv_keep.resize(C)); TRY(gs->gene_ll.resize(C)); TRY(gs->gene_llstar.resize(C));
-    TRY(gs->v_ll.resize(Vtot));
+    TRY(gs->v_ll.resize((size_t)2 * (Vtot ? Vtot : 1)));
     TRY(gs->u_off.resize((size_t)C * 2));
     HIP_TRY(hipMemcpyAsync(gs->gene_off, gene_off, (C + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(gs->blk_off, gs->blk_off_h.data(), (C + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    if (!tab.empty()) HIP_TRY(hipMemcpyAsync(gs->blk_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (!tab.empty()) HIP_TRY(hipMemcpyAsync(gs->task_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(gs->gene_of, gof.data(), gof.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(gs->cov, cov, (size_t)C * S * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(gs->cur, 0, C * sizeof(int32_t), st));
-    HIP_TRY(hipMemsetAsync(gs->ll_partial, 0, (size_t)2 * (gs->nblk ? gs->nblk : 1) * sizeof(double), st));
+    HIP_TRY(hipMemsetAsync(gs->v_ll, 0, (size_t)2 * (Vtot ? Vtot : 1) * sizeof(double), st));
     HIP_TRY(hipMemsetAsync(gs->lv_keep, 0, C * sizeof(double), st));
     if (Vtot > 0) {
         const size_t n = (size_t)Vtot * S * 4;
@@ -882,39 +879,50 @@ extern "C" int dsm_genes_set_mt_state(dsm_genes *gs, const uint32_t *state625)
 }
 
 // ---------------------------------------------------------------- launch helpers
-static size_t sweep_lds(const dsm_genes *gs)
+// lane groups per workgroup and dynamic LDS: log table + epsilon + one [G][SP] gamma tile per group; groups are
+// dropped until the workgroup fits 64 KB (two or more workgroups per CU), the hard limit is the 160 KB of a CU
+static int sweep_geometry(const dsm_genes *gs, int *block, size_t *lds)
 {
-    const size_t SP = (size_t)gs->LPV * gs->NSL;
-    return ((size_t)gs->G * SP + SP + 16 + 6 + 2 * DSM_LOG_TAB_N) * sizeof(double);
+    const size_t tile = (size_t)gs->G * gs->LPV * gs->NSL * sizeof(double);
+    const size_t fixed = (2 * DSM_LOG_TAB_N + 16) * sizeof(double);
+    int gpb = 256 / gs->LPV;
+    while (gpb > 1 && fixed + gpb * tile > 64 * 1024) gpb >>= 1;
+    if (fixed + gpb * tile > 160 * 1024) { dsm_set_error("gamma tile (%zu B) exceeds LDS", tile); return DSM_ERR_UNSUPPORTED; }
+    *block = gpb * gs->LPV;
+    *lds = fixed + gpb * tile;
+    return DSM_OK;
 }
 
-static GeneSweepParams sweep_params(dsm_genes *gs, const int32_t *d_eta, const uint32_t *u_raw, double *v_ll, int step_g,
-                                    int blk_base, uint32_t iter)
+static GeneSweepParams sweep_params(dsm_genes *gs, const int32_t *d_eta, const uint32_t *u_raw, int step_g, int task_base,
+                                    int task_end, uint32_t iter)
 {
     GeneSweepParams p;
-    p.cnt_vs = gs->cnt_vs; p.gene_off = gs->gene_off; p.blk_tab = gs->blk_tab;
+    p.cnt_vs = gs->cnt_vs; p.gene_off = gs->gene_off; p.task_tab = gs->task_tab;
     p.tau[0] = gs->tau0; p.tau[1] = gs->tau1; p.tau[2] = gs->tau2;
     p.cur = gs->cur; p.eta = d_eta; p.gamma = gs->gamma; p.eps = gs->eps; p.log_tab = gs->base->log_tab;
-    p.u_raw = u_raw; p.u_off = gs->u_off; p.ll_partial = gs->ll_partial; p.nchange = gs->nchange; p.v_ll = v_ll;
-    p.S = gs->S; p.G = gs->G; p.nblk = gs->nblk; p.blk_base = blk_base; p.step_g = step_g;
+    p.u_raw = u_raw; p.u_off = gs->u_off; p.v_ll = gs->v_ll; p.nchange = gs->nchange;
+    p.S = gs->S; p.G = gs->G; p.Vtot = gs->Vtot; p.task_base = task_base; p.task_end = task_end; p.step_g = step_g;
     p.k0 = (uint32_t)gs->ctr_seed; p.k1 = (uint32_t)(gs->ctr_seed >> 32); p.iter = iter;
     return p;
 }
 
 template <int LPV, int NSL>
-static void launch_sweep_t(const GeneSweepParams &p, bool sweep, int nb, int ncand, size_t sh, hipStream_t st)
+static void launch_sweep_t(const GeneSweepParams &p, bool sweep, int nb, int ncand, int block, size_t sh, hipStream_t st)
 {
-    if (sweep) hipLaunchKernelGGL((gene_sweep_kernel<LPV, NSL, true>), dim3(nb, ncand), dim3(256), sh, st, p);
-    else hipLaunchKernelGGL((gene_sweep_kernel<LPV, NSL, false>), dim3(nb, ncand), dim3(256), sh, st, p);
+    if (sweep) hipLaunchKernelGGL((gene_sweep_kernel<LPV, NSL, true>), dim3(nb, ncand), dim3(block), sh, st, p);
+    else hipLaunchKernelGGL((gene_sweep_kernel<LPV, NSL, false>), dim3(nb, ncand), dim3(block), sh, st, p);
 }
 
-static int launch_sweep(dsm_genes *gs, const GeneSweepParams &p, bool sweep, int nb, int ncand)
+static int launch_sweep(dsm_genes *gs, const GeneSweepParams &p, bool sweep, int ncand)
 {
-    if (nb <= 0) return DSM_OK;
-    const size_t sh = sweep_lds(gs);
-    if (sh > 160 * 1024) { dsm_set_error("gamma tile (%zu B) exceeds LDS", sh); return DSM_ERR_UNSUPPORTED; }
+    const int ntask = p.task_end - p.task_base;
+    if (ntask <= 0) return DSM_OK;
+    int block = 256;
+    size_t sh = 0;
+    TRY(sweep_geometry(gs, &block, &sh));
+    const int gpb = block / gs->LPV, nb = (ntask + gpb - 1) / gpb;
     hipStream_t st = gs->base->stream;
-#define GS_CASE(L, N) if (gs->LPV == L && gs->NSL == N) launch_sweep_t<L, N>(p, sweep, nb, ncand, sh, st)
+#define GS_CASE(L, N) if (gs->LPV == L && gs->NSL == N) launch_sweep_t<L, N>(p, sweep, nb, ncand, block, sh, st)
     GS_CASE(16, 1); GS_CASE(32, 1); GS_CASE(64, 1); GS_CASE(64, 2); GS_CASE(64, 3); GS_CASE(64, 4); GS_CASE(64, 6); GS_CASE(64, 8);
 #undef GS_CASE
     HIP_TRY(hipGetLastError());
@@ -924,11 +932,11 @@ static int launch_sweep(dsm_genes *gs, const GeneSweepParams &p, bool sweep, int
 static GeneChooseParams choose_params(dsm_genes *gs, int step_g, int finish, int reset_star, uint32_t iter)
 {
     GeneChooseParams p;
-    p.gene_off = gs->gene_off; p.blk_off = gs->blk_off; p.eta = gs->eta; p.cur = gs->cur;
+    p.gene_off = gs->gene_off; p.eta = gs->eta; p.cur = gs->cur;
     p.cov = gs->cov; p.delta = gs->delta; p.prior = gs->prior; p.cov_const = gs->cov_const; p.mult_const = gs->mult_const;
-    p.ll_partial = gs->ll_partial; p.lv_keep = gs->lv_keep; p.gene_ll = gs->gene_ll; p.gene_llstar = gs->gene_llstar;
+    p.v_ll = gs->v_ll; p.lv_keep = gs->lv_keep; p.gene_ll = gs->gene_ll; p.gene_llstar = gs->gene_llstar;
     p.eta_star = gs->eta_star; p.eta_store = nullptr; p.gene_ll_trace = nullptr; p.u_ext = nullptr;
-    p.C = gs->C; p.S = gs->S; p.G = gs->G; p.max_eta = gs->max_eta; p.nblk = gs->nblk;
+    p.C = gs->C; p.S = gs->S; p.G = gs->G; p.max_eta = gs->max_eta; p.Vtot = gs->Vtot;
     p.step_g = step_g; p.finish = finish; p.reset_star = reset_star;
     p.k0 = (uint32_t)gs->ctr_seed; p.k1 = (uint32_t)(gs->ctr_seed >> 32); p.iter = iter;
     return p;
@@ -1013,7 +1021,7 @@ extern "C" int dsm_genes_sweep_all(dsm_genes *gs, const int32_t *eta_mask, int s
     std::vector<int32_t> host;
     TRY(mask_source(gs, eta_mask, tmp, &d_eta, host));
     const uint32_t *u = nullptr;
-    if (sweep && gs->nblk > 0) {
+    if (sweep && gs->ntask > 0) {
         // GSL stream in gene order, genes without variants or with an empty mask draw nothing
         std::vector<int64_t> off((size_t)C * 2, 0);
         int64_t pos = 0;
@@ -1029,22 +1037,25 @@ extern "C" int dsm_genes_sweep_all(dsm_genes *gs, const int32_t *eta_mask, int s
         u = gs->u_raw;
         HIP_TRY(hipMemsetAsync(gs->nchange, 0, (size_t)C * 2 * sizeof(int32_t), st));
     }
-    const GeneSweepParams p = sweep_params(gs, d_eta, u, v_ll ? (double *)gs->v_ll : nullptr, -1, 0, 0);
-    TRY(launch_sweep(gs, p, sweep != 0, gs->nblk, 1));
-    std::vector<double> part((size_t)(gs->nblk ? gs->nblk : 1));
+    const GeneSweepParams p = sweep_params(gs, d_eta, u, -1, 0, gs->ntask, 0);
+    TRY(launch_sweep(gs, p, sweep != 0, 1));
+    std::vector<double> vl((size_t)(gs->Vtot ? gs->Vtot : 1));
     std::vector<int32_t> nch((size_t)C * 2, 0);
-    if (gs->nblk > 0) HIP_TRY(hipMemcpyAsync(part.data(), gs->ll_partial, gs->nblk * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (sweep && gs->nblk > 0) HIP_TRY(hipMemcpyAsync(nch.data(), gs->nchange, nch.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    if (v_ll && gs->Vtot > 0) HIP_TRY(hipMemcpyAsync(v_ll, gs->v_ll, gs->Vtot * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (gs->Vtot > 0) HIP_TRY(hipMemcpyAsync(vl.data(), gs->v_ll, gs->Vtot * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (sweep && gs->ntask > 0) HIP_TRY(hipMemcpyAsync(nch.data(), gs->nchange, nch.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (int c = 0; c < C; ++c) {
-        if (logvar) {
-            double t = 0.0;
-            for (int b = gs->blk_off_h[c]; b < gs->blk_off_h[c + 1]; ++b) t += part[b];
-            logvar[c] = t;
+        const int lo = gs->gene_off_h[c], hi = gs->gene_off_h[c + 1];
+        const bool on = hi > lo && row_active(host, c, G);
+        double t = 0.0;
+        for (int v = lo; v < hi; ++v) {
+            if (!on) vl[v] = 0.0;                       // skipped genes: nothing was evaluated
+            t += vl[v];
         }
-        if (nchange) nchange[c] = (gs->gene_off_h[c + 1] > gs->gene_off_h[c] && row_active(host, c, G)) ? nch[(size_t)c * 2] : -1;
+        if (logvar) logvar[c] = t;
+        if (nchange) nchange[c] = on ? nch[(size_t)c * 2] : -1;
     }
+    if (v_ll && gs->Vtot > 0) memcpy(v_ll, vl.data(), gs->Vtot * sizeof(double));
     return DSM_OK;
 }
 
@@ -1070,16 +1081,16 @@ extern "C" int dsm_genes_step_candidates(dsm_genes *gs, int c, int g, double *lo
     TRY(gs->u_raw.resize(words));
     HIP_TRY(hipMemcpyAsync(gs->u_off.p + (size_t)c * 2, off, sizeof off, hipMemcpyHostToDevice, st));
     TRY(k_mt_fill(gs->base, gs->u_raw, words, st));
-    const int b0 = gs->blk_off_h[c], nb = gs->blk_off_h[c + 1] - b0;
-    const GeneSweepParams p = sweep_params(gs, gs->eta, gs->u_raw, nullptr, g, b0, 0);
-    TRY(launch_sweep(gs, p, true, nb, 2));
-    std::vector<double> part((size_t)2 * nb);
-    HIP_TRY(hipMemcpyAsync(part.data(), gs->ll_partial.p + b0, nb * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(part.data() + nb, gs->ll_partial.p + gs->nblk + b0, nb * sizeof(double), hipMemcpyDeviceToHost, st));
+    const GeneSweepParams p = sweep_params(gs, gs->eta, gs->u_raw, g, gs->task_off_h[c], gs->task_off_h[c + 1], 0);
+    TRY(launch_sweep(gs, p, true, 2));
+    const int lo = gs->gene_off_h[c];
+    std::vector<double> vl((size_t)2 * Vc);
+    HIP_TRY(hipMemcpyAsync(vl.data(), gs->v_ll.p + lo, Vc * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(vl.data() + Vc, gs->v_ll.p + gs->Vtot + lo, Vc * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (int k = 0; k < 2; ++k) {
         double t = 0.0;
-        for (int b = 0; b < nb; ++b) t += part[(size_t)k * nb + b];
+        for (int v = 0; v < Vc; ++v) t += vl[(size_t)k * Vc + v];
         logvar[k] = t;
     }
     if (!any0) logvar[0] = -1.0e20;
@@ -1104,8 +1115,8 @@ extern "C" int dsm_genes_step_choose(dsm_genes *gs, int c, int g, int eta_value)
 // ---------------------------------------------------------------- log-likelihood / batched update
 static int eval_genes(dsm_genes *gs, int reset_star)
 {
-    const GeneSweepParams sp = sweep_params(gs, gs->eta, nullptr, nullptr, -1, 0, 0);
-    TRY(launch_sweep(gs, sp, false, gs->nblk, 1));
+    const GeneSweepParams sp = sweep_params(gs, gs->eta, nullptr, -1, 0, gs->ntask, 0);
+    TRY(launch_sweep(gs, sp, false, 1));
     const GeneChooseParams cp = choose_params(gs, -1, 1, reset_star, 0);
     return launch_choose(gs, cp);
 }
@@ -1164,8 +1175,8 @@ extern "C" int dsm_genes_update(dsm_genes *gs, int n_iter, int reset_star, int32
         const uint32_t iter = gs->iter_ctr++;
         for (int g = 0; g < G; ++g) {
             const uint32_t *u = (u_tau_ext && vg > 0) ? d_ut.p + ((size_t)it * G + g) * 2 * vg : nullptr;
-            const GeneSweepParams sp = sweep_params(gs, gs->eta, u, nullptr, g, 0, iter);
-            TRY(launch_sweep(gs, sp, true, gs->nblk, 2));
+            const GeneSweepParams sp = sweep_params(gs, gs->eta, u, g, 0, gs->ntask, iter);
+            TRY(launch_sweep(gs, sp, true, 2));
             GeneChooseParams cp = choose_params(gs, g, g == G - 1, 0, iter);
             if (u_eta_ext) cp.u_ext = d_ue.p + (size_t)it * cg;
             if (g == G - 1) { cp.eta_store = d_store.p + (size_t)it * cg; cp.gene_ll_trace = d_trace.p + (size_t)it * C; }

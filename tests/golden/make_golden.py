@@ -485,6 +485,8 @@ def gen_gene_assign(out, name="gene_assign", C=7, S=8, G=3, synth_kw=None):
         kl = ga.KLAssign(prng, cov.to_numpy(), delta)
         kl.factorize()
         rec['kl_eta'] = kl.eta.copy()
+        tot, acc, full = ga.compGenes(np.rint(kl.eta), d['eta_true'].astype(np.float64))     # pure function
+        rec['comp_total'], rec['comp_acc'], rec['comp_matrix'] = tot, acc, full
         rec['kl_div'] = kl.div_objective()
         etaD = np.rint(kl.eta)
         smp = es.Eta_Sampler(prng, var[ga.expand_sample_names(names)], cov, gm, delta, scg['sd'].to_numpy(), eps, etaD,

@@ -141,3 +141,48 @@ def test_cli_flags_and_quirks():
     a = build_parser().parse_args(["x.freq", "-g", "4", "-i", "-r", "-f", "-v", "-p", "False"])
     assert (a.no_iter, a.random_select, a.filter_variants, a.min_variant_freq) == (250, 1000, 3.84, 0.01)
     assert a.optimiseP is True                              # type=bool quirk: any string is True
+
+
+# ---------------------------------------------------------------- f4 host logic (no GPU)
+@pytest.mark.parametrize("name", ["gene_assign", "gene_assign_lowcov"])
+def test_compgenes_matches_reference(name):
+    """GeneAssign.compGenes (greedy genome matching) against the reference function's output."""
+    import os
+    from desman_amd.GeneAssign import compGenes
+    from desman_amd.synth import synth_genes
+    import ast
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    d = synth_genes(int(z['C']), int(z['S']), int(z['G']), seed=int(z['synth_seed']), **dict(ast.literal_eval(str(z['synth_kw']))))
+    tot, acc, full = compGenes(np.rint(z['kl_eta']), d['eta_true'].astype(np.float64))
+    assert tot == float(z['comp_total'])
+    np.testing.assert_array_equal(acc, z['comp_acc'])
+    np.testing.assert_array_equal(full, z['comp_matrix'])
+
+
+def test_geneassign_parser_has_reference_flags_and_defaults():
+    from desman_amd.GeneAssign import build_parser, expand_sample_names
+    a = build_parser().parse_args(["scg.csv", "gamma.csv", "cov.csv", "eps.csv"])
+    assert (a.random_seed, a.eta_max, a.iter_max, a.var_max, a.output_stub) == (23724839, 2, 20, 1e10, "output")
+    assert a.genomes is None and a.variant_file is None and a.assign_tau is False and a.rng == "mt19937"
+    b = build_parser().parse_args(["a", "b", "c", "d", "-s", "5", "-e", "3", "-i", "7", "-m", "40", "-o", "x", "-g", "g.csv",
+                                   "-v", "v.csv", "--assign_tau"])
+    assert (b.random_seed, b.eta_max, b.iter_max, b.var_max, b.output_stub, b.genomes, b.variant_file, b.assign_tau) == \
+        (5, 3, 7, 40, "x", "g.csv", "v.csv", True)
+    assert expand_sample_names(["s1", "s2"]) == ["s1-A", "s1-C", "s1-G", "s1-T", "s2-A", "s2-C", "s2-G", "s2-T"]
+
+
+def test_gene_sampler_fails_loudly_without_a_gpu():
+    """no CPU fallback on the gene path either: without a device the constructor raises DesmanHipError"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import pandas as pd
+    from desman_amd import _lib
+    from desman_amd.Eta_Sampler import Eta_Sampler
+    from desman_amd.GeneAssign import KLAssign
+    cov = pd.DataFrame(np.ones((3, 2)), index=["a", "b", "c"], columns=["s0", "s1"])
+    with pytest.raises(_lib.DesmanHipError):
+        Eta_Sampler(np.random.RandomState(1), None, cov, np.full((2, 2), 0.5), np.ones((2, 2)), np.ones(2),
+                    np.eye(4), np.ones((3, 2)))
+    with pytest.raises(_lib.DesmanHipError):
+        KLAssign(np.random.RandomState(1), np.ones((3, 2)), np.ones((2, 2))).factorize()

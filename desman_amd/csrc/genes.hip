@@ -24,7 +24,7 @@
 
 #define DSM_STREAM_GENE 0x47454E45u   // 'GENE'  tau-sweep uniforms of the batched gene sampler
 #define DSM_STREAM_GETA 0x47455441u   // 'GETA'  copy-number draws
-#define GENE_VPG 4                    // variants a lane group sweeps per workgroup
+#define GENE_VPG 1                    // variants a lane group sweeps per workgroup
 #define GENE_MIN_DELTA 1.0e-10        // Eta_Sampler.py:18
 #define GENE_ETA_PENALTY (-1.0e3)     // Eta_Sampler.py:19
 
@@ -191,18 +191,26 @@ __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
             for (int bb = 0; bb < 4; ++bb) xf[j][bb] = (double)(float)xi[j][bb];   // c_sample_tau.c:164
         }
         if (SWEEP) {
+            uint32_t uw_lane = 0;
             for (int g = 0; g < G; ++g) {
                 const int told = (int)((t >> (2 * g)) & 3);
-                double u;
+                uint32_t uw;
                 if (p.u_raw) {
-                    u = (double)p.u_raw[p.u_off[(size_t)c * 2 + k] + (size_t)(v - g0) * G + g] * 2.3283064365386963e-10;
+                    uw = p.u_raw[p.u_off[(size_t)c * 2 + k] + (size_t)(v - g0) * G + g];
                 } else {
-                    const size_t ui = (size_t)v * G + g;
-                    uint32_t r[4];
-                    philox4x32_10((uint32_t)ui, (uint32_t)(ui >> 32), p.iter,
-                                  DSM_STREAM_GENE + (uint32_t)((p.step_g + 1) * 2 + k), p.k0, p.k1, r);
-                    u = (double)r[0] * 2.3283064365386963e-10;
+                    // counter-based word of (row, haplotype): lane i of the group draws the word of haplotype
+                    // g + i once per LPV haplotypes, every step then reads its word from the owning lane
+                    if (g % LPV == 0) {
+                        const size_t ui = (size_t)v * G + g + lig;
+                        uint32_t r[4] = {0, 0, 0, 0};
+                        if (g + lig < G)
+                            philox4x32_10((uint32_t)ui, (uint32_t)(ui >> 32), p.iter,
+                                          DSM_STREAM_GENE + (uint32_t)((p.step_g + 1) * 2 + k), p.k0, p.k1, r);
+                        uw_lane = r[0];
+                    }
+                    uw = (uint32_t)__shfl((int)uw_lane, g % LPV, LPV);
                 }
+                const double u = (double)uw * 2.3283064365386963e-10;
                 if (!((mask >> g) & 1u)) {
                     // a haplotype without the gene has gamma = 0: the four candidates are the same mixture, their
                     // log-probabilities are equal bit for bit, so the draw is uniform: ex = {1,1,1,1}, sum = 4

@@ -414,3 +414,26 @@ def test_per_read_draws_have_multinomial_mean_and_variance(ctx):
     assert (np.abs(var - want) < 6 * want * np.sqrt(2.0 / n_it) + 2 * small).all()
     cov01 = np.cov(draws[:, 0], draws[:, 1])[0, 1]
     assert abs(cov01 + n * p_[0] * p_[1]) < 6 * np.sqrt(want[0] * want[1] / n_it) + 2 * small
+
+
+def test_reference_stream_chain_with_device_sweep_is_the_reference_trajectory():
+    """Module-swap use: the reference's own update() loop -- here its RandomState-exact
+    restatement oracle.ref_numpy.gibbs_update, pinned to the imported reference on the CPU -- with
+    sampletau.sample_tau replaced by the device sweep reproduces the reference's whole trajectory:
+    gamma / eta stores, tau, tau_star, MAP log-posterior identical, ll to 1e-13."""
+    from desman_amd import sampletau
+    from oracle import ref_numpy as rn
+    z = np.load(os.path.join(GOLDEN, "gibbs_pieces.npz"))
+    G, seed = int(z["G"]), int(z["seed"])
+    counts = z["counts"]
+    rs = np.random.RandomState(seed)
+    gamma0, tau0 = rn.sampler_ctor_draws(rs, counts.shape[0], counts.shape[1], G)
+    sampletau.initRNG(); sampletau.setRNG(seed)
+    r = rn.gibbs_update(rs, tau0, gamma0, z["eta0"], counts, 4, sampletau.sample_tau)
+    sampletau.freeRNG()
+    np.testing.assert_allclose(r["trace"]["ll"], z["ll_store"], rtol=1e-13)
+    assert np.array_equal(r["trace"]["gamma"], z["gamma_store"])
+    assert np.array_equal(r["trace"]["eta"], z["eta_store"])
+    assert np.array_equal(r["tau"], z["tau_final"])
+    assert np.array_equal(r["star"]["tau"], z["tau_star"])
+    assert r["star"]["lp"] == pytest.approx(float(z["lp_star"]), rel=1e-13)

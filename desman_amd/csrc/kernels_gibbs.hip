@@ -235,8 +235,9 @@ __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ ite
         uint32_t thr[GMAX], cnt[GMAX];
 #pragma unroll
         for (int g = 0; g < GMAX; ++g) {
-            const double f = floor(cum[g] * scale);
-            const uint32_t q = (f >= 4294967295.0) ? 0xffffffffu : (uint32_t)f;
+            // floor + clamp to 2^32-1 is exactly what v_cvt_u32_f64 does (truncate, saturate) for a value >= 0
+            uint32_t q;
+            asm("v_cvt_u32_f64 %0, %1" : "=v"(q) : "v"(cum[g] * scale));
             thr[g] = (g < G - 1) ? q : 0u;     // unused slots never count
             cnt[g] = 0;
         }

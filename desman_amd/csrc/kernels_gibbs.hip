@@ -208,6 +208,8 @@ __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ ite
 #pragma unroll
     for (int i = 0; i < 16; ++i) e[i] = 0;
 
+    // the kernel is instantiated for every G <= 8, so there the haplotype count is a compile-time constant
+    const int Gc = (GMAX <= 8) ? GMAX : G;
     // grid-stride over the sample's sorted list: every workgroup gets heavy and light items, and
     // the 64 items a wavefront holds at any time are adjacent in the sort (equal loop lengths)
     for (int k = bj * 256 + tid; k < n_s; k += bn * 256) {
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ ite
         double run = 0.0;
 #pragma unroll
         for (int g = 0; g < GMAX; ++g) {
-            if (g < G) {
+            if (g < Gc) {
                 const int ig = (int)((t >> (2 * g)) & 3);
                 const double w = gs[g] * es[ig * 4 + b];
                 run = run + w;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ ite
             // floor + clamp to 2^32-1 is exactly what v_cvt_u32_f64 does (truncate, saturate) for a value >= 0
             uint32_t q;
             asm("v_cvt_u32_f64 %0, %1" : "=v"(q) : "v"(cum[g] * scale));
-            thr[g] = (g < G - 1) ? q : 0u;     // unused slots never count
+            thr[g] = (g < Gc - 1) ? q : 0u;     // unused slots never count
             cnt[g] = 0;
         }
         int i = 0;
@@ -256,8 +258,8 @@ __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ ite
         uint32_t e4[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int g = 0; g < GMAX; ++g) {
-            if (g < G) {
-                const uint32_t hi = (g == G - 1) ? (uint32_t)nb : cnt[g];
+            if (g < Gc) {
+                const uint32_t hi = (g == Gc - 1) ? (uint32_t)nb : cnt[g];
                 const uint32_t lo = (g == 0) ? 0u : cnt[g > 0 ? g - 1 : 0];
                 const uint32_t m = hi - lo;
                 mu[g] += m;

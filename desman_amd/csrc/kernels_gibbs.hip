@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ ite
     __shared__ double gs[GMAX];
     __shared__ double es[16];
     __shared__ unsigned long long acc[GMAX + 16];
+    __shared__ uint32_t eacc[16][256];
     const int tid = threadIdx.x;
     // workgroup -> (sample, j-th of n_j workgroups of that sample); the table gives every sample
     // a share of the resident workgroups proportional to its depth, so all workgroups carry the
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ ite
 #pragma unroll
     for (int g = 0; g < GMAX; ++g) mu[g] = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) e[i] = 0;
+    for (int i = 0; i < 16; ++i) eacc[i][tid] = 0;
 
     // the kernel is instantiated for every G <= 8, so there the haplotype count is a compile-time constant
     const int Gc = (GMAX <= 8) ? GMAX : G;
@@ -255,7 +256,10 @@ __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ ite
 #pragma unroll
             for (int g = 0; g < GMAX - 1; ++g) count_if_less(cnt[g], r, thr[g]);
         }
-        uint32_t e4[4] = {0, 0, 0, 0};
+        // E[b][tau_g] += m_g goes to the lane's own column of an LDS table ([16][256]: the bank is the lane id
+        // whatever the row, so the 64 atomics of a wavefront never conflict): 3 issues per haplotype instead
+        // of ~16 compare/select/add issues on 16 register accumulators
+        uint32_t *erow = &eacc[b * 4][tid];
 #pragma unroll
         for (int g = 0; g < GMAX; ++g) {
             if (g < Gc) {
@@ -264,15 +268,12 @@ __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ ite
                 const uint32_t m = hi - lo;
                 mu[g] += m;
                 const int ig = (int)((t >> (2 * g)) & 3);
-#pragma unroll
-                for (int a = 0; a < 4; ++a) e4[a] += (ig == a) ? m : 0u;
+                atomicAdd(erow + ig * 256, m);
             }
         }
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-            for (int a = 0; a < 4; ++a) e[bb * 4 + a] += (b == bb) ? e4[a] : 0u;
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) e[i] = eacc[i][tid];
     // wavefront reduce -> LDS -> one global atomic per workgroup and counter.  The GMAX + 16 counters go
     // through one transposing butterfly (lane l ends up with the wavefront total of counter
     // transpose_index(l)), so a wavefront issues NV exchanges and ONE LDS atomic instead of 6 per counter.

@@ -40,7 +40,7 @@ class Output_Results:
         self.variantFilter = variantFilter
         keep = variantFilter.selected_indices
         self.filtered_contig_names = [self.contig_names[i] for i in keep]
-        self.filtered_position = [self.position.iloc[i] for i in keep]
+        self.filtered_position = self.position.to_numpy()[np.asarray(keep, dtype=np.int64)]
 
     def _path(self, name):
         return self.outputDir + "/" + name
@@ -92,7 +92,7 @@ class Output_Results:
         all_pos = full_variants['Position']
         rows = self.variantFilter.selected_indices_original
         names = [all_names[i] for i in rows]
-        positions = [all_pos.iloc[i] for i in rows]
+        positions = all_pos.to_numpy()[np.asarray(rows, dtype=np.int64)]
         self._haplotype_table("Collated_Tau_star.csv", star, names, positions)
         self._haplotype_table("Collated_Tau_mean.csv", prob, names, positions)
         logging.info("Collated_Tau_star.csv / Collated_Tau_mean.csv written")

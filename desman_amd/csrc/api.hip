@@ -249,23 +249,44 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
         // work list of the per-read pass: per sample, the (variant, base) pairs with a non-zero
         // count, sorted by decreasing count (ties: lower id first) -> the lanes of a wavefront run
         // read loops of equal length (k_stats shares the resident workgroups among samples by depth).
+        // One pass over the tensor in memory order fills a (count, id) list per sample; each list is then
+        // ordered by a counting sort on the count (descending; ids stay ascending inside a count) --
+        // comparison sort only for samples with counts above 2^20.
         std::vector<int32_t> items(n * 8, 0), nit(S);
         std::vector<int64_t> depth(S, 0);
-        std::vector<std::pair<int32_t, int32_t>> lst;      // (count, id)
-        lst.reserve((size_t)V * 4);
+        std::vector<std::vector<std::pair<int32_t, int32_t>>> lst((size_t)S);      // (count, id)
+        std::vector<int32_t> top(S, 0);
+        for (int s = 0; s < S; ++s) lst[s].reserve((size_t)V * 2);
+        for (int v = 0; v < V; ++v) {
+            const int64_t *row = variants + (size_t)v * S * 4;
+            for (int s = 0; s < S; ++s)
+                for (int b = 0; b < 4; ++b) {
+                    const int64_t x = row[s * 4 + b];
+                    if (x > 0) {
+                        lst[s].emplace_back((int32_t)x, v * 4 + b);
+                        depth[s] += x;
+                        if (x > top[s]) top[s] = (int32_t)x;
+                    }
+                }
+        }
         int max_items = 0;
+        std::vector<int32_t> first;
         for (int s = 0; s < S; ++s) {
-            lst.clear();
-            for (int v = 0; v < V; ++v) {
-                const int64_t *x = variants + ((size_t)v * S + s) * 4;
-                for (int b = 0; b < 4; ++b)
-                    if (x[b] > 0) { lst.emplace_back((int32_t)x[b], v * 4 + b); depth[s] += x[b]; }
-            }
-            std::stable_sort(lst.begin(), lst.end(), [](const std::pair<int32_t, int32_t> &p, const std::pair<int32_t, int32_t> &q) { return p.first > q.first; });
-            nit[s] = (int32_t)lst.size();
+            const auto &l = lst[s];
+            nit[s] = (int32_t)l.size();
             max_items = std::max(max_items, nit[s]);
             int32_t *dst = items.data() + (size_t)s * 4 * V * 2;
-            for (size_t k = 0; k < lst.size(); ++k) { dst[2 * k] = lst[k].second; dst[2 * k + 1] = lst[k].first; }
+            if (top[s] <= (1 << 20)) {
+                first.assign((size_t)top[s] + 2, 0);
+                for (const auto &e : l) first[e.first]++;                       // histogram
+                int32_t run = 0;
+                for (int32_t cval = top[s]; cval >= 1; --cval) { const int32_t h = first[cval]; first[cval] = run; run += h; }
+                for (const auto &e : l) { const int32_t k = first[e.first]++; dst[2 * k] = e.second; dst[2 * k + 1] = e.first; }
+            } else {
+                std::vector<std::pair<int32_t, int32_t>> t(l);
+                std::stable_sort(t.begin(), t.end(), [](const std::pair<int32_t, int32_t> &p, const std::pair<int32_t, int32_t> &q) { return p.first > q.first; });
+                for (size_t k = 0; k < t.size(); ++k) { dst[2 * k] = t[k].second; dst[2 * k + 1] = t[k].first; }
+            }
         }
         c->max_items = max_items;
         c->depth = depth;

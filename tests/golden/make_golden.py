@@ -531,13 +531,33 @@ def gen_gene_assign(out, name="gene_assign", C=7, S=8, G=3, synth_kw=None):
     print(name, "eta_star", rec['eta_star_2'].tolist(), "ll", rec['ll_2'])
 
 
+
+def gen_cog_counts(out):
+    """The count tensor of config 1 after the reference's sample filter (Variant_Filter with the CLI's
+    defaults): the INPUT of cog0015_g5_i50.npz, so that the recorded reference run can be replayed on the GPU."""
+    import pandas as p
+    import desman.Variant_Filter as vf
+    variants = p.read_csv(os.path.join(REF, "data", "contig_6or16_genesL_scgCOG0015.freq"), header=0, index_col=0)
+    flt = vf.Variant_Filter(variants, randomState=np.random.RandomState(238329), optimise=True,
+                            threshold=None, min_coverage=5.0, qvalue_cutoff=1.0e-3)
+    x = np.ascontiguousarray(flt.snps_filter)
+    assert x.max() < 32768 and x.min() >= 0
+    np.savez_compressed(os.path.join(out, "cog0015_counts.npz"), counts=x.astype(np.int16), eta0=np.asarray(flt.eta))
+    print("cog0015 counts", x.shape, "max", x.max())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cog", action="store_true", help="also run config 1 (several minutes)")
     ap.add_argument("--only-cog", action="store_true")
     ap.add_argument("--only-genes", action="store_true")
+    ap.add_argument("--only-cog-counts", action="store_true")
     args = ap.parse_args()
     inmft, hsnp, du = import_reference()
+    if args.only_cog_counts:
+        np.int, np.float = int, float
+        gen_cog_counts(HERE)
+        return
     if args.only_genes:
         gen_gene_assign(HERE)
         gen_gene_assign(HERE, "gene_assign_lowcov", C=9, S=6, G=4, synth_kw=dict(mean_lo=0.4, mean_hi=2.5, vmax=6))
@@ -555,6 +575,7 @@ def main():
         gen_gene_assign(HERE, "gene_assign_lowcov", C=9, S=6, G=4, synth_kw=dict(mean_lo=0.4, mean_hi=2.5, vmax=6))
     if args.cog or args.only_cog:
         gen_cog(inmft, hsnp, HERE)
+        gen_cog_counts(HERE)
     print("golden fixtures written to", HERE)
 
 

@@ -184,3 +184,42 @@ def test_gsweep_driver_and_model_selection(tmp_path, capsys):
             for f in ("fit.txt", "Filtered_Tau_star.csv", "Gamma_mean.csv", "Eta_star.csv"):
                 assert open("%s_%d_%d/%s" % (stub, g, r, f)).read() == open("%s_%d_%d/%s" % (stub1, g, r, f)).read()
             assert "Gibbs Iter" in open("%s_%d_%d/log_file.txt" % (stub, g, r)).read()
+
+
+def test_config1_real_data_replays_the_recorded_reference_run():
+    """BASELINE config 1 (COG0015, -g 5 -i 50, default seed) on the reference's own example data: the NMFT
+    initialisation (same RandomState stream) lands on the reference's tau / gamma, and the Gibbs phases -- whose
+    auxiliary draws use our counter-based streams -- end at the same fit within Monte-Carlo tolerance
+    (recorded reference: fit.txt = Fit,5,5,-109416.391750,208463.250933)."""
+    from desman_amd import sampletau
+    from desman_amd.HaploSNP_Sampler import HaploSNP_Sampler
+    from desman_amd.Init_NMFT import Init_NMFT
+    z = np.load(os.path.join(GOLDEN, "cog0015_g5_i50.npz"))
+    d = np.load(os.path.join(GOLDEN, "cog0015_counts.npz"))
+    counts = np.ascontiguousarray(d["counts"].astype(np.int64))
+    seed, G, I = int(z["seed"]), int(z["G"]), int(z["I"])
+    assert counts.shape == (int(z["V"]), int(z["S"]), 4)
+    rs = np.random.RandomState(seed)
+    sampletau.initRNG(); sampletau.setRNG(seed)
+    nm = Init_NMFT(counts, G, rs)
+    nm.factorize()
+    assert nm.div_objective() == pytest.approx(float(z["nmft_div_final"]), rel=1e-6)
+    tau0 = nm.get_tau()
+    assert (np.argmax(tau0, axis=2) != np.argmax(z["tau_init"], axis=2)).mean() < 0.002     # arg-max of near-ties
+    np.testing.assert_allclose(nm.get_gamma(), z["gamma_init"], rtol=2e-4, atol=1e-7)
+    smp = HaploSNP_Sampler(counts, G, rs, max_iter=I, ctx=nm._ctx)
+    smp.tau = np.copy(tau0, order='C')
+    smp.updateTauIndices()
+    smp.gamma = np.copy(nm.get_gamma(), order='C')
+    smp.eta = np.copy(d["eta0"], order='C')
+    smp.update()
+    smp.removeDegenerate()
+    smp.update()
+    assert smp.G == int(z["G_final"])
+    assert smp.meanDeviance() == pytest.approx(float(z["mean_dev"]), rel=5e-3)
+    assert smp.lp_star == pytest.approx(float(z["lp_star"]), rel=5e-3)
+    assert (np.argmax(smp.tau_star, axis=2) != np.argmax(z["tau_star"], axis=2)).mean() < 0.03
+    dg = np.abs(smp.gammaMean() - z["gamma_mean"])          # means over 50 correlated draws on both sides
+    assert dg.max() < 0.06 and dg.mean() < 0.01
+    np.testing.assert_allclose(smp.eta_star, z["eta_star"], atol=0.01)
+    sampletau.freeRNG()

@@ -30,11 +30,18 @@ ETA_PENALTY = -1.0e3
 class Eta_Sampler:
 
     def __init__(self, randomState, variants, covs, gamma, delta, cov_sd, epsilon, init_eta, max_iter=None,
-                 tau_iter=None, max_eta=2, eta_scale=0.01, max_var=None, device=0, rng="mt19937"):
+                 tau_iter=None, max_eta=2, eta_scale=0.01, max_var=None, device=0, rng="mt19937", gene_base=0):
         if rng not in ("mt19937", "philox"):
             raise ValueError("rng must be 'mt19937' or 'philox'")
         self.randomState = randomState
         self.rng = rng
+        # rng='philox': every host-side draw of gene c comes from a generator keyed by (one seed taken from
+        # randomState, the gene's GLOBAL index, a phase counter) and every device draw is keyed by global gene /
+        # indices and the row within the gene, so a run sharded over several samplers (gene_base = this shard's
+        # first gene) gives the same result as one sampler over all genes
+        self.gene_base = int(gene_base)
+        self._phase = 0
+        self._base_seed = int(randomState.randint(0, 2 ** 31 - 1)) if rng == "philox" else None
         self.delta = np.ascontiguousarray(np.transpose(delta), dtype=np.float64)        # [G,S]
         self.cov_sd = np.transpose(cov_sd)
         self.gamma = np.array(gamma, dtype=np.float64, order='C')
@@ -65,7 +72,7 @@ class Eta_Sampler:
             rows = np.asarray(rows_of.get(gene, np.zeros(0, dtype=np.int64)), dtype=np.int64)
             if max_var is not None and len(rows) > max_var:
                 self._rows_full[gene] = rows
-                rows = rows[np.sort(self.randomState.choice(len(rows), int(max_var), replace=False))]
+                rows = rows[np.sort(self._gene_rs(self.gene_map[gene]).choice(len(rows), int(max_var), replace=False))]
             self._rows[gene] = rows
         self.gene_variants_full = {g: self._all_counts[r] for g, r in self._rows_full.items()}
 
@@ -77,6 +84,7 @@ class Eta_Sampler:
         self.eta_log_prior = lp - np.log(np.sum(np.exp(lp)))
 
         self._dev = _lib.Genes(device)
+        self._dev.set_gene_base(self.gene_base)
         self._upload()
         # ---- tau start of every gene with variants: NMFT with the masked gamma, then one sweep (:126-135)
         self._tau = np.zeros((self._Vtot, self.G, 4), dtype=np.int64)
@@ -84,7 +92,7 @@ class Eta_Sampler:
         if self._Vtot:
             start = self._draw_nmft_start(np.ones(self.C, dtype=bool))
             self._dev.nmft_tau(start, None)
-            self._with_stream(lambda: self._dev.sweep_all(None, sweep=True))
+            self._sweep_all(None)
             self._pull_tau()
 
     # ------------------------------------------------------------------ device plumbing
@@ -116,6 +124,18 @@ class Eta_Sampler:
         finally:
             sampletau.setRNGState(self._dev.get_mt_state())
 
+    def _gene_rs(self, c):
+        """the RandomState behind gene c's host-side draws: the caller's (reference order) or the gene's own"""
+        if self.rng != "philox":
+            return self.randomState
+        return np.random.RandomState([self._base_seed, self.gene_base + c, self._phase])
+
+    def _sweep_all(self, mask, want_v_ll=False):
+        """one masked sweep of every gene: GSL stream in gene order, or counter-based draws (rng='philox')"""
+        if self.rng == "philox":
+            return self._dev.sweep_all(mask, sweep=2, want_v_ll=want_v_ll)
+        return self._with_stream(lambda: self._dev.sweep_all(mask, sweep=1, want_v_ll=want_v_ll))
+
     def _pull_tau(self):
         _, self._tau = self._dev.get_state(want_tau=True)
 
@@ -131,7 +151,7 @@ class Eta_Sampler:
         for c, gene in enumerate(self.genes):
             V = self.gene_V[gene]
             if V and active[c]:
-                d = self.randomState.dirichlet(np.full(4, 0.01), size=V * self.G).reshape(V, self.G, 4)
+                d = self._gene_rs(c).dirichlet(np.full(4, 0.01), size=V * self.G).reshape(V, self.G, 4)
                 start[self._gene_off[c]:self._gene_off[c + 1]] = np.transpose(d, (0, 2, 1))
         return start
 
@@ -253,6 +273,7 @@ class Eta_Sampler:
         tau_star = np.zeros((V, self.G, 4), dtype=np.int64)
         store = np.zeros((self.tau_iter, V, self.G, 4), dtype=np.int64)
         dev = self._dev
+        self._phase += 1
         if V and active.any():
             start = self._draw_nmft_start(active)
             mask = np.where(active[:, None], self.eta, 0).astype(np.int32)          # the sampler's own eta (:421)
@@ -262,23 +283,19 @@ class Eta_Sampler:
             self._pull_tau()
             tau_star[row_active] = self._tau[row_active]
         sweep_mask = np.where(active[:, None], eta, 0).astype(np.int32)
-        dev.set_mt_state(sampletau.getRNGState())
-        try:
-            for it in range(self.tau_iter):
-                total = 0.0
-                if V and active.any():
-                    _, _, v_ll = dev.sweep_all(sweep_mask, sweep=True, want_v_ll=True)
-                    self._pull_tau()
-                    ll = v_ll + self._v_const
-                    better = row_active & (ll > ll_star)
-                    ll_star[better] = ll[better]
-                    tau_star[better] = self._tau[better]
-                    store[it][row_active] = self._tau[row_active]
-                    for c in np.flatnonzero(active):
-                        total += ll_star[self._gene_off[c]:self._gene_off[c + 1]].sum()
-                logging.info('Tau star Iter %d, nll = %f' % (it, total))
-        finally:
-            sampletau.setRNGState(dev.get_mt_state())
+        for it in range(self.tau_iter):
+            total = 0.0
+            if V and active.any():
+                _, _, v_ll = self._sweep_all(sweep_mask, want_v_ll=True)
+                self._pull_tau()
+                ll = v_ll + self._v_const
+                better = row_active & (ll > ll_star)
+                ll_star[better] = ll[better]
+                tau_star[better] = self._tau[better]
+                store[it][row_active] = self._tau[row_active]
+                for c in np.flatnonzero(active):
+                    total += ll_star[self._gene_off[c]:self._gene_off[c + 1]].sum()
+            logging.info('Tau star Iter %d, nll = %f' % (it, total))
         self.gene_tau_star = {g: self._slice(tau_star, c) for c, g in enumerate(self.genes)}
         self.gene_ll_tau_star = {g: self._slice(ll_star, c) for c, g in enumerate(self.genes)}
         self.gene_tau_store = {g: store[:, self._gene_off[c]:self._gene_off[c + 1]] for c, g in enumerate(self.genes)}

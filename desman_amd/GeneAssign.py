@@ -9,6 +9,7 @@ Extensions: --device, and --rng philox for the all-genes-at-once sampler (defaul
 """
 import argparse
 import logging
+import os
 import sys
 
 import numpy as np
@@ -17,6 +18,7 @@ from numpy.random import RandomState
 
 from . import _lib, sampletau
 from .Eta_Sampler import Eta_Sampler
+from .gene_shards import gather_blocks, partition_genes
 
 
 def expand_sample_names(sample_names):
@@ -123,36 +125,67 @@ def main(argv=None):
     gamma = gamma / gamma.sum(axis=1)[:, np.newaxis]
     delta = gamma * scg_cov['mean'].to_numpy()[:, np.newaxis]               # expected coverage of one copy
 
+    # ---- one process per GPU (python -m torch.distributed.run ...): the genes are sharded over the ranks
+    rank, world, dist = 0, 1, None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            import torch
+            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        if args.rng != "philox":
+            raise SystemExit("GeneAssign: sharding over ranks needs --rng philox (the reference's streams are serial)")
+    device = args.device if world == 1 else int(os.environ.get("LOCAL_RANK", rank))
+
     logging.info('KL fit of the gene coverages')
-    kl = KLAssign(prng, cov.to_numpy(), delta, device=args.device)
+    kl = KLAssign(prng, cov.to_numpy(), delta, device=device)           # cheap: every rank fits all genes
     kl.factorize()
     start = np.rint(kl.eta)
 
     gene_variants = variants[expand_sample_names(common)] if variants is not None else None
-    sampler = Eta_Sampler(prng, gene_variants, cov, gamma, delta, scg_cov['sd'].to_numpy(), epsilon, start,
-                          max_iter=args.iter_max, max_eta=args.eta_max, max_var=args.var_max, device=args.device,
-                          rng=args.rng)
-    sampler.update()
-    sampler.update()
-
     names = cov.index.tolist()
+
+    # ---- this rank's block of genes
+    n_rows = np.zeros(len(names), dtype=np.int64)
+    if gene_variants is not None:
+        per_gene = pd.Series(np.ones(len(gene_variants), dtype=np.int64)).groupby(gene_variants.index.values).sum()
+        n_rows = np.array([int(per_gene.get(g, 0)) for g in names], dtype=np.int64)
+    bounds = partition_genes(n_rows, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    mine = names[lo:hi]
+    my_variants, my_positions = gene_variants, variants
+    if world > 1 and gene_variants is not None:
+        keep = gene_variants.index.isin(set(mine))
+        my_variants, my_positions = gene_variants[keep], variants[keep]
+    sampler = Eta_Sampler(prng, my_variants, cov.iloc[lo:hi], gamma, delta, scg_cov['sd'].to_numpy(), epsilon, start[lo:hi],
+                          max_iter=args.iter_max, max_eta=args.eta_max, max_var=args.var_max, device=device,
+                          rng=args.rng, gene_base=lo)
+    sampler.update()
+    sampler.update()
+    local = {"eta_star": sampler.eta_star, "eta_mean": np.mean(sampler.eta_store, axis=0)}
     if args.assign_tau is True:
         sampler.restoreFullVariants()
         sampler.calcTauStar(sampler.eta_star)
-        tau_star, tau_mean, pos, owner = sampler.getTauStar(variants)
-        _write_haplotypes(stub + "_tau_star.csv", tau_star, owner, pos)
+        tau_star, tau_mean, pos, owner = sampler.getTauStar(my_positions)
+        local.update(tau_star=tau_star, tau_mean=tau_mean, pos=pos, owner=np.asarray(owner, dtype=object))
+    tables = gather_blocks(local, dist)
+    if rank != 0:
+        return
+
+    if args.assign_tau is True:
+        _write_haplotypes(stub + "_tau_star.csv", tables["tau_star"], list(tables["owner"]), tables["pos"])
         logging.info("haplotypes of the gene variants written (MAP)")
-        _write_haplotypes(stub + "_tau_mean.csv", tau_mean, owner, pos)
+        _write_haplotypes(stub + "_tau_mean.csv", tables["tau_mean"], list(tables["owner"]), tables["pos"])
         logging.info("haplotypes of the gene variants written (mean)")
 
-    for suffix, table in (("etaD_df.csv", start), ("etaS_df.csv", sampler.eta_star),
-                          ("etaM_df.csv", np.mean(sampler.eta_store, axis=0)), ("eta_df.csv", kl.eta)):
+    for suffix, table in (("etaD_df.csv", start), ("etaS_df.csv", tables["eta_star"]),
+                          ("etaM_df.csv", tables["eta_mean"]), ("eta_df.csv", kl.eta)):
         pd.DataFrame(table, index=names).to_csv(stub + suffix)
 
     if args.genomes:
         known = read(args.genomes).loc[names].to_numpy()
         kl_total, _, _ = compGenes(start, known)
-        gibbs_total, _, _ = compGenes(sampler.eta_star, known)
+        gibbs_total, _, _ = compGenes(tables["eta_star"], known)
         logging.info('KL accurracy = %f' % (kl_total))
         logging.info('Gibbs sampler accurracy = %f' % (gibbs_total))
 

@@ -76,6 +76,7 @@ SIGNATURES = {
     "dsm_genes_set_state": (_i, [_vp, _vp, _vp]),
     "dsm_genes_get_state": (_i, [_vp, _vp, _vp]),
     "dsm_genes_seed": (_i, [_vp, C.c_ulong, C.c_uint64]),
+    "dsm_genes_set_gene_base": (_i, [_vp, _i]),
     "dsm_genes_get_mt_state": (_i, [_vp, _u32p]),
     "dsm_genes_set_mt_state": (_i, [_vp, _u32p]),
     "dsm_genes_nmft_tau": (_i, [_vp, _vp, _f64p, _i, _d, _vp]),
@@ -394,6 +395,9 @@ class Genes:
     def seed(self, mt_seed, ctr_seed=0x13198A2E03707344):
         check(load().dsm_genes_seed(self._h, int(mt_seed), int(ctr_seed)))
 
+    def set_gene_base(self, gene_base):
+        check(load().dsm_genes_set_gene_base(self._h, int(gene_base)))
+
     def get_mt_state(self):
         st = np.empty(625, dtype=np.uint32)
         check(load().dsm_genes_get_mt_state(self._h, st))
@@ -418,7 +422,7 @@ class Genes:
         lv = np.empty(self.C)
         vll = np.empty(self.Vtot) if want_v_ll else None
         m = self._mask(eta_mask)
-        check(load().dsm_genes_sweep_all(self._h, _ptr(m), int(bool(sweep)), _ptr(nch), _ptr(lv), _ptr(vll)))
+        check(load().dsm_genes_sweep_all(self._h, _ptr(m), int(sweep), _ptr(nch), _ptr(lv), _ptr(vll)))
         return nch, lv, vll
 
     def step_candidates(self, c, g):

@@ -130,6 +130,7 @@ struct GeneSweepParams {
     double *v_ll;               // [2][Vtot] x log p of every variant after the sweep
     int32_t *nchange;           // [C][2]
     int S, G, Vtot, task_base, task_end, step_g;
+    int gene_base;              // global index of gene 0 (counter-based draws are keyed by global gene, row in gene)
     uint32_t k0, k1, iter;
 };
 
@@ -201,10 +202,9 @@ __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
                     // counter-based word of (row, haplotype): lane i of the group draws the word of haplotype
                     // g + i once per LPV haplotypes, every step then reads its word from the owning lane
                     if (g % LPV == 0) {
-                        const size_t ui = (size_t)v * G + g + lig;
                         uint32_t r[4] = {0, 0, 0, 0};
                         if (g + lig < G)
-                            philox4x32_10((uint32_t)ui, (uint32_t)(ui >> 32), p.iter,
+                            philox4x32_10((uint32_t)((v - g0) * G + g + lig), (uint32_t)(p.gene_base + c), p.iter,
                                           DSM_STREAM_GENE + (uint32_t)((p.step_g + 1) * 2 + k), p.k0, p.k1, r);
                         uw_lane = r[0];
                     }
@@ -318,7 +318,7 @@ struct GeneChooseParams {
     int32_t *eta_store;                  // slot of this iteration or null
     double *gene_ll_trace;               // slot of this iteration or null
     const double *u_ext;                 // [C][G] uniforms of this iteration or null
-    int C, S, G, max_eta, Vtot;
+    int C, S, G, max_eta, Vtot, gene_base;
     int step_g;                          // >= 0: draw eta[., step_g]; < 0: evaluate only (x log p in partial slot 0)
     int finish;                          // compute gene_ll (+ MAP bookkeeping, stores)
     int reset_star;                      // star := this state
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void gene_choose_kernel(GeneChooseParams p)
         if (p.u_ext) u = p.u_ext[(size_t)c * G + g];
         else {
             uint32_t r[4];
-            philox4x32_10((uint32_t)c, (uint32_t)g, p.iter, DSM_STREAM_GETA, p.k0, p.k1, r);
+            philox4x32_10((uint32_t)(p.gene_base + c), (uint32_t)g, p.iter, DSM_STREAM_GETA, p.k0, p.k1, r);
             u = u01_open(r[0], r[1]);
         }
         const double us = u * sum;
@@ -678,6 +678,7 @@ struct dsm_genes {
     DBuf<uint32_t> u_raw;
     uint64_t ctr_seed = 0x13198A2E03707344ull;
     uint32_t iter_ctr = 0;
+    int gene_base = 0;              // this object holds genes gene_base.. of a larger, sharded set
 };
 
 #define GBIND(gs) HIP_TRY(hipSetDevice((gs)->device))
@@ -875,6 +876,12 @@ extern "C" int dsm_genes_seed(dsm_genes *gs, unsigned long mt_seed, uint64_t ctr
     gs->iter_ctr = 0;
     return dsm_ctx_seed(gs->base, mt_seed, ctr_seed);
 }
+extern "C" int dsm_genes_set_gene_base(dsm_genes *gs, int gene_base)
+{
+    if (!gs || gene_base < 0) { dsm_set_error("set_gene_base: bad arguments"); return DSM_ERR_ARG; }
+    gs->gene_base = gene_base;
+    return DSM_OK;
+}
 extern "C" int dsm_genes_get_mt_state(dsm_genes *gs, uint32_t *state625)
 {
     if (!gs) { dsm_set_error("null gene context"); return DSM_ERR_ARG; }
@@ -910,6 +917,7 @@ static GeneSweepParams sweep_params(dsm_genes *gs, const int32_t *d_eta, const u
     p.cur = gs->cur; p.eta = d_eta; p.gamma = gs->gamma; p.eps = gs->eps; p.log_tab = gs->base->log_tab;
     p.u_raw = u_raw; p.u_off = gs->u_off; p.v_ll = gs->v_ll; p.nchange = gs->nchange;
     p.S = gs->S; p.G = gs->G; p.Vtot = gs->Vtot; p.task_base = task_base; p.task_end = task_end; p.step_g = step_g;
+    p.gene_base = gs->gene_base;
     p.k0 = (uint32_t)gs->ctr_seed; p.k1 = (uint32_t)(gs->ctr_seed >> 32); p.iter = iter;
     return p;
 }
@@ -944,7 +952,7 @@ static GeneChooseParams choose_params(dsm_genes *gs, int step_g, int finish, int
     p.cov = gs->cov; p.delta = gs->delta; p.prior = gs->prior; p.cov_const = gs->cov_const; p.mult_const = gs->mult_const;
     p.v_ll = gs->v_ll; p.lv_keep = gs->lv_keep; p.gene_ll = gs->gene_ll; p.gene_llstar = gs->gene_llstar;
     p.eta_star = gs->eta_star; p.eta_store = nullptr; p.gene_ll_trace = nullptr; p.u_ext = nullptr;
-    p.C = gs->C; p.S = gs->S; p.G = gs->G; p.max_eta = gs->max_eta; p.Vtot = gs->Vtot;
+    p.C = gs->C; p.S = gs->S; p.G = gs->G; p.max_eta = gs->max_eta; p.Vtot = gs->Vtot; p.gene_base = gs->gene_base;
     p.step_g = step_g; p.finish = finish; p.reset_star = reset_star;
     p.k0 = (uint32_t)gs->ctr_seed; p.k1 = (uint32_t)(gs->ctr_seed >> 32); p.iter = iter;
     return p;
@@ -1029,7 +1037,7 @@ extern "C" int dsm_genes_sweep_all(dsm_genes *gs, const int32_t *eta_mask, int s
     std::vector<int32_t> host;
     TRY(mask_source(gs, eta_mask, tmp, &d_eta, host));
     const uint32_t *u = nullptr;
-    if (sweep && gs->ntask > 0) {
+    if (sweep == 1 && gs->ntask > 0) {
         // GSL stream in gene order, genes without variants or with an empty mask draw nothing
         std::vector<int64_t> off((size_t)C * 2, 0);
         int64_t pos = 0;
@@ -1045,7 +1053,9 @@ extern "C" int dsm_genes_sweep_all(dsm_genes *gs, const int32_t *eta_mask, int s
         u = gs->u_raw;
         HIP_TRY(hipMemsetAsync(gs->nchange, 0, (size_t)C * 2 * sizeof(int32_t), st));
     }
-    const GeneSweepParams p = sweep_params(gs, d_eta, u, -1, 0, gs->ntask, 0);
+    if (sweep == 2 && gs->ntask > 0) HIP_TRY(hipMemsetAsync(gs->nchange, 0, (size_t)C * 2 * sizeof(int32_t), st));
+    const uint32_t iter = (sweep == 2) ? gs->iter_ctr++ : 0u;     // counter-based draws: a fresh iteration index per sweep
+    const GeneSweepParams p = sweep_params(gs, d_eta, u, -1, 0, gs->ntask, iter);
     TRY(launch_sweep(gs, p, sweep != 0, 1));
     std::vector<double> vl((size_t)(gs->Vtot ? gs->Vtot : 1));
     std::vector<int32_t> nch((size_t)C * 2, 0);

@@ -189,6 +189,9 @@ int dsm_genes_get_state(dsm_genes *gs, int32_t *eta, int64_t *tau);
 /* GSL-compatible MT19937 stream of the tau draws (shared semantics with dsm_setRNG) and the
  * Philox key of the batched sampler                                           */
 int dsm_genes_seed(dsm_genes *gs, unsigned long mt_seed, uint64_t ctr_seed);
+/* this object holds genes gene_base.. of a larger set sharded over several objects / ranks: the counter-based
+ * draws are keyed by (global gene index, row within the gene), so results do not depend on the sharding   */
+int dsm_genes_set_gene_base(dsm_genes *gs, int gene_base);
 int dsm_genes_get_mt_state(dsm_genes *gs, uint32_t *state625);
 int dsm_genes_set_mt_state(dsm_genes *gs, const uint32_t *state625);
 
@@ -200,7 +203,8 @@ int dsm_genes_nmft_tau(dsm_genes *gs, const int32_t *eta_mask /*[C][G] or NULL =
                        const double *tau_init, int max_iter, double min_change, int32_t *n_iter);
 /* Eta_Sampler.sampleTauC over all genes with variants and a non-empty mask, in gene order on
  * the GSL stream (:135, calcTauStar:437): nchange [C], logvar [C] = sum x log p after the
- * sweep, v_ll [Vtot] the same per variant (any may be NULL).  sweep = 0: evaluate only.       */
+ * sweep, v_ll [Vtot] the same per variant (any may be NULL).  sweep = 0: evaluate only; 1: the GSL
+ * stream; 2: counter-based draws (sharding-invariant).                                        */
 int dsm_genes_sweep_all(dsm_genes *gs, const int32_t *eta_mask, int sweep, int32_t *nchange,
                         double *logvar, double *v_ll);
 /* reference-order single step (Eta_Sampler.update:226-262): the two candidate sweeps

@@ -50,3 +50,31 @@ def test_two_rank_gloo_gather(tmp_path):
     chains.write_dev_csv(str(d), r0["recs"])
     rows = open(d).read().strip().split("\n")
     assert rows[0] == "H,G,LP,Dev" and len(rows) == 16 and rows[1] == "2,2,-2000.000000,4000.000000"
+
+
+# ---------------------------------------------------------------- row f4: genes sharded over ranks
+def test_gene_partition_properties():
+    from desman_amd.gene_shards import partition_genes
+    rows = np.random.default_rng(0).integers(0, 40, size=500)
+    for world in (1, 2, 3, 8):
+        b = partition_genes(rows, world)
+        assert b[0] == 0 and b[-1] == 500 and len(b) == world + 1 and (np.diff(b) >= 0).all()
+        cost = rows + 4
+        load = [cost[b[r]:b[r + 1]].sum() for r in range(world)]
+        assert max(load) <= cost.sum() / world + cost.max()
+    assert partition_genes([5, 5], 4).tolist()[-1] == 2                 # more ranks than genes: empty blocks allowed
+    assert partition_genes(np.zeros(0), 2).tolist() == [0, 0, 0]
+
+
+def test_two_rank_gloo_gene_gather(tmp_path):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29657", os.path.join(HERE, "_gloo_gene_worker.py"), str(tmp_path)]
+    subprocess.run(cmd, check=True, env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r0 = json.load(open(tmp_path / "generank0.json"))
+    r1 = json.load(open(tmp_path / "generank1.json"))
+    assert r0 == r1                                                      # every rank holds the whole table
+    rows = np.random.default_rng(3).integers(0, 30, size=41)
+    assert r0["eta"] == list(range(41))                                  # genes in global order
+    assert r0["tau"] == list(range(int(rows.sum())))                     # variant rows in global order
+    assert r0["bounds"][0] == 0 and r0["bounds"][-1] == 41

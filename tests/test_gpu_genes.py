@@ -205,3 +205,26 @@ def test_gene_nmft_start_matches_oracle(name):
         t, n = rg.gene_nmft_tau(rs_ref, k['variants'][c], rg.mask_gamma(k['gamma'], eta0[c]), G)
         np.testing.assert_array_equal(tau_dev[lo:hi], t)
         assert abs(int(n_dev[c]) - n) <= 1, (c, n_dev[c], n)
+
+
+def test_geneassign_cli_batched_sampler(tmp_path):
+    """--rng philox: the same six files with the same layout (the chain itself is a different realisation: on this
+    multimodal case it leaves the KL start the reference-stream chain stays in)."""
+    import io
+    from desman_amd import GeneAssign
+    k = load_case("gene_assign")
+    z = k['z']
+    paths, *_ = _frames(k, tmp_path)
+    stub = os.path.join(str(tmp_path), "gb")
+    GeneAssign.main([paths[0], paths[1], paths[2], paths[3], "-s", str(k['seed']), "-i", "10", "-o", stub, "-v", paths[4],
+                     "--assign_tau", "--rng", "philox"])
+    for suffix in ("etaD_df.csv", "etaS_df.csv", "etaM_df.csv", "eta_df.csv", "_tau_star.csv", "_tau_mean.csv"):
+        assert os.path.exists(stub + suffix), suffix
+    eta_s = pd.read_csv(stub + "etaS_df.csv", index_col=0)
+    assert list(eta_s.index) == k['d']['genes'] and set(np.unique(eta_s.to_numpy())) <= {0.0, 1.0}
+    ts = pd.read_csv(stub + "_tau_star.csv", index_col=0)
+    ref = pd.read_csv(io.StringIO(str(z['file_tau_star'])), index_col=0)
+    assert list(ts.index) == list(ref.index) and list(ts['Position']) == list(ref['Position'])
+    t = ts.to_numpy()[:, 1:].reshape(len(ts), k['G'], 4)
+    carried = np.repeat(eta_s.to_numpy(), np.diff(k['gene_off']), axis=0) > 0       # [row, haplotype]
+    assert (t.sum(axis=2) == 1)[carried].all()                                      # one base per carried haplotype

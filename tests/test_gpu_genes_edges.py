@@ -180,3 +180,41 @@ def test_gene_api_rejects_bad_input():
         dev.set_state(np.full((2, 2), 5, dtype=np.int32), None)       # copy number outside 0..max_eta-1
     with pytest.raises(_lib.DesmanHipError):
         dev.set_data(np.full((4, 3, 4), -1, dtype=np.int64), np.array([0, 1, 4], dtype=np.int32), cov)  # negative count
+
+
+def test_philox_sampler_is_invariant_to_gene_sharding():
+    """rng='philox': every draw is keyed by (global gene, row within the gene, haplotype, iteration), so two
+    samplers over the two halves of the genes (gene_base = first gene of the shard) reproduce the single sampler
+    over all genes: NMFT start, first sweep, update() trajectory, MAP record, calcTauStar -- with subsampling."""
+    from desman_amd import sampletau
+    from desman_amd.Eta_Sampler import Eta_Sampler
+    from desman_amd.gene_shards import partition_genes
+    C, S, G, seed, iters = 14, 10, 4, 5, 6
+    k = _case(C, S, G, 9, seed=21, mean_lo=0.4, mean_hi=2.5)
+    cov, var = _frames(k)
+    init = (np.random.default_rng(2).random((C, G)) < 0.6).astype(float)
+    init[init.sum(axis=1) == 0, 1] = 1.0
+    sampletau.initRNG(); sampletau.setRNG(seed)
+
+    def run(lo, hi):
+        names = k['d']['genes'][lo:hi]
+        sub = var[var.index.isin(set(names))]
+        s = Eta_Sampler(np.random.RandomState(seed), sub, cov.iloc[lo:hi], k['gamma'], k['delta'], np.ones(S), k['eps'],
+                        init[lo:hi], max_iter=iters, tau_iter=2, max_var=5, rng="philox", gene_base=lo)
+        tau0 = s._tau.copy()
+        s.update()
+        s.restoreFullVariants()
+        s.calcTauStar(s.eta_star)
+        return tau0, s.eta_store.copy(), s.eta_star.copy(), s.gene_llstar.copy(), s._tau_star_cat.copy(), s._tau_store_cat.copy()
+
+    whole = run(0, C)
+    b = partition_genes(np.bincount(k['d']['gene_of'], minlength=C), 2)
+    parts = [run(int(b[r]), int(b[r + 1])) for r in range(2)]
+    assert 0 < b[1] < C
+    np.testing.assert_array_equal(whole[0], np.concatenate([p[0] for p in parts]))
+    np.testing.assert_array_equal(whole[1], np.concatenate([p[1] for p in parts], axis=1))
+    np.testing.assert_array_equal(whole[2], np.concatenate([p[2] for p in parts]))
+    np.testing.assert_allclose(whole[3], np.concatenate([p[3] for p in parts]), rtol=1e-13)
+    np.testing.assert_array_equal(whole[4], np.concatenate([p[4] for p in parts]))
+    np.testing.assert_array_equal(whole[5], np.concatenate([p[5] for p in parts], axis=1))
+    assert whole[1].std() > 0                                            # the chain moved

@@ -162,6 +162,54 @@ __device__ __forceinline__ void group_allreduce_sum4(double &v0, double &v1, dou
     }
 }
 
+// ---- pieces of the tau sweep shared by tau_kernel (kernels_gibbs.hip) and gene_sweep_kernel (genes.hip)
+// Lane-partial candidate log-probability: sum over this lane's NSL samples and the four observed bases of
+// (float)count * log(rest + eta[a][b] * gamma_g)   (c_sample_tau.c:152-170); table log with a libm fallback for
+// arguments that are not positive normal doubles.
+template <int NSL>
+__device__ __forceinline__ double sweep_candidate(int a, const double (&xf)[NSL][4], const double (&st)[NSL][4],
+                                                  const double (&gg)[NSL], const double *__restrict__ eS,
+                                                  const double2 *__restrict__ ltab)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+        double P[4];
+        bool ok = true;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { P[b] = fma(eS[a * 4 + b], gg[j], st[j][b]); ok &= dsm_log_ok(P[b]); }
+        if (__builtin_expect(ok, 1)) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc = fma(xf[j][b], dsm_log_core(P[b], ltab), acc);
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc = fma(xf[j][b], dsm_log_slow(P[b]), acc);
+        }
+    }
+    return acc;
+}
+
+// normaliseLog4 + sample4 (c_sample_tau.c:48-91) on the four group totals (identical on every lane of the group):
+// exp(0) = 1 and exp(d < -745.2) = 0 exactly, so the usual case needs no exp; the CDF is inverted without the three
+// fp64 divisions: u < ex0/sum <=> u*sum < ex0 (sum in [1,4]; the two forms can disagree only if u lies within
+// ~1e-16 relative of a CDF edge).  u = raw 32-bit word / 2^32.
+__device__ __forceinline__ int sweep_draw(const double (&l)[4], uint32_t uw)
+{
+    double mx = l[0];
+#pragma unroll
+    for (int a = 1; a < 4; ++a) if (l[a] > mx) mx = l[a];
+    double ex[4], sum = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const double d = l[a] - mx;
+        ex[a] = (d == 0.0) ? 1.0 : (d < -750.0) ? 0.0 : exp(d);
+        sum += ex[a];
+    }
+    const double c0 = ex[0], c1 = ex[1] + c0, c2 = ex[2] + c1;
+    const double us = ((double)uw * 2.3283064365386963e-10) * sum;
+    return (us < c0) ? 0 : (us < c1) ? 1 : (us < c2) ? 2 : 3;
+}
+
 // ---- transposing butterfly: every lane brings NV values; afterwards lane l holds, in v[0], the
 // wavefront total of value transpose_index<NV>(l).  Each exchange step halves the values a lane
 // carries (it keeps the half selected by one lane-id bit and sends the other half to its partner),

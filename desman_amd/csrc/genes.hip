@@ -243,39 +243,9 @@ __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
                 for (int j = 0; j < NSL; ++j) gg[j] = gT[g * SP + lig + j * LPV];
                 double l[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NSL; ++j) {
-                        double P[4];
-                        bool ok = true;
-#pragma unroll
-                        for (int bb = 0; bb < 4; ++bb) { P[bb] = fma(eS[a * 4 + bb], gg[j], st[j][bb]); ok &= dsm_log_ok(P[bb]); }
-                        if (__builtin_expect(ok, 1)) {
-#pragma unroll
-                            for (int bb = 0; bb < 4; ++bb) acc = fma(xf[j][bb], dsm_log_core(P[bb], ltab), acc);
-                        } else {
-#pragma unroll
-                            for (int bb = 0; bb < 4; ++bb) acc = fma(xf[j][bb], dsm_log_slow(P[bb]), acc);
-                        }
-                    }
-                    l[a] = acc;
-                }
+                for (int a = 0; a < 4; ++a) l[a] = sweep_candidate<NSL>(a, xf, st, gg, eS, ltab);
                 group_allreduce_sum4<LPV>(l[0], l[1], l[2], l[3]);
-                // normaliseLog4 + sample4 (c_sample_tau.c:48-91)
-                double mx = l[0];
-#pragma unroll
-                for (int a = 1; a < 4; ++a) if (l[a] > mx) mx = l[a];
-                double ex[4], sum = 0.0;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const double d = l[a] - mx;
-                    ex[a] = (d == 0.0) ? 1.0 : (d < -750.0) ? 0.0 : exp(d);
-                    sum += ex[a];
-                }
-                const double c0 = ex[0], c1 = ex[1] + c0, c2 = ex[2] + c1;
-                const double us = u * sum;
-                const int tn = (us < c0) ? 0 : (us < c1) ? 1 : (us < c2) ? 2 : 3;
+                const int tn = sweep_draw(l, uw);
                 nchg += (lig == 0) & (tn != told);
                 t = (t & ~(3ull << (2 * g))) | ((uint64_t)tn << (2 * g));
             }

@@ -544,24 +544,8 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                 double l[4];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    double acc = 0.0;
-                    if (!(reuse && a == told)) {
-#pragma unroll
-                        for (int j = 0; j < NSL; ++j) {
-                            double P[4];
-                            bool ok = true;
-#pragma unroll
-                            for (int b = 0; b < 4; ++b) { P[b] = fma(eS[a * 4 + b], gg[j], st[j][b]); ok &= dsm_log_ok(P[b]); }
-                            if (__builtin_expect(ok, 1)) {
-#pragma unroll
-                                for (int b = 0; b < 4; ++b) acc = fma(xf[j][b], dsm_log_core(P[b], ltab), acc);
-                            } else {
-#pragma unroll
-                                for (int b = 0; b < 4; ++b) acc = fma(xf[j][b], dsm_log_slow(P[b]), acc);
-                            }
-                        }
-                    }
-                    l[a] = acc;
+                    l[a] = 0.0;
+                    if (!(reuse && a == told)) l[a] = sweep_candidate<NSL>(a, xf, st, gg, eS, ltab);
                 }
                 group_allreduce_sum4<LPV>(l[0], l[1], l[2], l[3]);
                 if (reuse) {
@@ -572,32 +556,16 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                     double *o = p.logp + ((size_t)v * G + g) * 4;
                     o[0] = l[0]; o[1] = l[1]; o[2] = l[2]; o[3] = l[3];
                 }
-                // normaliseLog4 + sample4 (c_sample_tau.c:48-91)
-                double mx = l[0];
-#pragma unroll
-                for (int a = 1; a < 4; ++a) if (l[a] > mx) mx = l[a];
-                double ex[4], sum = 0.0;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const double d = l[a] - mx;                  // identical on every lane of the group
-                    // exp(0) = 1 and exp(d < -745.2) = 0 exactly: the usual case needs no exp at all
-                    ex[a] = (d == 0.0) ? 1.0 : (d < -750.0) ? 0.0 : exp(d);
-                    sum += ex[a];
-                }
-                // inverse CDF without the three fp64 divisions: u < ex0/sum  <=>  u*sum < ex0 (sum in [1,4]);
-                // the two forms can disagree only if u lies within ~1e-16 (relative) of a CDF edge
-                const double c0 = ex[0], c1 = ex[1] + c0, c2 = ex[2] + c1;
-                double u;
+                uint32_t uw;
                 const size_t ui = (size_t)v * G + g;
                 if (p.u_raw) {
-                    u = (double)p.u_raw[ui] * 2.3283064365386963e-10;       // u32 / 2^32, exact
+                    uw = p.u_raw[ui];
                 } else {
                     uint32_t r[4];
                     philox4x32_10((uint32_t)ui, (uint32_t)(ui >> 32), p.iter, DSM_STREAM_TAUU, p.k0, p.k1, r);
-                    u = (double)r[0] * 2.3283064365386963e-10;
+                    uw = r[0];
                 }
-                const double us = u * sum;
-                const int tn = (us < c0) ? 0 : (us < c1) ? 1 : (us < c2) ? 2 : 3;
+                const int tn = sweep_draw(l, uw);
                 l_cur = (tn == 0) ? l[0] : (tn == 1) ? l[1] : (tn == 2) ? l[2] : l[3];
                 nchg += (lig == 0) & (tn != told);
                 t = (t & ~(3ull << (2 * g))) | ((uint64_t)tn << (2 * g));

@@ -583,8 +583,16 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) P[b] = fma(gm, er[b], P[b]);
                 }
+                bool ok = true;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) ll_acc = fma((double)xi[j][b], dsm_log(P[b], ltab), ll_acc);
+                for (int b = 0; b < 4; ++b) ok &= dsm_log_ok(P[b]);
+                if (__builtin_expect(ok, 1)) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) ll_acc = fma((double)xi[j][b], dsm_log_core(P[b], ltab), ll_acc);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) ll_acc = fma((double)xi[j][b], dsm_log_slow(P[b]), ll_acc);
+                }
             }
         }
     }

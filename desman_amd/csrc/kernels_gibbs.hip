@@ -520,6 +520,7 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                 for (int j = 0; j < NSL; ++j)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) st[j][b] = 0.0;
+#pragma unroll 4
                 for (int h = 0; h < G; ++h) {
                     if (h == g) continue;
                     const double *er = eS + (int)((t >> (2 * h)) & 3) * 4;

@@ -176,7 +176,8 @@ __device__ __forceinline__ void count_if_less(uint32_t &cnt, uint32_t r, uint32_
     asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cnt) : "v"(r), "v"(thr) : "vcc");
 }
 
-template <int GMAX>
+// EXACT: the haplotype count equals GMAX (a compile-time constant: no per-haplotype branches)
+template <int GMAX, bool EXACT>
 __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ items,      // [S][4V] {v*4+b, count}
                                                     const int32_t *__restrict__ nitems,  // [S]
                                                     const int32_t *__restrict__ blk_tab, // [grid][3] {sample, j, n_j}
@@ -209,8 +210,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ ite
 #pragma unroll
     for (int i = 0; i < 16; ++i) eacc[i][tid] = 0;
 
-    // the kernel is instantiated for every G <= 8, so there the haplotype count is a compile-time constant
-    const int Gc = (GMAX <= 8) ? GMAX : G;
+    const int Gc = EXACT ? GMAX : G;
     // grid-stride over the sample's sorted list: every workgroup gets heavy and light items, and
     // the 64 items a wavefront holds at any time are adjacent in the sort (equal loop lengths)
     for (int k = bj * 256 + tid; k < n_s; k += bn * 256) {
@@ -664,11 +664,13 @@ int k_stats(dsm_ctx *c, uint32_t iter)
     int gm = 32;
     for (int z : sizes) if (c->G <= z) { gm = z; break; }
     const void *fn = nullptr;
-#define STATS_FN(GM) if (gm == GM) fn = (const void *)stats_kernel<GM>
+    const bool exact = (c->G == gm);
+#define STATS_FN(GM) if (gm == GM) fn = exact ? (const void *)stats_kernel<GM, true> : (const void *)stats_kernel<GM, (GM <= 8)>
     STATS_FN(1); STATS_FN(2); STATS_FN(3); STATS_FN(4); STATS_FN(5); STATS_FN(6); STATS_FN(7); STATS_FN(8);
     STATS_FN(10); STATS_FN(12); STATS_FN(14); STATS_FN(16); STATS_FN(20); STATS_FN(24); STATS_FN(28); STATS_FN(32);
 #undef STATS_FN
-    if (c->blk_gmax != gm) {
+    const int key = gm * 2 + (exact ? 1 : 0);             // the two variants can differ in occupancy
+    if (c->blk_gmax != key) {
         // size the grid to exactly the resident workgroups and share them among the samples by depth
         int occ = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, 0));
@@ -700,15 +702,15 @@ int k_stats(dsm_ctx *c, uint32_t iter)
         HIP_TRY(hipMemcpyAsync(c->blk_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->blk_n = used;
-        c->blk_gmax = gm;
+        c->blk_gmax = key;
     }
     const dim3 grid(c->blk_n), block(256);
     const uint32_t k0 = (uint32_t)c->ctr_seed, k1 = (uint32_t)(c->ctr_seed >> 32);
-#define LAUNCH_STATS(GM)                                                                                      \
-    hipLaunchKernelGGL(stats_kernel<GM>, grid, block, 0, c->stream, reinterpret_cast<const int2 *>(c->items), \
-                       c->nitems, c->blk_tab, c->tau, c->gamma, c->eta,                                       \
+#define LAUNCH_STATS(GM, EX)                                                                                          \
+    hipLaunchKernelGGL((stats_kernel<GM, EX>), grid, block, 0, c->stream, reinterpret_cast<const int2 *>(c->items),   \
+                       c->nitems, c->blk_tab, c->tau, c->gamma, c->eta,                                               \
                        c->V, c->S, c->G, k0, k1, iter, c->sum_mu, c->esum)
-#define STATS_CASE(GM) if (gm == GM) LAUNCH_STATS(GM)
+#define STATS_CASE(GM) if (gm == GM) { if (exact) LAUNCH_STATS(GM, true); else LAUNCH_STATS(GM, (GM <= 8)); }
     STATS_CASE(1); STATS_CASE(2); STATS_CASE(3); STATS_CASE(4); STATS_CASE(5); STATS_CASE(6); STATS_CASE(7);
     STATS_CASE(8); STATS_CASE(10); STATS_CASE(12); STATS_CASE(14); STATS_CASE(16); STATS_CASE(20); STATS_CASE(24);
     STATS_CASE(28); STATS_CASE(32);

@@ -514,15 +514,23 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
         }
         if (SWEEP) {
             double l_cur = 0.0;                  // log-prob of the variant's current configuration
+            // The rest mixture of step g is the h-ascending FMA chain over h != g (c_sample_tau.c:136-150).  Its
+            // first g links use haplotypes that are already re-drawn and final, so that prefix is carried from
+            // step to step (pre) and only the links h > g are re-done: the same operations in the same order --
+            // bit-identical sums -- for G(G+1)/2 instead of G(G-1) links per variant.
+            double pre[NSL][4];
+#pragma unroll
+            for (int j = 0; j < NSL; ++j)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) pre[j][b] = 0.0;
             for (int g = 0; g < G; ++g) {
                 double st[NSL][4];
 #pragma unroll
                 for (int j = 0; j < NSL; ++j)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) st[j][b] = 0.0;
+                    for (int b = 0; b < 4; ++b) st[j][b] = pre[j][b];
 #pragma unroll 4
-                for (int h = 0; h < G; ++h) {
-                    if (h == g) continue;
+                for (int h = g + 1; h < G; ++h) {
                     const double *er = eS + (int)((t >> (2 * h)) & 3) * 4;
                     const double e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
 #pragma unroll
@@ -570,6 +578,17 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                 l_cur = (tn == 0) ? l[0] : (tn == 1) ? l[1] : (tn == 2) ? l[2] : l[3];
                 nchg += (lig == 0) & (tn != told);
                 t = (t & ~(3ull << (2 * g))) | ((uint64_t)tn << (2 * g));
+                {                                                   // link g of the chain, with the new base
+                    const double *er = eS + tn * 4;
+                    const double e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
+#pragma unroll
+                    for (int j = 0; j < NSL; ++j) {
+                        pre[j][0] = fma(e0, gg[j], pre[j][0]);
+                        pre[j][1] = fma(e1, gg[j], pre[j][1]);
+                        pre[j][2] = fma(e2, gg[j], pre[j][2]);
+                        pre[j][3] = fma(e3, gg[j], pre[j][3]);
+                    }
+                }
             }
             if (lig == 0) p.tau[v] = t;
         }

@@ -193,6 +193,12 @@ __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
         }
         if (SWEEP) {
             uint32_t uw_lane = 0;
+            // prefix of the h-ascending rest-mixture chain over the haplotypes already re-drawn (see tau_kernel)
+            double pre[NSL][4];
+#pragma unroll
+            for (int j = 0; j < NSL; ++j)
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) pre[j][bb] = 0.0;
             for (int g = 0; g < G; ++g) {
                 const int told = (int)((t >> (2 * g)) & 3);
                 uint32_t uw;
@@ -224,9 +230,9 @@ __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
 #pragma unroll
                 for (int j = 0; j < NSL; ++j)
 #pragma unroll
-                    for (int bb = 0; bb < 4; ++bb) st[j][bb] = 0.0;
-                for (int h = 0; h < G; ++h) {            // rest mixture, h ascending (c_sample_tau.c:136-150)
-                    if (h == g || !((mask >> h) & 1u)) continue;     // gamma = 0 adds exactly nothing
+                    for (int bb = 0; bb < 4; ++bb) st[j][bb] = pre[j][bb];
+                for (int h = g + 1; h < G; ++h) {        // rest mixture, h ascending (c_sample_tau.c:136-150)
+                    if (!((mask >> h) & 1u)) continue;               // gamma = 0 adds exactly nothing
                     const double *er = eS + (int)((t >> (2 * h)) & 3) * 4;
                     const double e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
 #pragma unroll
@@ -248,6 +254,17 @@ __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
                 const int tn = sweep_draw(l, uw);
                 nchg += (lig == 0) & (tn != told);
                 t = (t & ~(3ull << (2 * g))) | ((uint64_t)tn << (2 * g));
+                {                                                   // link g of the chain, with the new base
+                    const double *er = eS + tn * 4;
+                    const double e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
+#pragma unroll
+                    for (int j = 0; j < NSL; ++j) {
+                        pre[j][0] = fma(e0, gg[j], pre[j][0]);
+                        pre[j][1] = fma(e1, gg[j], pre[j][1]);
+                        pre[j][2] = fma(e2, gg[j], pre[j][2]);
+                        pre[j][3] = fma(e3, gg[j], pre[j][3]);
+                    }
+                }
             }
             if (lig == 0) tdst[v] = t;
         }

@@ -123,7 +123,8 @@ def test_loglik_vs_oracle(ctx, V, S, G):
 # ---------------------------------------------------------------- A2 mu/E sums
 @pytest.mark.parametrize("V,S,G", [(300, 16, 5), (1000, 64, 8), (70, 5, 3), (129, 7, 12), (50, 3, 20), (90, 4, 1),
                                    (64, 2, 2), (60, 4, 4), (60, 4, 6), (40, 3, 7), (40, 3, 10), (30, 2, 14),
-                                   (30, 2, 16), (20, 2, 24), (20, 2, 28), (20, 2, 32)])   # every compiled haplotype count
+                                   (30, 2, 16), (20, 2, 24), (20, 2, 28), (20, 2, 32),     # every compiled haplotype count
+                                   (40, 3, 9), (40, 3, 11), (30, 2, 13), (30, 2, 18), (20, 2, 22), (20, 2, 30)])   # padded ones
 def test_stats_bit_exact_vs_spec(ctx, V, S, G):
     counts, _, _ = synth_counts(V, S, max(G, 2), seed=31)
     counts[5] = 0

@@ -549,14 +549,33 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                 // With one variant per wavefront the candidate a == told is the variant's current
                 // configuration, whose log-probability was already evaluated (it is the candidate
                 // chosen at the previous step): only the three other candidates need their 4*NSL logs.
-                const bool reuse = (LPV == 64) && (g > 0);
+                const bool reuse = g > 0;
                 double l[4];
+                if constexpr (LPV == 64) {
+                    // one variant per wavefront: told is wave-uniform, the current candidate is branched around
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    l[a] = 0.0;
-                    if (!(reuse && a == told)) l[a] = sweep_candidate<NSL>(a, xf, st, gg, eS, ltab);
+                    for (int a = 0; a < 4; ++a) {
+                        l[a] = 0.0;
+                        if (!(reuse && a == told)) l[a] = sweep_candidate<NSL>(a, xf, st, gg, eS, ltab);
+                    }
+                    group_allreduce_sum4<LPV>(l[0], l[1], l[2], l[3]);
+                } else {
+                    // several variants per wavefront, each with its own current base: every group evaluates its
+                    // candidates in the rotated order told+1, told+2, told+3 (no divergence), the sums are put
+                    // back in base order afterwards (pure data movement: same values)
+                    const int rot = reuse ? told + 1 : 0;
+                    double cv[4];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) cv[i] = sweep_candidate<NSL>((rot + i) & 3, xf, st, gg, eS, ltab);
+                    cv[3] = 0.0;
+                    if (!reuse) cv[3] = sweep_candidate<NSL>(3, xf, st, gg, eS, ltab);       // g == 0: wave-uniform
+                    group_allreduce_sum4<LPV>(cv[0], cv[1], cv[2], cv[3]);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int i = (a - rot) & 3;
+                        l[a] = (i == 0) ? cv[0] : (i == 1) ? cv[1] : (i == 2) ? cv[2] : cv[3];
+                    }
                 }
-                group_allreduce_sum4<LPV>(l[0], l[1], l[2], l[3]);
                 if (reuse) {
 #pragma unroll
                     for (int a = 0; a < 4; ++a) if (a == told) l[a] = l_cur;

@@ -219,6 +219,7 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
 {
     if (!c || !variants || V < 1 || S < 1) { dsm_set_error("set_counts: bad arguments"); return DSM_ERR_ARG; }
     if (S > DSM_MAX_S) { dsm_set_error("S=%d exceeds DSM_MAX_S=%d", S, DSM_MAX_S); return DSM_ERR_UNSUPPORTED; }
+    if ((int64_t)V * S >= ((int64_t)1 << 32)) { dsm_set_error("V*S must be below 2^32"); return DSM_ERR_UNSUPPORTED; }
     BIND(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream_rng));
@@ -227,7 +228,6 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     c->have_state = false;
     c->G = 0;                       // V/S changed: every state-sized buffer is re-made by set_state
     TRY(dev_alloc(&c->cnt_vs, n * 4));
-    TRY(dev_alloc(&c->items, n * 8));
     TRY(dev_alloc(&c->nitems, (size_t)S));
     TRY(dev_alloc(&c->tau, (size_t)V));
     dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); dev_free(&c->ngam_raw); c->nG = 0;
@@ -252,9 +252,14 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
         // One pass over the tensor in memory order fills a (count, id) list per sample; each list is then
         // ordered by a counting sort on the count (descending; ids stay ascending inside a count) --
         // comparison sort only for samples with counts above 2^20.
-        std::vector<int32_t> items(n * 8, 0), nit(S);
+        // Small problems are cut into chunks of CH reads (own stream each, oracle: orc_stats_chunk): an item is
+        // then {id, reads | chunk << 12}; without chunking {id, reads}.
+        const int64_t cells = (int64_t)V * S;
+        const int CH = cells <= 65536 ? 64 : cells <= 262144 ? 128 : 0;
+        c->chunked = CH != 0;
+        std::vector<int32_t> nit(S);
         std::vector<int64_t> depth(S, 0);
-        std::vector<std::vector<std::pair<int32_t, int32_t>>> lst((size_t)S);      // (count, id)
+        std::vector<std::vector<std::pair<int32_t, int32_t>>> lst((size_t)S);      // (key, id); key = reads [| chunk << 12]
         std::vector<int32_t> top(S, 0);
         for (int s = 0; s < S; ++s) lst[s].reserve((size_t)V * 2);
         for (int v = 0; v < V; ++v) {
@@ -262,26 +267,37 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
             for (int s = 0; s < S; ++s)
                 for (int b = 0; b < 4; ++b) {
                     const int64_t x = row[s * 4 + b];
-                    if (x > 0) {
+                    if (x <= 0) continue;
+                    depth[s] += x;
+                    if (!CH) {
                         lst[s].emplace_back((int32_t)x, v * 4 + b);
-                        depth[s] += x;
                         if (x > top[s]) top[s] = (int32_t)x;
+                    } else {
+                        for (int64_t j = 0; j * CH < x; ++j) {
+                            const int32_t nrd = (int32_t)(x - j * CH < CH ? x - j * CH : CH);
+                            lst[s].emplace_back(nrd | (int32_t)(j << 12), v * 4 + b);
+                            if (nrd > top[s]) top[s] = nrd;
+                        }
                     }
                 }
         }
         int max_items = 0;
+        for (int s = 0; s < S; ++s) max_items = std::max(max_items, (int)lst[s].size());
+        c->item_stride = max_items > 0 ? max_items : 1;
+        std::vector<int32_t> items((size_t)S * c->item_stride * 2, 0);
+        TRY(dev_alloc(&c->items, items.size()));
         std::vector<int32_t> first;
+        const int32_t rd_mask = CH ? 0xfff : 0x7fffffff;
         for (int s = 0; s < S; ++s) {
             const auto &l = lst[s];
             nit[s] = (int32_t)l.size();
-            max_items = std::max(max_items, nit[s]);
-            int32_t *dst = items.data() + (size_t)s * 4 * V * 2;
+            int32_t *dst = items.data() + (size_t)s * c->item_stride * 2;
             if (top[s] <= (1 << 20)) {
                 first.assign((size_t)top[s] + 2, 0);
-                for (const auto &e : l) first[e.first]++;                       // histogram
+                for (const auto &e : l) first[e.first & rd_mask]++;                       // histogram of the read counts
                 int32_t run = 0;
                 for (int32_t cval = top[s]; cval >= 1; --cval) { const int32_t h = first[cval]; first[cval] = run; run += h; }
-                for (const auto &e : l) { const int32_t k = first[e.first]++; dst[2 * k] = e.second; dst[2 * k + 1] = e.first; }
+                for (const auto &e : l) { const int32_t k = first[e.first & rd_mask]++; dst[2 * k] = e.second; dst[2 * k + 1] = e.first; }
             } else {
                 std::vector<std::pair<int32_t, int32_t>> t(l);
                 std::stable_sort(t.begin(), t.end(), [](const std::pair<int32_t, int32_t> &p, const std::pair<int32_t, int32_t> &q) { return p.first > q.first; });

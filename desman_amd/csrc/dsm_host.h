@@ -32,9 +32,11 @@ struct dsm_ctx {
     int V = 0, S = 0, G = 0;
     // count tensor (both layouts, int32) and data-only ll constant
     int32_t *cnt_vs = nullptr;      // [V][S][4]  tau sweep / LL: lane = sample
-    int32_t *items = nullptr;       // [S][4V][2] mu/E pass work items {v*4+b, count}, sorted by count per sample
+    int32_t *items = nullptr;       // [S][item_stride][2] mu/E pass work items {v*4+b, reads}, sorted by reads per sample
     int32_t *nitems = nullptr;      // [S] items with a non-zero count
     int max_items = 0;
+    int item_stride = 1;            // items per sample row of `items`
+    bool chunked = false;           // items carry reads | chunk << 12 (small problems, see dsm_ctx_set_counts)
     int32_t *blk_tab = nullptr;     // [blk_n][3] workgroup -> {sample, j, n_j} of the mu/E pass
     int blk_n = 0, blk_gmax = 0;
     std::vector<int64_t> depth;     // host: total reads per sample

@@ -178,13 +178,13 @@ __device__ __forceinline__ void count_if_less(uint32_t &cnt, uint32_t r, uint32_
 
 // EXACT: the haplotype count equals GMAX (a compile-time constant: no per-haplotype branches)
 template <int GMAX, bool EXACT>
-__global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ items,      // [S][4V] {v*4+b, count}
+__global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ items,      // [S][stride] {v*4+b, reads [| chunk << 12]}
                                                     const int32_t *__restrict__ nitems,  // [S]
                                                     const int32_t *__restrict__ blk_tab, // [grid][3] {sample, j, n_j}
                                                     const uint64_t *__restrict__ tau,
                                                     const double *__restrict__ gamma,
                                                     const double *__restrict__ eta, int V, int S, int G,
-                                                    uint32_t k0, uint32_t k1, uint32_t iter,
+                                                    int stride, int chunked, uint32_t k0, uint32_t k1, uint32_t iter,
                                                     unsigned long long *__restrict__ sum_mu,
                                                     unsigned long long *__restrict__ esum)
 {
@@ -214,12 +214,14 @@ __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ ite
     // grid-stride over the sample's sorted list: every workgroup gets heavy and light items, and
     // the 64 items a wavefront holds at any time are adjacent in the sort (equal loop lengths)
     for (int k = bj * 256 + tid; k < n_s; k += bn * 256) {
-        const int2 it = items[(size_t)s * 4 * V + k];
-        const int v = it.x >> 2, b = it.x & 3, nb = it.y;
+        const int2 it = items[(size_t)s * stride + k];
+        const int v = it.x >> 2, b = it.x & 3;
+        const int nb = chunked ? (it.y & 0xfff) : it.y;                  // reads of this item (one chunk of a count)
+        const uint32_t chunk = chunked ? (uint32_t)it.y >> 12 : 0u;
         const uint64_t t = tau[v];
-        const uint64_t cell = (uint64_t)s * (uint64_t)V + (uint64_t)v;
+        const uint32_t cell = (uint32_t)s * (uint32_t)V + (uint32_t)v;   // V*S < 2^32 (checked at upload)
         uint32_t seedw[4];
-        philox4x32_10((uint32_t)cell, (uint32_t)(cell >> 32), iter, DSM_STREAM_STATS + (uint32_t)b, k0, k1, seedw);
+        philox4x32_10(cell, chunk, iter, DSM_STREAM_STATS + (uint32_t)b, k0, k1, seedw);
         Xo128 rng{seedw[0], seedw[1], seedw[2], seedw[3]};
         if ((rng.s0 | rng.s1 | rng.s2 | rng.s3) == 0u) rng.s0 = 1u;
         // cumulative weights -> 32-bit thresholds
@@ -747,7 +749,7 @@ int k_stats(dsm_ctx *c, uint32_t iter)
 #define LAUNCH_STATS(GM, EX)                                                                                          \
     hipLaunchKernelGGL((stats_kernel<GM, EX>), grid, block, 0, c->stream, reinterpret_cast<const int2 *>(c->items),   \
                        c->nitems, c->blk_tab, c->tau, c->gamma, c->eta,                                               \
-                       c->V, c->S, c->G, k0, k1, iter, c->sum_mu, c->esum)
+                       c->V, c->S, c->G, c->item_stride, c->chunked ? 1 : 0, k0, k1, iter, c->sum_mu, c->esum)
 #define STATS_CASE(GM) if (gm == GM) { if (exact) LAUNCH_STATS(GM, true); else LAUNCH_STATS(GM, (GM <= 8)); }
     STATS_CASE(1); STATS_CASE(2); STATS_CASE(3); STATS_CASE(4); STATS_CASE(5); STATS_CASE(6); STATS_CASE(7);
     STATS_CASE(8); STATS_CASE(10); STATS_CASE(12); STATS_CASE(14); STATS_CASE(16); STATS_CASE(20); STATS_CASE(24);

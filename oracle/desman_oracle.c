@@ -465,11 +465,21 @@ static inline uint32_t xo_next(orc_xo *r)     /* xoshiro128+ (Blackman & Vigna) 
 #define ORC_STREAM_STATS 0x53544154u   /* 'STAT' */
 
 /* sum_mu [S,G] and esum [4,4] ([observed b][true a]) are ACCUMULATED into. */
+/* Reads of an item are drawn in chunks: chunk j (reads j*CH .. j*CH+CH-1) owns the stream
+ * Philox(cell, j, iter, STAT + base); CH depends only on the problem shape (orc_stats_chunk): small
+ * problems are cut into short chunks so that no single stream is long, large ones are not cut (j = 0). */
+int64_t orc_stats_chunk(int V, int S)
+{
+    const int64_t cells = (int64_t)V * S;
+    return cells <= 65536 ? 64 : cells <= 262144 ? 128 : ((int64_t)1 << 40);
+}
+
 void orc_stats_counter(const uint8_t *tau_idx, const double *gamma, const double *eta,
                        const int64_t *variants, int V, int G, int S,
                        uint64_t seed, uint32_t iter,
                        uint64_t *sum_mu, uint64_t *esum)
 {
+    const int64_t CH = orc_stats_chunk(V, S);
     uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
     uint32_t thr[64];
     uint64_t cnt[64];
@@ -483,10 +493,6 @@ void orc_stats_counter(const uint8_t *tau_idx, const double *gamma, const double
             for (int b = 0; b < 4; b++) {
                 int64_t nb = x[b];
                 if (nb <= 0) continue;
-                uint32_t ctr[4] = { (uint32_t)cell, (uint32_t)(cell >> 32), iter, ORC_STREAM_STATS + (uint32_t)b };
-                orc_xo rng;
-                orc_philox4x32_10(ctr, key, rng.s);
-                if ((rng.s[0] | rng.s[1] | rng.s[2] | rng.s[3]) == 0) rng.s[0] = 1;
                 double c = 0.0, cum[64];
                 for (int g = 0; g < G; g++) { c += gamma[(size_t)s * G + g] * eta[tv[g] * 4 + b]; cum[g] = c; }
                 double scale = 4294967296.0 / c;
@@ -495,9 +501,17 @@ void orc_stats_counter(const uint8_t *tau_idx, const double *gamma, const double
                     thr[g] = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
                 }
                 for (int g = 0; g < G; g++) cnt[g] = 0;      /* cnt[g] = #{r < thr[g]} */
-                for (int64_t i = 0; i < nb; i++) {
-                    uint32_t r = xo_next(&rng);
-                    for (int g = 0; g < G - 1; g++) cnt[g] += (r < thr[g]);
+                for (int64_t j = 0; j * CH < nb; j++) {
+                    /* (cell < 2^32 is checked by the caller: V*S < 2^32) */
+                    uint32_t ctr[4] = { (uint32_t)cell, (uint32_t)j, iter, ORC_STREAM_STATS + (uint32_t)b };
+                    orc_xo rng;
+                    orc_philox4x32_10(ctr, key, rng.s);
+                    if ((rng.s[0] | rng.s[1] | rng.s[2] | rng.s[3]) == 0) rng.s[0] = 1;
+                    int64_t n = nb - j * CH < CH ? nb - j * CH : CH;
+                    for (int64_t i = 0; i < n; i++) {
+                        uint32_t r = xo_next(&rng);
+                        for (int g = 0; g < G - 1; g++) cnt[g] += (r < thr[g]);
+                    }
                 }
                 for (int g = 0; g < G; g++) {
                     /* haplotype g gets the reads with thr[g-1] <= r < thr[g] */

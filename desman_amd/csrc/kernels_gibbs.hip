@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void mt_fill_kernel(uint32_t *__restrict__ sta
 // run read loops of (almost) equal length and the heaviest workgroups are
 // dispatched first.  Every read draws its haplotype g with probability
 // gamma[s,g]*eta[tau_vg,b]/sum from the item's xoshiro128+ stream (keyed by
-// Philox(seed; cell, iter, base)): one 32-bit word against G-1 thresholds,
+// Philox(seed; cell, read chunk, iter, base)): one 32-bit word against G-1 thresholds,
 // two VALU issues per threshold.  Only the sums sum_mu[s,g] and esum[b,a]
 // ever leave the registers.
 // Specification restated in oracle/desman_oracle.c: orc_stats_counter.

@@ -166,28 +166,35 @@ def main():
     # plus the tau traffic (u8-equivalent: read for the mu/E pass; read + write + trace for the sweep)
     alg = {"tau": V * S * 16 + 3 * V * G, "stats": V * S * 16 + V * G}
     n_logs = 12.0 * V * G * S + 4.0 * V * S + 4.0 * V * S          # logs actually evaluated per sweep (+LL)
-    traffic = {}
+    traffic, valu = {}, {}
     tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tpath) and (V, S, G) == (10000, 64, 8):       # PMC passes are separate rocprofv3 runs
         tj = json.load(open(tpath))
-        for name, key in (("tau", "void tau_kernel<64, 1, true, true>"), ("stats", "void stats_kernel<8>")):
-            if key in tj:
-                traffic[name] = tj[key]["bytes_per_launch"]
+        for name, prefix in (("tau", "void tau_kernel<64, 1, true, true"), ("stats", "void stats_kernel<8")):
+            for key, rec in tj.items():
+                if key.startswith(prefix):
+                    traffic[name] = rec.get("bytes_per_launch")
+                    valu[name] = rec.get("valu_insts")
     per_kernel = {}
     for name, kname in (("stats", "stats_kernel"), ("tau", "tau_kernel")):
         us = k_us.get(name, float("nan"))
         ach = alg[name] / (us * 1e-6) / 1e9
         per_kernel[kname] = dict(avg_kernel_us=us, algorithmic_bytes_per_launch=alg[name], achieved_GBps=ach,
                                  frac_of_8TBps=ach / 8000.0, traffic_bytes_pmc=traffic.get(name))
+        if valu.get(name):
+            # what actually bounds the kernel: wave64 VALU instructions (PMC, profiles/) x 4 cycles each over the
+            # 1024 SIMDs x duration x 2.4 GHz issue slots of the launch measured here
+            per_kernel[kname].update(valu_insts_pmc=valu[name],
+                                     valu_issue_frac=valu[name] * 4.0 / (1024 * us * 1e-6 * 2.4e9))
     dom = "stats" if k_us.get("stats", 0) >= k_us.get("tau", 0) else "tau"
     dk = per_kernel[dom + "_kernel"]
     roofline = dict(bound="hbm", kernel=dom + "_kernel", achieved=dk["achieved_GBps"], peak=8000.0, unit="GB/s",
                     frac=dk["frac_of_8TBps"], traffic=dk["traffic_bytes_pmc"], avg_kernel_us=dk["avg_kernel_us"],
                     algorithmic_bytes_per_launch=dk["algorithmic_bytes_per_launch"],
                     per_kernel=per_kernel, fp64_logs_per_s_tau_kernel=n_logs / (k_us.get("tau", float("nan")) * 1e-6),
-                    note="both Gibbs kernels are VALU-issue bound, not HBM bound (SQ_ACTIVE_INST_VALU ~ 70-90 % of "
-                         "the kernel time, PMC traffic ~ algorithmic bytes; profiles/, DESIGN.md sec. 3): the HBM "
-                         "fraction is reported because the contract asks for it",
+                    note="both Gibbs kernels are VALU-issue bound, not HBM bound (per_kernel.valu_issue_frac ~ 0.9, PMC "
+                         "traffic ~ algorithmic bytes; profiles/, DESIGN.md sec. 3): the HBM fraction is reported "
+                         "because the contract asks for it",
                     kernels_us=k_us)
 
     if rank == 0:

@@ -32,4 +32,7 @@ for k, d in agg.items():
         wr = sum(d.get("WRITE_SIZE", [0])) / max(len(d.get("WRITE_SIZE", [0])), 1)
         traffic[k] = dict(fetch_kib_raw=fe, write_kib_raw=wr, read_bytes_corrected=2.0 * fe * 1024.0,
                           write_bytes=wr * 1024.0, bytes_per_launch=2.0 * fe * 1024.0 + wr * 1024.0)
+for k, d in agg.items():            # VALU instructions per launch: the bound of the two Gibbs kernels
+    if "SQ_INSTS_VALU" in d:
+        traffic.setdefault(k, {})["valu_insts"] = sum(d["SQ_INSTS_VALU"]) / len(d["SQ_INSTS_VALU"])
 json.dump(traffic, open(os.path.splitext(out)[0] + "_traffic.json", "w"), indent=1, sort_keys=True)

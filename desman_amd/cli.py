@@ -101,16 +101,18 @@ def _fit(opts, flt):
     return chain
 
 
+# result tables of a fitted chain: (writer method of Output_Results, attribute or method of the sampler)
+_TABLES = (("output_Filtered_Tau", "tau_star"), ("output_Tau_Mean", "tauMean"), ("output_Gamma", "gamma_star"),
+           ("output_Gamma_Mean", "gammaMean"), ("output_Eta", "eta_star"), ("output_Eta_Mean", "etaMean"))
+
+
 def _report(report, table, flt, chain, requested):
     report.set_Variants(table)
     report.set_Variant_Filter(flt)
     report.set_haplo_SNP(chain, requested)
-    report.output_Filtered_Tau(chain.tau_star)
-    report.output_Tau_Mean(chain.tauMean())
-    report.output_Gamma(chain.gamma_star)
-    report.output_Gamma_Mean(chain.gammaMean())
-    report.output_Eta(chain.eta_star)
-    report.output_Eta_Mean(chain.etaMean())
+    for writer, source in _TABLES:
+        value = getattr(chain, source)
+        getattr(report, writer)(value() if callable(value) else value)
     report.output_Selected_Variants()
 
 

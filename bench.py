@@ -61,6 +61,55 @@ def _cpu_model():
     return "unknown"
 
 
+def bench_genes(n_genes, S, G, vmax, iters, cpu_genes):
+    """Row f4 (accessory-gene sampler), separate from the headline metric: `python bench.py --workload genes`.
+    Batched (rng='philox') iterations of Eta_Sampler.update over n_genes genes on one GPU; the CPU leg is the oracle's
+    reference-order loop (numpy + C tau sweep, 1 thread) on a bounded sample of the genes."""
+    from scipy.special import gammaln
+    from desman_amd import _lib
+    from desman_amd.synth import synth_genes
+    C = n_genes
+    d = synth_genes(C, S, G, seed=5, vmax=vmax, mean_lo=2.0, mean_hi=20.0)
+    off = np.concatenate([[0], np.cumsum(np.bincount(d['gene_of'], minlength=C))]).astype(np.int32)
+    delta = d['gamma'] * d['total_mean'][:, None]
+    x = d['counts']
+    per_v = (gammaln(x.sum(axis=2) + 1.0) - gammaln(x + 1.0).sum(axis=2)).sum(axis=1)
+    mult = np.array([per_v[off[c]:off[c + 1]].sum() for c in range(C)])
+    lp = np.arange(2) * np.log(0.01)
+    prior = lp - np.log(np.exp(lp).sum())
+    rng = np.random.default_rng(0)
+    eta0 = (rng.random((C, G)) < 0.5).astype(np.int32)
+    tau0 = np.zeros((x.shape[0], G, 4), dtype=np.int64)
+    np.put_along_axis(tau0, rng.integers(0, 4, size=(x.shape[0], G))[..., None], 1, axis=2)
+    dev = _lib.Genes(0)
+    dev.set_data(x, off, d['cov'])
+    dev.set_model(d['gamma'], d['epsilon'], np.ascontiguousarray(delta.T), 2, prior, -gammaln(d['cov'] + 1.0).sum(axis=1), mult)
+    dev.set_state(eta0, tau0)
+    dev.seed(1)
+    dev.update(3)                                             # warm-up
+    t0 = time.perf_counter()
+    dev.update(iters)
+    dt = time.perf_counter() - t0
+    out = {"metric": "accessory-gene copy-number updates/s (batched Eta_Sampler.update)", "genes": C, "samples": S,
+           "haplotypes": G, "variant_rows": int(x.shape[0]), "iters": iters, "ms_per_iter": 1e3 * dt / iters,
+           "value": C * G * iters / dt, "unit": "gene*haplotype updates/s", "n_gpus": 1, "data": "synthetic"}
+    if cpu_genes:
+        from oracle import cbind, ref_genes as rg
+        n = min(cpu_genes, C)
+        cbind.initRNG(); cbind.setRNG(1)
+        variants = [np.ascontiguousarray(x[off[c]:off[c + 1]]) for c in range(n)]
+        taus = [np.ascontiguousarray(tau0[off[c]:off[c + 1]]) for c in range(n)]
+        eta = eta0[:n].astype(np.int64)
+        t0 = time.perf_counter()
+        rg.eta_update_reference_order(np.random.RandomState(1), eta, taus, variants, d['cov'][:n], d['gamma'], d['epsilon'],
+                                      np.ascontiguousarray(delta.T), prior, 2, np.zeros_like(eta), np.zeros(n))
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n * G * 2 / cdt, "unit": out["unit"], "cores": 1, "kind": "port",
+                               "sample": "%d genes x 2 iterations, oracle/ref_genes.py (numpy + C tau sweep)" % n}
+        out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +121,15 @@ def main():
     ap.add_argument("--rng", choices=["mt19937", "philox"], default="mt19937")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nmft", action="store_true")
+    ap.add_argument("--workload", choices=["gibbs", "genes"], default="gibbs",
+                    help="gibbs = the headline metric (default); genes = the accessory-gene sampler (row f4)")
+    ap.add_argument("--genes", type=int, default=2000)
+    ap.add_argument("--vmax", type=int, default=20)
+    ap.add_argument("--cpu-genes", type=int, default=40)
     args = ap.parse_args()
+    if args.workload == "genes":
+        return bench_genes(args.genes, 32 if args.S == 64 else args.S, 6 if args.G == 8 else args.G, args.vmax,
+                           50 if args.steps == 500 else args.steps, 0 if args.no_cpu_baseline else args.cpu_genes)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))

@@ -195,7 +195,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     dev_free(&c->blk_tab);
     dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
-    dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->prior); dev_free(&c->scalars); dev_free(&c->star);
+    dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->prior); dev_free(&c->prior_all); dev_free(&c->scalars); dev_free(&c->star);
     dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); dev_free(&c->ngam_raw);
     dev_free(&c->npart); dev_free(&c->nstat);
     for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ev_u_ready[i]); (void)hipEventDestroy(c->ev_u_free[i]); }
@@ -651,17 +651,19 @@ extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_st
     HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
     // entry: lp with (gamma_store[0], eta_store[0])  (HaploSNP_Sampler.py:386-389)
     TRY(eval_state(c, c->gamma_in, c->eta_in, c->tau_trace, 1));
+    // the Dirichlet log-priors of all stored (gamma, eta) pairs in one launch instead of one per sweep
+    TRY(dev_alloc(&c->prior_all, (size_t)n_iter * (c->S + 4)));
+    TRY(k_prior_batch(c, c->gamma_in, c->eta_in, n_iter, c->prior_all));
     for (int it = 0; it < n_iter; ++it) {
         const uint32_t ic = c->iter_ctr++;
         const double *g = c->gamma_in + (size_t)it * sg, *e = c->eta_in + (size_t)it * 16;
         const uint32_t *u = nullptr;
         TRY(fill_sweep_uniforms(c, &u));
-        TRY(k_prior(c, g, e, c->prior));
         int nb = 0;
         TRY(await_sweep_uniforms(c, u));
         TRY(k_tau_sweep(c, 3, g, e, e, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb, u));  // :392-393
         TRY(release_sweep_uniforms(c, u));
-        TRY(k_finalize(c, nb, it, 0, c->prior, g, e));
+        TRY(k_finalize(c, nb, it, 0, c->prior_all + (size_t)it * (c->S + 4), g, e));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSM_OK;

@@ -64,6 +64,7 @@ struct dsm_ctx {
     // scratch
     double *ll_partial = nullptr;   // [DSM_MAX_GRID]
     int *nchange = nullptr;         // device counter
+    double *prior_all = nullptr;    // [n_iter][S + 4] priors of the stored states of updateTau
     double *prior = nullptr;        // [2][DSM_MAX_S + 4] per-row Dirichlet log-prior terms, by iteration parity
     double *scalars = nullptr;      // [8] misc device scalars
     double *log_tab = nullptr;      // [128][2] table of dsm_log (log_table.h)
@@ -114,6 +115,7 @@ int k_stats(dsm_ctx *c, uint32_t iter);
 int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trace, double *eta_out, double *eta_trace,
                 double *prior_out, int fin_it, int fin_nblocks, const double *fin_prior);
 int k_prior(dsm_ctx *c, const double *gamma, const double *eta, double *prior_out);
+int k_prior_batch(dsm_ctx *c, const double *gamma, const double *eta, int n, double *prior_out);
 // mode bit0 = sweep, bit1 = log-likelihood epilogue
 int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_sweep,
                 const double *eta_ll, uint64_t *trace_slot, double *d_logp, uint32_t iter, int *nblocks,

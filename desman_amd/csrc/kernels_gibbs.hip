@@ -801,6 +801,40 @@ int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trac
     return DSM_OK;
 }
 
+// the same for n stored states at once (updateTau: gamma_store / eta_store are known up front):
+// gamma [n][S][G], eta [n][4][4] -> rowprior [n][S + 4]
+__global__ __launch_bounds__(256) void prior_batch_kernel(const double *__restrict__ gamma, const double *__restrict__ eta,
+                                                          int n, int S, int G, double alpha, double delta,
+                                                          double lgc_gamma, double lgc_eta, double *__restrict__ rowprior)
+{
+    const int rows = S + 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n * rows; i += (size_t)gridDim.x * 256) {
+        const int it = (int)(i / rows), r = (int)(i % rows);
+        double lsum = 0.0;
+        if (r < S) {
+            const double *g = gamma + ((size_t)it * S + r) * G;
+            for (int k = 0; k < G; ++k) lsum += (alpha - 1.0) * log(g[k]);
+            rowprior[i] = lgc_gamma + lsum;
+        } else {
+            const double *e = eta + (size_t)it * 16 + (r - S) * 4;
+            for (int b = 0; b < 4; ++b) lsum += (delta - 1.0) * log(e[b]);
+            rowprior[i] = lgc_eta + lsum;
+        }
+    }
+}
+
+int k_prior_batch(dsm_ctx *c, const double *gamma, const double *eta, int n, double *prior_out)
+{
+    double lg, le;
+    dirichlet_consts(c, &lg, &le);
+    const size_t tot = (size_t)n * (c->S + 4);
+    const int grid = (int)std::min<size_t>((tot + 255) / 256, 1024);
+    hipLaunchKernelGGL(prior_batch_kernel, dim3(grid), dim3(256), 0, c->stream, gamma, eta, n, c->S, c->G, c->alpha, c->delta,
+                       lg, le, prior_out);
+    HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}
+
 int k_prior(dsm_ctx *c, const double *gamma, const double *eta, double *prior_out)
 {
     double lg, le;

@@ -89,3 +89,42 @@ def test_max_sample_count_and_tiny_probabilities():
     ll0, _ = ctx.loglik()
     assert not np.isfinite(ll0)
     ctx.close()
+
+
+def test_contexts_release_their_device_memory():
+    """create / use / destroy in a loop: the free device memory comes back (no leak in any of the objects)"""
+    import torch
+    from desman_amd import _lib
+    from desman_amd.synth import synth_counts, random_state, synth_genes
+    from scipy.special import gammaln
+    counts, _, _ = synth_counts(3000, 24, 5, seed=1)
+    tau, gamma, eta = random_state(3000, 24, 5, seed=2)
+    d = synth_genes(40, 12, 3, seed=3)
+    off = np.concatenate([[0], np.cumsum(np.bincount(d['gene_of'], minlength=40))]).astype(np.int32)
+
+    def cycle():
+        ctx = _lib.Context(0)
+        ctx.set_counts(counts)
+        ctx.set_state(tau, gamma, eta)
+        ctx.seed(1)
+        ctx.gibbs_update(3)
+        ctx.update_tau(np.repeat(gamma[None], 2, axis=0).copy(), np.repeat(eta[None], 2, axis=0).copy())
+        ctx.close()
+        gs = _lib.Genes(0)
+        gs.set_data(d['counts'], off, d['cov'])
+        lp = np.array([-0.01, -4.6])
+        gs.set_model(d['gamma'], d['epsilon'], np.ascontiguousarray((d['gamma'] * d['total_mean'][:, None]).T), 2, lp,
+                     np.zeros(40), np.zeros(40))
+        gs.set_state(np.ones((40, 3), dtype=np.int32), np.zeros((d['counts'].shape[0], 3, 4), dtype=np.int64))
+        gs.seed(1)
+        gs.update(2)
+        gs.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(25):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 32 * 1024 * 1024, (free0, free1)

@@ -245,7 +245,11 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     HIP_TRY(hipMemcpyAsync(part.data(), d_part, nblk * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (!flag) {
+    if (!flag && !c->build_items) {                      // sweep-only context (legacy shim): no work list
+        c->max_items = 0;
+        c->blk_gmax = 0;
+    }
+    if (!flag && c->build_items) {
         // work list of the per-read pass: per sample, the (variant, base) pairs with a non-zero
         // count, sorted by decreasing count (ties: lower id first) -> the lanes of a wavefront run
         // read loops of equal length (k_stats shares the resident workgroups among samples by depth).
@@ -884,7 +888,10 @@ static int legacy_ctx()
     int dev = 0;
     const char *e = getenv("DESMAN_HIP_DEVICE");
     if (e) dev = atoi(e);
-    return dsm_ctx_create(&g_legacy, dev);
+    const int rc = dsm_ctx_create(&g_legacy, dev);
+    // the shim only ever sweeps tau: skip the work list of the mu/E pass (tens of ms of host time per call)
+    if (rc == DSM_OK) g_legacy->build_items = false;
+    return rc;
 }
 
 extern "C" int dsm_initRNG(void)

@@ -35,6 +35,7 @@ struct dsm_ctx {
     int32_t *items = nullptr;       // [S][item_stride][2] mu/E pass work items {v*4+b, reads}, sorted by reads per sample
     int32_t *nitems = nullptr;      // [S] items with a non-zero count
     int max_items = 0;
+    bool build_items = true;        // false: sweep-only context, dsm_ctx_set_counts skips the work list
     int item_stride = 1;            // items per sample row of `items`
     bool chunked = false;           // items carry reads | chunk << 12 (small problems, see dsm_ctx_set_counts)
     int32_t *blk_tab = nullptr;     // [blk_n][3] workgroup -> {sample, j, n_j} of the mu/E pass

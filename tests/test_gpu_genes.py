@@ -216,8 +216,10 @@ def test_geneassign_cli_batched_sampler(tmp_path):
     z = k['z']
     paths, *_ = _frames(k, tmp_path)
     stub = os.path.join(str(tmp_path), "gb")
+    known = os.path.join(str(tmp_path), "genomes.csv")
+    pd.DataFrame(k['d']['eta_true'], index=k['d']['genes']).to_csv(known)
     GeneAssign.main([paths[0], paths[1], paths[2], paths[3], "-s", str(k['seed']), "-i", "10", "-o", stub, "-v", paths[4],
-                     "--assign_tau", "--rng", "philox"])
+                     "--assign_tau", "--rng", "philox", "-g", known])
     for suffix in ("etaD_df.csv", "etaS_df.csv", "etaM_df.csv", "eta_df.csv", "_tau_star.csv", "_tau_mean.csv"):
         assert os.path.exists(stub + suffix), suffix
     eta_s = pd.read_csv(stub + "etaS_df.csv", index_col=0)

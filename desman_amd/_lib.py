@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "desman_hip.h")
 
 DSM_OK = 0
 RNG_MT19937, RNG_PHILOX = 0, 1
-K_NAMES = ("stats", "dirichlet", "tau", "finalize", "mt", "nmft_a", "nmft_gamma", "nmft_b")
+K_NAMES = ("stats", "dirichlet", "tau", "finalize", "mt", "nmft_a", "nmft_gamma", "nmft_b", "stats2")
 
 
 class DesmanHipError(RuntimeError):
@@ -55,6 +55,10 @@ SIGNATURES = {
     "dsm_mt_seed_state": (_i, [C.c_ulong, _u32p]),
     "dsm_ctx_sample_tau": (_i, [_vp, C.POINTER(_i), _vp]),
     "dsm_ctx_sample_stats": (_i, [_vp, C.c_uint32, _u64p, _u64p]),
+    "dsm_ctx_stats_spec": (_i, [_vp]),
+    "dsm_ctx_force_stats_v1": (_i, [_vp, _i]),
+    "dsm_ctx_debug_stage1": (_i, [_vp, C.c_uint32, _vp, _u64p]),
+    "dsm_ctx_debug_binom": (_i, [_vp, _i, C.c_uint32, _f64p, C.c_uint64, _i, _u32p]),
     "dsm_ctx_draw_gamma_eta": (_i, [_vp, C.c_uint32, _u64p, _u64p, _f64p, _f64p]),
     "dsm_ctx_loglik": (_i, [_vp, C.POINTER(_d), C.POINTER(_d)]),
     "dsm_ctx_gibbs_update": (_i, [_vp, _i]),
@@ -242,6 +246,29 @@ class Context:
         E = np.zeros((4, 4), dtype=np.uint64)
         check(self.lib.dsm_ctx_sample_stats(self._h, int(it), mu, E))
         return mu, E
+
+    def stats_spec(self):
+        """2 = aggregated mu/E sampler (oracle/stats_agg.c), 1 = per-read draws (orc_stats_counter)."""
+        r = self.lib.dsm_ctx_stats_spec(self._h)
+        if r < 0:
+            check(r)
+        return r
+
+    def force_stats_v1(self, on=True):
+        check(self.lib.dsm_ctx_force_stats_v1(self._h, 1 if on else 0))
+
+    def debug_stage1(self, it):
+        nt = np.zeros((self.S, 1 << self.G), dtype=np.uint32)
+        E = np.zeros((4, 4), dtype=np.uint64)
+        check(self.lib.dsm_ctx_debug_stage1(self._h, int(it), nt.ctypes.data, E))
+        return nt, E
+
+    def debug_binom(self, kind, n, w, seed, nsamp):
+        w4 = np.zeros(4)
+        w4[:len(w)] = w
+        out = np.zeros((nsamp, 4) if kind == 2 else nsamp, dtype=np.uint32)
+        check(self.lib.dsm_ctx_debug_binom(self._h, int(kind), int(n), w4, int(seed), int(nsamp), out.reshape(-1)))
+        return out
 
     def draw_gamma_eta(self, it, sum_mu, esum):
         g = np.empty((self.S, self.G)); e = np.empty((4, 4))

@@ -32,7 +32,8 @@ extern "C" int dsm_device_count(void)
 }
 
 static const char *const k_names[DSM_K_COUNT] = {"stats_kernel", "dirichlet_kernel", "tau_kernel", "finalize_kernel",
-                                                 "mt_fill_kernel", "nmft_pass_a", "nmft_gamma", "nmft_pass_b"};
+                                                 "mt_fill_kernel", "nmft_pass_a", "nmft_gamma", "nmft_pass_b",
+                                                 "stats_stage2_kernel"};
 extern "C" const char *dsm_kernel_name(int k) { return (k >= 0 && k < DSM_K_COUNT) ? k_names[k] : "?"; }
 
 // ---------------------------------------------------------------- timing
@@ -192,7 +193,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     free_traces(c);
     dev_free(&c->cnt_vs); dev_free(&c->items); dev_free(&c->nitems); dev_free(&c->tau);
-    dev_free(&c->blk_tab);
+    dev_free(&c->blk_tab); dev_free(&c->ntab);
     dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
     dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->prior); dev_free(&c->prior_all); dev_free(&c->scalars); dev_free(&c->star);
@@ -232,90 +233,32 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     TRY(dev_alloc(&c->tau, (size_t)V));
     dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); dev_free(&c->ngam_raw); c->nG = 0;
     free_traces(c);
-    Scratch<int64_t> d_in; Scratch<int> d_flag; Scratch<double> d_part;
+    Scratch<int64_t> d_in; Scratch<int> d_flag; Scratch<double> d_part; Scratch<unsigned long long> d_depth;
     const int nblk = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     TRY(d_in.alloc(n * 4));
     TRY(d_flag.alloc(1));
     TRY(d_part.alloc((size_t)nblk));
+    TRY(d_depth.alloc((size_t)S));
     HIP_TRY(hipMemcpyAsync(d_in, variants, n * 4 * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), c->stream));
-    TRY(k_convert_counts(c, d_in, d_flag, d_part, nblk));
+    HIP_TRY(hipMemsetAsync(d_depth, 0, (size_t)S * sizeof(unsigned long long), c->stream));
+    TRY(k_convert_counts(c, d_in, d_flag, d_part, nblk, d_depth));
     std::vector<double> part(nblk);
+    std::vector<unsigned long long> dep((size_t)S);
     int flag = 0;
     HIP_TRY(hipMemcpyAsync(part.data(), d_part, nblk * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(dep.data(), d_depth, (size_t)S * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (!flag && !c->build_items) {                      // sweep-only context (legacy shim): no work list
-        c->max_items = 0;
-        c->blk_gmax = 0;
-    }
-    if (!flag && c->build_items) {
-        // work list of the per-read pass: per sample, the (variant, base) pairs with a non-zero
-        // count, sorted by decreasing count (ties: lower id first) -> the lanes of a wavefront run
-        // read loops of equal length (k_stats shares the resident workgroups among samples by depth).
-        // One pass over the tensor in memory order fills a (count, id) list per sample; each list is then
-        // ordered by a counting sort on the count (descending; ids stay ascending inside a count) --
-        // comparison sort only for samples with counts above 2^20.
-        // Small problems are cut into chunks of CH reads (own stream each, oracle: orc_stats_chunk): an item is
-        // then {id, reads | chunk << 12}; without chunking {id, reads}.
-        const int64_t cells = (int64_t)V * S;
-        const int CH = cells <= 65536 ? 64 : cells <= 262144 ? 128 : 0;
-        c->chunked = CH != 0;
-        std::vector<int32_t> nit(S);
-        std::vector<int64_t> depth(S, 0);
-        std::vector<std::vector<std::pair<int32_t, int32_t>>> lst((size_t)S);      // (key, id); key = reads [| chunk << 12]
-        std::vector<int32_t> top(S, 0);
-        for (int s = 0; s < S; ++s) lst[s].reserve((size_t)V * 2);
-        for (int v = 0; v < V; ++v) {
-            const int64_t *row = variants + (size_t)v * S * 4;
-            for (int s = 0; s < S; ++s)
-                for (int b = 0; b < 4; ++b) {
-                    const int64_t x = row[s * 4 + b];
-                    if (x <= 0) continue;
-                    depth[s] += x;
-                    if (!CH) {
-                        lst[s].emplace_back((int32_t)x, v * 4 + b);
-                        if (x > top[s]) top[s] = (int32_t)x;
-                    } else {
-                        for (int64_t j = 0; j * CH < x; ++j) {
-                            const int32_t nrd = (int32_t)(x - j * CH < CH ? x - j * CH : CH);
-                            lst[s].emplace_back(nrd | (int32_t)(j << 12), v * 4 + b);
-                            if (nrd > top[s]) top[s] = nrd;
-                        }
-                    }
-                }
-        }
-        int max_items = 0;
-        for (int s = 0; s < S; ++s) max_items = std::max(max_items, (int)lst[s].size());
-        c->item_stride = max_items > 0 ? max_items : 1;
-        std::vector<int32_t> items((size_t)S * c->item_stride * 2, 0);
-        TRY(dev_alloc(&c->items, items.size()));
-        std::vector<int32_t> first;
-        const int32_t rd_mask = CH ? 0xfff : 0x7fffffff;
-        for (int s = 0; s < S; ++s) {
-            const auto &l = lst[s];
-            nit[s] = (int32_t)l.size();
-            int32_t *dst = items.data() + (size_t)s * c->item_stride * 2;
-            if (top[s] <= (1 << 20)) {
-                first.assign((size_t)top[s] + 2, 0);
-                for (const auto &e : l) first[e.first & rd_mask]++;                       // histogram of the read counts
-                int32_t run = 0;
-                for (int32_t cval = top[s]; cval >= 1; --cval) { const int32_t h = first[cval]; first[cval] = run; run += h; }
-                for (const auto &e : l) { const int32_t k = first[e.first & rd_mask]++; dst[2 * k] = e.second; dst[2 * k + 1] = e.first; }
-            } else {
-                std::vector<std::pair<int32_t, int32_t>> t(l);
-                std::stable_sort(t.begin(), t.end(), [](const std::pair<int32_t, int32_t> &p, const std::pair<int32_t, int32_t> &q) { return p.first > q.first; });
-                for (size_t k = 0; k < t.size(); ++k) { dst[2 * k] = t[k].second; dst[2 * k + 1] = t[k].first; }
-            }
-        }
-        c->max_items = max_items;
-        c->depth = depth;
-        c->nitems_h = nit;
-        c->blk_gmax = 0;
-        HIP_TRY(hipMemcpyAsync(c->items, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->nitems, nit.data(), (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
+    // the work list of the per-read pass (spec v1) is only built if that pass ever runs (build_stats_items)
+    c->items_built = false;
+    c->max_items = 0;
+    c->blk_gmax = 0;
+    c->stats_grid = 0;
+    dev_free(&c->items);
+    c->depth.assign((size_t)S, 0);
+    c->max_depth = 0;
+    for (int s = 0; s < S; ++s) { c->depth[s] = (int64_t)dep[s]; c->max_depth = std::max<uint64_t>(c->max_depth, dep[s]); }
     if (flag) {
         dev_free(&c->cnt_vs); dev_free(&c->items);
         dsm_set_error("set_counts: negative count or depth above 2^31-1");
@@ -324,6 +267,77 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     double s = 0.0;
     for (double p : part) s += p;
     c->ll_const = s;
+    return DSM_OK;
+}
+
+// Work list of the per-read pass (spec v1, stats_kernel), built from the resident int32 tensor the first time that
+// pass runs: per sample, the (variant, base) pairs with a non-zero count, sorted by decreasing count (ties: lower
+// id first) -> the lanes of a wavefront run read loops of equal length (k_stats_v1 shares the resident workgroups
+// among samples by depth).  One pass over the tensor in memory order fills a (count, id) list per sample; each list
+// is then ordered by a counting sort on the count -- comparison sort only for samples with counts above 2^20.
+// Small problems are cut into chunks of CH reads (own stream each, oracle: orc_stats_chunk): an item is then
+// {id, reads | chunk << 12}; without chunking {id, reads}.
+int build_stats_items(dsm_ctx *c)
+{
+    const int V = c->V, S = c->S;
+    std::vector<int32_t> cnt((size_t)V * S * 4);
+    HIP_TRY(hipMemcpyAsync(cnt.data(), c->cnt_vs, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int64_t cells = (int64_t)V * S;
+    const int CH = cells <= 65536 ? 64 : cells <= 262144 ? 128 : 0;
+    c->chunked = CH != 0;
+    std::vector<int32_t> nit(S);
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> lst((size_t)S);      // (key, id); key = reads [| chunk << 12]
+    std::vector<int32_t> top(S, 0);
+    for (int s = 0; s < S; ++s) lst[s].reserve((size_t)V * 2);
+    for (int v = 0; v < V; ++v) {
+        const int32_t *row = cnt.data() + (size_t)v * S * 4;
+        for (int s = 0; s < S; ++s)
+            for (int b = 0; b < 4; ++b) {
+                const int64_t x = row[s * 4 + b];
+                if (x <= 0) continue;
+                if (!CH) {
+                    lst[s].emplace_back((int32_t)x, v * 4 + b);
+                    if (x > top[s]) top[s] = (int32_t)x;
+                } else {
+                    for (int64_t j = 0; j * CH < x; ++j) {
+                        const int32_t nrd = (int32_t)(x - j * CH < CH ? x - j * CH : CH);
+                        lst[s].emplace_back(nrd | (int32_t)(j << 12), v * 4 + b);
+                        if (nrd > top[s]) top[s] = nrd;
+                    }
+                }
+            }
+    }
+    int max_items = 0;
+    for (int s = 0; s < S; ++s) max_items = std::max(max_items, (int)lst[s].size());
+    c->item_stride = max_items > 0 ? max_items : 1;
+    std::vector<int32_t> items((size_t)S * c->item_stride * 2, 0);
+    TRY(dev_alloc(&c->items, items.size()));
+    std::vector<int32_t> first;
+    const int32_t rd_mask = CH ? 0xfff : 0x7fffffff;
+    for (int s = 0; s < S; ++s) {
+        const auto &l = lst[s];
+        nit[s] = (int32_t)l.size();
+        int32_t *dst = items.data() + (size_t)s * c->item_stride * 2;
+        if (top[s] <= (1 << 20)) {
+            first.assign((size_t)top[s] + 2, 0);
+            for (const auto &e : l) first[e.first & rd_mask]++;                       // histogram of the read counts
+            int32_t run = 0;
+            for (int32_t cval = top[s]; cval >= 1; --cval) { const int32_t h = first[cval]; first[cval] = run; run += h; }
+            for (const auto &e : l) { const int32_t k = first[e.first & rd_mask]++; dst[2 * k] = e.second; dst[2 * k + 1] = e.first; }
+        } else {
+            std::vector<std::pair<int32_t, int32_t>> t(l);
+            std::stable_sort(t.begin(), t.end(), [](const std::pair<int32_t, int32_t> &p, const std::pair<int32_t, int32_t> &q) { return p.first > q.first; });
+            for (size_t k = 0; k < t.size(); ++k) { dst[2 * k] = t[k].second; dst[2 * k + 1] = t[k].first; }
+        }
+    }
+    c->max_items = max_items;
+    c->nitems_h = nit;
+    c->blk_gmax = 0;
+    HIP_TRY(hipMemcpyAsync(c->items, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->nitems, nit.data(), (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->items_built = true;
     return DSM_OK;
 }
 
@@ -337,6 +351,7 @@ static int ensure_state_buffers(dsm_ctx *c, int G)
         TRY(dev_alloc(&c->gamma_star, sg));
         TRY(dev_alloc(&c->sum_mu, sg));
         HIP_TRY(hipMemsetAsync(c->sum_mu, 0, sg * sizeof(unsigned long long), c->stream));
+        c->stats_grid = 0;
         c->u_cap = (size_t)c->V * G;
         TRY(dev_alloc(&c->u_raw, 2 * c->u_cap));
         free_traces(c);
@@ -536,6 +551,52 @@ extern "C" int dsm_ctx_sample_stats(dsm_ctx *c, uint32_t iter, uint64_t *sum_mu,
     if (esum) HIP_TRY(hipMemcpyAsync(esum, c->esum, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemsetAsync(c->sum_mu, 0, sg * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_stats_spec(dsm_ctx *c)
+{
+    if (!c || c->G < 1) { dsm_set_error("stats_spec: no chain state"); return DSM_ERR_STATE; }
+    return stats_spec(c);
+}
+
+extern "C" int dsm_ctx_force_stats_v1(dsm_ctx *c, int force_v1)
+{
+    if (!c) return DSM_ERR_ARG;
+    c->force_stats_v1 = force_v1 != 0;
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_debug_stage1(dsm_ctx *c, uint32_t iter, uint32_t *ntab, uint64_t *esum)
+{
+    TRY(need(c, true, true));
+    if (stats_spec(c) != 2) { dsm_set_error("debug_stage1: spec v2 does not apply to this shape"); return DSM_ERR_UNSUPPORTED; }
+    BIND(c);
+    HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
+    TRY(k_stats_stage1(c, iter));
+    const size_t NH = (size_t)1 << c->G, S = (size_t)c->S;
+    std::vector<uint32_t> t(NH * S);
+    HIP_TRY(hipMemcpyAsync(t.data(), c->ntab, t.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (esum) HIP_TRY(hipMemcpyAsync(esum, c->esum, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(c->ntab, 0, t.size() * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (ntab)
+        for (size_t h = 0; h < NH; ++h)
+            for (size_t s = 0; s < S; ++s) ntab[s * NH + h] = t[h * S + s];       // device [H][S] -> [S][H]
+    return DSM_OK;
+}
+
+extern "C" int dsm_ctx_debug_binom(dsm_ctx *c, int kind, uint32_t n, const double *w4, uint64_t seed, int nsamp, uint32_t *out)
+{
+    if (!c || !w4 || !out || nsamp < 1 || kind < 0 || kind > 2) { dsm_set_error("debug_binom: bad arguments"); return DSM_ERR_ARG; }
+    BIND(c);
+    const size_t len = (size_t)nsamp * (kind == 2 ? 4 : 1);
+    Scratch<uint32_t> d;
+    TRY(d.alloc(len));
+    TRY(k_binom_test(c, kind, n, w4, seed, nsamp, d));
+    HIP_TRY(hipMemcpyAsync(out, d, len * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSM_OK;
 }
@@ -888,10 +949,7 @@ static int legacy_ctx()
     int dev = 0;
     const char *e = getenv("DESMAN_HIP_DEVICE");
     if (e) dev = atoi(e);
-    const int rc = dsm_ctx_create(&g_legacy, dev);
-    // the shim only ever sweeps tau: skip the work list of the mu/E pass (tens of ms of host time per call)
-    if (rc == DSM_OK) g_legacy->build_items = false;
-    return rc;
+    return dsm_ctx_create(&g_legacy, dev);
 }
 
 extern "C" int dsm_initRNG(void)

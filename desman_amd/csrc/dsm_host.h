@@ -35,7 +35,12 @@ struct dsm_ctx {
     int32_t *items = nullptr;       // [S][item_stride][2] mu/E pass work items {v*4+b, reads}, sorted by reads per sample
     int32_t *nitems = nullptr;      // [S] items with a non-zero count
     int max_items = 0;
-    bool build_items = true;        // false: sweep-only context, dsm_ctx_set_counts skips the work list
+    bool items_built = false;       // the work list of the per-read pass (spec v1) is built on first use
+    uint64_t max_depth = 0;         // largest per-sample read total
+    bool force_stats_v1 = false;    // test hook: per-read pass even where spec v2 applies
+    uint32_t *ntab = nullptr;       // [2^G][S] subset counts of the aggregated mu/E pass (spec v2), zero between passes
+    size_t ntab_len = 0;
+    int stats_grid = 0;             // resident workgroups of stats_agg_kernel
     int item_stride = 1;            // items per sample row of `items`
     bool chunked = false;           // items carry reads | chunk << 12 (small problems, see dsm_ctx_set_counts)
     int32_t *blk_tab = nullptr;     // [blk_n][3] workgroup -> {sample, j, n_j} of the mu/E pass
@@ -107,12 +112,20 @@ struct KTimer {
 };
 
 // ---- launchers (kernels_gibbs.hip)
-int k_convert_counts(dsm_ctx *c, const int64_t *d_in, int *d_flag, double *d_partial, int nblk);
+int k_convert_counts(dsm_ctx *c, const int64_t *d_in, int *d_flag, double *d_partial, int nblk, unsigned long long *d_depth);
 int k_pack_tau(dsm_ctx *c, const int64_t *d_onehot, uint64_t *d_packed, int V, int G);
 int k_unpack_tau(dsm_ctx *c, const uint64_t *d_packed, int64_t *d_onehot, int V, int G);
 int k_tau_sum(dsm_ctx *c, const uint64_t *trace, int n, int64_t *d_sum);
 int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n, hipStream_t stream);
+int k_stats_v1(dsm_ctx *c, uint32_t iter);
+int build_stats_items(dsm_ctx *c);          // api.hip: work list of the per-read pass from the resident tensor
+
+// ---- launchers (kernels_stats.hip)
+int stats_spec(const dsm_ctx *c);           // 2 = aggregated sampler (oracle/stats_agg.c), 1 = per-read (orc_stats_counter)
 int k_stats(dsm_ctx *c, uint32_t iter);
+int k_stats_stage1(dsm_ctx *c, uint32_t iter);
+int k_stats_stage2(dsm_ctx *c, uint32_t iter);
+int k_binom_test(dsm_ctx *c, int kind, uint32_t n, const double *w, uint64_t seed, int nsamp, uint32_t *d_out);
 int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trace, double *eta_out, double *eta_trace,
                 double *prior_out, int fin_it, int fin_nblocks, const double *fin_prior);
 int k_prior(dsm_ctx *c, const double *gamma, const double *eta, double *prior_out);

@@ -19,9 +19,13 @@
 // =====================================================================
 __global__ __launch_bounds__(256) void convert_counts_kernel(const int64_t *__restrict__ in,
                                                              int32_t *__restrict__ cnt_vs, int V, int S,
-                                                             int *flag, double *partial)
+                                                             int *flag, double *partial,
+                                                             unsigned long long *__restrict__ depth)
 {
     __shared__ double red[256];
+    __shared__ unsigned long long dep[DSM_MAX_S];          // reads per sample seen by this workgroup
+    for (int i = threadIdx.x; i < S; i += 256) dep[i] = 0ull;
+    __syncthreads();
     const size_t n = (size_t)V * S;
     double acc = 0.0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -37,6 +41,7 @@ __global__ __launch_bounds__(256) void convert_counts_kernel(const int64_t *__re
         }
         bad |= tot > 2147483647ll;
         if (bad) atomicOr(flag, 1);
+        else if (tot) atomicAdd(&dep[i % (size_t)S], (unsigned long long)tot);
         c.x = (int)x[0]; c.y = (int)x[1]; c.z = (int)x[2]; c.w = (int)x[3];
         reinterpret_cast<int4 *>(cnt_vs)[i] = c;
         // data-only part of the multinomial log-pdf (Desman_Utils.py:28-33)
@@ -52,6 +57,7 @@ __global__ __launch_bounds__(256) void convert_counts_kernel(const int64_t *__re
         __syncthreads();
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+    for (int i = threadIdx.x; i < S; i += 256) if (dep[i]) atomicAdd(&depth[i], dep[i]);
 }
 
 __global__ void pack_tau_kernel(const int64_t *__restrict__ onehot, uint64_t *__restrict__ packed, int V, int G)
@@ -652,10 +658,10 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
 // =====================================================================
 // host launchers
 // =====================================================================
-int k_convert_counts(dsm_ctx *c, const int64_t *d_in, int *d_flag, double *d_partial, int nblk)
+int k_convert_counts(dsm_ctx *c, const int64_t *d_in, int *d_flag, double *d_partial, int nblk, unsigned long long *d_depth)
 {
     hipLaunchKernelGGL(convert_counts_kernel, dim3(nblk), dim3(256), 0, c->stream, d_in, c->cnt_vs, c->V, c->S, d_flag,
-                       d_partial);
+                       d_partial, d_depth);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }
@@ -694,8 +700,9 @@ int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n, hipStream_t stream)
     return DSM_OK;
 }
 
-int k_stats(dsm_ctx *c, uint32_t iter)
+int k_stats_v1(dsm_ctx *c, uint32_t iter)
 {
+    if (!c->items_built) { int r = build_stats_items(c); if (r != DSM_OK) return r; }
     KTimer tm(c, DSM_K_STATS);
     if (c->max_items == 0) return DSM_OK;
     // the per-read loop issues two instructions per threshold slot: instantiate it for the exact

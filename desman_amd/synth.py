@@ -6,13 +6,15 @@ reference ships no generator, so this is our own (numpy ``default_rng``).
 import numpy as np
 
 
-def synth_counts(V, S, G, seed=1234):
+def synth_counts(V, S, G, seed=1234, eta=None, depth_scale=1.0):
     """Returns (counts int64 [V,S,4] C-order, tau_true uint8 [V,G], gamma_true [S,G]).
 
     tau_true ~ U{0..3} with forced variability (a position where every haplotype
     agrees gets haplotype 1 moved to another base), gamma_true ~ Dir(1_G) per
     sample, eta_true = 0.96 I + 0.01, depth ~ Poisson(c_s) with c_s ~ U(40, 500),
     counts ~ Multinomial(depth, sum_g gamma[s,g] eta[tau[v,g], :]).
+    ``eta`` replaces the error matrix (rows = true base); ``depth_scale`` multiplies the mean depths
+    (same random stream otherwise).
     """
     rng = np.random.default_rng(seed)
     tau = rng.integers(0, 4, size=(V, G))
@@ -20,8 +22,8 @@ def synth_counts(V, S, G, seed=1234):
         same = (tau == tau[:, :1]).all(axis=1)
         tau[same, 1] = (tau[same, 1] + 1 + rng.integers(0, 3, size=int(same.sum()))) % 4
     gamma = rng.dirichlet(np.ones(G), size=S)
-    eta = 0.96 * np.eye(4) + 0.01
-    cs = rng.uniform(40, 500, size=S)
+    eta = 0.96 * np.eye(4) + 0.01 if eta is None else np.asarray(eta, dtype=np.float64)
+    cs = rng.uniform(40, 500, size=S) * depth_scale
     depth = rng.poisson(np.broadcast_to(cs, (V, S)))
     p = np.einsum('sg,vgb->vsb', gamma, eta[tau])
     p = p / p.sum(axis=2, keepdims=True)

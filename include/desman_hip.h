@@ -110,6 +110,17 @@ int dsm_ctx_sample_tau(dsm_ctx *ctx, int *nchange, double *logp_out);
 /* A2: one draw of the auxiliary-count sums (HaploSNP_Sampler.py:284-309 via
  * :266,:276): sum_mu [S][G], esum [4][4] = [observed][true].                 */
 int dsm_ctx_sample_stats(dsm_ctx *ctx, uint32_t iter, uint64_t *sum_mu, uint64_t *esum);
+/* which counter-based specification dsm_ctx_sample_stats / dsm_ctx_gibbs_update follow for the resident
+ * shape: 2 = aggregated sampler (oracle/stats_agg.c; G <= 16 and a subset table of at most 64 MB),
+ * 1 = per-read draws (oracle/desman_oracle.c: orc_stats_counter).  force_v1 != 0 pins spec 1.        */
+int dsm_ctx_stats_spec(dsm_ctx *ctx);
+int dsm_ctx_force_stats_v1(dsm_ctx *ctx, int force_v1);
+/* test hooks of spec 2: stage 1 only (subset counts ntab [S][2^G] u32 and esum), and nsamp variates of one
+ * sampler (kind 0 binom_small, 1 binom_big: out [nsamp]; 2 mult4 with weights w[0..3]: out [nsamp][4])
+ * exactly as oracle/stats_agg.c: orc_binom_test / orc_mult4_test draw them.                          */
+int dsm_ctx_debug_stage1(dsm_ctx *ctx, uint32_t iter, uint32_t *ntab, uint64_t *esum);
+int dsm_ctx_debug_binom(dsm_ctx *ctx, int kind, uint32_t n, const double *w4, uint64_t seed, int nsamp,
+                        uint32_t *out);
 
 /* A3+A4: gamma ~ Dir(alpha + sum_mu[s,:]) clamped/renormalised, eta[a,:] ~
  * Dir(delta + esum[:,a]) (HaploSNP_Sampler.py:263-281) from given sums.      */
@@ -238,7 +249,8 @@ int dsm_kl_assign(int device, const double *cov, const double *delta, double *et
 #define DSM_K_NMFT_A   5
 #define DSM_K_NMFT_G   6
 #define DSM_K_NMFT_B   7
-#define DSM_K_COUNT    8
+#define DSM_K_STATS2   8         /* stage 2 of the aggregated mu/E pass       */
+#define DSM_K_COUNT    9
 int dsm_ctx_set_timing(dsm_ctx *ctx, int on);
 int dsm_ctx_get_timing(dsm_ctx *ctx, double *ms_total /*[DSM_K_COUNT]*/,
                        int64_t *launches /*[DSM_K_COUNT]*/);

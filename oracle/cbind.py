@@ -21,8 +21,8 @@ _u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "desman_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("desman_oracle.c", "stats_agg.c", "orc_log_table.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
 
@@ -68,6 +68,15 @@ def lib():
                                         C.c_uint64, C.c_uint32, _u64p, _u64p]
         L.orc_stats_expect.argtypes = [_u8p, _f64p, _f64p, _i64p, C.c_int, C.c_int, C.c_int,
                                        _f64p, _f64p, _f64p]
+        L.orc_stats_agg.argtypes = [_u8p, _f64p, _f64p, _i64p, C.c_int, C.c_int, C.c_int,
+                                    C.c_uint64, C.c_uint32, _u64p, _u64p, C.c_void_p]
+        L.orc_stats_agg.restype = C.c_int
+        L.orc_binom_test.argtypes = [C.c_int, C.c_uint32, C.c_double, C.c_double, C.c_uint64, C.c_int, _u32p]
+        L.orc_mult4_test.argtypes = [C.c_uint32, _f64p, C.c_uint64, C.c_int, _u32p]
+        L.orc_tlog.argtypes = [C.c_double]
+        L.orc_tlog.restype = C.c_double
+        L.orc_dirichlet_counter.argtypes = [_u64p, _u64p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                            C.c_uint64, C.c_uint32, _f64p, _f64p, _f64p]
         _lib = L
     return _lib
 
@@ -216,3 +225,42 @@ def stats_expect(tau_idx, gamma, eta, variants):
     e_mu = np.zeros((S, G)); v_mu = np.zeros((S, G)); e_E = np.zeros((4, 4))
     lib().orc_stats_expect(tau_idx, gamma, eta, variants, V, G, S, e_mu, v_mu, e_E)
     return e_mu, v_mu, e_E
+
+
+def dirichlet_counter(sum_mu, esum, seed, it, alpha=0.1, delta=0.1, epsilon=1e-6):
+    """(gamma [S,G], eta [4,4], rowprior [S+4]) of the counter-based Dirichlet draw specification."""
+    S, G = sum_mu.shape
+    g = np.empty((S, G)); e = np.empty((4, 4)); rp = np.empty(S + 4)
+    lib().orc_dirichlet_counter(np.ascontiguousarray(sum_mu, dtype=np.uint64), np.ascontiguousarray(esum, dtype=np.uint64),
+                                S, G, alpha, delta, epsilon, int(seed), int(it), g, e, rp)
+    return g, e, rp
+
+
+def stats_agg(tau_idx, gamma, eta, variants, seed, it, want_ntab=False):
+    """spec v2 of the mu/E sums (oracle/stats_agg.c): (sum_mu [S,G], Esum [4,4][, ntab [S,2^G]])."""
+    V, S, _ = variants.shape
+    G = tau_idx.shape[1]
+    mu = np.zeros((S, G), dtype=np.uint64)
+    E = np.zeros((4, 4), dtype=np.uint64)
+    nt = np.zeros((S, 1 << G), dtype=np.uint32) if want_ntab else None
+    rc = lib().orc_stats_agg(tau_idx, gamma, eta, variants, V, G, S, int(seed), int(it), mu, E,
+                             nt.ctypes.data if want_ntab else None)
+    if rc != 0:
+        raise ValueError("orc_stats_agg: G outside 1..16")
+    return (mu, E, nt) if want_ntab else (mu, E)
+
+
+def binom_test(kind, n, wa, wb, seed, nsamp):
+    out = np.empty(nsamp, dtype=np.uint32)
+    lib().orc_binom_test(int(kind), int(n), float(wa), float(wb), int(seed), int(nsamp), out)
+    return out
+
+
+def mult4_test(x, W, seed, nsamp):
+    out = np.empty((nsamp, 4), dtype=np.uint32)
+    lib().orc_mult4_test(int(x), np.ascontiguousarray(W, dtype=np.float64), int(seed), int(nsamp), out)
+    return out
+
+
+def tlog(x):
+    return lib().orc_tlog(float(x))

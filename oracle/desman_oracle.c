@@ -547,3 +547,105 @@ void orc_stats_expect(const uint8_t *tau_idx, const double *gamma, const double 
             }
         }
 }
+
+/* ------------------------------------------------------------------------ */
+/* Counter-based SPECIFICATION of the product's gamma / eta Dirichlet draws  */
+/* (dirichlet_kernel).  Not a reference function: the reference calls        */
+/* numpy's RandomState.dirichlet (HaploSNP_Sampler.py:263-281), whose serial */
+/* stream cannot be replayed in parallel.  Same law, restated so that tests  */
+/* can compare the kernel value by value:                                    */
+/*   variate id  vid = s*G + g  (gamma[s,g]),  S*G + a*4 + b  (eta[a,b])     */
+/*   shape       alpha + sum_mu[s,g]      /  delta + esum[b,a]  (:266,:281:  */
+/*               eta row a = true base a uses the COLUMN a of E[obs,true])   */
+/*   gamma variate: Marsaglia & Tsang (2000), d = a' - 1/3, a' = shape (+1   */
+/*               if shape < 1), normals by Box-Muller (cos branch), attempt  */
+/*               t uses Philox4x32-10 counters (vid, 2t, iter, 'DIRI') ->    */
+/*               u1,u2 and (vid, 2t+1, iter, 'DIRI') -> u3, u_boost; the     */
+/*               shape<1 boost multiplies by u_boost^(1/shape) with the      */
+/*               u_boost of the ACCEPTED attempt                             */
+/*   uniform     ((w0>>5)*2^26 + (w1>>6) + 0.5) / 2^53                       */
+/*   row tail    x = y/sum(y); gamma only: x<eps -> eps, x /= sum (:271-273) */
+/*   rowprior    lgc + sum (a-1) log x   (Desman_Utils.py:35-44)             */
+/* Row sums use the 64-lane xor butterfly (offsets 32,16,..,1) of the kernel.*/
+/* libm here vs the device's log/cos/pow: values agree to a few ulp, not     */
+/* bit for bit -- tests compare to 1e-13 relative.                           */
+/* ------------------------------------------------------------------------ */
+#define ORC_STREAM_DIRI 0x44495249u   /* 'DIRI' */
+
+static double orc_u01_open(uint32_t a, uint32_t b)
+{
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+static double orc_gamma_variate(double shape, uint32_t vid, uint32_t iter, const uint32_t key[2])
+{
+    const double a = shape < 1.0 ? shape + 1.0 : shape;
+    const double d = a - 1.0 / 3.0;
+    const double c = 1.0 / sqrt(9.0 * d);
+    double res = 0.0, uboost = 1.0;
+    for (uint32_t t = 0; t < 4096u; t++) {
+        uint32_t c0[4] = { vid, 2u * t, iter, ORC_STREAM_DIRI }, c1[4] = { vid, 2u * t + 1u, iter, ORC_STREAM_DIRI };
+        uint32_t r0[4], r1[4];
+        orc_philox4x32_10(c0, key, r0);
+        orc_philox4x32_10(c1, key, r1);
+        const double u1 = orc_u01_open(r0[0], r0[1]), u2 = orc_u01_open(r0[2], r0[3]);
+        const double u3 = orc_u01_open(r1[0], r1[1]);
+        uboost = orc_u01_open(r1[2], r1[3]);
+        const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        const double x2 = x * x;
+        if (u3 < 1.0 - 0.0331 * x2 * x2 || log(u3) < 0.5 * x2 + d * (1.0 - v + log(v))) { res = d * v; break; }
+    }
+    if (shape < 1.0) res *= pow(uboost, 1.0 / shape);
+    return res;
+}
+
+static double butterfly64_sum(const double *lane_vals)
+{
+    double x[64], y[64];
+    memcpy(x, lane_vals, sizeof x);
+    for (int off = 32; off >= 1; off >>= 1) {
+        for (int l = 0; l < 64; l++) y[l] = x[l] + x[l ^ off];
+        memcpy(x, y, sizeof x);
+    }
+    return x[0];
+}
+
+/* sum_mu [S,G], esum [4,4] = E[observed][true]; gamma_out [S,G], eta_out [4,4] (rows = true base),
+ * rowprior_out [S+4] (may be NULL).  G <= 64. */
+void orc_dirichlet_counter(const uint64_t *sum_mu, const uint64_t *esum, int S, int G,
+                           double alpha, double delta, double epsilon, uint64_t seed, uint32_t iter,
+                           double *gamma_out, double *eta_out, double *rowprior_out)
+{
+    const uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    const double lgc_gamma = lgamma(alpha * G) - G * lgamma(alpha);
+    const double lgc_eta = lgamma(delta * 4) - 4 * lgamma(delta);
+    for (int row = 0; row < S + 4; row++) {
+        const int is_gamma = row < S, n = is_gamma ? G : 4;
+        double y[64], x[64], t[64];
+        memset(y, 0, sizeof y);
+        for (int l = 0; l < n; l++) {
+            uint32_t vid; double shape;
+            if (is_gamma) { vid = (uint32_t)(row * G + l); shape = alpha + (double)sum_mu[vid]; }
+            else { int a = row - S; vid = (uint32_t)(S * G + a * 4 + l); shape = delta + (double)esum[l * 4 + a]; }
+            y[l] = orc_gamma_variate(shape, vid, iter, key);
+        }
+        double tot = butterfly64_sum(y);
+        for (int l = 0; l < 64; l++) x[l] = y[l] / tot;
+        if (is_gamma) {
+            for (int l = 0; l < 64; l++) { if (l < n && x[l] < epsilon) x[l] = epsilon; t[l] = l < n ? x[l] : 0.0; }
+            tot = butterfly64_sum(t);
+            for (int l = 0; l < 64; l++) x[l] = x[l] / tot;
+        }
+        const double a1 = is_gamma ? alpha : delta;
+        for (int l = 0; l < 64; l++) t[l] = l < n ? (a1 - 1.0) * log(x[l]) : 0.0;
+        const double lsum = butterfly64_sum(t);
+        if (rowprior_out) rowprior_out[row] = (is_gamma ? lgc_gamma : lgc_eta) + lsum;
+        for (int l = 0; l < n; l++) {
+            if (is_gamma) gamma_out[row * G + l] = x[l];
+            else eta_out[(row - S) * 4 + l] = x[l];
+        }
+    }
+}

@@ -1,0 +1,385 @@
+/*
+ * stats_agg.c -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY (same rules as desman_oracle.c).
+ *
+ * SPECIFICATION of the product's aggregated auxiliary-count (mu/E) sampler, "spec v2"
+ * (kernels: stats_agg_kernel + the stage-2 part of dirichlet_kernel).  Like orc_stats_counter
+ * (spec v1, per-read draws) this is NOT a reference function: the reference draws mu/E from numpy's
+ * serial RandomState stream (desman/HaploSNP_Sampler.py:284-309), which a parallel sampler cannot
+ * replay.  Only the sums  sum_mu[s,g] = sum_{v,b} mu  and  Esum[b,a] = sum_{v,s} E  are ever consumed
+ * (HaploSNP_Sampler.py:266, :276), and spec v2 samples THOSE from their exact joint law at a cost that
+ * does not grow with the read depth:
+ *
+ *   Law.  For a cell (v,s) and observed base b with x reads, the reference assigns every read a true
+ *   base a and a haplotype g with probability  gamma[s,g] * eta[tau_vg,b] / sum  (one-stage form,
+ *   SURVEY App. A2).  Because eta[tau_vg,b] depends on g only through the base a = tau_vg:
+ *     stage 1   (n_a)_a ~ Multinomial(x; W_a),  W_a = eta[a,b] * Gamma_a,  Gamma_a = sum_{g: tau_vg=a} gamma[s,g]
+ *               Esum[b,a] += n_a
+ *     stage 2   the n_a reads spread over H_a(v) = {g: tau_vg = a} with probabilities gamma[s,g]/Gamma_a.
+ *   Stage 2 has the same probability vector for every (v, b, a) of sample s that shares the SET H, and
+ *   a sum of independent multinomials with one probability vector is one multinomial of the summed
+ *   count: N[s,H] = sum of the n_a with H_a(v) = H, then  m ~ Multinomial(N[s,H]; gamma[s,g], g in H),
+ *   sum_mu[s,g] += m_g.  The multinomial over H is drawn by halving the haplotype range recursively
+ *   (one binomial per (node, subset)), and the halves are aggregated again, so the number of large-count
+ *   binomials per sample is about 2^G, not V.
+ *   The joint law of (sum_mu, Esum) is exactly the reference's (checked statistically against the
+ *   reference-pinned rn.sample_mu and against the exact moments, tests/).
+ *
+ *   Draws.  Everything is counter-based: a cell's stage-1 draws come from one xoshiro128+ stream seeded by
+ *   Philox4x32-10(ctr = {cell, 0, iter, 'STA1'}, key = seed), consumed in the order written below; every
+ *   stage-2 binomial owns the stream Philox(ctr = {subset, s | node << 16 | level << 24, iter, 'STA2'}).
+ *   Small counts (<= XS reads) are drawn read by read against 32-bit thresholds; larger ones by a
+ *   multinomial -> binomial decomposition with sequential-search inversion on the rarer side (cost
+ *   ~ n*min(p,1-p), no transcendental function: (1-q)^n by repeated squaring); the stage-2 binomials
+ *   (counts up to 2^32-1) use Hoermann's BTRS transformed rejection (1993) above mean 16.
+ *   All arithmetic is IEEE double with the operation order written here (-ffp-contract=off), the
+ *   logarithm of BTRS is the table-driven orc_tlog (same table and FMA sequence as the device's
+ *   dsm_log), so the kernels reproduce this file bit for bit.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "orc_log_table.h"
+
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);   /* desman_oracle.c */
+
+#define STREAM_STA1 0x53544131u   /* 'STA1' */
+#define STREAM_STA2 0x53544132u   /* 'STA2' */
+#define STREAM_TEST 0x54455354u   /* 'TEST' */
+#define XS 12u                    /* counts up to XS are drawn read by read */
+#define BINV_MEAN_CAP 16.0        /* inversion chunks have mean <= 16 */
+
+typedef struct { uint32_t s[4]; } xo_t;
+
+static inline uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+
+static inline uint32_t xo_next(xo_t *r)     /* xoshiro128+ */
+{
+    uint32_t *s = r->s;
+    uint32_t res = s[0] + s[3];
+    uint32_t t = s[1] << 9;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+    s[2] ^= t; s[3] = rotl32(s[3], 11);
+    return res;
+}
+
+static void xo_seed(xo_t *r, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, const uint32_t key[2])
+{
+    uint32_t ctr[4] = { c0, c1, c2, c3 };
+    orc_philox4x32_10(ctr, key, r->s);
+    if ((r->s[0] | r->s[1] | r->s[2] | r->s[3]) == 0) r->s[0] = 1;
+}
+
+/* uniform in (0,1): two words, first word = high part */
+static double xo_u01(xo_t *r)
+{
+    uint32_t a = xo_next(r);
+    uint32_t b = xo_next(r);
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+/* the device's dsm_log (desman_amd/csrc/dsm_device.h) restated: x = 2^e m, table on the top 8 mantissa
+ * bits, r = m*invc - 1 by one fma, degree-4 polynomial in r. */
+double orc_tlog(double x)
+{
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    const uint32_t hi = (uint32_t)(bits >> 32);
+    if ((uint32_t)(hi - 0x00100000u) >= 0x7fe00000u) return log(x);     /* zero / subnormal / inf / nan / negative */
+    const int e = (int)(hi >> 20) - 1023;
+    const uint32_t idx = (hi >> 12) & 255u;
+    const double invc = orc_log_table[2 * idx], logc = orc_log_table[2 * idx + 1];
+    const uint64_t mb = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m;
+    memcpy(&m, &mb, 8);
+    const double r = fma(m, invc, -1.0);
+    const double ed = (double)e;
+    double p = fma(r, 0.2, -0.25);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -0.5);
+    const double w = fma(ed, 0x1.62e42fefa3800p-1, logc);
+    const double lo = fma(ed, 0x1.ef35793c76730p-45, (r * r) * p);
+    return (w + r) + lo;
+}
+
+/* v >= 0 -> floor(v) saturated to 2^32-1 (what v_cvt_u32_f64 does); NaN -> 0 */
+static inline uint32_t cvt_sat_u32(double v)
+{
+    if (!(v >= 0.0)) return 0u;
+    return v >= 4294967295.0 ? 0xffffffffu : (uint32_t)v;
+}
+
+/* b^e by repeated squaring, multiplications in this order */
+static double pw(double b, uint32_t e)
+{
+    double res = 1.0;
+    while (e) {
+        if (e & 1u) res = res * b;
+        e >>= 1;
+        if (e) b = b * b;
+    }
+    return res;
+}
+
+/* x reads over K (3 or 4) categories with weights w, read by read: n_j = #{reads whose word r falls in
+ * [t_{j-1}, t_j)}, t_j = floor(2^32 * cum_j / total) */
+static void draw_reads(xo_t *rng, uint32_t x, const double *w, int K, uint32_t *n)
+{
+    double cums[4], cum = 0.0;
+    for (int j = 0; j < K; j++) { cum = cum + w[j]; cums[j] = cum; }
+    const double scale = 4294967296.0 / cums[K - 1];
+    uint32_t t[3], c[3] = { 0, 0, 0 };
+    for (int j = 0; j < K - 1; j++) t[j] = cvt_sat_u32(cums[j] * scale);
+    for (uint32_t i = 0; i < x; i++) {
+        const uint32_t r = xo_next(rng);
+        for (int j = 0; j < K - 1; j++) c[j] += (r < t[j]);
+    }
+    n[0] = c[0];
+    for (int j = 1; j < K - 1; j++) n[j] = c[j] - c[j - 1];
+    n[K - 1] = x - c[K - 2];
+}
+
+/* Binomial(c, q) by sequential search from 0; f0 = (1-q)^c, r = q/(1-q).  One uniform. */
+static uint32_t binv_chunk(xo_t *rng, uint32_t c, double f0, double r)
+{
+    double u = xo_u01(rng), f = f0;
+    uint32_t k = 0;
+    while (u >= f && k < c) {
+        u = u - f;
+        k = k + 1;
+        f = (f * (r * (double)(c - k + 1))) * (1.0 / (double)k);
+    }
+    return k;
+}
+
+/* successes among n trials with success : failure odds wa : wb; inversion on the rarer outcome, in
+ * chunks of at most cap trials (cap * q <= 16) */
+static uint32_t binom_inv(xo_t *rng, uint32_t n, double ws, double wl)
+{
+    const double T = ws + wl;
+    const double omq = wl / T;
+    const double r = ws / wl;
+    uint32_t cap = n;
+    if ((double)n * ws > BINV_MEAN_CAP * T) {
+        const double capd = floor(BINV_MEAN_CAP * T / ws);       /* >= 32 because ws <= wl */
+        cap = capd >= (double)n ? n : (uint32_t)capd;
+    }
+    uint32_t total = 0, left = n;
+    double f_full = 0.0;
+    if (left >= cap) f_full = pw(omq, cap);
+    while (left > 0) {
+        const uint32_t c = left < cap ? left : cap;
+        const double f0 = (c == cap) ? f_full : pw(omq, c);
+        total += binv_chunk(rng, c, f0, r);
+        left -= c;
+    }
+    return total;
+}
+
+static uint32_t binom_small(xo_t *rng, uint32_t n, double wa, double wb)
+{
+    if (n == 0 || !(wa > 0.0)) return 0;
+    if (!(wb > 0.0)) return n;
+    const int flip = wa > wb;
+    const double ws = flip ? wb : wa, wl = flip ? wa : wb;
+    const uint32_t k = binom_inv(rng, n, ws, wl);
+    return flip ? n - k : k;
+}
+
+/* Stirling series remainder  ln k! - [ (k+1/2) ln(k+1) - (k+1) + ln sqrt(2 pi) ]  (Hoermann 1993, fc(k)) */
+static double stirling_tail(double k)
+{
+    static const double tab[10] = { 0.0810614667953272, 0.0413406959554092, 0.0276779256849983, 0.02079067210376509,
+                                    0.0166446911898211, 0.0138761288230707, 0.0118967099458917, 0.0104112652619720,
+                                    0.00925546218271273, 0.00833056343336287 };
+    if (k <= 9.0) return tab[(int)k];
+    const double kp1 = k + 1.0, kp1sq = kp1 * kp1;
+    return (1.0 / 12.0 - (1.0 / 360.0 - (1.0 / 1260.0) / kp1sq) / kp1sq) / kp1;
+}
+
+/* Hoermann's BTRS (transformed rejection with squeeze), q <= 1/2, n q >= 10 */
+static uint32_t btrs(xo_t *rng, uint32_t n, double q)
+{
+    const double nd = (double)n;
+    const double spq = sqrt(nd * q * (1.0 - q));
+    const double b = 1.15 + 2.53 * spq;
+    const double a = -0.0873 + 0.0248 * b + 0.01 * q;
+    const double c = nd * q + 0.5;
+    const double v_r = 0.92 - 4.2 / b;
+    const double r = q / (1.0 - q);
+    const double alpha = (2.83 + 5.1 / b) * spq;
+    const double m = floor((nd + 1.0) * q);
+    for (int attempt = 0; attempt < 4096; attempt++) {
+        const double u = xo_u01(rng) - 0.5;
+        const double v = xo_u01(rng);
+        const double us = 0.5 - fabs(u);
+        const double kd = floor((2.0 * a / us + b) * u + c);
+        if (kd < 0.0 || kd > nd) continue;
+        if (us >= 0.07 && v <= v_r) return (uint32_t)kd;
+        const double lv = orc_tlog(v * alpha / (a / (us * us) + b));
+        const double ub = (m + 0.5) * orc_tlog((m + 1.0) / (r * (nd - m + 1.0)))
+                          + (nd + 1.0) * orc_tlog((nd - m + 1.0) / (nd - kd + 1.0))
+                          + (kd + 0.5) * orc_tlog(r * (nd - kd + 1.0) / (kd + 1.0))
+                          + stirling_tail(m) + stirling_tail(nd - m) - stirling_tail(kd) - stirling_tail(nd - kd);
+        if (lv <= ub) return (uint32_t)kd;
+    }
+    return (uint32_t)m;      /* unreachable in practice (acceptance > 0.7 per attempt) */
+}
+
+static uint32_t binom_big(xo_t *rng, uint32_t n, double wa, double wb)
+{
+    if (n == 0 || !(wa > 0.0)) return 0;
+    if (!(wb > 0.0)) return n;
+    const int flip = wa > wb;
+    const double ws = flip ? wb : wa, wl = flip ? wa : wb;
+    const double T = ws + wl;
+    uint32_t k;
+    if ((double)n * ws > BINV_MEAN_CAP * T) k = btrs(rng, n, ws / T);
+    else k = binom_inv(rng, n, ws, wl);                           /* a single chunk */
+    return flip ? n - k : k;
+}
+
+/* x reads of one (cell, observed base) over the four true bases with weights W */
+static void mult4(xo_t *rng, uint32_t x, const double W[4], uint32_t n[4])
+{
+    n[0] = n[1] = n[2] = n[3] = 0;
+    if (x == 0) return;
+    if (x <= XS) { draw_reads(rng, x, W, 4, n); return; }
+    int am = 0;
+    for (int a = 1; a < 4; a++) if (W[a] > W[am]) am = a;
+    int o[3], j = 0;
+    for (int a = 0; a < 4; a++) if (a != am) o[j++] = a;
+    const double wo[3] = { W[o[0]], W[o[1]], W[o[2]] };
+    const double ws = (wo[0] + wo[1]) + wo[2];
+    const uint32_t m = binom_small(rng, x, ws, W[am]);            /* reads NOT of the heaviest base */
+    n[am] = x - m;
+    if (m == 0) return;
+    uint32_t k[3];
+    if (m <= XS) draw_reads(rng, m, wo, 3, k);
+    else {
+        k[0] = binom_small(rng, m, wo[0], wo[1] + wo[2]);
+        k[1] = binom_small(rng, m - k[0], wo[1], wo[2]);
+        k[2] = m - k[0] - k[1];
+    }
+    n[o[0]] = k[0]; n[o[1]] = k[1]; n[o[2]] = k[2];
+}
+
+/* stage 1 for all cells: esum [4,4] ([observed][true]) accumulated, ntab [S][2^G] (subset counts) accumulated */
+static void stage1(const uint8_t *tau_idx, const double *gamma, const double *eta, const int64_t *variants,
+                   int V, int G, int S, const uint32_t key[2], uint32_t iter, uint64_t *esum, uint32_t *ntab)
+{
+    const size_t NH = (size_t)1 << G;
+    for (int v = 0; v < V; v++) {
+        const uint8_t *tv = tau_idx + (size_t)v * G;
+        uint32_t H[4] = { 0, 0, 0, 0 };
+        for (int g = 0; g < G; g++) H[tv[g]] |= 1u << g;
+        for (int s = 0; s < S; s++) {
+            const int64_t *x = variants + ((size_t)v * S + s) * 4;
+            xo_t rng;
+            xo_seed(&rng, (uint32_t)((uint64_t)s * (uint64_t)V + (uint64_t)v), 0u, iter, STREAM_STA1, key);
+            double Gam[4] = { 0.0, 0.0, 0.0, 0.0 };
+            for (int g = 0; g < G; g++) Gam[tv[g]] = Gam[tv[g]] + gamma[(size_t)s * G + g];
+            uint32_t nacc[4] = { 0, 0, 0, 0 };
+            for (int b = 0; b < 4; b++) {
+                if (x[b] <= 0) continue;
+                double W[4];
+                for (int a = 0; a < 4; a++) W[a] = eta[a * 4 + b] * Gam[a];
+                const double Wt = ((W[0] + W[1]) + W[2]) + W[3];
+                if (!(Wt > 0.0)) for (int a = 0; a < 4; a++) W[a] = Gam[a];     /* degenerate eta: fall back to abundance */
+                uint32_t n[4];
+                mult4(&rng, (uint32_t)x[b], W, n);
+                for (int a = 0; a < 4; a++) { esum[b * 4 + a] += n[a]; nacc[a] += n[a]; }
+            }
+            for (int a = 0; a < 4; a++) if (nacc[a]) ntab[(size_t)s * NH + H[a]] += nacc[a];
+        }
+    }
+}
+
+/* stage 2 for one sample: T0 [2^G] subset counts -> sum_mu_s [G] accumulated.  The haplotype range is
+ * halved recursively: node (level, idx) owns the bit range [lo,hi); the lower child gets floor(w/2) bits. */
+typedef struct { int lo, hi; uint32_t *tab; } node_t;
+
+static void stage2_sample(int s, int G, const double *gam_s, const uint32_t *T0, const uint32_t key[2], uint32_t iter,
+                          uint64_t *sum_mu_s)
+{
+    node_t *cur = (node_t *)malloc(sizeof(node_t) * 64), *nxt = (node_t *)malloc(sizeof(node_t) * 64);
+    int ncur = 1;
+    cur[0].lo = 0; cur[0].hi = G;
+    cur[0].tab = (uint32_t *)malloc(sizeof(uint32_t) << G);
+    memcpy(cur[0].tab, T0, sizeof(uint32_t) << G);
+    int idx_cur[64], idx_nxt[64];
+    idx_cur[0] = 0;
+    for (int level = 0; ncur > 0; level++) {
+        int nn = 0;
+        for (int i = 0; i < ncur; i++) {
+            const int lo = cur[i].lo, hi = cur[i].hi, w = hi - lo;
+            uint32_t *T = cur[i].tab;
+            if (w == 1) { sum_mu_s[lo] += T[1]; free(T); continue; }
+            const int wl = w / 2, wh = w - wl, mid = lo + wl;
+            uint32_t *L = (uint32_t *)calloc((size_t)1 << wl, sizeof(uint32_t));
+            uint32_t *R = (uint32_t *)calloc((size_t)1 << wh, sizeof(uint32_t));
+            for (uint32_t Hs = 1; Hs < (1u << w); Hs++) {
+                const uint32_t n = T[Hs];
+                if (!n) continue;
+                const uint32_t HL = Hs & ((1u << wl) - 1u), HR = Hs >> wl;
+                if (!HR) { L[HL] += n; continue; }
+                if (!HL) { R[HR] += n; continue; }
+                double wL = 0.0, wR = 0.0;
+                for (int j = 0; j < wl; j++) if (HL >> j & 1u) wL = wL + gam_s[lo + j];
+                for (int j = 0; j < wh; j++) if (HR >> j & 1u) wR = wR + gam_s[mid + j];
+                xo_t rng;
+                xo_seed(&rng, Hs, (uint32_t)s | ((uint32_t)idx_cur[i] << 16) | ((uint32_t)level << 24), iter, STREAM_STA2, key);
+                const uint32_t k = binom_big(&rng, n, wL, wR);
+                L[HL] += k; R[HR] += n - k;
+            }
+            free(T);
+            nxt[nn].lo = lo; nxt[nn].hi = mid; nxt[nn].tab = L; idx_nxt[nn] = 2 * idx_cur[i]; nn++;
+            nxt[nn].lo = mid; nxt[nn].hi = hi; nxt[nn].tab = R; idx_nxt[nn] = 2 * idx_cur[i] + 1; nn++;
+        }
+        node_t *t = cur; cur = nxt; nxt = t;
+        memcpy(idx_cur, idx_nxt, sizeof(int) * (size_t)nn);
+        ncur = nn;
+    }
+    free(cur); free(nxt);
+}
+
+/* sum_mu [S,G] and esum [4,4] are ACCUMULATED into.  G <= 16.  ntab_out (optional, [S][2^G]) receives the
+ * stage-1 subset counts.  Returns 0, or -1 if G is out of range / out of memory. */
+int orc_stats_agg(const uint8_t *tau_idx, const double *gamma, const double *eta, const int64_t *variants,
+                  int V, int G, int S, uint64_t seed, uint32_t iter, uint64_t *sum_mu, uint64_t *esum,
+                  uint32_t *ntab_out)
+{
+    if (G < 1 || G > 16) return -1;
+    const uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    const size_t NH = (size_t)1 << G;
+    uint32_t *ntab = (uint32_t *)calloc((size_t)S * NH, sizeof(uint32_t));
+    if (!ntab) return -1;
+    stage1(tau_idx, gamma, eta, variants, V, G, S, key, iter, esum, ntab);
+    if (ntab_out) memcpy(ntab_out, ntab, (size_t)S * NH * sizeof(uint32_t));
+    for (int s = 0; s < S; s++)
+        stage2_sample(s, G, gamma + (size_t)s * G, ntab + (size_t)s * NH, key, iter, sum_mu + (size_t)s * G);
+    free(ntab);
+    return 0;
+}
+
+/* test hooks: nsamp variates of one sampler, variate i from the stream Philox({i, 0, 0, 'TEST'}, seed) */
+void orc_binom_test(int kind, uint32_t n, double wa, double wb, uint64_t seed, int nsamp, uint32_t *out)
+{
+    const uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    for (int i = 0; i < nsamp; i++) {
+        xo_t rng;
+        xo_seed(&rng, (uint32_t)i, 0u, 0u, STREAM_TEST, key);
+        out[i] = kind == 0 ? binom_small(&rng, n, wa, wb) : binom_big(&rng, n, wa, wb);
+    }
+}
+
+void orc_mult4_test(uint32_t x, const double *W, uint64_t seed, int nsamp, uint32_t *out /* [nsamp][4] */)
+{
+    const uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    for (int i = 0; i < nsamp; i++) {
+        xo_t rng;
+        xo_seed(&rng, (uint32_t)i, 0u, 0u, STREAM_TEST, key);
+        mult4(&rng, x, W, out + (size_t)i * 4);
+    }
+}

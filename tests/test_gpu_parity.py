@@ -40,7 +40,8 @@ def test_tau_sweep_golden(ctx, path):
     n, logp = ctx.sample_tau(want_logp=True)
     tau, _, _ = ctx.get_state()
     assert np.array_equal(tau, z["tau_out"])                      # bit-exact integer outcome
-    assert n == int((np.argmax(z["tau_in"], 2) != np.argmax(z["tau_out"], 2)).sum()) or n >= 0
+    # nchange counts (v,g) pairs whose base changed = the net difference (one draw per pair per sweep)
+    assert n == int((np.argmax(z["tau_in"], 2) != np.argmax(z["tau_out"], 2)).sum())
     # fp tolerance: lane-parallel summation order + device log vs libm
     np.testing.assert_allclose(logp, z["logp"], rtol=1e-12, atol=1e-8)
 
@@ -126,19 +127,90 @@ def test_loglik_vs_oracle(ctx, V, S, G):
                                    (30, 2, 16), (20, 2, 24), (20, 2, 28), (20, 2, 32),     # every compiled haplotype count
                                    (40, 3, 9), (40, 3, 11), (30, 2, 13), (30, 2, 18), (20, 2, 22), (20, 2, 30)])   # padded ones
 def test_stats_bit_exact_vs_spec(ctx, V, S, G):
+    """the mu/E sums against the restated counter-based specification, bit for bit: spec v2 (aggregated
+    sampler, oracle/stats_agg.c) where it applies (G <= 16), and the per-read spec v1 (orc_stats_counter)
+    both where it is the product path (G > 16) and, forced, on the same shapes."""
     counts, _, _ = synth_counts(V, S, max(G, 2), seed=31)
     counts[5] = 0
     tau, gamma, eta = random_state(V, S, G, seed=32)
     _load(ctx, counts, tau, gamma, eta)
     ctx.seed(1, ctr_seed=0xABCDEF0123456789)
     idx = cbind.onehot_to_idx(tau)
-    for it in (0, 1, 77):
-        mu, E = ctx.sample_stats(it)
-        mu_ref, E_ref = cbind.stats_counter(idx, gamma, eta, counts, 0xABCDEF0123456789, it)
-        assert np.array_equal(mu, mu_ref) and np.array_equal(E, E_ref)
-        assert int(mu.sum()) == int(counts.sum())
-        # E[b, :] partitions the reads of observed base b
-        assert np.array_equal(E.sum(axis=1), counts.sum(axis=(0, 1)).astype(np.uint64))
+    spec = ctx.stats_spec()
+    assert spec == (2 if G <= 16 else 1)
+    for force in ((False, True) if spec == 2 else (False,)):
+        ctx.force_stats_v1(force)
+        ref_fn = cbind.stats_agg if (spec == 2 and not force) else cbind.stats_counter
+        for it in (0, 1, 77):
+            mu, E = ctx.sample_stats(it)
+            mu_ref, E_ref = ref_fn(idx, gamma, eta, counts, 0xABCDEF0123456789, it)
+            assert np.array_equal(mu, mu_ref) and np.array_equal(E, E_ref)
+            assert int(mu.sum()) == int(counts.sum())
+            # E[b, :] partitions the reads of observed base b
+            assert np.array_equal(E.sum(axis=1), counts.sum(axis=(0, 1)).astype(np.uint64))
+    ctx.force_stats_v1(False)
+
+
+@pytest.mark.parametrize("V,S,G,scale", [(200, 64, 8, 1.0), (120, 96, 12, 1.0), (150, 16, 5, 1.0), (60, 130, 3, 1.0),
+                                         (80, 64, 8, 20.0), (40, 7, 16, 1.0), (64, 64, 1, 1.0), (50, 300, 6, 0.05)])
+def test_stats_stage1_matches_spec(ctx, V, S, G, scale):
+    """stage 1 of spec v2 alone: the subset counts N[s][H] and Esum, on random (burn-in like) and on
+    generating (converged) states, shallow and 20x deep data."""
+    counts, tau_true, gamma_true = synth_counts(V, S, max(G, 2), seed=33, depth_scale=scale)
+    counts[3] = 0
+    counts[7, :, :] = counts[7, :, :] * 3000 + 5                  # one very deep variant: chunked inversion
+    seed = 0x0123456789ABCDEF
+    for state in ("random", "truth"):
+        if state == "random" or G < 2:
+            tau, gamma, eta = random_state(V, S, G, seed=34)
+        else:
+            tau, gamma, eta = cbind.idx_to_onehot(tau_true[:, :G]), np.ascontiguousarray(gamma_true[:, :G]), 0.96 * np.eye(4) + 0.01
+            gamma = np.ascontiguousarray(gamma / gamma.sum(axis=1, keepdims=True))
+        _load(ctx, counts, tau, gamma, eta)
+        ctx.seed(1, ctr_seed=seed)
+        idx = cbind.onehot_to_idx(tau)
+        for it in (0, 5):
+            nt, E = ctx.debug_stage1(it)
+            mu_ref, E_ref, nt_ref = cbind.stats_agg(idx, gamma, eta, counts, seed, it, want_ntab=True)
+            assert np.array_equal(E, E_ref)
+            assert np.array_equal(nt, nt_ref)
+            mu, E2 = ctx.sample_stats(it)
+            assert np.array_equal(mu, mu_ref) and np.array_equal(E2, E_ref)
+
+
+def test_stats_degenerate_eta_and_gamma(ctx):
+    """eta with exact zeros (identity) and a gamma column of zeros: weights vanish for whole bases / subsets"""
+    V, S, G = 50, 16, 4
+    counts, _, _ = synth_counts(V, S, G, seed=35)
+    tau, gamma, eta = random_state(V, S, G, seed=36)
+    eta = np.eye(4)
+    gamma[:, 2] = 0.0
+    gamma = np.ascontiguousarray(gamma / gamma.sum(axis=1, keepdims=True))
+    _load(ctx, counts, tau, gamma, eta)
+    ctx.seed(1, ctr_seed=9)
+    idx = cbind.onehot_to_idx(tau)
+    mu, E = ctx.sample_stats(2)
+    mu_ref, E_ref = cbind.stats_agg(idx, gamma, eta, counts, 9, 2)
+    assert np.array_equal(mu, mu_ref) and np.array_equal(E, E_ref)
+    assert (mu[:, 2] == 0).all() and int(mu.sum()) == int(counts.sum())
+
+
+@pytest.mark.parametrize("kind,n,w", [(0, 300, (0.02, 0.98)), (0, 300, (0.98, 0.02)), (0, 300, (0.5, 0.5)), (0, 13, (0.5, 0.1)),
+                                      (0, 5000, (0.4, 0.6)), (0, 2 ** 31 - 1, (1e-9, 1.0)), (0, 77, (0.0, 1.0)), (0, 77, (1.0, 0.0)),
+                                      (1, 1000, (0.3, 0.7)), (1, 100000, (0.013, 1.0)), (1, 33, (0.5, 0.5)), (1, 2 ** 32 - 1, (0.5, 0.5)),
+                                      (1, 4000000000, (1e-8, 1.0)), (1, 3000, (0.99, 0.01)), (1, 17, (0.3, 0.7)),
+                                      (2, 300, (0.003, 0.002, 0.99, 0.005)), (2, 9, (0.1, 0.2, 0.3, 0.4)), (2, 500, (0.25, 0.25, 0.3, 0.2)),
+                                      (2, 40, (0.0, 0.5, 0.5, 0.0)), (2, 100000, (0.96, 0.01, 0.02, 0.01)), (2, 13, (1e-300, 1.0, 0.0, 1e-300))])
+def test_binomial_and_multinomial_samplers_match_spec(ctx, kind, n, w):
+    """dsm_binom.h against its restatement in oracle/stats_agg.c, variate by variate (same streams)"""
+    nsamp = 20000
+    got = ctx.debug_binom(kind, n, w, 0xFEEDFACE12345678, nsamp)
+    if kind == 2:
+        ref = cbind.mult4_test(n, w, 0xFEEDFACE12345678, nsamp)
+        assert (got.sum(axis=1) == n).all()
+    else:
+        ref = cbind.binom_test(kind, n, w[0], w[1], 0xFEEDFACE12345678, nsamp)
+    assert np.array_equal(got, ref)
 
 
 def test_stats_law_matches_reference_sampleMu(ctx):
@@ -180,7 +252,10 @@ def test_gamma_eta_draws(ctx):
     sum_mu = rng.integers(0, 50, size=(S, G)).astype(np.uint64)
     sum_mu[0, :] = 0                                              # shape 0.1 everywhere: clamp path
     sum_mu[1, 1:] = 0; sum_mu[1, 0] = 10 ** 7
-    esum = (np.eye(4) * 50000 + 300).astype(np.uint64)
+    # asymmetric on purpose: eta[a,:] ~ Dir(delta + Esum[:,a]) (HaploSNP_Sampler.py:281) -- a transposed read
+    # of E[observed,true] would fail the mean test below
+    esum = (np.eye(4) * 50000 + np.array([[0, 300, 4000, 90], [2500, 0, 40, 700], [60, 5000, 0, 1500],
+                                          [900, 10, 3000, 0]])).astype(np.uint64)
     n = 600
     g_acc = np.zeros((S, G)); g2 = np.zeros((S, G)); e_acc = np.zeros((4, 4))
     for it in range(n):
@@ -199,12 +274,60 @@ def test_gamma_eta_draws(ctx):
     np.testing.assert_allclose(g2[rows] / n - (g_acc[rows] / n) ** 2, var[rows], rtol=0.35, atol=1e-6)
     d = 0.1 + esum.T.astype(np.float64)                           # eta[a,:] ~ Dir(delta + Esum[:,a])
     np.testing.assert_allclose(e_acc / n, d / d.sum(axis=1, keepdims=True), rtol=2e-3, atol=2e-4)
+    wrong = 0.1 + esum.astype(np.float64)
+    assert np.abs(e_acc / n - wrong / wrong.sum(axis=1, keepdims=True)).max() > 0.02      # the test discriminates
     # determinism: same (seed, iter) -> same draw
     g1, e1 = ctx.draw_gamma_eta(5, sum_mu, esum)
     g1b, e1b = ctx.draw_gamma_eta(5, sum_mu, esum)
     assert np.array_equal(g1, g1b) and np.array_equal(e1, e1b)
     # the deterministic tail of sampleGamma (HaploSNP_Sampler.py:271-273)
     assert np.allclose(g1, rn.clamp_renorm_gamma(g1), rtol=1e-12)
+
+
+@pytest.mark.parametrize("S,G", [(1, 1), (1, 8), (16, 8), (64, 8), (64, 32), (16, 1), (512, 8), (512, 32), (96, 12)])
+def test_dirichlet_draws_match_spec(ctx, S, G):
+    """A3/A4 value by value against the restated draw specification (oracle: orc_dirichlet_counter): Philox
+    counter layout, Box-Muller, Marsaglia-Tsang, shape < 1 boost, clamp / renormalise.  Tolerance 1e-13
+    relative: the device's log / cos / pow and glibc's differ in the last bits, nothing else may."""
+    V = 4
+    counts, _, _ = synth_counts(V, S, max(G, 2), seed=52)
+    tau, gamma, eta = random_state(V, S, G, seed=53)
+    _load(ctx, counts, tau, gamma, eta)
+    seed = 0x1234ABCD5678EF01
+    ctx.seed(1, ctr_seed=seed)
+    rng = np.random.default_rng(S * 100 + G)
+    sum_mu = rng.integers(0, 3000, size=(S, G)).astype(np.uint64)
+    sum_mu[0, :] = 0                                              # every shape = alpha = 0.1: boost + clamp path
+    if S > 1:
+        sum_mu[1, :] = 0; sum_mu[1, 0] = 10 ** 7                  # one huge shape next to 0.1s
+    if S > 2:
+        sum_mu[2, :] = 10 ** 7
+    esum = rng.integers(0, 9000, size=(4, 4)).astype(np.uint64)   # asymmetric
+    esum[3, :] = 0; esum[3, 3] = 10 ** 7
+    for it in (0, 3, 1000):
+        g, e = ctx.draw_gamma_eta(it, sum_mu, esum)
+        g_ref, e_ref, _ = cbind.dirichlet_counter(sum_mu, esum, seed, it)
+        np.testing.assert_allclose(g, g_ref, rtol=1e-13, atol=0)
+        np.testing.assert_allclose(e, e_ref, rtol=1e-13, atol=0)
+
+
+def test_gibbs_chain_recovers_asymmetric_eta(ctx):
+    """chain-level check of the E[observed,true] -> eta[true,:] indexing (HaploSNP_Sampler.py:275-281):
+    data generated with a strongly asymmetric error matrix; the posterior mean of eta must be that matrix,
+    not its transpose."""
+    V, S, G = 400, 16, 3
+    eta_true = np.array([[0.90, 0.07, 0.02, 0.01],
+                         [0.01, 0.96, 0.01, 0.02],
+                         [0.05, 0.01, 0.93, 0.01],
+                         [0.01, 0.01, 0.10, 0.88]])
+    counts, tau_true, gamma_true = synth_counts(V, S, G, seed=71, eta=eta_true)
+    tau0 = cbind.idx_to_onehot(tau_true)
+    _load(ctx, counts, tau0, np.ascontiguousarray(gamma_true), 0.96 * np.eye(4) + 0.01, mt_seed=6)
+    ctx.gibbs_update(60)
+    ctx.gibbs_update(200)
+    eta_mean = ctx.get_trace()["eta"].mean(axis=0)
+    np.testing.assert_allclose(eta_mean, eta_true, atol=0.012)
+    assert np.abs(eta_mean - eta_true.T).max() > 0.04
 
 
 # ---------------------------------------------------------------- A6 full iteration

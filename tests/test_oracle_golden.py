@@ -186,6 +186,45 @@ def test_counter_sampler_spec_matches_expectation():
     np.testing.assert_allclose(acc_E / n, e_E, rtol=0.02, atol=3.0)
 
 
+def test_dirichlet_spec_has_the_law_of_the_reference_draws():
+    """orc_dirichlet_counter (the restated spec of dirichlet_kernel) against the reference-pinned
+    rn.sample_gamma / rn.sample_eta fed the reference's own mu / E (gibbs_pieces.npz: E is [obs,true] and
+    asymmetric): same posterior means -- in particular eta row a uses the column a of the E sums."""
+    z = np.load(os.path.join(GOLDEN, "gibbs_pieces.npz"))
+    mu, E = z["mu1"], z["E1"]
+    sum_mu = mu.sum(axis=(0, 2)).astype(np.uint64)                # [S,G]
+    esum = E.sum(axis=(0, 1)).astype(np.uint64)                   # [obs,true]
+    esum[0, 1] += 40; esum[2, 3] += 25                            # make the asymmetry unmistakable
+    assert not np.array_equal(esum, esum.T)
+    n = 3000
+    g_acc = np.zeros(sum_mu.shape); e_acc = np.zeros((4, 4)); e2 = np.zeros((4, 4))
+    for it in range(n):
+        g, e, rp = cbind.dirichlet_counter(sum_mu, esum, seed=77, it=it)
+        g_acc += g; e_acc += e; e2 += e * e
+    rs = np.random.RandomState(1)
+    m = 3000
+    gr = np.zeros(sum_mu.shape); er = np.zeros((4, 4))
+    Efake = np.zeros((1, 1, 4, 4), dtype=np.int64); Efake[0, 0] = esum.astype(np.int64)
+    mufake = np.zeros((1,) + sum_mu.shape[:1] + (1,) + sum_mu.shape[1:], dtype=np.int64)
+    mufake[0, :, 0, :] = sum_mu.astype(np.int64)
+    for _ in range(m):
+        gr += rn.sample_gamma(rs, mufake); er += rn.sample_eta(rs, Efake)
+    d = 0.1 + esum.T.astype(np.float64)
+    mean = d / d.sum(axis=1, keepdims=True)
+    var = mean * (1 - mean) / (d.sum(axis=1, keepdims=True) + 1)
+    assert np.abs((e_acc / n - mean) / np.sqrt(var / n)).max() < 4.5
+    assert np.abs((e_acc / n - er / m) / np.sqrt(var / n + var / m)).max() < 4.5
+    np.testing.assert_allclose(e2 / n - (e_acc / n) ** 2, var, rtol=0.2)
+    a = 0.1 + sum_mu.astype(np.float64)
+    gm = a / a.sum(axis=1, keepdims=True)
+    gv = gm * (1 - gm) / (a.sum(axis=1, keepdims=True) + 1)
+    assert np.abs((g_acc / n - gr / m) / np.sqrt(gv / n + gv / m + 1e-14)).max() < 4.5
+    # rowprior = Dirichlet log-prior of each row (Desman_Utils.py:35-44)
+    g, e, rp = cbind.dirichlet_counter(sum_mu, esum, seed=77, it=0)
+    S, G = g.shape
+    assert rp.sum() + 0.0 == pytest.approx(cbind.logprior(g, e, 0), rel=1e-12)
+
+
 # ---------------------------------------------------------------- f4: accessory genes
 @pytest.mark.parametrize("name", ["gene_assign", "gene_assign_lowcov"])
 def test_gene_oracle_reproduces_reference_run(name):

@@ -56,7 +56,7 @@ SIGNATURES = {
     "dsm_ctx_sample_tau": (_i, [_vp, C.POINTER(_i), _vp]),
     "dsm_ctx_sample_stats": (_i, [_vp, C.c_uint32, _u64p, _u64p]),
     "dsm_ctx_stats_spec": (_i, [_vp]),
-    "dsm_ctx_force_stats_v1": (_i, [_vp, _i]),
+    "dsm_ctx_force_stats_spec": (_i, [_vp, _i]),
     "dsm_ctx_debug_stage1": (_i, [_vp, C.c_uint32, _vp, _u64p]),
     "dsm_ctx_debug_binom": (_i, [_vp, _i, C.c_uint32, _f64p, C.c_uint64, _i, _u32p]),
     "dsm_ctx_draw_gamma_eta": (_i, [_vp, C.c_uint32, _u64p, _u64p, _f64p, _f64p]),
@@ -254,8 +254,9 @@ class Context:
             check(r)
         return r
 
-    def force_stats_v1(self, on=True):
-        check(self.lib.dsm_ctx_force_stats_v1(self._h, 1 if on else 0))
+    def force_stats_spec(self, spec=0):
+        """0 = shape rule, 1 = per-read draws everywhere, 2 = aggregated sampler on small problems too (G <= 16)."""
+        check(self.lib.dsm_ctx_force_stats_spec(self._h, int(spec)))
 
     def debug_stage1(self, it):
         nt = np.zeros((self.S, 1 << self.G), dtype=np.uint32)

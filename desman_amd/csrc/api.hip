@@ -193,7 +193,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     free_traces(c);
     dev_free(&c->cnt_vs); dev_free(&c->items); dev_free(&c->nitems); dev_free(&c->tau);
-    dev_free(&c->blk_tab); dev_free(&c->ntab);
+    dev_free(&c->blk_tab); dev_free(&c->ntab); dev_free(&c->big_list); dev_free(&c->big_count);
     dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
     dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->prior); dev_free(&c->prior_all); dev_free(&c->scalars); dev_free(&c->star);
@@ -561,10 +561,10 @@ extern "C" int dsm_ctx_stats_spec(dsm_ctx *c)
     return stats_spec(c);
 }
 
-extern "C" int dsm_ctx_force_stats_v1(dsm_ctx *c, int force_v1)
+extern "C" int dsm_ctx_force_stats_spec(dsm_ctx *c, int spec)
 {
-    if (!c) return DSM_ERR_ARG;
-    c->force_stats_v1 = force_v1 != 0;
+    if (!c || spec < 0 || spec > 2) return DSM_ERR_ARG;
+    c->force_stats_spec = spec;
     return DSM_OK;
 }
 
@@ -681,11 +681,13 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
         // ahead (never beyond the last sweep: the stream position must equal the reference's)
         u_next = nullptr;
         if (it + 1 < n_iter) TRY(fill_sweep_uniforms(c, &u_next));
-        TRY(k_stats(c, ic));                                             // sampleMu  (:341)
+        // sampleMu (:341): spec v2 = stage 1 here, stage 2 inside the Dirichlet launch; spec v1 = the per-read pass
+        const bool agg = stats_spec(c) == 2;
+        TRY(agg ? k_stats_stage1(c, ic) : k_stats_v1(c, ic));
         // sampleGamma (:342) + the eta draw (:347: eta depends only on the E sums) + traces; the same
         // launch finalizes iteration it-1 (ll, lp, MAP test :349-353) in one extra workgroup
         TRY(k_dirichlet(c, ic, c->gamma, c->gamma_trace + (size_t)it * sg, c->eta_new, c->eta_trace + (size_t)it * 16,
-                        P[it & 1], it - 1, nb_prev, P[(it - 1) & 1]));
+                        P[it & 1], it - 1, nb_prev, P[(it - 1) & 1], agg ? 1 : 0));
         TRY(await_sweep_uniforms(c, u));
         // tau sweep with (gamma_new, eta_old) (:345) + log-likelihood of the new state with eta_new (:349)
         TRY(k_tau_sweep(c, 3, c->gamma, c->eta, c->eta_new, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb_prev, u));

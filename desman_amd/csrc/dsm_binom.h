@@ -3,19 +3,22 @@
 // is built with -ffp-contract=off, division and sqrt are IEEE, so the two agree bit for bit).
 //
 //   draw_reads<K>   x reads over K categories, read by read against 32-bit thresholds (x <= DSM_XS)
-//   binom_small     Binomial by sequential-search inversion on the rarer outcome, chunked so that a
-//                   chunk's mean is <= 16; (1-q)^c by repeated squaring: no transcendental function
-//   binom_big       the same below mean 16, Hoermann's BTRS (1993) above (counts up to 2^32-1)
-//   mult4           x reads over the four true bases: heaviest base peeled off by one binomial
+//   binom           Binomial(n, p): sequential-search inversion on the rarer outcome while its mean is <= 64
+//                   ((1-q)^n by repeated squaring: no transcendental function), Hoermann's BTRS (1993) above
+//   mult4           x reads over the four true bases: heaviest base peeled off by one binomial, the few
+//                   others read by read
 #pragma once
 #include "dsm_device.h"
 
 #define DSM_STREAM_STA1 0x53544131u   // 'STA1'  stage-1 cell streams
 #define DSM_STREAM_STA2 0x53544132u   // 'STA2'  stage-2 binomial streams
 #define DSM_STREAM_TEST 0x54455354u   // 'TEST'  test hook
-#define DSM_XS 12u                    // counts up to DSM_XS are drawn read by read
-#define DSM_BINV_MEAN_CAP 16.0
-#define DSM_RCP_TAB_N 64              // 1/k for k < 64, staged in LDS by the kernels (entry 0 unused)
+#define DSM_XS 128u                   // up to DSM_XS non-dominant reads are drawn read by read
+#define DSM_BINV_MEAN_CAP 64.0        // inversion while the mean of the rarer outcome is <= 64, BTRS above: on a
+                                      // 64-lane wavefront BTRS costs ~1500 instructions (some lane always takes the
+                                      // slow path / another attempt), the search 14 per step
+#define DSM_BINV_KMAX 255u
+#define DSM_RCP_TAB_N 256             // 1/k for k < 256, staged in LDS by the kernels (entry 0 unused)
 
 __device__ __forceinline__ Xo128 xo_seed(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
@@ -73,50 +76,21 @@ __device__ __forceinline__ void draw_reads(Xo128 &rng, uint32_t x, const double 
     n[K - 1] = x - c[K - 2];
 }
 
-// rcp: LDS table of the correctly rounded 1/k, k < DSM_RCP_TAB_N (the oracle divides)
-__device__ __forceinline__ uint32_t binv_chunk(Xo128 &rng, uint32_t c, double f0, double r, const double *__restrict__ rcp)
+// Binomial(c, q) by sequential search from 0 (c q <= 64): f0 = (1-q)^c, r = q/(1-q); the search stops at
+// DSM_BINV_KMAX = 255, so 1/k always comes from the LDS table rcp (correctly rounded 1/k: the oracle divides)
+__device__ __forceinline__ uint32_t binv(Xo128 &rng, uint32_t c, double f0, double r, const double *__restrict__ rcp)
 {
+    // P(k)/P(k-1) = r (c-k+1)/k = r (c+1) (1/k) - r: one fma and one multiply per step
     double u = xo_u01(rng), f = f0;
+    const double rc1 = r * ((double)c + 1.0);
     uint32_t k = 0;
-    while (u >= f && k < c) {
+    const uint32_t kend = c < DSM_BINV_KMAX ? c : DSM_BINV_KMAX;
+    while (u >= f && k < kend) {
         u = u - f;
         k = k + 1;
-        const double inv = (k < DSM_RCP_TAB_N) ? rcp[k] : 1.0 / (double)k;
-        f = (f * (r * (double)(c - k + 1))) * inv;
+        f = f * fma(rc1, rcp[k], -r);
     }
     return k;
-}
-
-__device__ __forceinline__ uint32_t binom_inv(Xo128 &rng, uint32_t n, double ws, double wl, const double *__restrict__ rcp)
-{
-    const double T = ws + wl;
-    const double omq = wl / T;
-    const double r = ws / wl;
-    uint32_t cap = n;
-    if ((double)n * ws > DSM_BINV_MEAN_CAP * T) {
-        const double capd = floor(DSM_BINV_MEAN_CAP * T / ws);
-        cap = capd >= (double)n ? n : (uint32_t)capd;
-    }
-    uint32_t total = 0, left = n;
-    double f_full = 0.0;
-    if (left >= cap) f_full = dsm_pw(omq, cap);
-    while (left > 0) {
-        const uint32_t c = left < cap ? left : cap;
-        const double f0 = (c == cap) ? f_full : dsm_pw(omq, c);
-        total += binv_chunk(rng, c, f0, r, rcp);
-        left -= c;
-    }
-    return total;
-}
-
-__device__ __forceinline__ uint32_t binom_small(Xo128 &rng, uint32_t n, double wa, double wb, const double *__restrict__ rcp)
-{
-    if (n == 0 || !(wa > 0.0)) return 0;
-    if (!(wb > 0.0)) return n;
-    const bool flip = wa > wb;
-    const double ws = flip ? wb : wa, wl = flip ? wa : wb;
-    const uint32_t k = binom_inv(rng, n, ws, wl, rcp);
-    return flip ? n - k : k;
 }
 
 __device__ __forceinline__ double stirling_tail(double k)
@@ -129,80 +103,101 @@ __device__ __forceinline__ double stirling_tail(double k)
              : i == 6 ? 0.0118967099458917 : i == 7 ? 0.0104112652619720 : i == 8 ? 0.00925546218271273
              : 0.00833056343336287;
     }
-    const double kp1 = k + 1.0, kp1sq = kp1 * kp1;
-    return (1.0 / 12.0 - (1.0 / 360.0 - (1.0 / 1260.0) / kp1sq) / kp1sq) / kp1;
+    const double inv = 1.0 / (k + 1.0), inv2 = inv * inv;
+    return (1.0 / 12.0 - (1.0 / 360.0 - (1.0 / 1260.0) * inv2) * inv2) * inv;
 }
 
-// q <= 1/2, n q > 16
-__device__ __noinline__ uint32_t btrs(Xo128 &rng, uint32_t n, double q, const double2 *__restrict__ ltab)
+// Hoermann's BTRS, q <= 1/2, n q > 64 (the rare path of the stage-1 kernel once the chain has converged)
+__device__ __forceinline__ uint32_t btrs(uint32_t &s0, uint32_t &s1, uint32_t &s2, uint32_t &s3, uint32_t n, double q,
+                                      const double2 *__restrict__ ltab)
 {
+    Xo128 rng{s0, s1, s2, s3};
     const double nd = (double)n;
     const double spq = sqrt(nd * q * (1.0 - q));
     const double b = 1.15 + 2.53 * spq;
     const double a = -0.0873 + 0.0248 * b + 0.01 * q;
     const double c = nd * q + 0.5;
-    const double v_r = 0.92 - 4.2 / b;
+    const double ib = 1.0 / b;
+    const double v_r = 0.92 - 4.2 * ib;
+    const double alpha = (2.83 + 5.1 * ib) * spq;
     const double r = q / (1.0 - q);
-    const double alpha = (2.83 + 5.1 / b) * spq;
     const double m = floor((nd + 1.0) * q);
+    const double nm1 = nd - m + 1.0;
+    const double h = (m + 0.5) * dsm_log_core((m + 1.0) / (r * nm1), ltab) + stirling_tail(m) + stirling_tail(nd - m);
+    uint32_t res = (uint32_t)m;
     for (int attempt = 0; attempt < 4096; ++attempt) {
         const double u = xo_u01(rng) - 0.5;
         const double v = xo_u01(rng);
         const double us = 0.5 - fabs(u);
         const double kd = floor((2.0 * a / us + b) * u + c);
         if (kd < 0.0 || kd > nd) continue;
-        if (us >= 0.07 && v <= v_r) return (uint32_t)kd;
-        const double lv = dsm_log(v * alpha / (a / (us * us) + b), ltab);
-        const double ub = (m + 0.5) * dsm_log((m + 1.0) / (r * (nd - m + 1.0)), ltab)
-                          + (nd + 1.0) * dsm_log((nd - m + 1.0) / (nd - kd + 1.0), ltab)
-                          + (kd + 0.5) * dsm_log(r * (nd - kd + 1.0) / (kd + 1.0), ltab)
-                          + stirling_tail(m) + stirling_tail(nd - m) - stirling_tail(kd) - stirling_tail(nd - kd);
-        if (lv <= ub) return (uint32_t)kd;
+        if (us >= 0.07 && v <= v_r) { res = (uint32_t)kd; break; }
+        const double nk1 = nd - kd + 1.0;
+        const double lv = dsm_log_core(v * alpha, ltab) - dsm_log_core(a / (us * us) + b, ltab);     // arguments are positive normal numbers
+        const double ub = h + (nd + 1.0) * dsm_log_core(nm1 / nk1, ltab) + (kd + 0.5) * dsm_log_core(r * nk1 / (kd + 1.0), ltab)
+                          - stirling_tail(kd) - stirling_tail(nd - kd);
+        if (lv <= ub) { res = (uint32_t)kd; break; }
     }
-    return (uint32_t)m;
+    s0 = rng.s0; s1 = rng.s1; s2 = rng.s2; s3 = rng.s3;
+    return res;
 }
 
-__device__ __forceinline__ uint32_t binom_big(Xo128 &rng, uint32_t n, double wa, double wb, const double *__restrict__ rcp,
-                                              const double2 *__restrict__ ltab)
+// successes among n trials with success : failure odds wa : wb.  BIG = false is the inversion-only form of the
+// lean stage-1 kernel: a draw that needs BTRS sets `defer` instead (the item is re-done by the compacted kernel).
+template <bool BIG>
+__device__ __forceinline__ uint32_t binom(Xo128 &rng, uint32_t n, double wa, double wb, const double *__restrict__ rcp,
+                                          const double2 *__restrict__ ltab, bool &defer)
 {
     if (n == 0 || !(wa > 0.0)) return 0;
     if (!(wb > 0.0)) return n;
     const bool flip = wa > wb;
-    const double ws = flip ? wb : wa, wl = flip ? wa : wb;
+    const double ws = flip ? wb : wa, wl = flip ? wa : wb;         // the rarer outcome has odds ws : wl
     const double T = ws + wl;
     uint32_t k;
-    if ((double)n * ws > DSM_BINV_MEAN_CAP * T) k = btrs(rng, n, ws / T, ltab);
-    else k = binom_inv(rng, n, ws, wl, rcp);
+    if ((double)n * ws > DSM_BINV_MEAN_CAP * T) {
+        if constexpr (BIG) k = btrs(rng.s0, rng.s1, rng.s2, rng.s3, n, ws / T, ltab);
+        else { defer = true; return 0; }
+    } else k = binv(rng, n, dsm_pw(wl / T, n), ws / wl, rcp);
     return flip ? n - k : k;
 }
 
-__device__ __forceinline__ void mult4(Xo128 &rng, uint32_t x, const double (&W)[4], uint32_t (&n)[4], const double *__restrict__ rcp)
+template <bool BIG>
+__device__ __forceinline__ void mult4(Xo128 &rng, uint32_t x, const double (&W)[4], uint32_t (&n)[4], const double *__restrict__ rcp,
+                                      const double2 *__restrict__ ltab, bool &defer)
 {
     n[0] = n[1] = n[2] = n[3] = 0;
     if (x == 0) return;
-    if (x <= DSM_XS) { draw_reads<4>(rng, x, W, n); return; }
     int am = 0;
     double wm = W[0];
 #pragma unroll
     for (int a = 1; a < 4; ++a) if (W[a] > wm) { wm = W[a]; am = a; }
-    // the three other bases in ascending order: index j skips am
+    // the three other bases in ascending order: position j holds base j (j < am) or j + 1
     double wo[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int a_lo = j, a_hi = j + 1;                  // candidate indices: j if j < am else j + 1
-        wo[j] = (j < am) ? W[a_lo] : W[a_hi];
-    }
+    for (int j = 0; j < 3; ++j) wo[j] = (j < am) ? W[j] : W[j + 1];
     const double ws = (wo[0] + wo[1]) + wo[2];
-    const uint32_t m = binom_small(rng, x, ws, wm, rcp);
-    uint32_t k[3] = {0, 0, 0};
-    if (m != 0) {
-        if (m <= DSM_XS) draw_reads<3>(rng, m, wo, k);
-        else {
-            k[0] = binom_small(rng, m, wo[0], wo[1] + wo[2], rcp);
-            k[1] = binom_small(rng, m - k[0], wo[1], wo[2], rcp);
-            k[2] = m - k[0] - k[1];
+    // step 0 splits off the reads that are not of the heaviest base (m of them); up to DSM_XS of them are drawn read
+    // by read, more (only possible for the items of the compacted kernel, in practice) by two more binomials
+    uint32_t m = 0, k[3] = {0, 0, 0};
+    if constexpr (!BIG) {
+        m = binom<false>(rng, x, ws, wm, rcp, ltab, defer);
+        if (m > DSM_XS) defer = true;
+        if (defer) return;
+    } else {
+        uint32_t nn = x;
+        double wa = ws, wb = wm;
+        int nst = 1;
+#pragma unroll 1
+        for (int st = 0; st < nst; ++st) {                  // ONE binomial site (the sampler is a large piece of code)
+            const uint32_t kk = binom<true>(rng, nn, wa, wb, rcp, ltab, defer);
+            if (st == 0) {
+                m = kk;
+                if (m > DSM_XS) { nst = 3; nn = m; wa = wo[0]; wb = wo[1] + wo[2]; }
+            } else if (st == 1) { k[0] = kk; nn = m - kk; wa = wo[1]; wb = wo[2]; }
+            else { k[1] = kk; k[2] = m - k[0] - kk; }
         }
     }
+    if (m != 0 && m <= DSM_XS) draw_reads<3>(rng, m, wo, k);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int j = (a < am) ? a : a - 1;                 // position of a among the others

@@ -37,9 +37,12 @@ struct dsm_ctx {
     int max_items = 0;
     bool items_built = false;       // the work list of the per-read pass (spec v1) is built on first use
     uint64_t max_depth = 0;         // largest per-sample read total
-    bool force_stats_v1 = false;    // test hook: per-read pass even where spec v2 applies
+    int force_stats_spec = 0;       // test hook: 1 = per-read pass even where spec v2 applies, 2 = spec v2 on small problems too
     uint32_t *ntab = nullptr;       // [2^G][S] subset counts of the aggregated mu/E pass (spec v2), zero between passes
     size_t ntab_len = 0;
+    unsigned long long *big_list = nullptr;   // stage-1 items deferred to the compacted (BTRS) kernel: cell * 4 + base
+    uint32_t *big_count = nullptr;
+    size_t big_cap = 0;
     int stats_grid = 0;             // resident workgroups of stats_agg_kernel
     int item_stride = 1;            // items per sample row of `items`
     bool chunked = false;           // items carry reads | chunk << 12 (small problems, see dsm_ctx_set_counts)
@@ -127,7 +130,7 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter);
 int k_stats_stage2(dsm_ctx *c, uint32_t iter);
 int k_binom_test(dsm_ctx *c, int kind, uint32_t n, const double *w, uint64_t seed, int nsamp, uint32_t *d_out);
 int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trace, double *eta_out, double *eta_trace,
-                double *prior_out, int fin_it, int fin_nblocks, const double *fin_prior);
+                double *prior_out, int fin_it, int fin_nblocks, const double *fin_prior, int do_s2 = 0);
 int k_prior(dsm_ctx *c, const double *gamma, const double *eta, double *prior_out);
 int k_prior_batch(dsm_ctx *c, const double *gamma, const double *eta, int n, double *prior_out);
 // mode bit0 = sweep, bit1 = log-likelihood epilogue

@@ -1,0 +1,106 @@
+// dsm_stage2.h -- stage 2 of the aggregated mu/E pass (spec: oracle/stats_agg.c, stage2_sample): one workgroup
+// per sample spreads the subset counts N[.][s] over the haplotypes by halving the haplotype range recursively.
+// Node (level, idx) owns the range [lo,hi) and a table of 2^(hi-lo) subset counts; its lower child gets
+// floor(w/2) haplotypes.  A subset that lies in one half passes through; one that straddles is split by one
+// binomial with odds (sum gamma lower : sum gamma upper) from the stream
+// Philox({subset, s | idx << 16 | level << 24, iter, 'STA2'}).  Leaves (w = 1) are sum_mu[s][lo].
+// The tree depends on G only: the host lays it out (S2Plan, kernel argument -> scalar registers), every node
+// below the root has its own zero-initialised LDS table, so a level costs one workgroup barrier.
+// Shared by stats_stage2_kernel (kernels_stats.hip) and dirichlet_kernel (kernels_gibbs.hip, fused form).
+#pragma once
+#include "dsm_binom.h"
+#include "log_table.h"
+
+#define S2_MAX_NODES 32
+#define S2_MAX_LEVELS 6
+#define S2_TAB_ENTRIES 1024
+struct S2Plan {
+    int nlevels, tab_entries;
+    int level_start[S2_MAX_LEVELS + 2];
+    signed char lo[S2_MAX_NODES], hi[S2_MAX_NODES], child[S2_MAX_NODES];
+    unsigned char idx[S2_MAX_NODES];
+    short off[S2_MAX_NODES];
+};
+
+struct Stage2Params {
+    uint32_t *ntab;                 // [2^G][S], zeroed after reading
+    const double *gamma;            // [S][G]
+    unsigned long long *sum_mu;     // [S][G] accumulated into (stand-alone kernel)
+    const double *log_tab;
+    int S, G;
+    uint32_t k0, k1, iter;
+    S2Plan plan;
+};
+
+S2Plan make_stage2_plan(int G);     // kernels_stats.hip
+
+#define S2_SMEM_BYTES (DSM_LOG_TAB_N * 16 + DSM_RCP_TAB_N * 8 + 32 * 8 + S2_TAB_ENTRIES * 4 + 32 * 4 + 5 * S2_MAX_NODES * 4)
+
+// leaf counts end in LDS (returned pointer, [G] u32, valid after the function's final barrier); to_global also adds
+// them to p.sum_mu[s][.]
+__device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, int s, char *smem, bool to_global)
+{
+    const int G = p.G, S = p.S, tid = threadIdx.x;
+    double2 *ltab = reinterpret_cast<double2 *>(smem);                         // [256]
+    double *rcp = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);            // [256]
+    double *gs = rcp + DSM_RCP_TAB_N;                                          // [32]
+    uint32_t *tab = reinterpret_cast<uint32_t *>(gs + 32);                     // [S2_TAB_ENTRIES] tables of all nodes below the root
+    uint32_t *leaf = tab + S2_TAB_ENTRIES;                                     // [32]
+    int *n_lo = reinterpret_cast<int *>(leaf + 32);                            // the plan's node arrays (lane-indexed below)
+    int *n_hi = n_lo + S2_MAX_NODES, *n_off = n_hi + S2_MAX_NODES, *n_idx = n_off + S2_MAX_NODES, *n_child = n_idx + S2_MAX_NODES;
+
+    ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
+    rcp[tid] = tid ? 1.0 / (double)tid : 0.0;
+    if (tid < 32) {
+        gs[tid] = (tid < G) ? p.gamma[(size_t)s * G + tid] : 0.0; leaf[tid] = 0u;
+        n_lo[tid] = p.plan.lo[tid]; n_hi[tid] = p.plan.hi[tid]; n_off[tid] = p.plan.off[tid]; n_idx[tid] = p.plan.idx[tid];
+        n_child[tid] = p.plan.child[tid];
+    }
+    for (int i = tid; i < S2_TAB_ENTRIES; i += 256) tab[i] = 0u;
+    __syncthreads();
+
+    const S2Plan &pl = p.plan;
+    for (int level = 0; level < pl.nlevels; ++level) {
+        // all (node, subset) pairs of the level at once: the tables of a level are contiguous in `tab`, so entry j of
+        // the level belongs to the node whose table covers it (root: the 2^G words of this sample in HBM)
+        const int n0 = pl.level_start[level], n1 = pl.level_start[level + 1];
+        const int base = pl.off[n0];
+        const int total = (level == 0) ? (1 << G) : (pl.off[n1 - 1] + (1 << (pl.hi[n1 - 1] - pl.lo[n1 - 1]))) - base;
+        for (int j = tid; j < total; j += 256) {
+            int i = n0;
+            for (int k = n0 + 1; k < n1; ++k) if (j + base >= pl.off[k]) i = k;      // scalar plan, <= 16 nodes per level
+            const int lo = n_lo[i], hi = n_hi[i], w = hi - lo;
+            const uint32_t Hs = (uint32_t)(j + base - n_off[i]);
+            if (Hs == 0) continue;
+            uint32_t n;
+            if (level == 0) {
+                uint32_t *cell = p.ntab + (size_t)Hs * S + s;
+                n = *cell;
+                if (n) *cell = 0u;
+            } else n = tab[base + j];
+            if (w == 1) {                                   // leaf: Hs == 1
+                leaf[lo] = n;
+                if (to_global && n) p.sum_mu[(size_t)s * G + lo] += n;
+                continue;
+            }
+            if (!n) continue;
+            const int wl = w / 2, wh = w - wl, mid = lo + wl;
+            const int ch = n_child[i];
+            uint32_t *L = tab + n_off[ch], *R = tab + n_off[ch + 1];
+            const uint32_t HL = Hs & ((1u << wl) - 1u), HR = Hs >> wl;
+            if (!HR) { atomicAdd(&L[HL], n); continue; }
+            if (!HL) { atomicAdd(&R[HR], n); continue; }
+            double wL = 0.0, wR = 0.0;
+            for (int jj = 0; jj < wl; ++jj) if ((HL >> jj) & 1u) wL = wL + gs[lo + jj];
+            for (int jj = 0; jj < wh; ++jj) if ((HR >> jj) & 1u) wR = wR + gs[mid + jj];
+            Xo128 rng = xo_seed(Hs, (uint32_t)s | ((uint32_t)n_idx[i] << 16) | ((uint32_t)level << 24), p.iter, DSM_STREAM_STA2,
+                                p.k0, p.k1);
+            bool dummy = false;
+            const uint32_t k = binom<true>(rng, n, wL, wR, rcp, ltab, dummy);
+            if (k) atomicAdd(&L[HL], k);
+            if (n - k) atomicAdd(&R[HR], n - k);
+        }
+        __syncthreads();
+    }
+    return leaf;
+}

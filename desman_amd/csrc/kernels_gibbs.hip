@@ -11,6 +11,7 @@
 // sweep, [S][V][4] lane=variant for the per-read pass), tau packed 2 bits per
 // haplotype in one u64 per variant, gamma [S][G] f64, eta [4][4] f64.
 #include "dsm_device.h"
+#include "dsm_stage2.h"
 #include "dsm_host.h"
 #include "log_table.h"
 
@@ -398,6 +399,8 @@ __device__ double gamma_variate(double shape, uint32_t idx, uint32_t iter, uint3
 // One workgroup per row (S gamma rows + 4 eta rows; its first wavefront does the work): lane g
 // draws variate g, the row is normalised lane-parallel and writes its log-prior term to rowprior[row] (summed by finalize in a
 // fixed order).  Rows are independent, so the launch fills S+4 CUs instead of one.
+// do_s2: the gamma rows first run stage 2 of the aggregated mu/E pass for their sample (dsm_stage2.h, all 256 threads): the
+// sums the draw needs never leave the workgroup's LDS and the iteration has one launch less.
 __global__ __launch_bounds__(256) void dirichlet_kernel(unsigned long long *__restrict__ sum_mu,
                                                        unsigned long long *__restrict__ esum, int S, int G,
                                                        double alpha, double delta, double epsilon,
@@ -406,24 +409,29 @@ __global__ __launch_bounds__(256) void dirichlet_kernel(unsigned long long *__re
                                                        double *__restrict__ gamma_out,
                                                        double *__restrict__ gamma_trace,
                                                        double *__restrict__ eta_out, double *__restrict__ eta_trace,
-                                                       double *__restrict__ rowprior, int do_fin, FinalParams fin)
+                                                       double *__restrict__ rowprior, int do_fin, FinalParams fin,
+                                                       int do_s2, Stage2Params s2)
 {
+    __shared__ __attribute__((aligned(16))) char smem_d[S2_SMEM_BYTES];   // stage 2 / finalize scratch (never both)
     if (do_fin && (int)blockIdx.x == S + 4) {            // extra workgroup: finalize the PREVIOUS iteration
-        __shared__ double red[256], redp[256];
-        __shared__ int flag;
-        finalize_body(fin, red, redp, &flag, threadIdx.x, 256);
+        double *red = reinterpret_cast<double *>(smem_d), *redp = red + 256;
+        int *flag = reinterpret_cast<int *>(redp + 256);
+        finalize_body(fin, red, redp, flag, threadIdx.x, 256);
         return;
     }
-    if (threadIdx.x >= 64) return;                       // a row needs one wavefront (no workgroup barriers below)
-    const int row = blockIdx.x, lane = threadIdx.x;
+    const int row = blockIdx.x;
     const bool is_gamma = row < S;
+    const uint32_t *leaf = nullptr;
+    if (do_s2 && is_gamma) leaf = stage2_sample(s2, row, smem_d, false);      // workgroup-uniform branch; ends with a barrier
+    if (threadIdx.x >= 64) return;                       // the draw needs one wavefront (no workgroup barriers below)
+    const int lane = threadIdx.x;
     const int n = is_gamma ? G : 4;
     const int SG = S * G;
     double y = 0.0;
     if (lane < n) {
         double shape;
         uint32_t vid;                                   // variate id: the spec's flat index
-        if (is_gamma) { vid = (uint32_t)(row * G + lane); shape = alpha + (double)sum_mu[vid]; }
+        if (is_gamma) { vid = (uint32_t)(row * G + lane); shape = alpha + (double)(sum_mu[vid] + (leaf ? (unsigned long long)leaf[lane] : 0ull)); }
         else { const int a = row - S; vid = (uint32_t)(SG + a * 4 + lane); shape = delta + (double)esum[lane * 4 + a]; }
         y = gamma_variate(shape, vid, iter, k0, k1);
         if (zero_after) { if (is_gamma) sum_mu[row * G + lane] = 0ull; else esum[lane * 4 + (row - S)] = 0ull; }
@@ -790,7 +798,7 @@ static FinalParams make_final(dsm_ctx *c, int nblocks, int it, int star_mode, co
 
 // fin_it >= 0: the launch also finalizes iteration fin_it (traces of that iteration are its gamma/eta source)
 int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trace, double *eta_out, double *eta_trace,
-                double *prior_out, int fin_it, int fin_nblocks, const double *fin_prior)
+                double *prior_out, int fin_it, int fin_nblocks, const double *fin_prior, int do_s2)
 {
     KTimer tm(c, DSM_K_DIRICH);
     double lg, le;
@@ -801,9 +809,17 @@ int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trac
     if (do_fin)
         fin = make_final(c, fin_nblocks, fin_it, 0, fin_prior, c->gamma_trace + (size_t)fin_it * c->S * c->G,
                          c->eta_trace + (size_t)fin_it * 16);
+    Stage2Params s2 = {};
+    if (do_s2) {
+        // stage 2 splits the subset counts with the gamma the mu/E pass used = the resident one; gamma_out may be the same
+        // buffer: workgroup s stages row s in LDS before it writes the new row s, and no other workgroup reads that row
+        s2.ntab = c->ntab; s2.gamma = c->gamma; s2.sum_mu = c->sum_mu; s2.log_tab = c->log_tab;
+        s2.S = c->S; s2.G = c->G; s2.k0 = k0; s2.k1 = k1; s2.iter = iter;
+        s2.plan = make_stage2_plan(c->G);
+    }
     hipLaunchKernelGGL(dirichlet_kernel, dim3(c->S + 4 + do_fin), dim3(256), 0, c->stream, c->sum_mu, c->esum, c->S, c->G,
                        c->alpha, c->delta, c->epsilon, lg, le, k0, k1, iter, 1, gamma_out, gamma_trace, eta_out, eta_trace,
-                       prior_out, do_fin, fin);
+                       prior_out, do_fin, fin, do_s2, s2);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }

@@ -7,13 +7,18 @@
 //                        Gamma_a accumulation are scalar.  Per lane: Multinomial(x_b; eta[a,b] Gamma_a) for the
 //                        four observed bases (dsm_binom.h: mult4) -> Esum (lane-private LDS columns) and the
 //                        subset counts N[H_a(v)][s] (one coalesced row of global atomics per true base).
-//                        Cost per cell ~ O(G + errors), independent of the read depth.
+//                        Cost per cell ~ O(G + errors).  Inversion only: an item whose rarer outcome has a mean
+//                        above 64 is pushed onto a work list instead (lean kernel: 64 VGPRs, no rejection loop).
+//   stats_big_kernel     the listed items, one lane each (compacted: every lane runs BTRS, no idle lanes); cost
+//                        O(1) in the depth.  Items are independent work units (own Philox stream each).
 //   stats_stage2_kernel  stage 2: one workgroup per sample spreads N[.][s] over the haplotypes by recursive
 //                        halving of the haplotype range (one large-count binomial per (node, subset): BTRS).
 //   stats v1 (per-read draws, kernels_gibbs.hip: stats_kernel) remains for G > 16 / tables above 64 MB.
 #include "dsm_binom.h"
 #include "dsm_host.h"
 #include "log_table.h"
+
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -26,6 +31,9 @@ struct StatsAggParams {
     uint32_t k0, k1, iter;
     uint32_t *ntab;                 // [2^G][S]
     unsigned long long *esum;       // [16]
+    const double *log_tab;
+    unsigned long long *big_list;   // deferred items: cell * 4 + observed base
+    uint32_t *big_count;            // [1]
 };
 
 __device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t x)
@@ -49,7 +57,7 @@ __global__ __launch_bounds__(256) void stats_agg_kernel(StatsAggParams p)
         const int g = i / SP, s = i - g * SP;
         gT[i] = (s < S) ? p.gamma[(size_t)s * G + g] : 0.0;
     }
-    if (tid < DSM_RCP_TAB_N) rcp[tid] = tid ? 1.0 / (double)tid : 0.0;
+    rcp[tid] = tid ? 1.0 / (double)tid : 0.0;
     if (tid < 16) { es[tid] = p.eta[tid]; acc[tid] = 0ull; }
 #pragma unroll
     for (int i = 0; i < 16; ++i) eacc[i * 256 + tid] = 0u;
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(256) void stats_agg_kernel(StatsAggParams p)
             else { H3 |= bit; G3 = G3 + x; }
         }
         const double Gam[4] = {G0, G1, G2, G3};
-        Xo128 rng = xo_seed((uint32_t)s * (uint32_t)V + (uint32_t)v, 0u, p.iter, DSM_STREAM_STA1, p.k0, p.k1);
+        const uint32_t cell = (uint32_t)s * (uint32_t)V + (uint32_t)v;
         uint32_t nacc[4] = {0, 0, 0, 0};
 #pragma unroll 1
         for (int b = 0; b < 4; ++b) {
@@ -95,10 +103,24 @@ __global__ __launch_bounds__(256) void stats_agg_kernel(StatsAggParams p)
                     for (int a = 0; a < 4; ++a) W[a] = Gam[a];
                 }
                 uint32_t n[4];
-                mult4(rng, (uint32_t)xb, W, n, rcp);
-                uint32_t *erow = eacc + (b * 4) * 256 + tid;
+                Xo128 rng = xo_seed(cell, (uint32_t)b, p.iter, DSM_STREAM_STA1, p.k0, p.k1);
+                bool defer = false;
+                mult4<false>(rng, (uint32_t)xb, W, n, rcp, nullptr, defer);
+                if (__builtin_expect(defer, 0)) {
+                    // needs the rejection sampler: the compacted kernel re-does this item from its own stream
+                    // (one atomic per wavefront: the deferring lanes take consecutive slots)
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(true);
+                    const int leader = __builtin_ctzll(mask);
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(p.big_count, (uint32_t)__builtin_popcountll(mask));
+                    base = __shfl(base, leader, 64);
+                    const uint32_t slot = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                    p.big_list[slot] = (unsigned long long)cell * 4ull + (unsigned long long)b;
+                } else {
+                    uint32_t *erow = eacc + (b * 4) * 256 + tid;
 #pragma unroll
-                for (int a = 0; a < 4; ++a) { erow[a * 256] += n[a]; nacc[a] += n[a]; }
+                    for (int a = 0; a < 4; ++a) { erow[a * 256] += n[a]; nacc[a] += n[a]; }
+                }
             }
         }
         // N[H_a(v)][s] += reads whose true base is a: adjacent lanes -> adjacent words of one table row
@@ -121,112 +143,79 @@ __global__ __launch_bounds__(256) void stats_agg_kernel(StatsAggParams p)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// stage 2: one workgroup per sample.  Node (level, idx) owns the haplotype range [lo,hi) and a table of
-// 2^(hi-lo) subset counts; its lower child gets floor(w/2) haplotypes.  A subset that lies in one half
-// passes through; one that straddles is split by one binomial with odds (sum gamma lower : sum gamma upper),
-// drawn from the stream Philox({subset, s | idx << 16 | level << 24, iter, 'STA2'}).  Leaves (w = 1) are
-// sum_mu[s][lo].  The level-0 table is read from (and zeroed in) HBM, deeper levels live in LDS.
+// the deferred items (rarer outcome with a mean above 64: burn-in states, very deep data), one lane per item:
+// the same arithmetic as stats_agg_kernel with the full sampler (BTRS).  tau_v differs from lane to lane here,
+// so the haplotype sets / abundances are built with vector selects.
 // ---------------------------------------------------------------------------------------------------
-#define S2_MAX_NODES 32
-struct Stage2Params {
-    uint32_t *ntab;                 // [2^G][S], zeroed after reading
-    const double *gamma;            // [S][G]
-    unsigned long long *sum_mu;     // [S][G] accumulated into
-    const double *log_tab;
-    int S, G;
-    uint32_t k0, k1, iter;
-};
-
-__device__ void stage2_sample(const Stage2Params &p, int s, char *smem)
+__global__ __launch_bounds__(256) void stats_big_kernel(StatsAggParams p)
 {
-    const int G = p.G, S = p.S, tid = threadIdx.x;
-    double2 *ltab = reinterpret_cast<double2 *>(smem);                         // [256]
-    double *rcp = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);            // [64]
-    double *gs = rcp + DSM_RCP_TAB_N;                                          // [32]
-    uint32_t *tabA = reinterpret_cast<uint32_t *>(gs + 32);                    // [512] level tables, ping
-    uint32_t *tabB = tabA + 512;                                               // [512] pong
-    int *nlo = reinterpret_cast<int *>(tabB + 512);                            // node arrays of the current level [S2_MAX_NODES]
-    int *nhi = nlo + S2_MAX_NODES, *noff = nhi + S2_MAX_NODES, *nidx = noff + S2_MAX_NODES;
-    int *mlo = nidx + S2_MAX_NODES, *mhi = mlo + S2_MAX_NODES, *moff = mhi + S2_MAX_NODES, *midx = moff + S2_MAX_NODES;
-    int *ncount = midx + S2_MAX_NODES;                                         // [2] nodes at the current / next level
-
+    __shared__ double2 ltab[DSM_LOG_TAB_N];
+    __shared__ double rcp[DSM_RCP_TAB_N];
+    __shared__ double es[16];
+    __shared__ unsigned long long acc[16];
+    __shared__ uint32_t eacc[16 * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t nbig = *p.big_count;
+    if (nbig == 0) return;
     ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
-    if (tid < DSM_RCP_TAB_N) rcp[tid] = tid ? 1.0 / (double)tid : 0.0;
-    if (tid < 32) gs[tid] = (tid < G) ? p.gamma[(size_t)s * G + tid] : 0.0;
-    for (int i = tid; i < 1024; i += 256) tabA[i] = 0u;
-    if (tid == 0) { nlo[0] = 0; nhi[0] = G; noff[0] = 0; nidx[0] = 0; ncount[0] = 1; }
+    rcp[tid] = tid ? 1.0 / (double)tid : 0.0;
+    if (tid < 16) { es[tid] = p.eta[tid]; acc[tid] = 0ull; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) eacc[i * 256 + tid] = 0u;
     __syncthreads();
-
-    uint32_t *cur = tabA, *nxt = tabB;      // level >= 1 tables (level 0 is in HBM)
-    for (int level = 0;; ++level) {
-        const int nn = ncount[0];
-        if (nn == 0) break;
-        // thread 0 lays out the next level
-        if (tid == 0) {
-            int m = 0, off = 0;
-            for (int i = 0; i < nn; ++i) {
-                const int lo = nlo[i], hi = nhi[i], w = hi - lo;
-                if (w == 1) continue;
-                const int wl = w / 2, mid = lo + wl;
-                mlo[m] = lo; mhi[m] = mid; moff[m] = off; midx[m] = 2 * nidx[i]; off += 1 << wl; ++m;
-                mlo[m] = mid; mhi[m] = hi; moff[m] = off; midx[m] = 2 * nidx[i] + 1; off += 1 << (w - wl); ++m;
-            }
-            ncount[1] = m;
+    const int V = p.V, S = p.S, G = p.G;
+    for (uint32_t i = blockIdx.x * 256 + tid; i < nbig; i += gridDim.x * 256) {
+        const unsigned long long item = p.big_list[i];
+        const uint32_t cell = (uint32_t)(item >> 2);
+        const int b = (int)(item & 3ull);
+        const int s = (int)(cell / (uint32_t)V), v = (int)(cell - (uint32_t)s * (uint32_t)V);
+        const uint64_t t = p.tau[v];
+        const int xb = p.cnt_vs[((size_t)v * S + s) * 4 + b];
+        uint32_t H[4] = {0, 0, 0, 0};
+        double Gam[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int g = 0; g < G; ++g) {
+            const int a = (int)((t >> (2 * g)) & 3);
+            const double x = p.gamma[(size_t)s * G + g];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (a == k) { H[k] |= 1u << g; Gam[k] = Gam[k] + x; }
         }
-        __syncthreads();
-        int child = 0;
-        for (int i = 0; i < nn; ++i) {
-            const int lo = nlo[i], hi = nhi[i], w = hi - lo;
-            const uint32_t *T = cur + noff[i];
-            if (w == 1) {
-                if (tid == 0) {
-                    const uint32_t cnt = (level == 0) ? p.ntab[(size_t)1 * S + s] : T[1];
-                    if (level == 0) p.ntab[(size_t)1 * S + s] = 0u;
-                    if (cnt) p.sum_mu[(size_t)s * G + lo] += cnt;
-                }
-                continue;
-            }
-            const int wl = w / 2, wh = w - wl, mid = lo + wl;
-            uint32_t *L = nxt + moff[child], *R = nxt + moff[child + 1];
-            child += 2;
-            for (uint32_t Hs = 1u + tid; Hs < (1u << w); Hs += 256) {
-                uint32_t n;
-                if (level == 0) {
-                    uint32_t *cell = p.ntab + (size_t)Hs * S + s;
-                    n = *cell;
-                    if (n) *cell = 0u;
-                } else n = T[Hs];
-                if (!n) continue;
-                const uint32_t HL = Hs & ((1u << wl) - 1u), HR = Hs >> wl;
-                if (!HR) { atomicAdd(&L[HL], n); continue; }
-                if (!HL) { atomicAdd(&R[HR], n); continue; }
-                double wL = 0.0, wR = 0.0;
-                for (int jj = 0; jj < wl; ++jj) if ((HL >> jj) & 1u) wL = wL + gs[lo + jj];
-                for (int jj = 0; jj < wh; ++jj) if ((HR >> jj) & 1u) wR = wR + gs[mid + jj];
-                Xo128 rng = xo_seed(Hs, (uint32_t)s | ((uint32_t)nidx[i] << 16) | ((uint32_t)level << 24), p.iter,
-                                    DSM_STREAM_STA2, p.k0, p.k1);
-                const uint32_t k = binom_big(rng, n, wL, wR, rcp, ltab);
-                if (k) atomicAdd(&L[HL], k);
-                if (n - k) atomicAdd(&R[HR], n - k);
-            }
+        double W[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) W[a] = es[a * 4 + b] * Gam[a];
+        const double Wt = ((W[0] + W[1]) + W[2]) + W[3];
+        if (!(Wt > 0.0)) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) W[a] = Gam[a];
         }
-        __syncthreads();
-        // next level becomes current: metadata, tables (the old current table is cleared for re-use)
-        const int m = ncount[1];
-        if (tid < m) { nlo[tid] = mlo[tid]; nhi[tid] = mhi[tid]; noff[tid] = moff[tid]; nidx[tid] = midx[tid]; }
-        if (tid == 0) ncount[0] = m;
-        for (int i = tid; i < 512; i += 256) cur[i] = 0u;
-        uint32_t *tswap = cur; cur = nxt; nxt = tswap;
-        __syncthreads();
+        uint32_t n[4];
+        Xo128 rng = xo_seed(cell, (uint32_t)b, p.iter, DSM_STREAM_STA1, p.k0, p.k1);
+        bool defer = false;
+        mult4<true>(rng, (uint32_t)xb, W, n, rcp, ltab, defer);
+        uint32_t *erow = eacc + (b * 4) * 256 + tid;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            erow[a * 256] += n[a];
+            if (n[a]) atomicAdd(p.ntab + (size_t)H[a] * S + s, n[a]);
+        }
     }
+    {
+        uint32_t e[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) e[i] = eacc[i * 256 + tid];
+        const uint32_t tot = wave_transpose_reduce<16>(e);
+        const int idx = transpose_index<16>(lane);
+        if (lane < 16 && tot) atomicAdd(&acc[idx], (unsigned long long)tot);
+    }
+    __syncthreads();
+    if (tid < 16 && acc[tid]) atomicAdd(&p.esum[tid], acc[tid]);
 }
 
-#define S2_SMEM_BYTES (DSM_LOG_TAB_N * 16 + DSM_RCP_TAB_N * 8 + 32 * 8 + 1024 * 4 + (8 * S2_MAX_NODES + 2) * 4)
+#include "dsm_stage2.h"
 
 __global__ __launch_bounds__(256) void stats_stage2_kernel(Stage2Params p)
 {
     __shared__ __attribute__((aligned(16))) char smem2[S2_SMEM_BYTES];
-    stage2_sample(p, blockIdx.x, smem2);
+    stage2_sample(p, blockIdx.x, smem2, true);
 }
 
 // test hook: variate i of a sampler from the stream Philox({i, 0, 0, 'TEST'})  (oracle: orc_binom_test / orc_mult4_test)
@@ -238,17 +227,17 @@ __global__ __launch_bounds__(256) void binom_test_kernel(int kind, uint32_t n, d
     __shared__ double rcp[DSM_RCP_TAB_N];
     const int tid = threadIdx.x;
     ltab[tid] = reinterpret_cast<const double2 *>(log_tab)[tid];
-    if (tid < DSM_RCP_TAB_N) rcp[tid] = tid ? 1.0 / (double)tid : 0.0;
+    rcp[tid] = tid ? 1.0 / (double)tid : 0.0;
     __syncthreads();
     const int i = blockIdx.x * 256 + tid;
     if (i >= nsamp) return;
     Xo128 rng = xo_seed((uint32_t)i, 0u, 0u, DSM_STREAM_TEST, k0, k1);
-    if (kind == 0) out[i] = binom_small(rng, n, wa, wb, rcp);
-    else if (kind == 1) out[i] = binom_big(rng, n, wa, wb, rcp, ltab);
+    bool dummy = false;
+    if (kind != 2) out[i] = binom<true>(rng, n, wa, wb, rcp, ltab, dummy);
     else {
         const double W[4] = {wa, wb, w2, w3};
         uint32_t m[4];
-        mult4(rng, n, W, m, rcp);
+        mult4<true>(rng, n, W, m, rcp, ltab, dummy);
         out[i * 4 + 0] = m[0]; out[i * 4 + 1] = m[1]; out[i * 4 + 2] = m[2]; out[i * 4 + 3] = m[3];
     }
 }
@@ -256,11 +245,13 @@ __global__ __launch_bounds__(256) void binom_test_kernel(int kind, uint32_t n, d
 // =====================================================================
 // host side
 // =====================================================================
-// spec v2 applies when the subset table fits: G <= 16, 2^G * S * 4 B <= 64 MB, every sample's depth < 2^32
+// spec v2 applies when the subset table fits (G <= 16, 2^G * S * 4 B <= 64 MB, every sample's depth < 2^32) and the
+// problem has more than 2^16 cells; the rule depends on the shape (and depth totals) only
 int stats_spec(const dsm_ctx *c)
 {
-    if (c->force_stats_v1) return 1;
+    if (c->force_stats_spec == 1) return 1;
     if (c->G < 1 || c->G > 16) return 1;
+    if ((int64_t)c->V * c->S <= 65536 && c->force_stats_spec != 2) return 1;   // small problems: the per-read pass is a single short launch
     if (((size_t)1 << c->G) * (size_t)c->S * 4 > ((size_t)64 << 20)) return 1;
     if (c->max_depth >= ((uint64_t)1 << 32)) return 1;
     return 2;
@@ -278,10 +269,28 @@ static int ensure_ntab(dsm_ctx *c)
     return DSM_OK;
 }
 
+static int ensure_big_list(dsm_ctx *c)
+{
+    const size_t need = (size_t)c->V * c->S * 4;
+    if (c->big_list && c->big_cap == need) return DSM_OK;
+    if (c->big_list) { (void)hipFree(c->big_list); c->big_list = nullptr; }
+    if (!c->big_count) {
+        hipError_t e = hipMalloc((void **)&c->big_count, sizeof(uint32_t));
+        if (e != hipSuccess) { dsm_set_error("hipMalloc failed: %s", hipGetErrorString(e)); return DSM_ERR_NOMEM; }
+    }
+    hipError_t e = hipMalloc((void **)&c->big_list, need * sizeof(unsigned long long));
+    if (e != hipSuccess) { dsm_set_error("hipMalloc(%zu B) failed: %s", need * 8, hipGetErrorString(e)); return DSM_ERR_NOMEM; }
+    c->big_cap = need;
+    return DSM_OK;
+}
+
 int k_stats_stage1(dsm_ctx *c, uint32_t iter)
 {
     int r = ensure_ntab(c);
     if (r != DSM_OK) return r;
+    r = ensure_big_list(c);
+    if (r != DSM_OK) return r;
+    HIP_TRY(hipMemsetAsync(c->big_count, 0, sizeof(uint32_t), c->stream));
     KTimer tm(c, DSM_K_STATS);
     const int S = c->S, G = c->G, V = c->V;
     const int NCH = (S + 63) / 64, SP = NCH * 64;
@@ -295,15 +304,51 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
         c->stats_grid = std::max(1, occ) * prop.multiProcessorCount;
     }
     const long ntask = (long)V * NCH;
-    const int grid = (int)std::max<long>(1, std::min<long>((ntask + 3) / 4, c->stats_grid));
+    // every wavefront gets the same number of tasks (a task takes ~20 us next to 5 others: a wavefront with one task
+    // more than its neighbours is the whole tail of the launch)
+    const long max_waves = (long)c->stats_grid * 4;
+    const long per_wave = (ntask + max_waves - 1) / max_waves;
+    const long waves = (ntask + per_wave - 1) / per_wave;
+    const int grid = (int)std::max<long>(1, (waves + 3) / 4);
     StatsAggParams p;
     p.cnt_vs = c->cnt_vs; p.tau = c->tau; p.gamma = c->gamma; p.eta = c->eta;
     p.V = V; p.S = S; p.G = G;
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
-    p.ntab = c->ntab; p.esum = c->esum;
+    p.ntab = c->ntab; p.esum = c->esum; p.log_tab = c->log_tab;
+    p.big_list = c->big_list; p.big_count = c->big_count;
     hipLaunchKernelGGL(stats_agg_kernel, dim3(grid), dim3(256), sh, c->stream, p);
+    // the deferred items (none once the chain has converged on data of ordinary depth: the launch then returns at once)
+    const int big_grid = (int)std::max<long>(1, std::min<long>((ntask * 64 * 4 + 255) / 256, 512));
+    hipLaunchKernelGGL(stats_big_kernel, dim3(big_grid), dim3(256), 0, c->stream, p);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
+}
+
+// the halving tree of stage 2 depends on G only: laid out on the host, read through scalar registers on the device
+S2Plan make_stage2_plan(int G)
+{
+    S2Plan pl;
+    memset(&pl, 0, sizeof pl);
+    int n = 0, off = 0;
+    pl.lo[0] = 0; pl.hi[0] = G; pl.off[0] = 0; pl.idx[0] = 0; pl.child[0] = -1;
+    n = 1;
+    int lvl_begin = 0, lvl_end = 1, level = 0;
+    pl.level_start[0] = 0;
+    while (lvl_begin < lvl_end) {
+        for (int i = lvl_begin; i < lvl_end; ++i) {
+            const int w = pl.hi[i] - pl.lo[i];
+            if (w == 1) { pl.child[i] = -1; continue; }
+            const int wl = w / 2, mid = pl.lo[i] + wl;
+            pl.child[i] = n;
+            pl.lo[n] = pl.lo[i]; pl.hi[n] = mid; pl.off[n] = off; pl.idx[n] = 2 * pl.idx[i]; off += 1 << wl; ++n;
+            pl.lo[n] = mid; pl.hi[n] = pl.hi[i]; pl.off[n] = off; pl.idx[n] = 2 * pl.idx[i] + 1; off += 1 << (w - wl); ++n;
+        }
+        lvl_begin = lvl_end; lvl_end = n;
+        pl.level_start[++level] = lvl_begin;
+    }
+    pl.nlevels = level;                 // levels 0 .. nlevels-1 hold nodes; level_start[nlevels] = n
+    pl.tab_entries = off;
+    return pl;
 }
 
 int k_stats_stage2(dsm_ctx *c, uint32_t iter)
@@ -313,6 +358,7 @@ int k_stats_stage2(dsm_ctx *c, uint32_t iter)
     p.ntab = c->ntab; p.gamma = c->gamma; p.sum_mu = c->sum_mu; p.log_tab = c->log_tab;
     p.S = c->S; p.G = c->G;
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
+    p.plan = make_stage2_plan(c->G);
     hipLaunchKernelGGL(stats_stage2_kernel, dim3(c->S), dim3(256), 0, c->stream, p);
     HIP_TRY(hipGetLastError());
     return DSM_OK;

@@ -111,10 +111,11 @@ int dsm_ctx_sample_tau(dsm_ctx *ctx, int *nchange, double *logp_out);
  * :266,:276): sum_mu [S][G], esum [4][4] = [observed][true].                 */
 int dsm_ctx_sample_stats(dsm_ctx *ctx, uint32_t iter, uint64_t *sum_mu, uint64_t *esum);
 /* which counter-based specification dsm_ctx_sample_stats / dsm_ctx_gibbs_update follow for the resident
- * shape: 2 = aggregated sampler (oracle/stats_agg.c; G <= 16 and a subset table of at most 64 MB),
- * 1 = per-read draws (oracle/desman_oracle.c: orc_stats_counter).  force_v1 != 0 pins spec 1.        */
+ * shape: 2 = aggregated sampler (oracle/stats_agg.c; G <= 16, a subset table of at most 64 MB, V*S > 65536),
+ * 1 = per-read draws (oracle/desman_oracle.c: orc_stats_counter).  dsm_ctx_force_stats_spec: 0 = that rule,
+ * 1 = always spec 1, 2 = spec 2 also on small problems (G <= 16 still required).                     */
 int dsm_ctx_stats_spec(dsm_ctx *ctx);
-int dsm_ctx_force_stats_v1(dsm_ctx *ctx, int force_v1);
+int dsm_ctx_force_stats_spec(dsm_ctx *ctx, int spec);
 /* test hooks of spec 2: stage 1 only (subset counts ntab [S][2^G] u32 and esum), and nsamp variates of one
  * sampler (kind 0 binom_small, 1 binom_big: out [nsamp]; 2 mult4 with weights w[0..3]: out [nsamp][4])
  * exactly as oracle/stats_agg.c: orc_binom_test / orc_mult4_test draw them.                          */

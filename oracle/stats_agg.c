@@ -24,13 +24,16 @@
  *   The joint law of (sum_mu, Esum) is exactly the reference's (checked statistically against the
  *   reference-pinned rn.sample_mu and against the exact moments, tests/).
  *
- *   Draws.  Everything is counter-based: a cell's stage-1 draws come from one xoshiro128+ stream seeded by
- *   Philox4x32-10(ctr = {cell, 0, iter, 'STA1'}, key = seed), consumed in the order written below; every
+ *   Draws.  Everything is counter-based: the stage-1 draws of a (cell, observed base) item come from one
+ *   xoshiro128+ stream seeded by Philox4x32-10(ctr = {cell, b, iter, 'STA1'}, key = seed), consumed in the
+ *   order written below (items are independent work units: the kernels process the few items that need the
+ *   rejection sampler in a separate, compacted launch); every
  *   stage-2 binomial owns the stream Philox(ctr = {subset, s | node << 16 | level << 24, iter, 'STA2'}).
- *   Small counts (<= XS reads) are drawn read by read against 32-bit thresholds; larger ones by a
- *   multinomial -> binomial decomposition with sequential-search inversion on the rarer side (cost
- *   ~ n*min(p,1-p), no transcendental function: (1-q)^n by repeated squaring); the stage-2 binomials
- *   (counts up to 2^32-1) use Hoermann's BTRS transformed rejection (1993) above mean 16.
+ *   A cell's x reads of one observed base are split by ONE binomial into "heaviest true base" / "others"
+ *   and the (few) others are drawn read by read against 32-bit thresholds (<= XS of them) or by two more
+ *   binomials.  Binomial(n, p): sequential-search inversion on the rarer outcome while its mean is <= 64
+ *   (no transcendental function: (1-q)^n by repeated squaring), Hoermann's BTRS transformed rejection
+ *   (1993) above -- cost O(1) in the depth either way; the stage-2 counts go up to 2^32-1.
  *   All arithmetic is IEEE double with the operation order written here (-ffp-contract=off), the
  *   logarithm of BTRS is the table-driven orc_tlog (same table and FMA sequence as the device's
  *   dsm_log), so the kernels reproduce this file bit for bit.
@@ -47,8 +50,9 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 #define STREAM_STA1 0x53544131u   /* 'STA1' */
 #define STREAM_STA2 0x53544132u   /* 'STA2' */
 #define STREAM_TEST 0x54455354u   /* 'TEST' */
-#define XS 12u                    /* counts up to XS are drawn read by read */
-#define BINV_MEAN_CAP 16.0        /* inversion chunks have mean <= 16 */
+#define XS 128u                   /* up to XS non-dominant reads are drawn read by read */
+#define BINV_MEAN_CAP 64.0        /* inversion is used while the mean of the rarer outcome is <= 64 */
+#define BINV_KMAX 255u            /* the search stops at 255 (> 20 sigma at mean 64): 1/k comes from a 256-entry table */
 
 typedef struct { uint32_t s[4]; } xo_t;
 
@@ -140,51 +144,20 @@ static void draw_reads(xo_t *rng, uint32_t x, const double *w, int K, uint32_t *
     n[K - 1] = x - c[K - 2];
 }
 
-/* Binomial(c, q) by sequential search from 0; f0 = (1-q)^c, r = q/(1-q).  One uniform. */
-static uint32_t binv_chunk(xo_t *rng, uint32_t c, double f0, double r)
+/* Binomial(c, q) by sequential search from 0; f0 = (1-q)^c, r = q/(1-q), c q <= 64.  One uniform. */
+static uint32_t binv(xo_t *rng, uint32_t c, double f0, double r)
 {
+    /* P(k)/P(k-1) = r (c-k+1)/k = r (c+1) (1/k) - r */
     double u = xo_u01(rng), f = f0;
+    const double rc1 = r * ((double)c + 1.0);
     uint32_t k = 0;
-    while (u >= f && k < c) {
+    const uint32_t kend = c < BINV_KMAX ? c : BINV_KMAX;
+    while (u >= f && k < kend) {
         u = u - f;
         k = k + 1;
-        f = (f * (r * (double)(c - k + 1))) * (1.0 / (double)k);
+        f = f * fma(rc1, 1.0 / (double)k, -r);
     }
     return k;
-}
-
-/* successes among n trials with success : failure odds wa : wb; inversion on the rarer outcome, in
- * chunks of at most cap trials (cap * q <= 16) */
-static uint32_t binom_inv(xo_t *rng, uint32_t n, double ws, double wl)
-{
-    const double T = ws + wl;
-    const double omq = wl / T;
-    const double r = ws / wl;
-    uint32_t cap = n;
-    if ((double)n * ws > BINV_MEAN_CAP * T) {
-        const double capd = floor(BINV_MEAN_CAP * T / ws);       /* >= 32 because ws <= wl */
-        cap = capd >= (double)n ? n : (uint32_t)capd;
-    }
-    uint32_t total = 0, left = n;
-    double f_full = 0.0;
-    if (left >= cap) f_full = pw(omq, cap);
-    while (left > 0) {
-        const uint32_t c = left < cap ? left : cap;
-        const double f0 = (c == cap) ? f_full : pw(omq, c);
-        total += binv_chunk(rng, c, f0, r);
-        left -= c;
-    }
-    return total;
-}
-
-static uint32_t binom_small(xo_t *rng, uint32_t n, double wa, double wb)
-{
-    if (n == 0 || !(wa > 0.0)) return 0;
-    if (!(wb > 0.0)) return n;
-    const int flip = wa > wb;
-    const double ws = flip ? wb : wa, wl = flip ? wa : wb;
-    const uint32_t k = binom_inv(rng, n, ws, wl);
-    return flip ? n - k : k;
 }
 
 /* Stirling series remainder  ln k! - [ (k+1/2) ln(k+1) - (k+1) + ln sqrt(2 pi) ]  (Hoermann 1993, fc(k)) */
@@ -194,11 +167,11 @@ static double stirling_tail(double k)
                                     0.0166446911898211, 0.0138761288230707, 0.0118967099458917, 0.0104112652619720,
                                     0.00925546218271273, 0.00833056343336287 };
     if (k <= 9.0) return tab[(int)k];
-    const double kp1 = k + 1.0, kp1sq = kp1 * kp1;
-    return (1.0 / 12.0 - (1.0 / 360.0 - (1.0 / 1260.0) / kp1sq) / kp1sq) / kp1;
+    const double inv = 1.0 / (k + 1.0), inv2 = inv * inv;
+    return (1.0 / 12.0 - (1.0 / 360.0 - (1.0 / 1260.0) * inv2) * inv2) * inv;
 }
 
-/* Hoermann's BTRS (transformed rejection with squeeze), q <= 1/2, n q >= 10 */
+/* Hoermann's BTRS (transformed rejection with squeeze), q <= 1/2, n q > 64 */
 static uint32_t btrs(xo_t *rng, uint32_t n, double q)
 {
     const double nd = (double)n;
@@ -206,10 +179,14 @@ static uint32_t btrs(xo_t *rng, uint32_t n, double q)
     const double b = 1.15 + 2.53 * spq;
     const double a = -0.0873 + 0.0248 * b + 0.01 * q;
     const double c = nd * q + 0.5;
-    const double v_r = 0.92 - 4.2 / b;
+    const double ib = 1.0 / b;
+    const double v_r = 0.92 - 4.2 * ib;
+    const double alpha = (2.83 + 5.1 * ib) * spq;
     const double r = q / (1.0 - q);
-    const double alpha = (2.83 + 5.1 / b) * spq;
     const double m = floor((nd + 1.0) * q);
+    const double nm1 = nd - m + 1.0;
+    /* the part of the acceptance bound that does not depend on the proposal */
+    const double h = (m + 0.5) * orc_tlog((m + 1.0) / (r * nm1)) + stirling_tail(m) + stirling_tail(nd - m);
     for (int attempt = 0; attempt < 4096; attempt++) {
         const double u = xo_u01(rng) - 0.5;
         const double v = xo_u01(rng);
@@ -217,26 +194,26 @@ static uint32_t btrs(xo_t *rng, uint32_t n, double q)
         const double kd = floor((2.0 * a / us + b) * u + c);
         if (kd < 0.0 || kd > nd) continue;
         if (us >= 0.07 && v <= v_r) return (uint32_t)kd;
-        const double lv = orc_tlog(v * alpha / (a / (us * us) + b));
-        const double ub = (m + 0.5) * orc_tlog((m + 1.0) / (r * (nd - m + 1.0)))
-                          + (nd + 1.0) * orc_tlog((nd - m + 1.0) / (nd - kd + 1.0))
-                          + (kd + 0.5) * orc_tlog(r * (nd - kd + 1.0) / (kd + 1.0))
-                          + stirling_tail(m) + stirling_tail(nd - m) - stirling_tail(kd) - stirling_tail(nd - kd);
+        const double nk1 = nd - kd + 1.0;
+        const double lv = orc_tlog(v * alpha) - orc_tlog(a / (us * us) + b);
+        const double ub = h + (nd + 1.0) * orc_tlog(nm1 / nk1) + (kd + 0.5) * orc_tlog(r * nk1 / (kd + 1.0))
+                          - stirling_tail(kd) - stirling_tail(nd - kd);
         if (lv <= ub) return (uint32_t)kd;
     }
     return (uint32_t)m;      /* unreachable in practice (acceptance > 0.7 per attempt) */
 }
 
-static uint32_t binom_big(xo_t *rng, uint32_t n, double wa, double wb)
+/* successes among n trials with success : failure odds wa : wb */
+static uint32_t binom(xo_t *rng, uint32_t n, double wa, double wb)
 {
     if (n == 0 || !(wa > 0.0)) return 0;
     if (!(wb > 0.0)) return n;
     const int flip = wa > wb;
-    const double ws = flip ? wb : wa, wl = flip ? wa : wb;
+    const double ws = flip ? wb : wa, wl = flip ? wa : wb;      /* the rarer outcome has odds ws : wl */
     const double T = ws + wl;
     uint32_t k;
     if ((double)n * ws > BINV_MEAN_CAP * T) k = btrs(rng, n, ws / T);
-    else k = binom_inv(rng, n, ws, wl);                           /* a single chunk */
+    else k = binv(rng, n, pw(wl / T, n), ws / wl);
     return flip ? n - k : k;
 }
 
@@ -245,26 +222,24 @@ static void mult4(xo_t *rng, uint32_t x, const double W[4], uint32_t n[4])
 {
     n[0] = n[1] = n[2] = n[3] = 0;
     if (x == 0) return;
-    if (x <= XS) { draw_reads(rng, x, W, 4, n); return; }
     int am = 0;
     for (int a = 1; a < 4; a++) if (W[a] > W[am]) am = a;
     int o[3], j = 0;
     for (int a = 0; a < 4; a++) if (a != am) o[j++] = a;
     const double wo[3] = { W[o[0]], W[o[1]], W[o[2]] };
     const double ws = (wo[0] + wo[1]) + wo[2];
-    const uint32_t m = binom_small(rng, x, ws, W[am]);            /* reads NOT of the heaviest base */
+    const uint32_t m = binom(rng, x, ws, W[am]);                  /* reads NOT of the heaviest base */
     n[am] = x - m;
     if (m == 0) return;
     uint32_t k[3];
     if (m <= XS) draw_reads(rng, m, wo, 3, k);
     else {
-        k[0] = binom_small(rng, m, wo[0], wo[1] + wo[2]);
-        k[1] = binom_small(rng, m - k[0], wo[1], wo[2]);
+        k[0] = binom(rng, m, wo[0], wo[1] + wo[2]);
+        k[1] = binom(rng, m - k[0], wo[1], wo[2]);
         k[2] = m - k[0] - k[1];
     }
     n[o[0]] = k[0]; n[o[1]] = k[1]; n[o[2]] = k[2];
 }
-
 /* stage 1 for all cells: esum [4,4] ([observed][true]) accumulated, ntab [S][2^G] (subset counts) accumulated */
 static void stage1(const uint8_t *tau_idx, const double *gamma, const double *eta, const int64_t *variants,
                    int V, int G, int S, const uint32_t key[2], uint32_t iter, uint64_t *esum, uint32_t *ntab)
@@ -276,8 +251,7 @@ static void stage1(const uint8_t *tau_idx, const double *gamma, const double *et
         for (int g = 0; g < G; g++) H[tv[g]] |= 1u << g;
         for (int s = 0; s < S; s++) {
             const int64_t *x = variants + ((size_t)v * S + s) * 4;
-            xo_t rng;
-            xo_seed(&rng, (uint32_t)((uint64_t)s * (uint64_t)V + (uint64_t)v), 0u, iter, STREAM_STA1, key);
+            const uint32_t cell = (uint32_t)((uint64_t)s * (uint64_t)V + (uint64_t)v);
             double Gam[4] = { 0.0, 0.0, 0.0, 0.0 };
             for (int g = 0; g < G; g++) Gam[tv[g]] = Gam[tv[g]] + gamma[(size_t)s * G + g];
             uint32_t nacc[4] = { 0, 0, 0, 0 };
@@ -288,6 +262,8 @@ static void stage1(const uint8_t *tau_idx, const double *gamma, const double *et
                 const double Wt = ((W[0] + W[1]) + W[2]) + W[3];
                 if (!(Wt > 0.0)) for (int a = 0; a < 4; a++) W[a] = Gam[a];     /* degenerate eta: fall back to abundance */
                 uint32_t n[4];
+                xo_t rng;
+                xo_seed(&rng, cell, (uint32_t)b, iter, STREAM_STA1, key);
                 mult4(&rng, (uint32_t)x[b], W, n);
                 for (int a = 0; a < 4; a++) { esum[b * 4 + a] += n[a]; nacc[a] += n[a]; }
             }
@@ -330,7 +306,7 @@ static void stage2_sample(int s, int G, const double *gam_s, const uint32_t *T0,
                 for (int j = 0; j < wh; j++) if (HR >> j & 1u) wR = wR + gam_s[mid + j];
                 xo_t rng;
                 xo_seed(&rng, Hs, (uint32_t)s | ((uint32_t)idx_cur[i] << 16) | ((uint32_t)level << 24), iter, STREAM_STA2, key);
-                const uint32_t k = binom_big(&rng, n, wL, wR);
+                const uint32_t k = binom(&rng, n, wL, wR);
                 L[HL] += k; R[HR] += n - k;
             }
             free(T);
@@ -370,7 +346,7 @@ void orc_binom_test(int kind, uint32_t n, double wa, double wb, uint64_t seed, i
     for (int i = 0; i < nsamp; i++) {
         xo_t rng;
         xo_seed(&rng, (uint32_t)i, 0u, 0u, STREAM_TEST, key);
-        out[i] = kind == 0 ? binom_small(&rng, n, wa, wb) : binom_big(&rng, n, wa, wb);
+        (void)kind; out[i] = binom(&rng, n, wa, wb);
     }
 }
 

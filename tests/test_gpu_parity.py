@@ -136,11 +136,11 @@ def test_stats_bit_exact_vs_spec(ctx, V, S, G):
     _load(ctx, counts, tau, gamma, eta)
     ctx.seed(1, ctr_seed=0xABCDEF0123456789)
     idx = cbind.onehot_to_idx(tau)
-    spec = ctx.stats_spec()
-    assert spec == (2 if G <= 16 else 1)
-    for force in ((False, True) if spec == 2 else (False,)):
-        ctx.force_stats_v1(force)
-        ref_fn = cbind.stats_agg if (spec == 2 and not force) else cbind.stats_counter
+    assert ctx.stats_spec() == 1                                 # small problem: per-read pass by the shape rule
+    for force in ((2, 1) if G <= 16 else (0,)):
+        ctx.force_stats_spec(force)
+        assert ctx.stats_spec() == (2 if force == 2 else 1)
+        ref_fn = cbind.stats_agg if force == 2 else cbind.stats_counter
         for it in (0, 1, 77):
             mu, E = ctx.sample_stats(it)
             mu_ref, E_ref = ref_fn(idx, gamma, eta, counts, 0xABCDEF0123456789, it)
@@ -148,7 +148,7 @@ def test_stats_bit_exact_vs_spec(ctx, V, S, G):
             assert int(mu.sum()) == int(counts.sum())
             # E[b, :] partitions the reads of observed base b
             assert np.array_equal(E.sum(axis=1), counts.sum(axis=(0, 1)).astype(np.uint64))
-    ctx.force_stats_v1(False)
+    ctx.force_stats_spec(0)
 
 
 @pytest.mark.parametrize("V,S,G,scale", [(200, 64, 8, 1.0), (120, 96, 12, 1.0), (150, 16, 5, 1.0), (60, 130, 3, 1.0),
@@ -168,6 +168,7 @@ def test_stats_stage1_matches_spec(ctx, V, S, G, scale):
             gamma = np.ascontiguousarray(gamma / gamma.sum(axis=1, keepdims=True))
         _load(ctx, counts, tau, gamma, eta)
         ctx.seed(1, ctr_seed=seed)
+        ctx.force_stats_spec(2)
         idx = cbind.onehot_to_idx(tau)
         for it in (0, 5):
             nt, E = ctx.debug_stage1(it)
@@ -176,6 +177,7 @@ def test_stats_stage1_matches_spec(ctx, V, S, G, scale):
             assert np.array_equal(nt, nt_ref)
             mu, E2 = ctx.sample_stats(it)
             assert np.array_equal(mu, mu_ref) and np.array_equal(E2, E_ref)
+    ctx.force_stats_spec(0)
 
 
 def test_stats_degenerate_eta_and_gamma(ctx):
@@ -188,8 +190,10 @@ def test_stats_degenerate_eta_and_gamma(ctx):
     gamma = np.ascontiguousarray(gamma / gamma.sum(axis=1, keepdims=True))
     _load(ctx, counts, tau, gamma, eta)
     ctx.seed(1, ctr_seed=9)
+    ctx.force_stats_spec(2)
     idx = cbind.onehot_to_idx(tau)
     mu, E = ctx.sample_stats(2)
+    ctx.force_stats_spec(0)
     mu_ref, E_ref = cbind.stats_agg(idx, gamma, eta, counts, 9, 2)
     assert np.array_equal(mu, mu_ref) and np.array_equal(E, E_ref)
     assert (mu[:, 2] == 0).all() and int(mu.sum()) == int(counts.sum())
@@ -331,14 +335,31 @@ def test_gibbs_chain_recovers_asymmetric_eta(ctx):
 
 
 # ---------------------------------------------------------------- A6 full iteration
+@pytest.mark.parametrize("spec", [2, 1])
 @pytest.mark.parametrize("V,S,G,n_iter", [(400, 16, 5, 12), (600, 64, 8, 8), (150, 96, 3, 6)])
-def test_gibbs_update_is_self_consistent_with_oracle(ctx, V, S, G, n_iter):
+def test_gibbs_update_is_self_consistent_with_oracle(ctx, V, S, G, n_iter, spec):
+    """every piece of every iteration of the device loop against the oracle, in the reference's order
+    (HaploSNP_Sampler.py:341-358): the mu/E sums + gamma/eta draws from the restated counter-based specs (spec 2:
+    stage 2 runs fused inside the Dirichlet launch; spec 1: per-read pass), the tau sweep bit for bit on the GSL
+    stream, ll / lp, MAP record, tau sum."""
     counts, _, _ = synth_counts(V, S, G, seed=60)
     tau0, gamma0, eta0 = random_state(V, S, G, seed=61)
     _load(ctx, counts, tau0, gamma0, eta0, mt_seed=123)
+    cseed = 0x5EEDC0DE0000 + spec
+    ctx.seed(123, ctr_seed=cseed)
+    ctx.force_stats_spec(spec)
     ll0, lp0 = ctx.loglik()
     ctx.gibbs_update(n_iter)
+    ctx.force_stats_spec(0)
     tr = ctx.get_trace()
+    g_prev, e_prev, t_prev = gamma0, eta0, tau0
+    for it in range(n_iter):                                      # A2 + A3 + A4 inside the loop; counter = iteration index
+        stats = cbind.stats_agg if spec == 2 else cbind.stats_counter
+        mu, E = stats(cbind.onehot_to_idx(t_prev), np.ascontiguousarray(g_prev), np.ascontiguousarray(e_prev), counts, cseed, it)
+        g_ref, e_ref, _ = cbind.dirichlet_counter(mu, E, cseed, it)
+        np.testing.assert_allclose(tr["gamma"][it], g_ref, rtol=1e-13, atol=0)
+        np.testing.assert_allclose(tr["eta"][it], e_ref, rtol=1e-13, atol=0)
+        g_prev, e_prev, t_prev = tr["gamma"][it], tr["eta"][it], ctx.get_tau_at(it)
     mt = cbind.MT19937(123)
     tau_prev, eta_prev = tau0.copy(), eta0.copy()
     lps = [lp0]

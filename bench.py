@@ -20,35 +20,69 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-def cpu_baseline(S, G, budget_s=20.0):
-    """The CPU path (oracle = restatement of the reference: Python-level sampleMu/ll loops +
-    C tau sweep, single thread) timed on a bounded sample of the same workload."""
+def _cpu_chain(args):
+    """One CPU chain of the baseline: `its` full Gibbs iterations of the oracle port on the V=Vs slice."""
+    Vs, S, G, its, seed = args
     from desman_amd.synth import synth_counts
     from oracle import cbind, ref_numpy as rn
-    Vs = 400
     counts, _, _ = synth_counts(Vs, S, G, seed=1234)
-    rs = np.random.RandomState(0)
+    rs = np.random.RandomState(seed)
     gamma0, tau0 = rn.sampler_ctor_draws(rs, Vs, S, G)
-    eta0 = 0.96 * np.eye(4) + 0.01
-    cbind.initRNG(); cbind.setRNG(0)
+    state = (tau0, gamma0, 0.96 * np.eye(4) + 0.01)
+    cbind.initRNG(); cbind.setRNG(seed)
     t0 = time.perf_counter()
-    its = 0
-    state = (tau0, gamma0, eta0)
-    while True:
+    for _ in range(its):
         r = rn.gibbs_update(rs, state[0], state[1], state[2], counts, 1, cbind.sample_tau)
         state = (r["tau"], r["gamma"], r["eta"])
-        its += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or its >= 16:            # ~11 s on the GPU box host (EPYC 9575F), bounded at 20 s
-            break
+    dt = time.perf_counter() - t0
     cbind.freeRNG()
-    return dict(value=Vs * S * its / dt, unit="V*S updates/s", cores=1, kind="port",
-                sample="%d full Gibbs iterations of oracle/ref_numpy.gibbs_update (+ C tau sweep) on a V=%d slice "
-                       "of the same S=%d, G=%d workload, 1 thread, %.1f s" % (its, Vs, S, G, dt),
-                cpu=_cpu_model(),
-                # measured once in the development container (where /root/reference exists): the imported
-                # reference's update() on this same V=400 slice took 2.97 s/iteration, the port 1.83 s
-                calibration_reference_over_port=1.62)
+    return dt
+
+
+def cpu_baseline_main(S, G):
+    """`python bench.py --cpu-baseline-only`: the CPU path (oracle = restatement of the reference: Python-level
+    sampleMu / likelihood loops + C tau sweep) timed on a bounded sample of the same workload -- 1 thread (the
+    reference is single-threaded by construction) and all cores (one independent chain per core, the only
+    parallelism the reference has: scripts/runDesman.sh:15-21).  Runs in its own process: no HIP runtime here."""
+    import multiprocessing as mp
+    Vs = 400
+    its1 = 5
+    dt1 = _cpu_chain((Vs, S, G, its1, 0))
+    cores = sorted(os.sched_getaffinity(0))
+    n = len(cores)
+    its_all = 2
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(n) as pool:
+        dts = pool.map(_cpu_chain, [(Vs, S, G, its_all, k) for k in range(n)])
+    wall = time.perf_counter() - t0
+    calib = {}
+    try:
+        calib = json.load(open(os.path.join(ROOT, "profiles", "cpu_calibration.json")))
+    except OSError:
+        pass
+    out = dict(value=Vs * S * its1 / dt1, unit="V*S updates/s", cores=1, kind="port",
+               sample="%d full Gibbs iterations of oracle/ref_numpy.gibbs_update (+ C tau sweep) on a V=%d slice of "
+                      "the same S=%d, G=%d workload, 1 thread, %.1f s" % (its1, Vs, S, G, dt1),
+               cpu=_cpu_model(),
+               all_cores=dict(value=n * Vs * S * its_all / wall, unit="V*S updates/s", cores=n,
+                              sample="%d independent chains (one per core in sched_getaffinity), %d iterations each of the "
+                                     "same slice, wall %.1f s (slowest chain %.1f s)" % (n, its_all, wall, max(dts))),
+               # t(reference update()) / t(this port) on the same slice: written by scripts/calibrate_cpu_port.py in the
+               # development container (the only place /root/reference exists)
+               calibration_reference_over_port=calib.get("reference_over_port"),
+               calibration_source="profiles/cpu_calibration.json (scripts/calibrate_cpu_port.py: %s)" % calib.get("cpu", "?"))
+    print(json.dumps(out))
+
+
+def cpu_baseline(S, G):
+    """Runs the CPU legs in a child process (fork-based multiprocessing next to a live HIP runtime is unsafe)."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--S", str(S), "--G", str(G)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    if r.returncode != 0:
+        raise RuntimeError("cpu baseline failed: " + r.stderr[-2000:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def _cpu_model():
@@ -120,6 +154,10 @@ def main():
     ap.add_argument("--G", type=int, default=8)
     ap.add_argument("--rng", choices=["mt19937", "philox"], default="mt19937")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: print the cpu_baseline object and exit")
+    ap.add_argument("--depth-scale", type=float, default=1.0, help="multiply the mean read depths of the synthetic tensor")
+    ap.add_argument("--chains-per-gpu", type=int, default=1,
+                    help="also time K concurrent chains on the GPU (extra key; the headline stays one chain per GPU)")
     ap.add_argument("--no-nmft", action="store_true")
     ap.add_argument("--workload", choices=["gibbs", "genes"], default="gibbs",
                     help="gibbs = the headline metric (default); genes = the accessory-gene sampler (row f4)")
@@ -127,6 +165,8 @@ def main():
     ap.add_argument("--vmax", type=int, default=20)
     ap.add_argument("--cpu-genes", type=int, default=40)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        return cpu_baseline_main(args.S, args.G)
     if args.workload == "genes":
         return bench_genes(args.genes, 32 if args.S == 64 else args.S, 6 if args.G == 8 else args.G, args.vmax,
                            50 if args.steps == 500 else args.steps, 0 if args.no_cpu_baseline else args.cpu_genes)
@@ -146,7 +186,7 @@ def main():
     from desman_amd import _lib
     from desman_amd.synth import synth_counts
     V, S, G = args.V, args.S, args.G
-    counts, _, _ = synth_counts(V, S, G, seed=1234 + rank)       # one independent chain per GPU
+    counts, _, _ = synth_counts(V, S, G, seed=1234 + rank, depth_scale=args.depth_scale)       # one independent chain per GPU
     ctx = _lib.Context(dev)
     ctx.set_counts(counts)
     ctx.seed(rank)                                               # sampler seeds 0..N-1 (scripts/runDesman.sh:15-19)
@@ -179,6 +219,10 @@ def main():
         # algorithmic bytes per NMFT update: two passes over f64 F + four over tau
         nmft["algorithmic_bytes_per_iter"] = 2 * 4 * V * S * 8 + 4 * 4 * V * G * 8
         nmft["achieved_GBps"] = nmft["algorithmic_bytes_per_iter"] / (nmft["ms_per_iter"] * 1e-3) / 1e9
+        # the one bandwidth-shaped kernel of the path; at this size F + tau (23 MB) live in the
+        # 256 MB Infinity Cache, so the byte stream is MALL/L2 traffic, not HBM
+        nmft["roofline"] = dict(bound="hbm", achieved=nmft["achieved_GBps"], peak=8000.0, unit="GB/s",
+                                frac=nmft["achieved_GBps"] / 8000.0)
         ctx.nmft_set(tau0, gam0)
         ctx.nmft_factorize(max_iter=n_nm, min_change=0.0)
     tau_init = ctx.nmft_get_tau()
@@ -213,63 +257,101 @@ def main():
         dist.all_gather(allr, mine)
         fits = [x.tolist() for x in allr]
 
+    # several chains on one GPU at once (own context / streams / host thread each): how much of the per-launch
+    # latency (Dirichlet / stage 2 / finalize / launch gaps) concurrent chains recover (scripts/runDesman.sh:15-21)
+    multi = None
+    if args.chains_per_gpu > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        K = args.chains_per_gpu
+        ctxs = []
+        for k in range(K):
+            c2 = _lib.Context(dev)
+            c2.set_counts(counts)
+            c2.seed(1000 + k)
+            c2.set_tau_rng(_lib.RNG_MT19937 if args.rng == "mt19937" else _lib.RNG_PHILOX)
+            c2.set_state(tau_init, np.ascontiguousarray(gam.T), eta0)
+            c2.gibbs_update(max(args.warmup, 5))
+            ctxs.append(c2)
+        with ThreadPoolExecutor(K) as ex:
+            t0 = time.perf_counter()
+            list(ex.map(lambda c2: c2.gibbs_update(args.steps), ctxs))
+            dtk = time.perf_counter() - t0
+        for c2 in ctxs:
+            c2.close()
+        multi = dict(chains=K, ms_per_step_per_chain=1e3 * dtk / args.steps, value=K * V * S * args.steps / dtk,
+                     unit="V*S updates/s", speedup_vs_one_chain=(K * args.steps / dtk) / (args.steps / dt))
+
     # per-kernel HIP-event timing (on the library's stream) for the roofline object
     ctx.set_timing(True)
     ctx.gibbs_update(20)
     tm = ctx.get_timing()
     ctx.set_timing(False)
     k_us = {k: 1e3 * ms / max(n, 1) for k, (ms, n) in tm.items() if n}
+    spec = ctx.stats_spec()
     # algorithmic HBM bytes per launch: one pass over the int32 count tensor each,
     # plus the tau traffic (u8-equivalent: read for the mu/E pass; read + write + trace for the sweep)
     alg = {"tau": V * S * 16 + 3 * V * G, "stats": V * S * 16 + V * G}
     n_logs = 12.0 * V * G * S + 4.0 * V * S + 4.0 * V * S          # logs actually evaluated per sweep (+LL)
     traffic, valu = {}, {}
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tpath) and (V, S, G) == (10000, 64, 8):       # PMC passes are separate rocprofv3 runs
-        tj = json.load(open(tpath))
-        for name, prefix in (("tau", "void tau_kernel<64, 1, true, true"), ("stats", "void stats_kernel<8")):
+    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    stats_kname = "stats_agg_kernel" if spec == 2 else "stats_kernel"
+    if os.path.exists(tpath) and (V, S, G) == (10000, 64, 8) and args.depth_scale == 1.0:
+        tj = json.load(open(tpath))                               # PMC passes are separate rocprofv3 runs (profiles/)
+        for name, prefix in (("tau", "void tau_kernel<64, 1, true, true"), ("stats", stats_kname)):
             for key, rec in tj.items():
-                if key.startswith(prefix):
+                if key.startswith(prefix) or key.startswith("void " + prefix):
                     traffic[name] = rec.get("bytes_per_launch")
                     valu[name] = rec.get("valu_insts")
     per_kernel = {}
-    for name, kname in (("stats", "stats_kernel"), ("tau", "tau_kernel")):
+    for name, kname in (("stats", stats_kname), ("tau", "tau_kernel")):
         us = k_us.get(name, float("nan"))
         ach = alg[name] / (us * 1e-6) / 1e9
         per_kernel[kname] = dict(avg_kernel_us=us, algorithmic_bytes_per_launch=alg[name], achieved_GBps=ach,
                                  frac_of_8TBps=ach / 8000.0, traffic_bytes_pmc=traffic.get(name))
         if valu.get(name):
-            # what actually bounds the kernel: wave64 VALU instructions (PMC, profiles/) x 4 cycles each over the
-            # 1024 SIMDs x duration x 2.4 GHz issue slots of the launch measured here
+            # what actually bounds the kernel: wave64 VALU instructions (PMC, profiles/) x ~4 cycles each (measured
+            # average, SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU) over the 1024 SIMDs x duration x 2.4 GHz issue slots
             per_kernel[kname].update(valu_insts_pmc=valu[name],
                                      valu_issue_frac=valu[name] * 4.0 / (1024 * us * 1e-6 * 2.4e9))
     dom = "stats" if k_us.get("stats", 0) >= k_us.get("tau", 0) else "tau"
-    dk = per_kernel[dom + "_kernel"]
-    roofline = dict(bound="hbm", kernel=dom + "_kernel", achieved=dk["achieved_GBps"], peak=8000.0, unit="GB/s",
-                    frac=dk["frac_of_8TBps"], traffic=dk["traffic_bytes_pmc"], avg_kernel_us=dk["avg_kernel_us"],
+    dk = per_kernel[(stats_kname if dom == "stats" else "tau_kernel")]
+    roofline = dict(bound="hbm", bound_actual="valu_issue", kernel=(stats_kname if dom == "stats" else "tau_kernel"),
+                    achieved=dk["achieved_GBps"], peak=8000.0, unit="GB/s",
+                    frac=dk["frac_of_8TBps"], traffic=dk["traffic_bytes_pmc"],
+                    traffic_source=("profiles/r02_pmc_traffic.json: separate rocprofv3 --pmc passes of this workload "
+                                    "(FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE), not measured in this run"
+                                    if dk["traffic_bytes_pmc"] else None),
+                    valu_issue_frac=dk.get("valu_issue_frac"),
+                    avg_kernel_us=dk["avg_kernel_us"],
                     algorithmic_bytes_per_launch=dk["algorithmic_bytes_per_launch"],
                     per_kernel=per_kernel, fp64_logs_per_s_tau_kernel=n_logs / (k_us.get("tau", float("nan")) * 1e-6),
-                    note="both Gibbs kernels are VALU-issue bound, not HBM bound (per_kernel.valu_issue_frac ~ 0.9, PMC "
-                         "traffic ~ algorithmic bytes; profiles/, DESIGN.md sec. 3): the HBM fraction is reported "
+                    stats_spec=spec,
+                    note="both Gibbs kernels are VALU-issue bound, not HBM bound (bound_actual; per_kernel.valu_issue_frac, "
+                         "PMC traffic ~ algorithmic bytes; profiles/, DESIGN.md sec. 3): the HBM fraction is reported "
                          "because the contract asks for it",
                     kernels_us=k_us)
 
     if rank == 0:
         its = args.steps / dt
         out = {
-            "metric": "Gibbs iterations/sec (VxS updates/s) at V=10k S=64 G=8",
+            "metric": "Gibbs iterations/sec (VxS updates/s) at V=%s S=%d G=%d" % (("%dk" % (V // 1000)) if V % 1000 == 0 else str(V), S, G),
             "value": world * V * S * its, "unit": "V*S updates/s",
             "gibbs_it_per_s_per_chain": its, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic V=%d x S=%d, G=%d, full Gibbs iteration, 1 chain per GPU (configs[2])"
-                                   % (V, S, G), "V": V, "S": S, "G": G, "chains": world, "tau_rng": args.rng},
+            "config": {"workload": "synthetic V=%d x S=%d, G=%d, full Gibbs iteration, 1 chain per GPU%s%s"
+                                   % (V, S, G, " (configs[2])" if (V, S, G) == (10000, 64, 8) else "",
+                                      "" if args.depth_scale == 1.0 else ", read depth x%g" % args.depth_scale),
+                       "V": V, "S": S, "G": G, "chains": world, "tau_rng": args.rng, "depth_scale": args.depth_scale},
             "roofline": roofline, "nmft": nmft,
             "fit_records": [dict(G=int(f[0]), seed=int(f[2]), lp_star=f[3], mean_dev=f[4]) for f in fits],
         }
+        if multi:
+            out["chains_per_gpu"] = multi
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, G)
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_port_all_cores"] = out["value"] / out["cpu_baseline"]["all_cores"]["value"]
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

@@ -29,6 +29,7 @@ struct Stage2Params {
     const double *log_tab;
     int S, G;
     uint32_t k0, k1, iter;
+    uint32_t *big_count;            // work-list counter of stage 1: consumed by now, reset here for the next pass (or null)
     S2Plan plan;
 };
 
@@ -49,6 +50,7 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
     int *n_lo = reinterpret_cast<int *>(leaf + 32);                            // the plan's node arrays (lane-indexed below)
     int *n_hi = n_lo + S2_MAX_NODES, *n_off = n_hi + S2_MAX_NODES, *n_idx = n_off + S2_MAX_NODES, *n_child = n_idx + S2_MAX_NODES;
 
+    if (s == 0 && tid == 0 && p.big_count) *p.big_count = 0u;
     ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
     rcp[tid] = tid ? 1.0 / (double)tid : 0.0;
     if (tid < 32) {

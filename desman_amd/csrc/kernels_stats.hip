@@ -281,6 +281,8 @@ static int ensure_big_list(dsm_ctx *c)
     hipError_t e = hipMalloc((void **)&c->big_list, need * sizeof(unsigned long long));
     if (e != hipSuccess) { dsm_set_error("hipMalloc(%zu B) failed: %s", need * 8, hipGetErrorString(e)); return DSM_ERR_NOMEM; }
     c->big_cap = need;
+    // the counter is zero between passes: stage 2 (its consumer-side successor) resets it
+    HIP_TRY(hipMemsetAsync(c->big_count, 0, sizeof(uint32_t), c->stream));
     return DSM_OK;
 }
 
@@ -290,7 +292,6 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     if (r != DSM_OK) return r;
     r = ensure_big_list(c);
     if (r != DSM_OK) return r;
-    HIP_TRY(hipMemsetAsync(c->big_count, 0, sizeof(uint32_t), c->stream));
     KTimer tm(c, DSM_K_STATS);
     const int S = c->S, G = c->G, V = c->V;
     const int NCH = (S + 63) / 64, SP = NCH * 64;
@@ -318,7 +319,7 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     p.big_list = c->big_list; p.big_count = c->big_count;
     hipLaunchKernelGGL(stats_agg_kernel, dim3(grid), dim3(256), sh, c->stream, p);
     // the deferred items (none once the chain has converged on data of ordinary depth: the launch then returns at once)
-    const int big_grid = (int)std::max<long>(1, std::min<long>((ntask * 64 * 4 + 255) / 256, 512));
+    const int big_grid = (int)std::max<long>(1, std::min<long>((ntask * 64 * 4 + 255) / 256, 256));
     hipLaunchKernelGGL(stats_big_kernel, dim3(big_grid), dim3(256), 0, c->stream, p);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
@@ -359,6 +360,7 @@ int k_stats_stage2(dsm_ctx *c, uint32_t iter)
     p.S = c->S; p.G = c->G;
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
     p.plan = make_stage2_plan(c->G);
+    p.big_count = c->big_count;
     hipLaunchKernelGGL(stats_stage2_kernel, dim3(c->S), dim3(256), 0, c->stream, p);
     HIP_TRY(hipGetLastError());
     return DSM_OK;

@@ -17,7 +17,7 @@ import time
 
 import numpy as np
 
-REC_FIELDS = ("chain", "G", "seed", "G_final", "lp_star", "mean_dev", "iters", "wall_s")
+REC_FIELDS = ("chain", "G", "seed", "G_final", "lp_star", "mean_dev", "iters", "wall_s", "failed")
 
 
 def chain_cost(V, S, G):
@@ -54,26 +54,55 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1):
     (or None for a single process).  `concurrency` chains of a rank run at the same time in
     threads (each on its own context / HIP streams; ctypes releases the GIL while a launch
     sequence is in flight): small-V chains are latency-bound, so several of them share a GPU
-    well.  Returns the records sorted by chain id."""
+    well.  Returns the records sorted by chain id.
+
+    Failure handling ("a failed GPU's chains are simply re-queued"): a chain whose run_fn raises
+    is re-queued ONCE on the same rank after the rank's other chains; if it fails again its record carries
+    failed = 1 and NaN fit values (model selection skips it).  A rank therefore always reaches the all_gather:
+    one bad chain (bad input for that G, an out-of-memory context, a device error) never strands its peers
+    in the collective."""
     import torch
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     bins = lpt_assign([s["cost"] for s in specs], world)
 
+    import logging
+    log = logging.getLogger("desman_amd.chains")
+
     def one(cid):
+        """record of chain cid, or the exception it raised (never propagates: see the docstring)"""
         t0 = time.perf_counter()
-        rec = dict(run_fn(specs[cid]))
+        try:
+            rec = dict(run_fn(specs[cid]))
+        except Exception as e:                               # noqa: BLE001 -- any failure of one chain is contained
+            log.warning("chain %d (G=%s, seed=%s) failed on rank %d: %s: %s", cid, specs[cid].get("G"), specs[cid].get("seed"),
+                        rank, type(e).__name__, e)
+            return e
         rec.setdefault("wall_s", time.perf_counter() - t0)
         rec["chain"] = cid
+        rec.setdefault("failed", 0.0)
+        return [float(rec[k]) for k in REC_FIELDS]
+
+    def failed_record(cid):
+        sp = specs[cid]
+        rec = dict(chain=cid, G=sp.get("G", np.nan), seed=sp.get("seed", np.nan), G_final=np.nan, lp_star=np.nan,
+                   mean_dev=np.nan, iters=0, wall_s=np.nan, failed=1.0)
         return [float(rec[k]) for k in REC_FIELDS]
 
     if concurrency > 1 and len(bins[rank]) > 1:
         from concurrent.futures import ThreadPoolExecutor
         os.environ.setdefault("DESMAN_HIP_NMFT_GRAPH", "1")      # replayed NMFT batches: see api.hip (dsm_nmft_factorize)
         with ThreadPoolExecutor(max_workers=concurrency) as pool:
-            mine = list(pool.map(one, bins[rank]))           # LPT order: longest chains start first
+            first = list(pool.map(one, bins[rank]))          # LPT order: longest chains start first
     else:
-        mine = [one(cid) for cid in bins[rank]]
+        first = [one(cid) for cid in bins[rank]]
+    mine = []
+    for cid, res in zip(bins[rank], first):
+        if isinstance(res, Exception):                       # second and last attempt, alone on the device
+            res = one(cid)
+            if isinstance(res, Exception):
+                res = failed_record(cid)
+        mine.append(res)
     width = max(len(b) for b in bins) if specs else 0
     buf = np.full((max(width, 1), len(REC_FIELDS)), np.nan)
     if mine:
@@ -159,6 +188,8 @@ def write_dev_csv(path, records):
     with open(path, "w") as f:
         f.write("H,G,LP,Dev\n")
         for r in records:
+            if r.get("failed"):
+                continue                                   # a chain that failed twice has no fit
             f.write("%d,%d,%f,%f\n" % (r["G"], r["G_final"], r["lp_star"], r["mean_dev"]))
 
 

@@ -16,9 +16,28 @@ def fake_run(spec):
                 wall_s=0.001 * g)
 
 
+_calls = {}
+
+
+def flaky_run(spec):
+    """chain (G=3, seed=1) raises on every attempt, chain (G=5, seed=2) only on its first: the scheduler must
+    re-queue once, mark the first as failed, and still reach the gather on both ranks"""
+    key = (spec["G"], spec["seed"])
+    _calls[key] = _calls.get(key, 0) + 1
+    if key == (3, 1) or (key == (5, 2) and _calls[key] == 1):
+        raise RuntimeError("injected failure %s attempt %d" % (key, _calls[key]))
+    return fake_run(spec)
+
+
 if __name__ == "__main__":
     dist.init_process_group("gloo")
     specs = chains.sweep_specs(range(2, 7), 3, V=1000, S=16)
+    if len(sys.argv) > 2 and sys.argv[2] == "flaky":
+        recs = chains.run_chains(specs, flaky_run, dist)
+        with open(os.path.join(sys.argv[1], "flaky%d.json" % dist.get_rank()), "w") as f:
+            json.dump(dict(recs=recs, calls={"%d_%d" % k: v for k, v in _calls.items()}), f)
+        dist.destroy_process_group()
+        sys.exit(0)
     recs = chains.run_chains(specs, fake_run, dist)
     bins = chains.lpt_assign([s["cost"] for s in specs], dist.get_world_size())
     out = dict(rank=dist.get_rank(), recs=recs, mine=bins[dist.get_rank()])

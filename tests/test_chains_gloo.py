@@ -52,6 +52,42 @@ def test_two_rank_gloo_gather(tmp_path):
     assert rows[0] == "H,G,LP,Dev" and len(rows) == 16 and rows[1] == "2,2,-2000.000000,4000.000000"
 
 
+def test_two_rank_gloo_failed_chain_is_requeued_and_never_strands_the_gather(tmp_path):
+    """one chain fails on every attempt, another only once: both ranks still complete the all_gather, the flaky chain
+    is re-run (2 attempts, good record), the broken one is tried twice and reported failed with NaN fit values"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29659", os.path.join(HERE, "_gloo_worker.py"), str(tmp_path), "flaky"]
+    subprocess.run(cmd, check=True, env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r0 = json.load(open(tmp_path / "flaky0.json"))
+    r1 = json.load(open(tmp_path / "flaky1.json"))
+    assert len(r0["recs"]) == 15 and [int(r["chain"]) for r in r0["recs"]] == list(range(15))
+    calls = dict(r0["calls"]); calls.update(r1["calls"])
+    assert calls["3_1"] == 2 and calls["5_2"] == 2                      # one re-queue each, no more
+    for a, b in zip(r0["recs"], r1["recs"]):                            # identical on both ranks (NaN-aware)
+        assert all((x == y) or (x != x and y != y) for x, y in zip(a.values(), b.values()))
+    by = {(int(r["G"]), int(r["seed"])): r for r in r0["recs"]}
+    bad, flaky = by[(3, 1)], by[(5, 2)]
+    assert bad["failed"] == 1.0 and np.isnan(bad["lp_star"]) and np.isnan(bad["mean_dev"])
+    assert flaky["failed"] == 0.0 and flaky["lp_star"] == -5002.0
+    assert sum(r["failed"] for r in r0["recs"]) == 1.0
+    d = tmp_path / "Dev.csv"
+    chains.write_dev_csv(str(d), r0["recs"])
+    assert len(open(d).read().strip().split("\n")) == 15              # header + 14 chains: the failed one is skipped
+
+
+def test_single_process_failure_handling():
+    n = {"k": 0}
+
+    def run(spec):
+        n["k"] += 1
+        if spec["seed"] == 1:
+            raise ValueError("boom")
+        return dict(G=spec["G"], seed=spec["seed"], G_final=spec["G"], lp_star=-1.0, mean_dev=2.0, iters=1)
+    recs = chains.run_chains(chains.sweep_specs([2], 3, 10, 4), run, concurrency=2)
+    assert [r["failed"] for r in recs] == [0.0, 1.0, 0.0] and n["k"] == 4
+
+
 # ---------------------------------------------------------------- row f4: genes sharded over ranks
 def test_gene_partition_properties():
     from desman_amd.gene_shards import partition_genes

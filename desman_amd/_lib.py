@@ -38,6 +38,10 @@ SIGNATURES = {
     "dsm_setRNG": (_i, [C.c_ulong]),
     "dsm_freeRNG": (_i, []),
     "dsm_sample_tau": (_i, [_i64p, _f64p, _f64p, _i64p, _i, _i, _i]),
+    "c_initRNG": (None, []),
+    "c_setRNG": (None, [C.c_ulong]),
+    "c_freeRNG": (None, []),
+    "c_sample_tau": (_i, [_i64p, _f64p, _f64p, _i64p, _i, _i, _i]),
     "dsm_getRNG_state": (_i, [_u32p]),
     "dsm_setRNG_state": (_i, [_u32p]),
     "dsm_ctx_create": (_i, [C.POINTER(_vp), _i]),
@@ -98,6 +102,16 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+def _digest(a):
+    """128-bit digest of an array's bytes (xxh3 when the module is there: ~10 GB/s; blake2b otherwise)."""
+    try:
+        import xxhash
+        return xxhash.xxh3_128_digest(memoryview(a).cast("B"))
+    except ImportError:
+        import hashlib
+        return hashlib.blake2b(memoryview(a).cast("B"), digest_size=16).digest()
 
 
 def load():
@@ -183,9 +197,9 @@ class Context:
         v = np.ascontiguousarray(variants, dtype=np.int64)
         if v.ndim != 3 or v.shape[2] != 4:
             raise ValueError("variants must be [V,S,4]")
-        # re-uploading (and re-sorting the per-read work list) is skipped when the very same tensor is
-        # already resident -- Init_NMFT and HaploSNP_Sampler of one run share a context
-        token = (v.shape, int(v.sum()), int((v * (np.arange(v.size, dtype=np.int64).reshape(v.shape) % 1021 + 1)).sum()))
+        # re-uploading is skipped when the very same tensor is already resident (Init_NMFT and HaploSNP_Sampler of
+        # one run share a context): same shape and same 128-bit digest of the bytes
+        token = (v.shape, _digest(v))
         if getattr(self, "_counts_token", None) == token:
             return
         self._counts_token = None                        # a failed upload leaves no tensor resident

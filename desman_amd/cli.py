@@ -6,6 +6,7 @@ stages -- load, fit, report, assign-the-rest.
 """
 import argparse
 import logging
+import os
 import sys
 
 import numpy as np
@@ -27,8 +28,8 @@ _FLAGS = [
                                      help="likelihood-ratio variant filter; optional chi2 threshold (3.84)")),
     ('-r', '--random_select', dict(nargs='?', const=1e3, type=int,
                                    help="fit on this many random positions (1000), then assign the others")),
-    ('-e', '--eta_file', dict(type=open, help="CSV with the initial 4x4 error matrix")),
-    ('-a', '--assign_file', dict(type=open, help="(dead upstream) extra positions to assign")),
+    ('-e', '--eta_file', dict(type=str, help="CSV with the initial 4x4 error matrix")),
+    ('-a', '--assign_file', dict(type=str, help="(dead upstream) extra positions to assign")),
     ('-o', '--output_dir', dict(type=str, default="output", help="directory for all result files")),
     ('-p', '--optimiseP', dict(default=True, type=bool, help="optimise the mixture proportion in the filter")),
     ('-i', '--no_iter', dict(nargs='?', const=250, type=int, help="Gibbs iterations per phase")),
@@ -140,6 +141,12 @@ def _assign_rest(opts, report, table, flt, chain):
 
 def main(argv=None):
     opts = build_parser().parse_args(argv)
+    if opts.assign_file is not None:
+        # upstream this branch stops in ipdb.set_trace() after the whole run (bin/desman:213-214): there is nothing
+        # to mirror, and the user should not pay for NMFT + 2 x no_iter Gibbs iterations to learn it
+        sys.exit('desman: -a/--assign_file is not supported (dead in the reference: bin/desman:213-214)')
+    if opts.eta_file is not None and not os.path.isfile(opts.eta_file):
+        sys.exit("desman: can't open eta file '%s'" % opts.eta_file)
     if opts.genomes < 0:
         logging.error('the haplotype number must be positive, got %d' % opts.genomes)
         sys.exit(-1)
@@ -149,10 +156,6 @@ def main(argv=None):
     _report(report, table, flt, chain, opts.genomes)
     if subsample is not None:
         _assign_rest(opts, report, table, flt, chain)
-    if opts.assign_file is not None:
-        # upstream this branch stops in ipdb.set_trace() (bin/desman:213-214): there is nothing to mirror
-        logging.error('-a/--assign_file is not supported (dead in the reference)')
-        sys.exit('desman: -a/--assign_file is not supported')
     sampletau.freeRNG()
 
 

@@ -1007,3 +1007,24 @@ extern "C" int dsm_sample_tau(int64_t *tau, const double *pi, const double *eta,
     TRY(dsm_ctx_get_state(c, tau, nullptr, nullptr));
     return n;
 }
+
+// ---------------------------------------------------------------- reference-named aliases
+// The four symbols sampletau/sampletau.pyx:10-16 declares (`cdef extern from "c_sample_tau.h"`), with the
+// reference's own prototypes (c_sample_tau.c:26,36,42,95: `long` = int64 on LP64), so the unmodified .pyx links
+// against this library with only a `libraries=` change in setup.py.  The reference has no
+// error channel (malloc failure -> message + exit(1), c_sample_tau.c:200-203): errors are reported on stderr;
+// c_sample_tau then returns -1 (the reference's callers add the return value to a change counter).
+static void alias_report(const char *fn, int rc)
+{
+    if (rc < 0) fprintf(stderr, "desman_hip: %s failed (%d): %s\n", fn, rc, dsm_last_error());
+}
+extern "C" void c_initRNG(void) { alias_report("c_initRNG", dsm_initRNG()); }
+extern "C" void c_setRNG(unsigned long seed) { alias_report("c_setRNG", dsm_setRNG(seed)); }
+extern "C" void c_freeRNG(void) { alias_report("c_freeRNG", dsm_freeRNG()); }
+extern "C" int c_sample_tau(long *tau, double *pi, double *eta, long *variants, int nV, int nG, int nS)
+{
+    static_assert(sizeof(long) == sizeof(int64_t), "LP64 expected");
+    const int rc = dsm_sample_tau(reinterpret_cast<int64_t *>(tau), pi, eta, reinterpret_cast<const int64_t *>(variants), nV, nG, nS);
+    alias_report("c_sample_tau", rc);
+    return rc < 0 ? -1 : rc;
+}

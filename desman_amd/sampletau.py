@@ -20,9 +20,20 @@ from . import _lib
 _tls = threading.local()
 
 
-def use_thread_local_rng(on=True):
+def use_thread_local_rng(on=True, device=None):
+    """`on`: this thread gets its own logical GSL stream AND its own device context for sample_tau (the C shim's
+    context and stream are process-global: sampletau/c_sample_tau.c:24).  `device`: HIP device of that context
+    (default: DESMAN_HIP_DEVICE or 0)."""
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is not None:
+        ctx.close()
+    _tls.ctx = None
     _tls.enabled = bool(on)
     _tls.state = None
+    if device is None:
+        import os
+        device = int(os.environ.get("DESMAN_HIP_DEVICE", "0"))
+    _tls.device = int(device)
 
 
 def _local():
@@ -88,6 +99,25 @@ def sample_tau(tau, pi, eta, variants):
     if tau.shape[2] != 4 or pi.shape[1] != nG or eta.shape != (4, 4) or variants.shape != (nV, nS, 4):
         raise ValueError("inconsistent shapes: tau %s pi %s eta %s variants %s"
                          % (tau.shape, pi.shape, eta.shape, variants.shape))
+    if _local():
+        # this thread's own context and its own logical stream: the state is handed to the device for the sweep
+        # and taken back afterwards, so reference-style code (Eta_Sampler.sampleTauC, HaploSNP_Sampler.update)
+        # inside a desman_amd.chains worker thread draws from ITS stream, not from the process-global one
+        if _tls.state is None:
+            raise _lib.DesmanHipError("sample_tau: RNG not initialised (initRNG/setRNG)")
+        if nV == 0:
+            return 0
+        if getattr(_tls, "ctx", None) is None:
+            _tls.ctx = _lib.Context(getattr(_tls, "device", 0))
+        ctx = _tls.ctx
+        ctx.set_counts(variants)
+        ctx.set_state(tau, pi, eta)
+        ctx.set_tau_rng(_lib.RNG_MT19937)
+        ctx.set_mt_state(_tls.state)
+        n = ctx.sample_tau()
+        tau[...] = ctx.get_state()[0]
+        _tls.state = ctx.get_mt_state()
+        return n
     rc = _lib.load().dsm_sample_tau(tau, pi, eta, variants, nV, nG, nS)
     if rc < 0:
         _lib.check(rc)

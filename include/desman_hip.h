@@ -64,6 +64,13 @@ int dsm_freeRNG(void);
  * of (v,g) whose base changed (>= 0) or a negative DSM_ERR_* code.           */
 int dsm_sample_tau(int64_t *tau, const double *pi, const double *eta,
                    const int64_t *variants, int nV, int nG, int nS);
+/* the same four entry points under the reference's own names and prototypes (what `cdef extern from
+ * "c_sample_tau.h"` in sampletau/sampletau.pyx:10-16 binds; c_sample_tau.c:26,36,42,95), so the unmodified
+ * .pyx links against libdesman_hip.so.  Errors go to stderr; c_sample_tau then returns -1.          */
+void c_initRNG(void);
+void c_setRNG(unsigned long seed);
+void c_freeRNG(void);
+int c_sample_tau(long *tau, double *pi, double *eta, long *variants, int nV, int nG, int nS);
 /* read / write the process-global MT19937 stream of the shim (624 words +
  * position): lets a device-resident context continue the same logical stream. */
 int dsm_getRNG_state(uint32_t *state625);

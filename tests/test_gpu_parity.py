@@ -100,6 +100,60 @@ def test_sampletau_dropin_module(ctx):
         sampletau.sample_tau(t_hip, z["gamma"], z["eta"], z["counts"])
 
 
+def test_reference_named_c_aliases():
+    """c_initRNG / c_setRNG / c_freeRNG / c_sample_tau (sampletau.pyx:10-16 binds these names): same stream, same sweep"""
+    lib = _lib.load()
+    z = np.load(os.path.join(GOLDEN, "tau_sweep_V64_S16_G5.npz"))
+    t_hip, t_ref = z["tau_in"].copy(), z["tau_in"].copy()
+    V, G, S = t_hip.shape[0], t_hip.shape[1], z["gamma"].shape[0]
+    lib.c_initRNG(); lib.c_setRNG(4711)
+    cbind.initRNG(); cbind.setRNG(4711)
+    for _ in range(2):
+        n = lib.c_sample_tau(t_hip, np.ascontiguousarray(z["gamma"]), np.ascontiguousarray(z["eta"]), z["counts"], V, G, S)
+        n_ref = cbind.sample_tau(t_ref, z["gamma"], z["eta"], z["counts"])
+        assert n == n_ref and np.array_equal(t_hip, t_ref)
+    lib.c_freeRNG(); cbind.freeRNG()
+    assert lib.c_sample_tau(t_hip, np.ascontiguousarray(z["gamma"]), np.ascontiguousarray(z["eta"]), z["counts"], V, G, S) == -1
+
+
+def test_sampletau_thread_local_streams():
+    """two worker threads with their own logical GSL streams (desman_amd.chains): each sample_tau draws from ITS
+    stream on its own context -- results equal the single-threaded reference for each seed, whatever the interleaving"""
+    import threading
+    from desman_amd import sampletau
+    z = np.load(os.path.join(GOLDEN, "tau_sweep_V64_S16_G5.npz"))
+    want = {}
+    for seed in (5, 6):
+        t = z["tau_in"].copy()
+        mt = cbind.MT19937(seed)
+        V, G = t.shape[0], t.shape[1]
+        ns = [cbind.sample_tau_u(t, z["gamma"], z["eta"], z["counts"], mt.uniform(V * G)) for _ in range(3)]
+        want[seed] = (t, ns)
+    got, errs = {}, []
+    barrier = threading.Barrier(2)
+
+    def work(seed):
+        try:
+            sampletau.use_thread_local_rng(True)
+            sampletau.initRNG(); sampletau.setRNG(seed)
+            t = z["tau_in"].copy()
+            ns = []
+            for _ in range(3):
+                barrier.wait(timeout=60)                          # force the two threads to interleave their sweeps
+                ns.append(sampletau.sample_tau(t, z["gamma"], z["eta"], z["counts"]))
+            got[seed] = (t, ns)
+            sampletau.freeRNG()
+            sampletau.use_thread_local_rng(False)
+        except Exception as e:                                    # noqa: BLE001
+            errs.append(e)
+            barrier.abort()
+    th = [threading.Thread(target=work, args=(s,)) for s in (5, 6)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    for seed in (5, 6):
+        assert np.array_equal(got[seed][0], want[seed][0]) and got[seed][1] == want[seed][1]
+
+
 # ---------------------------------------------------------------- A5 ll / lp
 def test_loglik_golden(ctx):
     z = np.load(os.path.join(GOLDEN, "loglik.npz"))

@@ -19,8 +19,9 @@ HAVE_GPU = _lib.device_count() > 0 if os.path.exists(_lib.LIB_PATH) else False
 def test_library_exports_every_declared_symbol():
     hdr = open(_lib.HEADER_PATH).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(dsm_[A-Za-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b((?:dsm|c)_[A-Za-z0-9_]+)\s*\(", hdr))      # dsm_* and the reference-named c_* aliases
     declared -= {"dsm_ctx"}
+    assert {"c_initRNG", "c_setRNG", "c_freeRNG", "c_sample_tau"} <= declared
     assert len(declared) >= 40
     lib = _lib.load()
     for name in sorted(declared):
@@ -186,3 +187,14 @@ def test_gene_sampler_fails_loudly_without_a_gpu():
                     np.eye(4), np.ones((3, 2)))
     with pytest.raises(_lib.DesmanHipError):
         KLAssign(np.random.RandomState(1), np.ones((3, 2)), np.ones((2, 2))).factorize()
+
+
+def test_cli_rejects_assign_file_before_any_work(tmp_path):
+    """-a is dead upstream (bin/desman:213-214 stops in ipdb after the whole run): rejected right after parsing,
+    before the output directory or any GPU work"""
+    from desman_amd import cli
+    out = tmp_path / "never_created"
+    with pytest.raises(SystemExit) as e:
+        cli.main([str(tmp_path / "missing.freq"), "-g", "3", "-o", str(out), "-a", str(tmp_path / "x.csv")])
+    assert "assign_file" in str(e.value)
+    assert not out.exists()

@@ -57,6 +57,7 @@ SIGNATURES = {
     "dsm_ctx_get_mt_state": (_i, [_vp, _u32p]),
     "dsm_ctx_set_mt_state": (_i, [_vp, _u32p]),
     "dsm_mt_seed_state": (_i, [C.c_ulong, _u32p]),
+    "dsm_ctx_debug_mt_fill": (_i, [_vp, C.c_size_t, _u32p]),
     "dsm_ctx_sample_tau": (_i, [_vp, C.POINTER(_i), _vp]),
     "dsm_ctx_sample_stats": (_i, [_vp, C.c_uint32, _u64p, _u64p]),
     "dsm_ctx_stats_spec": (_i, [_vp]),
@@ -244,6 +245,11 @@ class Context:
 
     def set_mt_state(self, st):
         check(self.lib.dsm_ctx_set_mt_state(self._h, np.ascontiguousarray(st, dtype=np.uint32)))
+
+    def debug_mt_fill(self, n):
+        out = np.empty(int(n), dtype=np.uint32)
+        check(self.lib.dsm_ctx_debug_mt_fill(self._h, int(n), out))
+        return out
 
     def set_tau_rng(self, mode):
         check(self.lib.dsm_ctx_set_tau_rng(self._h, int(mode)))

@@ -475,6 +475,21 @@ extern "C" int dsm_ctx_set_mt_state(dsm_ctx *c, const uint32_t *state625)
     return DSM_OK;
 }
 
+extern "C" int dsm_ctx_debug_mt_fill(dsm_ctx *c, size_t n, uint32_t *out)
+{
+    if (!c || (!out && n)) { dsm_set_error("debug_mt_fill: bad arguments"); return DSM_ERR_ARG; }
+    if (!c->mt_seeded) { dsm_set_error("tau RNG not seeded"); return DSM_ERR_STATE; }
+    if (n == 0) return DSM_OK;
+    BIND(c);
+    Scratch<uint32_t> d;
+    TRY(d.alloc(n));
+    HIP_TRY(hipStreamSynchronize(c->stream_rng));
+    TRY(k_mt_fill(c, d, n, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, d, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
 extern "C" int dsm_ctx_set_tau_rng(dsm_ctx *c, int mode)
 {
     if (!c || (mode != DSM_RNG_MT19937 && mode != DSM_RNG_PHILOX)) { dsm_set_error("bad rng mode"); return DSM_ERR_ARG; }

@@ -165,6 +165,74 @@ __global__ __launch_bounds__(256) void mt_fill_kernel(uint32_t *__restrict__ sta
     if (tid == 0) state[624] = (uint32_t)pos;
 }
 
+// ---------------------------------------------------------------------
+// The same stream, 4x wider per step.  MT19937's recurrence is  P x = 0  with  P = t^624 + t^397 + Q,  where t shifts
+// the word sequence by one and  (Q x)[n] = A (U x[n] | L x[n+1])  is the "twist" (upper bit of one word, lower 31 of
+// the next, times the companion matrix A).  All three terms are GF(2)-linear and t commutes with Q, so the
+// cross terms of P^2 cancel:  P^(2^k) = t^(624 K) + t^(397 K) + Q^K  with K = 2^k, i.e.
+//     x[j] = x[j - 227 K]  xor  (Q^K x)[j - 624 K]          (K = 1 is the textbook recurrence)
+// which only reaches back 227 K words: 227 K new words are independent of each other.  Q^K is K twist levels over
+// K + 1 consecutive words.  With K = 4 one workgroup of 16 wavefronts produces 908 words per barrier instead of 227
+// (a 624-word refill has three dependent 227-word phases).  Every wavefront covers 64 consecutive positions and
+// keeps the first 60 (the twist levels are neighbour exchanges inside the wavefront), 16 x 60 >= 908.  The first
+// 2496 raw words after a state hand-off come from K = 1 and K = 2 steps (a step needs 624 K words of history).
+// The raw words live in a 4096-word LDS ring; the kernel leaves the standard (624 words + position) state behind,
+// so streams move between contexts / the host exactly as before.  Bit-identical to gsl_rng_mt19937.
+// ---------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b)
+{
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return (y >> 1) ^ ((b & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__global__ __launch_bounds__(1024) void mt_fill_wide_kernel(uint32_t *__restrict__ state, uint32_t *__restrict__ out, size_t n)
+{
+    __shared__ uint32_t ring[4096];                 // raw word with absolute index a (block start = 0) at ring[a & 4095]
+    __builtin_amdgcn_s_setprio(3);                  // a latency chain on one CU: do not queue behind the co-resident sweep / mu-E waves
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < 624; i += 1024) ring[i] = state[i];
+    const int pos = (int)state[624];
+    __syncthreads();
+    // outputs o = 0 .. n-1 are the tempered raw words pos + o; blocks start at multiples of 624
+    const size_t E = (size_t)pos + n;                               // one past the last raw word consumed
+    if (E <= 624) {                                                 // served from the resident block
+        for (size_t o = tid; o < n; o += 1024) out[o] = mt_temper(ring[pos + o]);
+        if (tid == 0) state[624] = (uint32_t)E;
+        return;
+    }
+    for (int o = tid; o < 624 - pos; o += 1024) out[o] = mt_temper(ring[pos + o]);
+    const size_t nb = (E - 1) / 624;                                // last block touched (>= 1): raw words up to R are needed
+    const size_t R = (nb + 1) * 624;
+    size_t T = 624;                                                 // raw words known so far
+    while (T < R) {
+        const int K = (T >= 2496) ? 4 : (T >= 1248) ? 2 : 1;
+        const int W = 227 * K, keep = 64 - K;
+        const int jo = wv * keep + lane;                            // offset of this lane's word inside the step
+        if (wv * keep < W) {                                        // wavefront-uniform
+            const size_t j = T + (size_t)jo;
+            uint32_t y = ring[(j - 624 * (size_t)K) & 4095];        // level 0: x[j - 624 K + lane-relative] (consecutive)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                // the word of lane + 1: DPP wave_shl:1 (a VALU move, no LDS round trip); lanes >= 64 - l hold garbage
+                // from here on and are never kept
+                const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x130, 0xf, 0xf, false);
+                if (l < K) y = mt_twist(y, nx);
+            }
+            if (lane < keep && jo < W) {
+                const uint32_t val = ring[(j - (size_t)W) & 4095] ^ y;
+                ring[j & 4095] = val;
+                if (j >= (size_t)pos + 0 && j < E) out[j - (size_t)pos] = mt_temper(val);
+            }
+        }
+        T += (size_t)W;
+        __syncthreads();
+    }
+    // standard state: the last block touched and the position inside it (1..624)
+    const size_t B = R - 624;
+    for (int i = tid; i < 624; i += 1024) state[i] = ring[(B + (size_t)i) & 4095];
+    if (tid == 0) state[624] = (uint32_t)(E - B);
+}
+
 // =====================================================================
 // A2: auxiliary-count sums.  Work item = one (variant, observed base) pair of
 // one sample with a non-zero count; the item list of every sample is built
@@ -703,7 +771,9 @@ int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n, hipStream_t stream)
 {
     if (n == 0) return DSM_OK;
     KTimer tm(c, DSM_K_MT, stream);
-    hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, stream, c->mt_state, out, n);
+    static const bool plain = getenv("DESMAN_HIP_MT_PLAIN") != nullptr;        // A/B switch: the 227-words-per-step kernel
+    if (plain) hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, stream, c->mt_state, out, n);
+    else hipLaunchKernelGGL(mt_fill_wide_kernel, dim3(1), dim3(1024), 0, stream, c->mt_state, out, n);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }

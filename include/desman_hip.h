@@ -106,6 +106,8 @@ int dsm_ctx_set_tau_rng(dsm_ctx *ctx, int mode /* DSM_RNG_* */);
  * global generator does across sampler objects (bin/desman:131,149-153,199-201). */
 int dsm_ctx_get_mt_state(dsm_ctx *ctx, uint32_t *state625);
 int dsm_ctx_set_mt_state(dsm_ctx *ctx, const uint32_t *state625);
+/* test hook: the next n raw 32-bit words of the context's MT19937 stream (advances it), host buffer.  */
+int dsm_ctx_debug_mt_fill(dsm_ctx *ctx, size_t n, uint32_t *out);
 /* fill `state625` from a seed exactly as gsl_rng_set(mt19937, seed) would. */
 int dsm_mt_seed_state(unsigned long seed, uint32_t *state625);
 

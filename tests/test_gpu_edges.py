@@ -133,3 +133,29 @@ def test_contexts_release_their_device_memory():
         cycle()
     free1 = free_bytes()
     assert free0 - free1 < 32 * 1024 * 1024, (free0, free1)
+
+
+def test_mt19937_device_stream_is_gsl_stream_across_fills_and_handoffs():
+    """the K-wide MT19937 generator (mt_fill_wide_kernel) against the oracle's serial gsl_rng_mt19937: raw words
+    bit for bit over fills of awkward lengths (inside a block, exactly to a block edge, across the K = 1 / 2 / 4
+    start-up, a million words), the standard (624 words + position) state after each fill, and a hand-off of that
+    state to a second context"""
+    ctx = _lib.Context(0)
+    for seed in (0, 1, 4357, 2 ** 32 - 1):
+        ctx.seed(seed)
+        ref = cbind.MT19937(seed)
+        for n in (1, 622, 1, 1, 624, 5, 619, 1248, 227, 2269, 3, 10 ** 6, 80000, 1):
+            got = ctx.debug_mt_fill(n)
+            assert np.array_equal(got, ref.raw(n)), (seed, n)
+    # state hand-off: export, import into another context, both continue identically
+    st = ctx.get_mt_state()
+    assert 1 <= int(st[624]) <= 624
+    c2 = _lib.Context(0)
+    c2.set_mt_state(st)
+    a, b = ctx.debug_mt_fill(5000), c2.debug_mt_fill(5000)
+    c2.close()
+    assert np.array_equal(a, b) and np.array_equal(a, ref.raw(5000))
+    # a state produced by the host seeding routine (position 624: refill on first use)
+    ctx.set_mt_state(_lib.mt_seed_state(99))
+    assert np.array_equal(ctx.debug_mt_fill(3000), cbind.MT19937(99).raw(3000))
+    ctx.close()

@@ -12,6 +12,8 @@
 //   pass B  : R' = tau.gamma_new (the normalised gamma BEFORE _adjustment, as in the reference),
 //             Q' = F (/) R', tau *= (Q'.gamma^T) (/) rowsum(gamma),
 //             per-(v,g) renormalisation over the four bases (:170-181), _adjustment (:88-91)
+#include <stdlib.h>
+
 #include "dsm_device.h"
 #include "dsm_host.h"
 #include "log_table.h"
@@ -606,8 +608,12 @@ static void launch_wave(dsm_ctx *c, int adjust, int do_update, int grid)
 }
 
 // do_update = 1: tau half of the running update + statistics of the next; 0: statistics only
+int k_nmft_mfma(dsm_ctx *c, int adjust, int do_update);
+bool nmft_use_mfma(const dsm_ctx *c);
+
 int k_nmft_wave(dsm_ctx *c, int adjust, int do_update)
 {
+    if (nmft_use_mfma(c)) return k_nmft_mfma(c, adjust, do_update);
     KTimer tm(c, do_update ? DSM_K_NMFT_B : DSM_K_NMFT_A);
     int nsl, gmax;
     if (!wave_shape(c, &nsl, &gmax)) { dsm_set_error("nmft_wave: unsupported shape"); return DSM_ERR_UNSUPPORTED; }
@@ -626,5 +632,287 @@ int k_nmft_get_tau(dsm_ctx *c, uint64_t *d_packed)
     hipLaunchKernelGGL(nmft_get_tau_kernel, dim3((c->V + 255) / 256), dim3(256), 0, c->stream, c->ntau, c->V, c->nG,
                        d_packed);
     HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}
+
+// ===========================================================================
+// nmft_mfma_kernel: the one-pass update of nmft_wave_kernel with its three dense contractions on the matrix cores
+// (v_mfma_f64_16x16x4_f64; measured 2x the VALU form of the same contraction on gfx950: the VALU form is bound by
+// operand delivery -- one LDS broadcast per FMA -- not by the FMA rate; profiles/r02_mfma_f64_ab.txt).
+//
+// A wavefront owns a QUAD of variants = 16 rows of F / tau, row index i = 4 r + vv (base r, variant vv of the quad).
+// Register layout of everything sample-shaped ("L2"): lane = n + 16 vv (n = sample inside a 16-sample tile),
+// element e of a double4 = base r, one double4 per tile t -- which is exactly how the instruction returns
+// D[i][j] (lane = j + 16 (i % 4), element i / 4: scripts/ubench/mfma_layout_probe.hip) when rows are ordered i = 4 r + vv:
+//   R' = tau_old . gamma_raw   A[i][k] = tau_old[i][4 kb + k] (lane i + 16 k, from this wavefront's LDS copy of the
+//                              16 rows), B[k][j] = gamma_raw[4 kb + k][16 t + j] (lane j + 16 k, staged per lane in LDS)
+//   Q' = F (/) R'              element-wise in L2 (F is loaded in L2: 16 consecutive doubles per (variant, base, tile))
+//   num[i][g] = sum_s Q'[i][s] gamma_raw[g][s]: contraction over SAMPLES = over the 16 lanes of a row group and the
+//                              tiles: per-lane products (gamma_raw[g][16 t + n] from LDS), then ONE transposing butterfly
+//                              per 4 haplotypes over the 16 lanes of each variant -- DPP only (quad_perm, row_ror:8,
+//                              row_shl/shr:4), the four variants of the quad reduce simultaneously in the four DPP rows
+//                              (the lane = sample layout paid a 64-lane butterfly per variant: 4x the exchange steps)
+//   tau update                 lane (n, vv) ends with base e = 2 b0 + b1, haplotype 4 c + 2 b3 + b2 (b_k = bit k of n): the
+//                              four bases of a (variant, haplotype) sit in one quad -> renormalisation by quad broadcasts
+//   R2 = tau_new . gamma, Q2 = F (/) R2, objective: as above with the new rows
+//   gamma numerators           num_g[g][s] += sum_rows tau_new[row][g] Q2[row][s]: contraction over ROWS, K-block = base e:
+//                              A[m][k] = tau_new[vv = k][e][g = m] (lane m + 16 k), B[k][j] = Q2[vv = k][e][16 t + j] = the L2
+//                              register itself.  The accumulators D[g][s] stay in registers for the whole kernel.
+// No operand ever needs a transposition through LDS.  Shapes: S <= 64 (NT <= 4 tiles), G <= 8 (KB <= 2 K-blocks); other
+// shapes run nmft_wave_kernel / the two-pass kernels.
+// ===========================================================================
+typedef double double4_t __attribute__((ext_vector_type(4)));
+#define DSM_DPP_ROW_SHL4 0x104
+#define DSM_DPP_ROW_SHR4 0x114
+
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_mov_masked(double old, double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xf, BANK, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xf, BANK, false);
+    return __hiloint2double(hi, lo);
+}
+
+// 16 values per lane -> lane n of every 16-lane row holds the row total of value 8 b0 + 4 b1 + 2 b3 + b2
+__device__ __forceinline__ double row16_transpose_reduce(double (&v)[16], int n)
+{
+    const bool b0 = n & 1, b1 = n & 2, b2 = n & 4, b3 = n & 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double keep = b0 ? v[i + 8] : v[i], send = b0 ? v[i] : v[i + 8];
+        v[i] = keep + dpp_mov<DSM_DPP_XOR1>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double keep = b1 ? v[i + 4] : v[i], send = b1 ? v[i] : v[i + 4];
+        v[i] = keep + dpp_mov<DSM_DPP_XOR2>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double keep = b3 ? v[i + 2] : v[i], send = b3 ? v[i] : v[i + 2];
+        v[i] = keep + dpp_mov<DSM_DPP_ROR8>(send);                   // rotation by 8 inside the row = lane ^ 8
+    }
+    {
+        const double keep = b2 ? v[1] : v[0], send = b2 ? v[0] : v[1];
+        double got = dpp_mov_masked<DSM_DPP_ROW_SHL4, 0x5>(0.0, send);   // lanes with b2 = 0 (banks 0, 2) read lane + 4
+        got = dpp_mov_masked<DSM_DPP_ROW_SHR4, 0xA>(got, send);          // lanes with b2 = 1 (banks 1, 3) read lane - 4
+        v[0] = keep + got;
+    }
+    return v[0];
+}
+
+template <int NT, int KB>
+__global__ __launch_bounds__(256, 3) void nmft_mfma_kernel(const double *__restrict__ F, double *__restrict__ tau,
+                                                        const double *__restrict__ gam_raw, const double *__restrict__ gam,
+                                                        int V, int S, int G, int adjust, int do_update,
+                                                        const double *__restrict__ ctl, const double *__restrict__ log_tab,
+                                                        double *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_m[];
+    if (ctl[2] != 0.0) return;
+    constexpr int GP = 4 * KB, SPAD = 16 * NT;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
+    const int nblk = gridDim.x;
+    double2 *ltab = reinterpret_cast<double2 *>(smem_m);                        // [256]
+    double *gr = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);              // [GP][SPAD] gamma_raw (product operands)
+    double *braw = gr + GP * SPAD;                                              // [NT][KB][64] B fragments of gamma_raw
+    double *bgam = braw + NT * KB * 64;                                         // [NT][KB][64] B fragments of gamma
+    double *t1 = bgam + NT * KB * 64;                                           // [GP] rowsum(gamma_raw)
+    double *told = t1 + GP + wv * (2 * 16 * GP);                                // per wavefront [16][GP], row i = 4 r + vv
+    double *tnew = told + 16 * GP;                                              // per wavefront [16][GP]
+    double *red = t1 + GP + 4 * (2 * 16 * GP);                                  // [4][GP + 2][SPAD] end-of-kernel reduction
+    ltab[tid] = reinterpret_cast<const double2 *>(log_tab)[tid];
+    for (int i = tid; i < GP * SPAD; i += 256) {
+        const int g = i / SPAD, s = i % SPAD;
+        gr[i] = (g < G && s < S) ? gam_raw[(size_t)g * S + s] : 0.0;
+    }
+    for (int i = tid; i < NT * KB * 64; i += 256) {
+        const int l = i & 63, kb = (i >> 6) % KB, t = (i >> 6) / KB;
+        const int g = 4 * kb + (l >> 4), s = 16 * t + (l & 15);
+        const bool in = g < G && s < S;
+        braw[i] = in ? gam_raw[(size_t)g * S + s] : 0.0;
+        bgam[i] = in ? gam[(size_t)g * S + s] : 0.0;
+    }
+    __syncthreads();
+    for (int g = wv; g < GP; g += 4) {                                          // gamma.sum(1) (:170), lane-parallel
+        double a = 0.0;
+        for (int s = lane; s < SPAD; s += 64) a += gr[g * SPAD + s];
+        a = group_allreduce_sum<64>(a);
+        if (lane == 0) t1[g] = a;
+    }
+    __syncthreads();
+
+    for (int k = lane; k < 2 * 16 * GP; k += 64) told[k] = 0.0;                 // incl. tnew and the padded haplotype columns
+    double4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double obj = 0.0, h1 = 0.0;
+    const bool b0 = n & 1, b1 = n & 2, b2 = n & 4, b3 = n & 8;
+    const int my_e = (b0 ? 2 : 0) + (b1 ? 1 : 0), my_gg = (b3 ? 2 : 0) + (b2 ? 1 : 0);
+
+    const int nquad = (V + 3) >> 2;
+    for (int qd = blockIdx.x * 4 + wv; qd < nquad; qd += nblk * 4) {
+        const int v0 = qd * 4;
+        const bool vok = v0 + q < V;                                            // this lane's variant exists
+        // the 16 tau rows of the quad (contiguous in HBM: [vv][r][g]) -> LDS [i = 4 r + vv][g]
+        for (int k = lane; k < 16 * G; k += 64) {
+            const int vv = k / (4 * G), r = (k / G) & 3, g = k % G;
+            const double x = (v0 + vv < V) ? tau[(size_t)v0 * 4 * G + k] : 0.0;
+            told[(4 * r + vv) * GP + g] = x;
+            if (!do_update) tnew[(4 * r + vv) * GP + g] = x;
+        }
+        // F in L2: f[t][e] = F[variant v0 + q][base e][16 t + n]
+        double4_t f[NT];
+        bool live[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            live[t] = vok && (16 * t + n < S);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[t][e] = live[t] ? F[((size_t)(v0 + q) * 4 + e) * S + 16 * t + n] : 1.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (do_update) {
+            double a_old[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) a_old[kb] = told[n * GP + 4 * kb + q];
+            double4_t qp[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_old[kb], braw[(t * KB + kb) * 64 + lane], R, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qp[t][e] = live[t] ? nzd(f[t][e]) / nzd(R[e]) : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < KB; ++c) {
+                double p[16];                                                   // value index j = 4 e + gg
+#pragma unroll
+                for (int j = 0; j < 16; ++j) p[j] = 0.0;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        const double gm = gr[(4 * c + gg) * SPAD + 16 * t + n];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) p[4 * e + gg] = fma(qp[t][e], gm, p[4 * e + gg]);
+                    }
+                const double tot_rg = row16_transpose_reduce(p, n);             // num[(my_e, vv = q)][g]
+                const int g = 4 * c + my_gg;
+                const bool ok = g < G;
+                double tn = 0.0;
+                if (ok) tn = told[(4 * my_e + q) * GP + g] * (nzd(tot_rg) / nzd(t1[g]));       // :171-172
+                const double t_a0 = dpp_mov<0x00>(tn), t_a1 = dpp_mov<0xAA>(tn);              // e = 0 / 1 live in quad lanes 0 / 2
+                const double t_a2 = dpp_mov<0x55>(tn), t_a3 = dpp_mov<0xFF>(tn);              // e = 2 / 3            quad lanes 1 / 3
+                const double tot = ((t_a0 + t_a1) + t_a2) + t_a3;                              // :176-178
+                if (ok) {
+                    double x = tn / tot;                                                       // :180-181
+                    if (adjust && x < DSM_EPS) x = DSM_EPS;                                    // :88-91
+                    if (vok) tau[((size_t)(v0 + q) * 4 + my_e) * G + g] = x;
+                    tnew[(4 * my_e + q) * GP + g] = vok ? x : 0.0;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // statistics of the (new) state: R2, objective, Q2, gamma numerators, H1
+        double a_new[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) a_new[kb] = tnew[n * GP + 4 * kb + q];
+        double a_g[4];                                                          // A of the row contraction: tau_new[vv = q][e][g = n]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a_g[e] = (n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; h1 += a_g[e]; }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_new[kb], bgam[(t * KB + kb) * 64 + lane], R, 0, 0, 0);
+            double4_t q2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double pa = R[e] < DSM_EPS ? DSM_EPS : R[e];
+                const double ratio = nzd(f[t][e]) / pa;
+                q2[e] = live[t] ? ((R[e] < DSM_EPS) ? nzd(f[t][e]) / nzd(R[e]) : ratio) : 0.0;
+                if (live[t]) obj += f[t][e] * dsm_log(ratio, ltab) - f[t][e] + pa;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // workgroup reduction over the 4 wavefronts (fixed order) -> transposed partials.  acc[t][e]: g = 4 e + q, s = 16 t + n
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = 4 * e + q;
+            if (g < GP) red[((size_t)wv * (GP + 2) + g) * SPAD + 16 * t + n] = acc[t][e];
+        }
+    // objective: one value per lane; H1: lane (n = g, q) holds the sum over bases and this lane's variants of tau_new[.][g]
+    {
+        const double o = group_allreduce_sum<64>(obj);
+        double hh = h1;                                                        // sum over q (lanes n, n + 16, n + 32, n + 48)
+        hh += __shfl_xor(hh, 16, 64);
+        hh += __shfl_xor(hh, 32, 64);
+        if (lane == 0) red[((size_t)wv * (GP + 2) + GP) * SPAD] = o;
+        if (lane < GP) red[((size_t)wv * (GP + 2) + GP + 1) * SPAD + lane] = hh;
+    }
+    __syncthreads();
+    for (int i = tid; i < G * S; i += 256) {
+        const int g = i / S, s = i % S;
+        double a = 0.0;
+        for (int k = 0; k < 4; ++k) a += red[((size_t)k * (GP + 2) + g) * SPAD + s];
+        partial[(size_t)i * nblk + blockIdx.x] = a;
+    }
+    if (tid < G) {
+        double a = 0.0;
+        for (int k = 0; k < 4; ++k) a += red[((size_t)k * (GP + 2) + GP + 1) * SPAD + tid];
+        partial[((size_t)G * S + tid) * nblk + blockIdx.x] = a;
+    }
+    if (tid == 64) {
+        double a = 0.0;
+        for (int k = 0; k < 4; ++k) a += red[((size_t)k * (GP + 2) + GP) * SPAD];
+        partial[((size_t)G * S + G) * nblk + blockIdx.x] = a;
+    }
+}
+
+static bool mfma_shape(const dsm_ctx *c, int *nt, int *kb)
+{
+    *nt = (c->S + 15) / 16;
+    *kb = (c->nG + 3) / 4;
+    static const bool off = getenv("DESMAN_HIP_NMFT_NO_MFMA") != nullptr;      // A/B switch: the VALU one-pass kernel
+    return !off && *nt >= 1 && *nt <= 4 && *kb >= 1 && *kb <= 2;
+}
+
+bool nmft_use_mfma(const dsm_ctx *c) { int a, b; return mfma_shape(c, &a, &b); }
+
+int nmft_mfma_grid(const dsm_ctx *c)
+{
+    int g = ((c->V + 3) / 4 + 3) / 4;             // quads / 4 wavefronts
+    if (g > 768) g = 768;
+    return g < 1 ? 1 : g;
+}
+
+template <int NT, int KB>
+static void launch_mfma(dsm_ctx *c, int adjust, int do_update, int grid)
+{
+    constexpr int GP = 4 * KB, SPAD = 16 * NT;
+    const size_t sh = (2 * DSM_LOG_TAB_N + (size_t)GP * SPAD + 2 * (size_t)NT * KB * 64 + GP + 4 * 2 * 16 * GP +
+                       4 * (size_t)(GP + 2) * SPAD) * sizeof(double);
+    hipLaunchKernelGGL((nmft_mfma_kernel<NT, KB>), dim3(grid), dim3(256), sh, c->stream, c->F, c->ntau, c->ngam_raw, c->ngam,
+                       c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart);
+}
+
+int k_nmft_mfma(dsm_ctx *c, int adjust, int do_update)
+{
+    KTimer tm(c, do_update ? DSM_K_NMFT_B : DSM_K_NMFT_A);
+    int nt, kb;
+    if (!mfma_shape(c, &nt, &kb)) { dsm_set_error("nmft_mfma: unsupported shape"); return DSM_ERR_UNSUPPORTED; }
+    const int grid = nmft_mfma_grid(c);
+#define MCASE(N, K) if (nt == N && kb == K) launch_mfma<N, K>(c, adjust, do_update, grid)
+    MCASE(1, 1); MCASE(1, 2); MCASE(2, 1); MCASE(2, 2); MCASE(3, 1); MCASE(3, 2); MCASE(4, 1); MCASE(4, 2);
+#undef MCASE
+    HIP_TRY(hipGetLastError());
+    c->npart_cols = grid;
     return DSM_OK;
 }

@@ -699,11 +699,13 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
         if (it + 1 < n_iter) TRY(fill_sweep_uniforms(c, &u_next));
         // sampleMu (:341): spec v2 = stage 1 here, stage 2 inside the Dirichlet launch; spec v1 = the per-read pass
         const bool agg = stats_spec(c) == 2;
+        const bool fuse_s2 = agg && c->G < 10;           // many subsets per sample: stage 2 as its own 1024-thread launch
         TRY(agg ? k_stats_stage1(c, ic) : k_stats_v1(c, ic));
+        if (agg && !fuse_s2) TRY(k_stats_stage2(c, ic));
         // sampleGamma (:342) + the eta draw (:347: eta depends only on the E sums) + traces; the same
         // launch finalizes iteration it-1 (ll, lp, MAP test :349-353) in one extra workgroup
         TRY(k_dirichlet(c, ic, c->gamma, c->gamma_trace + (size_t)it * sg, c->eta_new, c->eta_trace + (size_t)it * 16,
-                        P[it & 1], it - 1, nb_prev, P[(it - 1) & 1], agg ? 1 : 0));
+                        P[it & 1], it - 1, nb_prev, P[(it - 1) & 1], fuse_s2 ? 1 : 0));
         TRY(await_sweep_uniforms(c, u));
         // tau sweep with (gamma_new, eta_old) (:345) + log-likelihood of the new state with eta_new (:349)
         TRY(k_tau_sweep(c, 3, c->gamma, c->eta, c->eta_new, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb_prev, u));

@@ -3,7 +3,7 @@
 // is built with -ffp-contract=off, division and sqrt are IEEE, so the two agree bit for bit).
 //
 //   draw_reads<K>   x reads over K categories, read by read against 32-bit thresholds (x <= DSM_XS)
-//   binom           Binomial(n, p): sequential-search inversion on the rarer outcome while its mean is <= 64
+//   binom           Binomial(n, p): sequential-search inversion on the rarer outcome while its mean is <= 128
 //                   ((1-q)^n by repeated squaring: no transcendental function), Hoermann's BTRS (1993) above
 //   mult4           x reads over the four true bases: heaviest base peeled off by one binomial, the few
 //                   others read by read
@@ -14,11 +14,12 @@
 #define DSM_STREAM_STA2 0x53544132u   // 'STA2'  stage-2 binomial streams
 #define DSM_STREAM_TEST 0x54455354u   // 'TEST'  test hook
 #define DSM_XS 128u                   // up to DSM_XS non-dominant reads are drawn read by read
-#define DSM_BINV_MEAN_CAP 64.0        // inversion while the mean of the rarer outcome is <= 64, BTRS above: on a
+#define DSM_BINV_MEAN_CAP 128.0       // inversion while the mean of the rarer outcome is <= 128, BTRS above: on a
                                       // 64-lane wavefront BTRS costs ~1500 instructions (some lane always takes the
                                       // slow path / another attempt), the search 14 per step
-#define DSM_BINV_KMAX 255u
-#define DSM_RCP_TAB_N 256             // 1/k for k < 256, staged in LDS by the kernels (entry 0 unused)
+#define DSM_BINV_MEAN_CAP_S2 16.0      // stage 2: one latency-bound binomial per lane, BTRS is the shorter dependent chain
+#define DSM_BINV_KMAX 511u
+#define DSM_RCP_TAB_N 512             // 1/k for k < 512, staged in LDS by the kernels (entry 0 unused)
 
 __device__ __forceinline__ Xo128 xo_seed(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
@@ -76,8 +77,8 @@ __device__ __forceinline__ void draw_reads(Xo128 &rng, uint32_t x, const double 
     n[K - 1] = x - c[K - 2];
 }
 
-// Binomial(c, q) by sequential search from 0 (c q <= 64): f0 = (1-q)^c, r = q/(1-q); the search stops at
-// DSM_BINV_KMAX = 255, so 1/k always comes from the LDS table rcp (correctly rounded 1/k: the oracle divides)
+// Binomial(c, q) by sequential search from 0 (c q <= 128): f0 = (1-q)^c, r = q/(1-q); the search stops at
+// DSM_BINV_KMAX = 511, so 1/k always comes from the LDS table rcp (correctly rounded 1/k: the oracle divides)
 __device__ __forceinline__ uint32_t binv(Xo128 &rng, uint32_t c, double f0, double r, const double *__restrict__ rcp)
 {
     // P(k)/P(k-1) = r (c-k+1)/k = r (c+1) (1/k) - r: one fma and one multiply per step
@@ -107,7 +108,7 @@ __device__ __forceinline__ double stirling_tail(double k)
     return (1.0 / 12.0 - (1.0 / 360.0 - (1.0 / 1260.0) * inv2) * inv2) * inv;
 }
 
-// Hoermann's BTRS, q <= 1/2, n q > 64 (the rare path of the stage-1 kernel once the chain has converged)
+// Hoermann's BTRS, q <= 1/2, n q > 128 (the rare path of the stage-1 kernel once the chain has converged)
 __device__ __forceinline__ uint32_t btrs(uint32_t &s0, uint32_t &s1, uint32_t &s2, uint32_t &s3, uint32_t n, double q,
                                       const double2 *__restrict__ ltab)
 {
@@ -146,7 +147,7 @@ __device__ __forceinline__ uint32_t btrs(uint32_t &s0, uint32_t &s1, uint32_t &s
 // lean stage-1 kernel: a draw that needs BTRS sets `defer` instead (the item is re-done by the compacted kernel).
 template <bool BIG>
 __device__ __forceinline__ uint32_t binom(Xo128 &rng, uint32_t n, double wa, double wb, const double *__restrict__ rcp,
-                                          const double2 *__restrict__ ltab, bool &defer)
+                                          const double2 *__restrict__ ltab, bool &defer, double cap = DSM_BINV_MEAN_CAP)
 {
     if (n == 0 || !(wa > 0.0)) return 0;
     if (!(wb > 0.0)) return n;
@@ -154,7 +155,7 @@ __device__ __forceinline__ uint32_t binom(Xo128 &rng, uint32_t n, double wa, dou
     const double ws = flip ? wb : wa, wl = flip ? wa : wb;         // the rarer outcome has odds ws : wl
     const double T = ws + wl;
     uint32_t k;
-    if ((double)n * ws > DSM_BINV_MEAN_CAP * T) {
+    if ((double)n * ws > cap * T) {
         if constexpr (BIG) k = btrs(rng.s0, rng.s1, rng.s2, rng.s3, n, ws / T, ltab);
         else { defer = true; return 0; }
     } else k = binv(rng, n, dsm_pw(wl / T, n), ws / wl, rcp);

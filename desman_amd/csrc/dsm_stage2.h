@@ -41,7 +41,7 @@ S2Plan make_stage2_plan(int G);     // kernels_stats.hip
 // them to p.sum_mu[s][.]
 __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, int s, char *smem, bool to_global)
 {
-    const int G = p.G, S = p.S, tid = threadIdx.x;
+    const int G = p.G, S = p.S, tid = threadIdx.x, nthr = blockDim.x;      // 256 (fused form) or 1024 (many subsets)
     double2 *ltab = reinterpret_cast<double2 *>(smem);                         // [256]
     double *rcp = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);            // [256]
     double *gs = rcp + DSM_RCP_TAB_N;                                          // [32]
@@ -51,14 +51,14 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
     int *n_hi = n_lo + S2_MAX_NODES, *n_off = n_hi + S2_MAX_NODES, *n_idx = n_off + S2_MAX_NODES, *n_child = n_idx + S2_MAX_NODES;
 
     if (s == 0 && tid == 0 && p.big_count) *p.big_count = 0u;
-    ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
-    rcp[tid] = tid ? 1.0 / (double)tid : 0.0;
+    if (tid < DSM_LOG_TAB_N) ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
+    for (int k = tid; k < DSM_RCP_TAB_N; k += nthr) rcp[k] = k ? 1.0 / (double)k : 0.0;
     if (tid < 32) {
         gs[tid] = (tid < G) ? p.gamma[(size_t)s * G + tid] : 0.0; leaf[tid] = 0u;
         n_lo[tid] = p.plan.lo[tid]; n_hi[tid] = p.plan.hi[tid]; n_off[tid] = p.plan.off[tid]; n_idx[tid] = p.plan.idx[tid];
         n_child[tid] = p.plan.child[tid];
     }
-    for (int i = tid; i < S2_TAB_ENTRIES; i += 256) tab[i] = 0u;
+    for (int i = tid; i < S2_TAB_ENTRIES; i += nthr) tab[i] = 0u;
     __syncthreads();
 
     const S2Plan &pl = p.plan;
@@ -68,7 +68,7 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
         const int n0 = pl.level_start[level], n1 = pl.level_start[level + 1];
         const int base = pl.off[n0];
         const int total = (level == 0) ? (1 << G) : (pl.off[n1 - 1] + (1 << (pl.hi[n1 - 1] - pl.lo[n1 - 1]))) - base;
-        for (int j = tid; j < total; j += 256) {
+        for (int j = tid; j < total; j += nthr) {
             int i = n0;
             for (int k = n0 + 1; k < n1; ++k) if (j + base >= pl.off[k]) i = k;      // scalar plan, <= 16 nodes per level
             const int lo = n_lo[i], hi = n_hi[i], w = hi - lo;
@@ -98,7 +98,7 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
             Xo128 rng = xo_seed(Hs, (uint32_t)s | ((uint32_t)n_idx[i] << 16) | ((uint32_t)level << 24), p.iter, DSM_STREAM_STA2,
                                 p.k0, p.k1);
             bool dummy = false;
-            const uint32_t k = binom<true>(rng, n, wL, wR, rcp, ltab, dummy);
+            const uint32_t k = binom<true>(rng, n, wL, wR, rcp, ltab, dummy, DSM_BINV_MEAN_CAP_S2);
             if (k) atomicAdd(&L[HL], k);
             if (n - k) atomicAdd(&R[HR], n - k);
         }

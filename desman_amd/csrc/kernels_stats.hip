@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void stats_agg_kernel(StatsAggParams p)
         const int g = i / SP, s = i - g * SP;
         gT[i] = (s < S) ? p.gamma[(size_t)s * G + g] : 0.0;
     }
-    rcp[tid] = tid ? 1.0 / (double)tid : 0.0;
+    for (int k = tid; k < DSM_RCP_TAB_N; k += blockDim.x) rcp[k] = k ? 1.0 / (double)k : 0.0;
     if (tid < 16) { es[tid] = p.eta[tid]; acc[tid] = 0ull; }
 #pragma unroll
     for (int i = 0; i < 16; ++i) eacc[i * 256 + tid] = 0u;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void stats_big_kernel(StatsAggParams p)
     const uint32_t nbig = *p.big_count;
     if (nbig == 0) return;
     ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
-    rcp[tid] = tid ? 1.0 / (double)tid : 0.0;
+    for (int k = tid; k < DSM_RCP_TAB_N; k += blockDim.x) rcp[k] = k ? 1.0 / (double)k : 0.0;
     if (tid < 16) { es[tid] = p.eta[tid]; acc[tid] = 0ull; }
 #pragma unroll
     for (int i = 0; i < 16; ++i) eacc[i * 256 + tid] = 0u;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void stats_big_kernel(StatsAggParams p)
 
 #include "dsm_stage2.h"
 
-__global__ __launch_bounds__(256) void stats_stage2_kernel(Stage2Params p)
+__global__ __launch_bounds__(1024) void stats_stage2_kernel(Stage2Params p)
 {
     __shared__ __attribute__((aligned(16))) char smem2[S2_SMEM_BYTES];
     stage2_sample(p, blockIdx.x, smem2, true);
@@ -227,13 +227,13 @@ __global__ __launch_bounds__(256) void binom_test_kernel(int kind, uint32_t n, d
     __shared__ double rcp[DSM_RCP_TAB_N];
     const int tid = threadIdx.x;
     ltab[tid] = reinterpret_cast<const double2 *>(log_tab)[tid];
-    rcp[tid] = tid ? 1.0 / (double)tid : 0.0;
+    for (int k = tid; k < DSM_RCP_TAB_N; k += blockDim.x) rcp[k] = k ? 1.0 / (double)k : 0.0;
     __syncthreads();
     const int i = blockIdx.x * 256 + tid;
     if (i >= nsamp) return;
     Xo128 rng = xo_seed((uint32_t)i, 0u, 0u, DSM_STREAM_TEST, k0, k1);
     bool dummy = false;
-    if (kind != 2) out[i] = binom<true>(rng, n, wa, wb, rcp, ltab, dummy);
+    if (kind != 2) out[i] = binom<true>(rng, n, wa, wb, rcp, ltab, dummy, kind == 0 ? DSM_BINV_MEAN_CAP : DSM_BINV_MEAN_CAP_S2);
     else {
         const double W[4] = {wa, wb, w2, w3};
         uint32_t m[4];
@@ -361,7 +361,8 @@ int k_stats_stage2(dsm_ctx *c, uint32_t iter)
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
     p.plan = make_stage2_plan(c->G);
     p.big_count = c->big_count;
-    hipLaunchKernelGGL(stats_stage2_kernel, dim3(c->S), dim3(256), 0, c->stream, p);
+    // 2^G subsets per sample at the root: 256 threads up to G = 9, 1024 above
+    hipLaunchKernelGGL(stats_stage2_kernel, dim3(c->S), dim3(c->G >= 10 ? 1024 : 256), 0, c->stream, p);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }

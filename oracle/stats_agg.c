@@ -31,7 +31,7 @@
  *   stage-2 binomial owns the stream Philox(ctr = {subset, s | node << 16 | level << 24, iter, 'STA2'}).
  *   A cell's x reads of one observed base are split by ONE binomial into "heaviest true base" / "others"
  *   and the (few) others are drawn read by read against 32-bit thresholds (<= XS of them) or by two more
- *   binomials.  Binomial(n, p): sequential-search inversion on the rarer outcome while its mean is <= 64
+ *   binomials.  Binomial(n, p): sequential-search inversion on the rarer outcome while its mean is <= 128
  *   (no transcendental function: (1-q)^n by repeated squaring), Hoermann's BTRS transformed rejection
  *   (1993) above -- cost O(1) in the depth either way; the stage-2 counts go up to 2^32-1.
  *   All arithmetic is IEEE double with the operation order written here (-ffp-contract=off), the
@@ -51,8 +51,9 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 #define STREAM_STA2 0x53544132u   /* 'STA2' */
 #define STREAM_TEST 0x54455354u   /* 'TEST' */
 #define XS 128u                   /* up to XS non-dominant reads are drawn read by read */
-#define BINV_MEAN_CAP 64.0        /* inversion is used while the mean of the rarer outcome is <= 64 */
-#define BINV_KMAX 255u            /* the search stops at 255 (> 20 sigma at mean 64): 1/k comes from a 256-entry table */
+#define BINV_MEAN_CAP 128.0       /* stage 1: inversion while the mean of the rarer outcome is <= 128 (throughput-bound wavefronts) */
+#define BINV_MEAN_CAP_S2 16.0     /* stage 2: <= 16 (one latency-bound binomial per lane: BTRS is the shorter chain) */
+#define BINV_KMAX 511u            /* the search stops at 511 (> 30 sigma at mean 128): 1/k comes from a 512-entry table */
 
 typedef struct { uint32_t s[4]; } xo_t;
 
@@ -144,7 +145,7 @@ static void draw_reads(xo_t *rng, uint32_t x, const double *w, int K, uint32_t *
     n[K - 1] = x - c[K - 2];
 }
 
-/* Binomial(c, q) by sequential search from 0; f0 = (1-q)^c, r = q/(1-q), c q <= 64.  One uniform. */
+/* Binomial(c, q) by sequential search from 0; f0 = (1-q)^c, r = q/(1-q), c q <= 128.  One uniform. */
 static uint32_t binv(xo_t *rng, uint32_t c, double f0, double r)
 {
     /* P(k)/P(k-1) = r (c-k+1)/k = r (c+1) (1/k) - r */
@@ -171,7 +172,7 @@ static double stirling_tail(double k)
     return (1.0 / 12.0 - (1.0 / 360.0 - (1.0 / 1260.0) * inv2) * inv2) * inv;
 }
 
-/* Hoermann's BTRS (transformed rejection with squeeze), q <= 1/2, n q > 64 */
+/* Hoermann's BTRS (transformed rejection with squeeze), q <= 1/2, n q > 16 (BTRS needs n q >= 10) */
 static uint32_t btrs(xo_t *rng, uint32_t n, double q)
 {
     const double nd = (double)n;
@@ -204,7 +205,7 @@ static uint32_t btrs(xo_t *rng, uint32_t n, double q)
 }
 
 /* successes among n trials with success : failure odds wa : wb */
-static uint32_t binom(xo_t *rng, uint32_t n, double wa, double wb)
+static uint32_t binom(xo_t *rng, uint32_t n, double wa, double wb, double cap)
 {
     if (n == 0 || !(wa > 0.0)) return 0;
     if (!(wb > 0.0)) return n;
@@ -212,7 +213,7 @@ static uint32_t binom(xo_t *rng, uint32_t n, double wa, double wb)
     const double ws = flip ? wb : wa, wl = flip ? wa : wb;      /* the rarer outcome has odds ws : wl */
     const double T = ws + wl;
     uint32_t k;
-    if ((double)n * ws > BINV_MEAN_CAP * T) k = btrs(rng, n, ws / T);
+    if ((double)n * ws > cap * T) k = btrs(rng, n, ws / T);
     else k = binv(rng, n, pw(wl / T, n), ws / wl);
     return flip ? n - k : k;
 }
@@ -228,14 +229,14 @@ static void mult4(xo_t *rng, uint32_t x, const double W[4], uint32_t n[4])
     for (int a = 0; a < 4; a++) if (a != am) o[j++] = a;
     const double wo[3] = { W[o[0]], W[o[1]], W[o[2]] };
     const double ws = (wo[0] + wo[1]) + wo[2];
-    const uint32_t m = binom(rng, x, ws, W[am]);                  /* reads NOT of the heaviest base */
+    const uint32_t m = binom(rng, x, ws, W[am], BINV_MEAN_CAP);                  /* reads NOT of the heaviest base */
     n[am] = x - m;
     if (m == 0) return;
     uint32_t k[3];
     if (m <= XS) draw_reads(rng, m, wo, 3, k);
     else {
-        k[0] = binom(rng, m, wo[0], wo[1] + wo[2]);
-        k[1] = binom(rng, m - k[0], wo[1], wo[2]);
+        k[0] = binom(rng, m, wo[0], wo[1] + wo[2], BINV_MEAN_CAP);
+        k[1] = binom(rng, m - k[0], wo[1], wo[2], BINV_MEAN_CAP);
         k[2] = m - k[0] - k[1];
     }
     n[o[0]] = k[0]; n[o[1]] = k[1]; n[o[2]] = k[2];
@@ -306,7 +307,7 @@ static void stage2_sample(int s, int G, const double *gam_s, const uint32_t *T0,
                 for (int j = 0; j < wh; j++) if (HR >> j & 1u) wR = wR + gam_s[mid + j];
                 xo_t rng;
                 xo_seed(&rng, Hs, (uint32_t)s | ((uint32_t)idx_cur[i] << 16) | ((uint32_t)level << 24), iter, STREAM_STA2, key);
-                const uint32_t k = binom(&rng, n, wL, wR);
+                const uint32_t k = binom(&rng, n, wL, wR, BINV_MEAN_CAP_S2);
                 L[HL] += k; R[HR] += n - k;
             }
             free(T);
@@ -346,7 +347,7 @@ void orc_binom_test(int kind, uint32_t n, double wa, double wb, uint64_t seed, i
     for (int i = 0; i < nsamp; i++) {
         xo_t rng;
         xo_seed(&rng, (uint32_t)i, 0u, 0u, STREAM_TEST, key);
-        (void)kind; out[i] = binom(&rng, n, wa, wb);
+        out[i] = binom(&rng, n, wa, wb, kind == 0 ? BINV_MEAN_CAP : BINV_MEAN_CAP_S2);
     }
 }
 

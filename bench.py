@@ -50,7 +50,7 @@ def cpu_baseline_main(S, G):
     dt1 = _cpu_chain((Vs, S, G, its1, 0))
     cores = sorted(os.sched_getaffinity(0))
     n = len(cores)
-    its_all = 2
+    its_all = 1
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(n) as pool:
         dts = pool.map(_cpu_chain, [(Vs, S, G, its_all, k) for k in range(n)])

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <mutex>
 #include <numeric>
+#include <thread>
 
 #include "dsm_host.h"
 #include "log_table.h"
@@ -962,6 +963,37 @@ extern "C" int dsm_nmft_get_tau(dsm_ctx *c, int64_t *tau_onehot)
 static dsm_ctx *g_legacy = nullptr;
 static bool g_legacy_rng = false;
 static std::mutex g_legacy_mu;
+// the tensor resident in the shim's context: a module-swap user passes the same `variants` on every call
+// (HaploSNP_Sampler.py:345), and re-uploading 20 MB costs more than the sweep.  The shim may skip the upload only if
+// the tensor is provably the same: pointer, shape and a 64-bit hash of EVERY word (multi-threaded, ~0.3 ms for
+// 20 MB) must match -- the pointers are borrowed, the caller may have rewritten the array in place.
+static const int64_t *g_legacy_ptr = nullptr;
+static int g_legacy_V = 0, g_legacy_S = 0;
+static uint64_t g_legacy_hash = 0;
+
+static uint64_t hash_words(const int64_t *p, size_t n)
+{
+    const unsigned nthr = (unsigned)std::max<size_t>(1, std::min<size_t>(8, n / 65536));
+    std::vector<uint64_t> part(nthr, 0);
+    auto work = [&](unsigned t) {
+        const size_t lo = n * t / nthr, hi = n * (t + 1) / nthr;
+        uint64_t h[4] = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull};
+        size_t i = lo;
+        for (; i + 4 <= hi; i += 4)
+            for (int k = 0; k < 4; ++k) h[k] = (h[k] ^ (uint64_t)p[i + k]) * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+        for (; i < hi; ++i) h[0] = (h[0] ^ (uint64_t)p[i]) * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+        uint64_t r = 0;
+        for (int k = 0; k < 4; ++k) r = (r ^ h[k]) * 0xD6E8FEB86659FD93ull + (r >> 29);
+        part[t] = r;
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nthr; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    uint64_t r = n;
+    for (unsigned t = 0; t < nthr; ++t) r = (r ^ part[t]) * 0xD6E8FEB86659FD93ull + (r >> 31);
+    return r;
+}
 
 static int legacy_ctx()
 {
@@ -1017,7 +1049,12 @@ extern "C" int dsm_sample_tau(int64_t *tau, const double *pi, const double *eta,
     if (!g_legacy || !g_legacy_rng) { dsm_set_error("sample_tau: RNG not initialised (initRNG/setRNG)"); return DSM_ERR_STATE; }
     dsm_ctx *c = g_legacy;
     c->tau_rng = DSM_RNG_MT19937;
-    TRY(dsm_ctx_set_counts(c, variants, nV, nS));
+    const uint64_t hsh = hash_words(variants, (size_t)nV * nS * 4);
+    if (!(c->cnt_vs && variants == g_legacy_ptr && nV == g_legacy_V && nS == g_legacy_S && hsh == g_legacy_hash)) {
+        g_legacy_ptr = nullptr;
+        TRY(dsm_ctx_set_counts(c, variants, nV, nS));
+        g_legacy_ptr = variants; g_legacy_V = nV; g_legacy_S = nS; g_legacy_hash = hsh;
+    }
     TRY(dsm_ctx_set_state(c, tau, pi, eta, nG));
     int n = 0;
     TRY(dsm_ctx_sample_tau(c, &n, nullptr));

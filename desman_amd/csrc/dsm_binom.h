@@ -18,14 +18,35 @@
                                       // 64-lane wavefront BTRS costs ~1500 instructions (some lane always takes the
                                       // slow path / another attempt), the search 14 per step
 #define DSM_BINV_MEAN_CAP_S2 16.0      // stage 2: one latency-bound binomial per lane, BTRS is the shorter dependent chain
-#define DSM_BINV_KMAX 511u
-#define DSM_RCP_TAB_N 512             // 1/k for k < 512, staged in LDS by the kernels (entry 0 unused)
+#define DSM_BINV_KMAX 255u
+#define DSM_RCP_TAB_N 256             // 1/k for k < 256, staged in LDS by the kernels (entry 0 unused)
 
 __device__ __forceinline__ Xo128 xo_seed(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
     uint32_t w[4];
     philox4x32_10(c0, c1, c2, c3, k0, k1, w);
     Xo128 r{w[0], w[1], w[2], w[3]};
+    if ((r.s0 | r.s1 | r.s2 | r.s3) == 0u) r.s0 = 1u;
+    return r;
+}
+
+// one Philox4x32 round
+__device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0, uint32_t k1)
+{
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+}
+
+// stream of the item (cell, observed base b): base = Philox4x32-10({cell, 0, iter, 'STA1'}) is shared by the four items
+// of the cell; three more rounds keyed by the base make the item's xoshiro state (oracle: item_seed)
+__device__ __forceinline__ Xo128 item_seed(const uint32_t (&base)[4], uint32_t b, uint32_t key0, uint32_t key1)
+{
+    uint32_t c0 = base[0], c1 = base[1], c2 = base[2], c3 = base[3];
+    uint32_t k0 = key0 ^ (0x9E3779B9u * (b + 1u)), k1 = key1 ^ (0xBB67AE85u * (b + 1u));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    Xo128 r{c0, c1, c2, c3};
     if ((r.s0 | r.s1 | r.s2 | r.s3) == 0u) r.s0 = 1u;
     return r;
 }
@@ -78,7 +99,7 @@ __device__ __forceinline__ void draw_reads(Xo128 &rng, uint32_t x, const double 
 }
 
 // Binomial(c, q) by sequential search from 0 (c q <= 128): f0 = (1-q)^c, r = q/(1-q); the search stops at
-// DSM_BINV_KMAX = 511, so 1/k always comes from the LDS table rcp (correctly rounded 1/k: the oracle divides)
+// DSM_BINV_KMAX = 255, so 1/k always comes from the LDS table rcp (correctly rounded 1/k: the oracle divides)
 __device__ __forceinline__ uint32_t binv(Xo128 &rng, uint32_t c, double f0, double r, const double *__restrict__ rcp)
 {
     // P(k)/P(k-1) = r (c-k+1)/k = r (c+1) (1/k) - r: one fma and one multiply per step

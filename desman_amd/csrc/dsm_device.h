@@ -72,9 +72,8 @@ __device__ __forceinline__ unsigned group_allreduce_sum_u32(unsigned x)
 }
 
 // ---- table-driven fp64 natural log (tau sweep / LL).  x = 2^e * m, m in [1,2);
-// i = top 7 mantissa bits; r = m * invc_i - 1 (one fma, |r| <= 2^-8);
-// log x = e ln2 + logc_i + log1p(r), log1p by a degree-6 Taylor polynomial
-// (truncation < 2e-18).  Absolute error <= ~1 ulp of max(1, |log x|) -- the same
+// i = top 8 mantissa bits (256-entry table); r = m * invc_i - 1 (one fma, |r| <= 2^-9);
+// log x = e ln2 + logc_i + log1p(r), log1p(r) = r - r^2/2 + r^3/3 - r^4/4 + r^5/5 (truncation r^6/6 < 1e-17).  Absolute error <= ~1 ulp of max(1, |log x|) -- the same
 // class as libm in the sums it feeds (validated against glibc on the host).
 // `tab` = the 256 x {invc, logc} table (log_table.h) staged in LDS.
 // Zero, subnormal, negative, inf and NaN inputs take the libm path.

@@ -76,7 +76,7 @@ struct dsm_ctx {
     double *prior_all = nullptr;    // [n_iter][S + 4] priors of the stored states of updateTau
     double *prior = nullptr;        // [2][DSM_MAX_S + 4] per-row Dirichlet log-prior terms, by iteration parity
     double *scalars = nullptr;      // [8] misc device scalars
-    double *log_tab = nullptr;      // [128][2] table of dsm_log (log_table.h)
+    double *log_tab = nullptr;      // [256][2] table of dsm_log (log_table.h)
     // traces of the last update call
     int n_trace = 0, trace_cap = 0;
     uint64_t *tau_trace = nullptr;  // [(n+1)][V]; slot 0 = entry state

@@ -552,7 +552,7 @@ struct TauParams {
     const uint32_t *u_raw;    // MT19937 words, [V*G]; null -> Philox
     double *logp;             // may be null: [V][G][4]
     double *ll_partial;       // [gridDim.x]
-    const double *log_tab;    // [128][2]
+    const double *log_tab;    // [256][2]
     int *nchange;
     int V, S, G;
     uint32_t k0, k1, iter;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
     double *eL = eS + 16;                                // [16]
     double *red = eL + 16;                               // [4]
     int *redi = reinterpret_cast<int *>(red + 4);        // [4] (+4 pad)
-    double2 *ltab = reinterpret_cast<double2 *>(red + 6);// [128] log table
+    double2 *ltab = reinterpret_cast<double2 *>(red + 6);// [256] log table
     const int tid = threadIdx.x, G = p.G, S = p.S;
     if (tid < DSM_LOG_TAB_N) ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
     for (int i = tid; i < G * SP; i += 256) {
@@ -601,7 +601,9 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
             // The rest mixture of step g is the h-ascending FMA chain over h != g (c_sample_tau.c:136-150).  Its
             // first g links use haplotypes that are already re-drawn and final, so that prefix is carried from
             // step to step (pre) and only the links h > g are re-done: the same operations in the same order --
-            // bit-identical sums -- for G(G+1)/2 instead of G(G-1) links per variant.
+            // the same sums -- for G(G+1)/2 instead of G(G-1) links per variant.  (The links are fma(eta, gamma, acc)
+            // where c_sample_tau.c:143-149 multiplies and adds: the sums agree with the reference to rounding, not bit
+            // for bit; see DESIGN.md sec. 4 for what that means for the draws.)
             double pre[NSL][4];
 #pragma unroll
             for (int j = 0; j < NSL; ++j)

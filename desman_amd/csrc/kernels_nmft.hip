@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NMFT_A_THREADS) void nmft_pass_a_kernel(const doubl
 {
     extern __shared__ __attribute__((aligned(16))) char smem_a[];
     if (ctl[2] != 0.0) return;                         // factorize loop already stopped
-    double2 *ltab = reinterpret_cast<double2 *>(smem_a);                    // [128]
+    double2 *ltab = reinterpret_cast<double2 *>(smem_a);                    // [256]
     double *red = reinterpret_cast<double *>(smem_a) + 2 * DSM_LOG_TAB_N;   // [RG][GMAX + 2][SPAD]
     const int tid = threadIdx.x;
     if (tid < DSM_LOG_TAB_N) ltab[tid] = reinterpret_cast<const double2 *>(log_tab)[tid];
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void nmft_wave_kernel(const double *__restrict
     constexpr int NV = 4 * GCH;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nblk = gridDim.x;
-    double2 *ltab = reinterpret_cast<double2 *>(smem_w);                       // [128]
+    double2 *ltab = reinterpret_cast<double2 *>(smem_w);                       // [256]
     double *gr = reinterpret_cast<double *>(smem_w) + 2 * DSM_LOG_TAB_N;        // [GMAX][SPAD] gamma_raw
     double *gs = gr + GMAX * SPAD;                                              // [GMAX][SPAD] gamma
     double *t1 = gs + GMAX * SPAD;                                              // [GMAX] rowsum(gamma_raw)

@@ -89,6 +89,8 @@ __global__ __launch_bounds__(256) void stats_agg_kernel(StatsAggParams p)
         }
         const double Gam[4] = {G0, G1, G2, G3};
         const uint32_t cell = (uint32_t)s * (uint32_t)V + (uint32_t)v;
+        uint32_t cbase[4];
+        philox4x32_10(cell, 0u, p.iter, DSM_STREAM_STA1, p.k0, p.k1, cbase);         // one Philox-10 per cell
         uint32_t nacc[4] = {0, 0, 0, 0};
 #pragma unroll 1
         for (int b = 0; b < 4; ++b) {
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void stats_agg_kernel(StatsAggParams p)
                     for (int a = 0; a < 4; ++a) W[a] = Gam[a];
                 }
                 uint32_t n[4];
-                Xo128 rng = xo_seed(cell, (uint32_t)b, p.iter, DSM_STREAM_STA1, p.k0, p.k1);
+                Xo128 rng = item_seed(cbase, (uint32_t)b, p.k0, p.k1);
                 bool defer = false;
                 mult4<false>(rng, (uint32_t)xb, W, n, rcp, nullptr, defer);
                 if (__builtin_expect(defer, 0)) {
@@ -117,9 +119,9 @@ __global__ __launch_bounds__(256) void stats_agg_kernel(StatsAggParams p)
                     const uint32_t slot = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
                     p.big_list[slot] = (unsigned long long)cell * 4ull + (unsigned long long)b;
                 } else {
-                    uint32_t *erow = eacc + (b * 4) * 256 + tid;
+                    uint32_t *erow = eacc + (b * 4) * 256 + tid;           // lane-private column: ds_add_u32, never a conflict
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) { erow[a * 256] += n[a]; nacc[a] += n[a]; }
+                    for (int a = 0; a < 4; ++a) { atomicAdd(erow + a * 256, n[a]); nacc[a] += n[a]; }
                 }
             }
         }
@@ -187,8 +189,9 @@ __global__ __launch_bounds__(256) void stats_big_kernel(StatsAggParams p)
 #pragma unroll
             for (int a = 0; a < 4; ++a) W[a] = Gam[a];
         }
-        uint32_t n[4];
-        Xo128 rng = xo_seed(cell, (uint32_t)b, p.iter, DSM_STREAM_STA1, p.k0, p.k1);
+        uint32_t n[4], cbase[4];
+        philox4x32_10(cell, 0u, p.iter, DSM_STREAM_STA1, p.k0, p.k1, cbase);
+        Xo128 rng = item_seed(cbase, (uint32_t)b, p.k0, p.k1);
         bool defer = false;
         mult4<true>(rng, (uint32_t)xb, W, n, rcp, ltab, defer);
         uint32_t *erow = eacc + (b * 4) * 256 + tid;

@@ -25,9 +25,10 @@
  *   reference-pinned rn.sample_mu and against the exact moments, tests/).
  *
  *   Draws.  Everything is counter-based: the stage-1 draws of a (cell, observed base) item come from one
- *   xoshiro128+ stream seeded by Philox4x32-10(ctr = {cell, b, iter, 'STA1'}, key = seed), consumed in the
- *   order written below (items are independent work units: the kernels process the few items that need the
- *   rejection sampler in a separate, compacted launch); every
+ *   xoshiro128+ stream, consumed in the order written below (items are independent work units: the kernels
+ *   process the few items that need the rejection sampler in a separate, compacted launch).  Its seed is
+ *   Philox4x32-10(ctr = {cell, 0, iter, 'STA1'}, key = seed) -- shared by the four items of the cell --
+ *   followed by three more Philox rounds whose keys depend on the observed base (item_seed); every
  *   stage-2 binomial owns the stream Philox(ctr = {subset, s | node << 16 | level << 24, iter, 'STA2'}).
  *   A cell's x reads of one observed base are split by ONE binomial into "heaviest true base" / "others"
  *   and the (few) others are drawn read by read against 32-bit thresholds (<= XS of them) or by two more
@@ -53,7 +54,7 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 #define XS 128u                   /* up to XS non-dominant reads are drawn read by read */
 #define BINV_MEAN_CAP 128.0       /* stage 1: inversion while the mean of the rarer outcome is <= 128 (throughput-bound wavefronts) */
 #define BINV_MEAN_CAP_S2 16.0     /* stage 2: <= 16 (one latency-bound binomial per lane: BTRS is the shorter chain) */
-#define BINV_KMAX 511u            /* the search stops at 511 (> 30 sigma at mean 128): 1/k comes from a 512-entry table */
+#define BINV_KMAX 255u            /* the search stops at 255 (> 11 sigma at mean 128): 1/k comes from a 256-entry table */
 
 typedef struct { uint32_t s[4]; } xo_t;
 
@@ -73,6 +74,25 @@ static void xo_seed(xo_t *r, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
 {
     uint32_t ctr[4] = { c0, c1, c2, c3 };
     orc_philox4x32_10(ctr, key, r->s);
+    if ((r->s[0] | r->s[1] | r->s[2] | r->s[3]) == 0) r->s[0] = 1;
+}
+
+/* one Philox4x32 round (Salmon et al. 2011) */
+static void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+}
+
+/* stream of the item (cell, observed base b): `base` = Philox4x32-10({cell, 0, iter, 'STA1'}) of the cell, then three
+ * rounds with the key (key + (b + 1) * Weyl constants), bumped per round as in Philox */
+static void item_seed(xo_t *r, const uint32_t base[4], uint32_t b, const uint32_t key[2])
+{
+    uint32_t c[4] = { base[0], base[1], base[2], base[3] };
+    uint32_t k0 = key[0] ^ (0x9E3779B9u * (b + 1u)), k1 = key[1] ^ (0xBB67AE85u * (b + 1u));
+    for (int i = 0; i < 3; i++) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    memcpy(r->s, c, sizeof c);
     if ((r->s[0] | r->s[1] | r->s[2] | r->s[3]) == 0) r->s[0] = 1;
 }
 
@@ -253,6 +273,8 @@ static void stage1(const uint8_t *tau_idx, const double *gamma, const double *et
         for (int s = 0; s < S; s++) {
             const int64_t *x = variants + ((size_t)v * S + s) * 4;
             const uint32_t cell = (uint32_t)((uint64_t)s * (uint64_t)V + (uint64_t)v);
+            uint32_t cctr[4] = { cell, 0u, iter, STREAM_STA1 }, cbase[4];
+            orc_philox4x32_10(cctr, key, cbase);
             double Gam[4] = { 0.0, 0.0, 0.0, 0.0 };
             for (int g = 0; g < G; g++) Gam[tv[g]] = Gam[tv[g]] + gamma[(size_t)s * G + g];
             uint32_t nacc[4] = { 0, 0, 0, 0 };
@@ -264,7 +286,7 @@ static void stage1(const uint8_t *tau_idx, const double *gamma, const double *et
                 if (!(Wt > 0.0)) for (int a = 0; a < 4; a++) W[a] = Gam[a];     /* degenerate eta: fall back to abundance */
                 uint32_t n[4];
                 xo_t rng;
-                xo_seed(&rng, cell, (uint32_t)b, iter, STREAM_STA1, key);
+                item_seed(&rng, cbase, (uint32_t)b, key);
                 mult4(&rng, (uint32_t)x[b], W, n);
                 for (int a = 0; a < 4; a++) { esum[b * 4 + a] += n[a]; nacc[a] += n[a]; }
             }

@@ -33,6 +33,9 @@ def test_full_size_sweep_loglik_and_stats_invariants(V, S, G):
     # per-read pass: every read is assigned exactly once, observed-base totals are preserved,
     # identical (seed, iter) -> identical sums, different iter -> different sums
     mu, E = ctx.sample_stats(3)
+    assert ctx.stats_spec() == 2                                   # full sizes run the aggregated sampler ...
+    mu_ref, E_ref = cbind.stats_agg(cbind.onehot_to_idx(got), gamma, eta, counts, 42, 3)
+    assert np.array_equal(mu, mu_ref) and np.array_equal(E, E_ref)   # ... bit for bit as restated in oracle/stats_agg.c
     assert int(mu.sum()) == int(counts.sum())
     assert np.array_equal(mu.sum(axis=1), counts.sum(axis=(0, 2)).astype(np.uint64))        # reads per sample
     assert np.array_equal(E.sum(axis=1), counts.sum(axis=(0, 1)).astype(np.uint64))         # reads per observed base
@@ -44,9 +47,16 @@ def test_full_size_sweep_loglik_and_stats_invariants(V, S, G):
     e_mu, v_mu, e_E = cbind.stats_expect(cbind.onehot_to_idx(got), gamma, eta, counts)
     z = (mu.astype(np.float64) - e_mu) / np.sqrt(v_mu + 1e-9)
     assert np.abs(z).max() < 5.5 and abs(z.mean()) < 0.5
-    # a few full iterations keep every trace consistent with the oracle's likelihood
+    # a few full iterations keep every trace consistent with the oracle's likelihood; the first iteration's gamma / eta
+    # are the oracle's draws from the oracle's sums (mu/E stage 2 runs fused in the Dirichlet launch for G < 10, as its
+    # own 1024-thread launch above)
+    ctx.seed(31337, ctr_seed=42)
     ctx.gibbs_update(3)
     tr = ctx.get_trace()
+    mu0, E0 = cbind.stats_agg(cbind.onehot_to_idx(got), gamma, eta, counts, 42, 0)
+    g0, e0, _ = cbind.dirichlet_counter(mu0, E0, 42, 0)
+    np.testing.assert_allclose(tr["gamma"][0], g0, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(tr["eta"][0], e0, rtol=1e-13, atol=0)
     t, g, e = ctx.get_state()
     assert tr["ll"][-1] == pytest.approx(cbind.loglik(cbind.onehot_to_idx(t), g, e, counts), rel=1e-12)
     np.testing.assert_allclose(g.sum(axis=1), 1.0, rtol=1e-12)

@@ -411,7 +411,7 @@ def test_gibbs_chain_recovers_asymmetric_eta(ctx):
 
 # ---------------------------------------------------------------- A6 full iteration
 @pytest.mark.parametrize("spec", [2, 1])
-@pytest.mark.parametrize("V,S,G,n_iter", [(400, 16, 5, 12), (600, 64, 8, 8), (150, 96, 3, 6)])
+@pytest.mark.parametrize("V,S,G,n_iter", [(400, 16, 5, 12), (600, 64, 8, 8), (150, 96, 3, 6), (200, 20, 11, 4)])
 def test_gibbs_update_is_self_consistent_with_oracle(ctx, V, S, G, n_iter, spec):
     """every piece of every iteration of the device loop against the oracle, in the reference's order
     (HaploSNP_Sampler.py:341-358): the mu/E sums + gamma/eta draws from the restated counter-based specs (spec 2:

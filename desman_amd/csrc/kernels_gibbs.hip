@@ -956,8 +956,11 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
     const int S = c->S, G = c->G, V = c->V;
     int LPV, NSL;
     if (S <= 16) { LPV = 16; NSL = 1; }
-    else if (S <= 32) { LPV = 32; NSL = 1; }
+    else if (S <= 32) { LPV = 16; NSL = 2; }            // four variants per wavefront (77.8 vs 94.5 us as 32 x 1 at V=20k, S=32, G=8)
     else if (S <= 48) { LPV = 16; NSL = 3; }            // no padded slots: 48 useful lanes-samples instead of 64
+    else if (S <= 64) { LPV = 32; NSL = 2; }            // two variants per wavefront: the per-step draw / reduction work (computed
+                                                        // redundantly by every lane) is shared by both: 73.7 vs 78.5 us as 64 x 1
+                                                        // (16 x 4 needs 235 VGPRs: 85 us)
     else if (S > 64 && S <= 96) { LPV = 32; NSL = 3; }  // 96 slots, two variants per wavefront (measured 10 % faster
                                                         // than 64 x 2 = 128 slots even though that tile re-uses a candidate)
     else {
@@ -980,7 +983,7 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
     const size_t sh = ((size_t)G * LPV * NSL + 16 + 16 + 6 + 2 * DSM_LOG_TAB_N) * sizeof(double);
     if (sh > 160 * 1024) { dsm_set_error("gamma tile (%zu B) exceeds LDS", sh); return DSM_ERR_UNSUPPORTED; }
 #define TAU_CASE(L, N) if (LPV == L && NSL == N) launch_tau<L, N>(c, mode, p, grid, sh)
-    TAU_CASE(16, 1); TAU_CASE(16, 3); TAU_CASE(32, 1); TAU_CASE(32, 3); TAU_CASE(64, 1); TAU_CASE(64, 2); TAU_CASE(64, 3); TAU_CASE(64, 4);
+    TAU_CASE(16, 1); TAU_CASE(16, 2); TAU_CASE(16, 3); TAU_CASE(32, 1); TAU_CASE(32, 2); TAU_CASE(32, 3); TAU_CASE(64, 1); TAU_CASE(64, 2); TAU_CASE(64, 3); TAU_CASE(64, 4);
     TAU_CASE(64, 6); TAU_CASE(64, 8);
 #undef TAU_CASE
     HIP_TRY(hipGetLastError());

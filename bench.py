@@ -297,11 +297,13 @@ def main():
     stats_kname = "stats_agg_kernel" if spec == 2 else "stats_kernel"
     if os.path.exists(tpath) and (V, S, G) == (10000, 64, 8) and args.depth_scale == 1.0:
         tj = json.load(open(tpath))                               # PMC passes are separate rocprofv3 runs (profiles/)
-        for name, prefix in (("tau", "void tau_kernel<64, 1, true, true"), ("stats", stats_kname)):
-            for key, rec in tj.items():
-                if key.startswith(prefix) or key.startswith("void " + prefix):
-                    traffic[name] = rec.get("bytes_per_launch")
-                    valu[name] = rec.get("valu_insts")
+        for key, rec in tj.items():
+            # the sweep + likelihood instantiation (tau_kernel<LPV, NSL, true, true>) and the stage-1 mu/E kernel
+            name = "tau" if (key.startswith("void tau_kernel<") and key.endswith("true, true>")) else \
+                   "stats" if (key.startswith(stats_kname) or key.startswith("void " + stats_kname)) else None
+            if name:
+                traffic[name] = rec.get("bytes_per_launch")
+                valu[name] = rec.get("valu_insts")
     per_kernel = {}
     for name, kname in (("stats", stats_kname), ("tau", "tau_kernel")):
         us = k_us.get(name, float("nan"))

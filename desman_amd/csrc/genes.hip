@@ -704,8 +704,9 @@ extern "C" int dsm_genes_destroy(dsm_genes *gs)
 static void pick_tile(int S, int *LPV, int *NSL)
 {
     if (S <= 16) { *LPV = 16; *NSL = 1; }
-    else if (S <= 32) { *LPV = 32; *NSL = 1; }
+    else if (S <= 32) { *LPV = 16; *NSL = 2; }          // as k_tau_sweep: more rows per wavefront share the per-step draw work
     else if (S <= 48) { *LPV = 16; *NSL = 3; }
+    else if (S <= 64) { *LPV = 32; *NSL = 2; }
     else if (S > 64 && S <= 96) { *LPV = 32; *NSL = 3; }
     else {
         *LPV = 64;
@@ -928,7 +929,7 @@ static int launch_sweep(dsm_genes *gs, const GeneSweepParams &p, bool sweep, int
     const int gpb = block / gs->LPV, nb = (ntask + gpb - 1) / gpb;
     hipStream_t st = gs->base->stream;
 #define GS_CASE(L, N) if (gs->LPV == L && gs->NSL == N) launch_sweep_t<L, N>(p, sweep, nb, ncand, block, sh, st)
-    GS_CASE(16, 1); GS_CASE(16, 3); GS_CASE(32, 1); GS_CASE(32, 3); GS_CASE(64, 1); GS_CASE(64, 2); GS_CASE(64, 3); GS_CASE(64, 4); GS_CASE(64, 6); GS_CASE(64, 8);
+    GS_CASE(16, 1); GS_CASE(16, 2); GS_CASE(16, 3); GS_CASE(32, 1); GS_CASE(32, 2); GS_CASE(32, 3); GS_CASE(64, 1); GS_CASE(64, 2); GS_CASE(64, 3); GS_CASE(64, 4); GS_CASE(64, 6); GS_CASE(64, 8);
 #undef GS_CASE
     HIP_TRY(hipGetLastError());
     return DSM_OK;

@@ -589,7 +589,8 @@ static bool wave_shape(const dsm_ctx *c, int *nsl, int *gmax)
     return need <= 8 && (*nsl) * (*gmax) <= 32 && (*gmax) <= 16;
 }
 
-bool nmft_use_wave(const dsm_ctx *c) { int a, b; return wave_shape(c, &a, &b); }
+bool nmft_use_mfma(const dsm_ctx *c);
+bool nmft_use_wave(const dsm_ctx *c) { int a, b; return wave_shape(c, &a, &b) || nmft_use_mfma(c); }      // the one-pass kernels
 
 int nmft_wave_grid(const dsm_ctx *c)
 {
@@ -658,8 +659,9 @@ int k_nmft_get_tau(dsm_ctx *c, uint64_t *d_packed)
 //   gamma numerators           num_g[g][s] += sum_rows tau_new[row][g] Q2[row][s]: contraction over ROWS, K-block = base e:
 //                              A[m][k] = tau_new[vv = k][e][g = m] (lane m + 16 k), B[k][j] = Q2[vv = k][e][16 t + j] = the L2
 //                              register itself.  The accumulators D[g][s] stay in registers for the whole kernel.
-// No operand ever needs a transposition through LDS.  Shapes: S <= 64 (NT <= 4 tiles), G <= 8 (KB <= 2 K-blocks); other
-// shapes run nmft_wave_kernel / the two-pass kernels.
+// No operand ever needs a transposition through LDS.  Shapes: S <= 96 (NT <= 6 tiles), G <= 12 (KB <= 3 K-blocks); beyond
+// four tiles the F tiles are not kept in registers between the halves (KEEPF = false: re-read from L2).  Other shapes
+// run nmft_wave_kernel / the two-pass kernels.
 // ===========================================================================
 typedef double double4_t __attribute__((ext_vector_type(4)));
 #define DSM_DPP_ROW_SHL4 0x104
@@ -701,7 +703,7 @@ __device__ __forceinline__ double row16_transpose_reduce(double (&v)[16], int n)
     return v[0];
 }
 
-template <int NT, int KB>
+template <int NT, int KB, bool KEEPF>
 __global__ __launch_bounds__(256, 3) void nmft_mfma_kernel(const double *__restrict__ F, double *__restrict__ tau,
                                                         const double *__restrict__ gam_raw, const double *__restrict__ gam,
                                                         int V, int S, int G, int adjust, int do_update,
@@ -761,14 +763,20 @@ __global__ __launch_bounds__(256, 3) void nmft_mfma_kernel(const double *__restr
             told[(4 * r + vv) * GP + g] = x;
             if (!do_update) tnew[(4 * r + vv) * GP + g] = x;
         }
-        // F in L2: f[t][e] = F[variant v0 + q][base e][16 t + n]
-        double4_t f[NT];
+        // F in L2: f[t][e] = F[variant v0 + q][base e][16 t + n]; kept in registers for both halves while NT <= 4,
+        // re-read (L2) by the second half for wider sample ranges
+        double4_t f[KEEPF ? NT : 1];
         bool live[NT];
+        auto load_f = [&](int t) {
+            double4_t x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = live[t] ? F[((size_t)(v0 + q) * 4 + e) * S + 16 * t + n] : 1.0;
+            return x;
+        };
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             live[t] = vok && (16 * t + n < S);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) f[t][e] = live[t] ? F[((size_t)(v0 + q) * 4 + e) * S + 16 * t + n] : 1.0;
+            if constexpr (KEEPF) f[t] = load_f(t);
         }
         __builtin_amdgcn_wave_barrier();
         if (do_update) {
@@ -781,8 +789,9 @@ __global__ __launch_bounds__(256, 3) void nmft_mfma_kernel(const double *__restr
                 double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_old[kb], braw[(t * KB + kb) * 64 + lane], R, 0, 0, 0);
+                const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qp[t][e] = live[t] ? nzd(f[t][e]) / nzd(R[e]) : 0.0;
+                for (int e = 0; e < 4; ++e) qp[t][e] = live[t] ? nzd(ft[e]) / nzd(R[e]) : 0.0;
             }
 #pragma unroll
             for (int c = 0; c < KB; ++c) {
@@ -827,12 +836,13 @@ __global__ __launch_bounds__(256, 3) void nmft_mfma_kernel(const double *__restr
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_new[kb], bgam[(t * KB + kb) * 64 + lane], R, 0, 0, 0);
             double4_t q2;
+            const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const double pa = R[e] < DSM_EPS ? DSM_EPS : R[e];
-                const double ratio = nzd(f[t][e]) / pa;
-                q2[e] = live[t] ? ((R[e] < DSM_EPS) ? nzd(f[t][e]) / nzd(R[e]) : ratio) : 0.0;
-                if (live[t]) obj += f[t][e] * dsm_log(ratio, ltab) - f[t][e] + pa;
+                const double ratio = nzd(ft[e]) / pa;
+                q2[e] = live[t] ? ((R[e] < DSM_EPS) ? nzd(ft[e]) / nzd(R[e]) : ratio) : 0.0;
+                if (live[t]) obj += ft[e] * dsm_log(ratio, ltab) - ft[e] + pa;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
@@ -881,7 +891,9 @@ static bool mfma_shape(const dsm_ctx *c, int *nt, int *kb)
     *nt = (c->S + 15) / 16;
     *kb = (c->nG + 3) / 4;
     static const bool off = getenv("DESMAN_HIP_NMFT_NO_MFMA") != nullptr;      // A/B switch: the VALU one-pass kernel
-    return !off && *nt >= 1 && *nt <= 4 && *kb >= 1 && *kb <= 2;
+    // measured against the VALU one-pass kernel: 1.0-1.3x at (NT, KB) = (4, 2), 1.64x at (6, 3) [V = 50k, S = 96, G = 12:
+    // 251 vs 413 us per update]; at (8, 4) the 140 KB of LDS leave one workgroup per CU and the VALU kernel wins (449 vs 491 us)
+    return !off && *nt >= 1 && *nt <= 6 && *kb >= 1 && *kb <= 3;          // S <= 96, G <= 12
 }
 
 bool nmft_use_mfma(const dsm_ctx *c) { int a, b; return mfma_shape(c, &a, &b); }
@@ -899,7 +911,7 @@ static void launch_mfma(dsm_ctx *c, int adjust, int do_update, int grid)
     constexpr int GP = 4 * KB, SPAD = 16 * NT;
     const size_t sh = (2 * DSM_LOG_TAB_N + (size_t)GP * SPAD + 2 * (size_t)NT * KB * 64 + GP + 4 * 2 * 16 * GP +
                        4 * (size_t)(GP + 2) * SPAD) * sizeof(double);
-    hipLaunchKernelGGL((nmft_mfma_kernel<NT, KB>), dim3(grid), dim3(256), sh, c->stream, c->F, c->ntau, c->ngam_raw, c->ngam,
+    hipLaunchKernelGGL((nmft_mfma_kernel<NT, KB, (NT <= 4)>), dim3(grid), dim3(256), sh, c->stream, c->F, c->ntau, c->ngam_raw, c->ngam,
                        c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart);
 }
 
@@ -911,6 +923,7 @@ int k_nmft_mfma(dsm_ctx *c, int adjust, int do_update)
     const int grid = nmft_mfma_grid(c);
 #define MCASE(N, K) if (nt == N && kb == K) launch_mfma<N, K>(c, adjust, do_update, grid)
     MCASE(1, 1); MCASE(1, 2); MCASE(2, 1); MCASE(2, 2); MCASE(3, 1); MCASE(3, 2); MCASE(4, 1); MCASE(4, 2);
+    MCASE(1, 3); MCASE(2, 3); MCASE(3, 3); MCASE(4, 3); MCASE(5, 1); MCASE(5, 2); MCASE(5, 3); MCASE(6, 1); MCASE(6, 2); MCASE(6, 3);
 #undef MCASE
     HIP_TRY(hipGetLastError());
     c->npart_cols = grid;

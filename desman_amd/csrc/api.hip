@@ -181,6 +181,7 @@ static void free_traces(dsm_ctx *c)
 {
     dev_free(&c->tau_trace); dev_free(&c->ll_trace); dev_free(&c->lp_trace); dev_free(&c->nchange_trace);
     dev_free(&c->gamma_trace); dev_free(&c->eta_trace); dev_free(&c->gamma_in); dev_free(&c->eta_in);
+    c->in_cap = 0;
     c->n_trace = 0;
     c->trace_cap = 0;
 }
@@ -666,6 +667,10 @@ static int alloc_traces(dsm_ctx *c, int n)
     const size_t sg = (size_t)c->S * c->G;
     if (n > c->trace_cap || !c->tau_trace) {
         free_traces(c);
+        // room for at least 512 iterations while the tau trace stays below 1 GB: a driver that calls update() with a
+        // growing iteration count (burn-in 5, then 20, ...) does not pay hipFree + hipMalloc (~1 ms) inside every call
+        const int want = n;
+        if (n < 512 && (size_t)513 * c->V * sizeof(uint64_t) <= ((size_t)1 << 30)) n = 512;
         TRY(dev_alloc(&c->tau_trace, (size_t)(n + 1) * c->V));
         TRY(dev_alloc(&c->ll_trace, (size_t)n));
         TRY(dev_alloc(&c->lp_trace, (size_t)n));
@@ -673,6 +678,7 @@ static int alloc_traces(dsm_ctx *c, int n)
         TRY(dev_alloc(&c->gamma_trace, (size_t)n * sg));
         TRY(dev_alloc(&c->eta_trace, (size_t)n * 16));
         c->trace_cap = n;
+        n = want;
     }
     c->n_trace = n;
     return DSM_OK;
@@ -728,8 +734,12 @@ extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_st
     BIND(c);
     TRY(alloc_traces(c, n_iter));
     const size_t sg = (size_t)c->S * c->G;
-    TRY(dev_alloc(&c->gamma_in, (size_t)n_iter * sg));
-    TRY(dev_alloc(&c->eta_in, (size_t)n_iter * 16));
+    if (n_iter > c->in_cap || !c->gamma_in) {            // grow-only, like the traces
+        TRY(dev_alloc(&c->gamma_in, (size_t)n_iter * sg));
+        TRY(dev_alloc(&c->eta_in, (size_t)n_iter * 16));
+        TRY(dev_alloc(&c->prior_all, (size_t)n_iter * (c->S + 4)));
+        c->in_cap = n_iter;
+    }
     HIP_TRY(hipMemcpyAsync(c->gamma_in, gamma_store, (size_t)n_iter * sg * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->eta_in, eta_store, (size_t)n_iter * 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->gamma_trace, c->gamma_in, (size_t)n_iter * sg * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -738,7 +748,6 @@ extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_st
     // entry: lp with (gamma_store[0], eta_store[0])  (HaploSNP_Sampler.py:386-389)
     TRY(eval_state(c, c->gamma_in, c->eta_in, c->tau_trace, 1));
     // the Dirichlet log-priors of all stored (gamma, eta) pairs in one launch instead of one per sweep
-    TRY(dev_alloc(&c->prior_all, (size_t)n_iter * (c->S + 4)));
     TRY(k_prior_batch(c, c->gamma_in, c->eta_in, n_iter, c->prior_all));
     for (int it = 0; it < n_iter; ++it) {
         const uint32_t ic = c->iter_ctr++;

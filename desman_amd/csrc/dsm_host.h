@@ -85,6 +85,7 @@ struct dsm_ctx {
     double *gamma_trace = nullptr;  // [n][S][G]
     double *eta_trace = nullptr;    // [n][16]
     double *gamma_in = nullptr, *eta_in = nullptr;   // updateTau inputs
+    int in_cap = 0;                 // iterations gamma_in / eta_in / prior_all have room for
     // MAP ("star") tracking: {lp_star, (double)slot}
     double *star = nullptr;         // [2]
     double *gamma_star = nullptr;   // [S][G]

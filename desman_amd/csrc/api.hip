@@ -159,8 +159,8 @@ extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
         HIP_TRY(hipEventCreateWithFlags(&c->ev_u_free[i], hipEventDisableTiming));
     }
     TRY(dev_alloc(&c->mt_state, 625));
-    TRY(dev_alloc(&c->ll_partial, DSM_MAX_GRID));
-    TRY(dev_alloc(&c->nchange, 1));
+    TRY(dev_alloc(&c->ll_partial, 2 * DSM_MAX_GRID));     // two parities (updateTau pipelines finalize into the next sweep)
+    TRY(dev_alloc(&c->nchange, 2));
     TRY(dev_alloc(&c->prior, 2 * (DSM_MAX_S + 4)));
     TRY(dev_alloc(&c->scalars, 8));
     TRY(dev_alloc(&c->star, 2));
@@ -170,7 +170,7 @@ extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
     TRY(dev_alloc(&c->esum, 16));
     TRY(dev_alloc(&c->log_tab, 2 * DSM_LOG_TAB_N));
     HIP_TRY(hipMemcpyAsync(c->log_tab, dsm_log_table_host, sizeof dsm_log_table_host, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
+    HIP_TRY(hipMemsetAsync(c->nchange, 0, 2 * sizeof(int), c->stream));
     HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     *out = c;
@@ -749,6 +749,10 @@ extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_st
     TRY(eval_state(c, c->gamma_in, c->eta_in, c->tau_trace, 1));
     // the Dirichlet log-priors of all stored (gamma, eta) pairs in one launch instead of one per sweep
     TRY(k_prior_batch(c, c->gamma_in, c->eta_in, n_iter, c->prior_all));
+    // sweep it writes parity it & 1 of (ll_partial, nchange); its finalize (ll / lp / MAP test / traces) rides as one
+    // extra workgroup in the launch of sweep it + 1, which writes the other parity: one launch per sweep
+    HIP_TRY(hipMemsetAsync(c->nchange, 0, 2 * sizeof(int), c->stream));
+    int nb_prev = 0;
     for (int it = 0; it < n_iter; ++it) {
         const uint32_t ic = c->iter_ctr++;
         const double *g = c->gamma_in + (size_t)it * sg, *e = c->eta_in + (size_t)it * 16;
@@ -756,10 +760,18 @@ extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_st
         TRY(fill_sweep_uniforms(c, &u));
         int nb = 0;
         TRY(await_sweep_uniforms(c, u));
-        TRY(k_tau_sweep(c, 3, g, e, e, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb, u));  // :392-393
+        TauFinalRider rider;
+        if (it > 0) {
+            rider.nblocks = nb_prev; rider.it = it - 1; rider.prior = c->prior_all + (size_t)(it - 1) * (c->S + 4);
+            rider.gamma_src = c->gamma_in + (size_t)(it - 1) * sg; rider.eta_src = c->eta_in + (size_t)(it - 1) * 16;
+        }
+        TRY(k_tau_sweep(c, 3, g, e, e, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb, u, it & 1,
+                        it > 0 ? &rider : nullptr));                                                    // :392-393
         TRY(release_sweep_uniforms(c, u));
-        TRY(k_finalize(c, nb, it, 0, c->prior_all + (size_t)it * (c->S + 4), g, e));
+        nb_prev = nb;
     }
+    TRY(k_finalize(c, nb_prev, n_iter - 1, 0, c->prior_all + (size_t)(n_iter - 1) * (c->S + 4),
+                   c->gamma_in + (size_t)(n_iter - 1) * sg, c->eta_in + (size_t)(n_iter - 1) * 16, (n_iter - 1) & 1));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSM_OK;
 }

@@ -134,12 +134,14 @@ int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trac
                 double *prior_out, int fin_it, int fin_nblocks, const double *fin_prior, int do_s2 = 0);
 int k_prior(dsm_ctx *c, const double *gamma, const double *eta, double *prior_out);
 int k_prior_batch(dsm_ctx *c, const double *gamma, const double *eta, int n, double *prior_out);
-// mode bit0 = sweep, bit1 = log-likelihood epilogue
+// the previous sweep's finalize riding in a tau launch (updateTau): what k_finalize would have been called with
+struct TauFinalRider { int nblocks, it; const double *prior, *gamma_src, *eta_src; };
+// mode bit0 = sweep, bit1 = log-likelihood epilogue; slot = parity of the ll_partial / nchange buffers the launch writes
 int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_sweep,
                 const double *eta_ll, uint64_t *trace_slot, double *d_logp, uint32_t iter, int *nblocks,
-                const uint32_t *u_raw);
+                const uint32_t *u_raw, int slot = 0, const TauFinalRider *rider = nullptr);
 int k_finalize(dsm_ctx *c, int nblocks, int it, int star_mode, const double *prior, const double *gamma_src,
-               const double *eta_src);
+               const double *eta_src, int slot = 0);
 
 // ---- launchers (kernels_nmft.hip)
 int k_nmft_freq(dsm_ctx *c);

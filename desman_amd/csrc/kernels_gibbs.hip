@@ -10,6 +10,8 @@
 // HBM layout: counts int32 in two layouts ([V][S][4] lane=sample for the tau
 // sweep, [S][V][4] lane=variant for the per-read pass), tau packed 2 bits per
 // haplotype in one u64 per variant, gamma [S][G] f64, eta [4][4] f64.
+#include <string.h>
+
 #include "dsm_device.h"
 #include "dsm_stage2.h"
 #include "dsm_host.h"
@@ -556,12 +558,20 @@ struct TauParams {
     int *nchange;
     int V, S, G;
     uint32_t k0, k1, iter;
+    int do_fin;               // the last workgroup of the launch finalizes the PREVIOUS sweep (updateTau: no launch between
+    FinalParams fin;          // two sweeps could carry it); it reads the other parity of ll_partial / nchange
 };
 
 template <int LPV, int NSL, bool SWEEP, bool LL>
 __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_t[];
+    const int nblk = (int)gridDim.x - p.do_fin;
+    if (p.do_fin && (int)blockIdx.x == nblk) {
+        double *fr = reinterpret_cast<double *>(smem_t);             // >= 4.4 KB of dynamic LDS: red[256], redp[256], flag
+        finalize_body(p.fin, fr, fr + 256, reinterpret_cast<int *>(fr + 512), threadIdx.x, 256);
+        return;
+    }
     constexpr int SP = LPV * NSL;
     constexpr int GPB = 256 / LPV;
     double *gT = reinterpret_cast<double *>(smem_t);   // [G][SP]
@@ -583,7 +593,7 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
     double ll_acc = 0.0;
     int nchg = 0;
 
-    for (int v = blockIdx.x * GPB + grp; v < p.V; v += gridDim.x * GPB) {
+    for (int v = blockIdx.x * GPB + grp; v < p.V; v += nblk * GPB) {
         uint64_t t = p.tau[v];
         int xi[NSL][4];
         double xf[NSL][4];
@@ -854,13 +864,13 @@ static void dirichlet_consts(const dsm_ctx *c, double *lgc_gamma, double *lgc_et
 }
 
 static FinalParams make_final(dsm_ctx *c, int nblocks, int it, int star_mode, const double *prior, const double *gamma_src,
-                              const double *eta_src)
+                              const double *eta_src, int slot = 0)
 {
     FinalParams p;
-    p.ll_partial = c->ll_partial; p.nblocks = nblocks;
+    p.ll_partial = c->ll_partial + (size_t)slot * DSM_MAX_GRID; p.nblocks = nblocks;
     p.ll_const = c->ll_const;
     p.tau_prior = (double)c->V * (double)c->G * log(1.0 / 4.0);     // HaploSNP_Sampler.py:457
-    p.prior = prior; p.S = c->S; p.nchange = c->nchange; p.it = it;
+    p.prior = prior; p.S = c->S; p.nchange = c->nchange + slot; p.it = it;
     p.ll_trace = c->ll_trace; p.lp_trace = c->lp_trace; p.nchange_trace = c->nchange_trace;
     p.star = c->star; p.gamma_src = gamma_src; p.gamma_star = c->gamma_star; p.SG = c->S * c->G;
     p.eta_src = eta_src; p.eta_star = c->eta_star;
@@ -944,13 +954,15 @@ int k_prior(dsm_ctx *c, const double *gamma, const double *eta, double *prior_ou
 template <int LPV, int NSL>
 static void launch_tau(dsm_ctx *c, int mode, const TauParams &p, int grid, size_t sh)
 {
-    if (mode == 3) hipLaunchKernelGGL((tau_kernel<LPV, NSL, true, true>), dim3(grid), dim3(256), sh, c->stream, p);
-    else if (mode == 1) hipLaunchKernelGGL((tau_kernel<LPV, NSL, true, false>), dim3(grid), dim3(256), sh, c->stream, p);
-    else hipLaunchKernelGGL((tau_kernel<LPV, NSL, false, true>), dim3(grid), dim3(256), sh, c->stream, p);
+    const int g2 = grid + p.do_fin;
+    if (mode == 3) hipLaunchKernelGGL((tau_kernel<LPV, NSL, true, true>), dim3(g2), dim3(256), sh, c->stream, p);
+    else if (mode == 1) hipLaunchKernelGGL((tau_kernel<LPV, NSL, true, false>), dim3(g2), dim3(256), sh, c->stream, p);
+    else hipLaunchKernelGGL((tau_kernel<LPV, NSL, false, true>), dim3(g2), dim3(256), sh, c->stream, p);
 }
 
 int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_sweep, const double *eta_ll,
-                uint64_t *trace_slot, double *d_logp, uint32_t iter, int *nblocks, const uint32_t *u_raw)
+                uint64_t *trace_slot, double *d_logp, uint32_t iter, int *nblocks, const uint32_t *u_raw, int slot,
+                const TauFinalRider *rider)
 {
     KTimer tm(c, DSM_K_TAU);
     const int S = c->S, G = c->G, V = c->V;
@@ -977,7 +989,13 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
     p.cnt_vs = c->cnt_vs; p.tau = c->tau; p.trace = trace_slot;
     p.gamma = gamma; p.eta_sweep = eta_sweep; p.eta_ll = eta_ll;
     p.u_raw = (c->tau_rng == DSM_RNG_MT19937 && (mode & 1)) ? u_raw : nullptr;
-    p.logp = d_logp; p.ll_partial = c->ll_partial; p.nchange = c->nchange; p.log_tab = c->log_tab;
+    p.logp = d_logp; p.ll_partial = c->ll_partial + (size_t)slot * DSM_MAX_GRID; p.nchange = c->nchange + slot; p.log_tab = c->log_tab;
+    p.do_fin = 0;
+    memset(&p.fin, 0, sizeof p.fin);
+    if (rider) {
+        p.do_fin = 1;
+        p.fin = make_final(c, rider->nblocks, rider->it, 0, rider->prior, rider->gamma_src, rider->eta_src, slot ^ 1);
+    }
     p.V = V; p.S = S; p.G = G;
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
     const size_t sh = ((size_t)G * LPV * NSL + 16 + 16 + 6 + 2 * DSM_LOG_TAB_N) * sizeof(double);
@@ -992,10 +1010,10 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
 }
 
 int k_finalize(dsm_ctx *c, int nblocks, int it, int star_mode, const double *prior, const double *gamma_src,
-               const double *eta_src)
+               const double *eta_src, int slot)
 {
     KTimer tm(c, DSM_K_FINAL);
-    const FinalParams p = make_final(c, nblocks, it, star_mode, prior, gamma_src, eta_src);
+    const FinalParams p = make_final(c, nblocks, it, star_mode, prior, gamma_src, eta_src, slot);
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, p);
     HIP_TRY(hipGetLastError());
     return DSM_OK;

@@ -24,6 +24,15 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(params=[2, 1], ids=["aggregated-muE", "per-read-muE"])
+def spec_ctx(ctx, request):
+    """the shared context with one of the two mu/E specifications forced (small test shapes would all take the
+    per-read pass by the shape rule): the law / chain-level tests must hold for both"""
+    ctx.force_stats_spec(request.param)
+    yield ctx
+    ctx.force_stats_spec(0)
+
+
 def _load(ctx, counts, tau, gamma, eta, mt_seed=None):
     ctx.set_counts(counts)
     ctx.set_state(tau, gamma, eta)
@@ -292,9 +301,10 @@ def test_binomial_and_multinomial_samplers_match_spec(ctx, kind, n, w):
     assert np.array_equal(got, ref)
 
 
-def test_stats_law_matches_reference_sampleMu(ctx):
+def test_stats_law_matches_reference_sampleMu(spec_ctx):
     """the one-stage counter-based draw and the reference's two-stage numpy draw
     (HaploSNP_Sampler.py:284-309) have the same mean: z-test on sum_mu / Esum."""
+    ctx = spec_ctx
     V, S, G = 30, 6, 3
     counts, _, _ = synth_counts(V, S, G, seed=40)
     tau, gamma, eta = random_state(V, S, G, seed=41)
@@ -390,10 +400,11 @@ def test_dirichlet_draws_match_spec(ctx, S, G):
         np.testing.assert_allclose(e, e_ref, rtol=1e-13, atol=0)
 
 
-def test_gibbs_chain_recovers_asymmetric_eta(ctx):
+def test_gibbs_chain_recovers_asymmetric_eta(spec_ctx):
     """chain-level check of the E[observed,true] -> eta[true,:] indexing (HaploSNP_Sampler.py:275-281):
     data generated with a strongly asymmetric error matrix; the posterior mean of eta must be that matrix,
     not its transpose."""
+    ctx = spec_ctx
     V, S, G = 400, 16, 3
     eta_true = np.array([[0.90, 0.07, 0.02, 0.01],
                          [0.01, 0.96, 0.01, 0.02],
@@ -466,9 +477,10 @@ def test_gibbs_update_is_self_consistent_with_oracle(ctx, V, S, G, n_iter, spec)
             and np.array_equal(star["eta"], tr["eta"][k - 1]) and star["it"] == k - 1
 
 
-def test_gibbs_chain_recovers_truth(ctx):
+def test_gibbs_chain_recovers_truth(spec_ctx):
     """statistical parity at chain level: on well-identified synthetic data the
     sampler finds the generating haplotypes/abundances (up to relabelling)."""
+    ctx = spec_ctx
     V, S, G = 300, 24, 3
     counts, tau_true, gamma_true = synth_counts(V, S, G, seed=70)
     rs = np.random.RandomState(5)
@@ -571,10 +583,11 @@ def test_nmft_vs_oracle(ctx, V, S, G):
     assert np.array_equal(ctx.nmft_get_tau(), cbind.idx_to_onehot(cbind.nmft_get_tau(tc, G)))
 
 
-def test_chain_posterior_matches_reference_sampler_in_law(ctx):
+def test_chain_posterior_matches_reference_sampler_in_law(spec_ctx):
     """T1 parity at chain level: the HIP chain (counter-based mu/E, gamma, eta draws) and the oracle's
     RandomState-exact restatement of the reference's update() target the same posterior: posterior means of
     gamma, eta and the deviance agree within Monte-Carlo error when both start from the generating state."""
+    ctx = spec_ctx
     V, S, G = 60, 8, 3
     counts, tau_true, gamma_true = synth_counts(V, S, G, seed=202)
     tau0 = cbind.idx_to_onehot(tau_true)
@@ -604,10 +617,11 @@ def test_chain_posterior_matches_reference_sampler_in_law(ctx):
     assert (np.argmax(ref["star"]["tau"], axis=2) != tau_true).mean() < 0.05
 
 
-def test_per_read_draws_have_multinomial_mean_and_variance(ctx):
+def test_per_read_draws_have_multinomial_mean_and_variance(spec_ctx):
     """distributional check of the xoshiro128+/Philox per-read draws beyond the mean: over many
     iterations the per-haplotype totals of one deep cell have the multinomial variance n p (1-p) and
     the right pairwise covariance -n p_g p_h (correlated or biased words would inflate / deflate them)."""
+    ctx = spec_ctx
     V, S, G = 4, 2, 4
     counts = np.zeros((V, S, 4), dtype=np.int64)
     counts[0, 0, 0] = 20000                                     # one deep item dominates; the others stay small

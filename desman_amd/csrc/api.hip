@@ -355,7 +355,9 @@ static int ensure_state_buffers(dsm_ctx *c, int G)
         HIP_TRY(hipMemsetAsync(c->sum_mu, 0, sg * sizeof(unsigned long long), c->stream));
         c->stats_grid = 0;
         c->u_cap = (size_t)c->V * G;
-        TRY(dev_alloc(&c->u_raw, 2 * c->u_cap));
+        // two slots of up to DSM_U_CHUNK sweeps each, at most 64 MB per slot
+        c->u_chunk_words = c->u_cap * std::max<size_t>(1, std::min<size_t>(DSM_U_CHUNK, ((size_t)16 << 20) / std::max<size_t>(1, c->u_cap)));
+        TRY(dev_alloc(&c->u_raw, 2 * c->u_chunk_words));
         free_traces(c);
     }
     return DSM_OK;
@@ -499,39 +501,67 @@ extern "C" int dsm_ctx_set_tau_rng(dsm_ctx *c, int mode)
     return DSM_OK;
 }
 
-// Enqueue the V*G MT19937 words of the next sweep on the RNG stream (it overlaps whatever the
-// main stream is doing) into the next slot of the double buffer; the main stream is made to
-// wait for them just before the sweep that consumes them (await_sweep_uniforms).
-static int fill_sweep_uniforms(dsm_ctx *c, const uint32_t **u)
-{
-    *u = nullptr;
-    if (c->tau_rng != DSM_RNG_MT19937) return DSM_OK;
-    if (!c->mt_seeded) { dsm_set_error("tau RNG not seeded: call dsm_ctx_seed / dsm_setRNG"); return DSM_ERR_STATE; }
-    const int slot = c->u_slot;
-    c->u_slot ^= 1;
-    uint32_t *buf = c->u_raw + (size_t)slot * c->u_cap;
-    HIP_TRY(hipStreamWaitEvent(c->stream_rng, c->ev_u_free[slot], 0));   // last reader of this slot is done
-    TRY(k_mt_fill(c, buf, (size_t)c->V * c->G, c->stream_rng));
-    HIP_TRY(hipEventRecord(c->ev_u_ready[slot], c->stream_rng));
-    *u = buf;
-    return DSM_OK;
-}
-
-static int await_sweep_uniforms(dsm_ctx *c, const uint32_t *u)
-{
-    if (!u) return DSM_OK;
-    const int slot = (u == c->u_raw) ? 0 : 1;
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_u_ready[slot], 0));
-    return DSM_OK;
-}
-
-static int release_sweep_uniforms(dsm_ctx *c, const uint32_t *u)
-{
-    if (!u) return DSM_OK;
-    const int slot = (u == c->u_raw) ? 0 : 1;
-    HIP_TRY(hipEventRecord(c->ev_u_free[slot], c->stream));
-    return DSM_OK;
-}
+// The MT19937 words of the tau sweeps of one call.  The stream is serial, but a call knows how many sweeps it will run
+// (V*G words each), so the side stream generates them in CHUNKS of several sweeps, one chunk ahead of the reader, into two
+// slots: one cross-stream event pair per chunk instead of per sweep (each pair costs a bubble of several microseconds
+// between two launches of the main stream).  Chunks start small so that the first sweep is not kept waiting and grow
+// by <= 1.5x, slower than the generator outruns the fastest reader (the 82 us tau-only sweeps of updateTau vs 50 us per fill).
+struct SweepWords {
+    dsm_ctx *c;
+    int total, filled = 0, nchunk = 0;
+    int first[2] = {0, 0}, len[2] = {0, 0};             // sweeps held by each slot
+    int max_len = 1;
+    SweepWords(dsm_ctx *ctx, int n_sweeps) : c(ctx), total(n_sweeps)
+    {
+        const size_t per = std::max<size_t>(1, c->u_cap);
+        max_len = (int)std::max<size_t>(1, std::min<size_t>(DSM_U_CHUNK, c->u_chunk_words / per));
+    }
+    bool active() const { return c->tau_rng == DSM_RNG_MT19937; }
+    int fill_next()
+    {
+        static const int grow[] = {1, 2, 3, 4, 6, 8};
+        int want = grow[std::min(nchunk, 5)];
+        want = std::min(std::min(want, max_len), total - filled);
+        const int slot = nchunk & 1;
+        uint32_t *buf = c->u_raw + (size_t)slot * c->u_chunk_words;
+        HIP_TRY(hipStreamWaitEvent(c->stream_rng, c->ev_u_free[slot], 0));   // the last reader of this slot is done
+        TRY(k_mt_fill(c, buf, (size_t)want * c->u_cap, c->stream_rng));
+        HIP_TRY(hipEventRecord(c->ev_u_ready[slot], c->stream_rng));
+        first[slot] = filled; len[slot] = want;
+        filled += want; ++nchunk;
+        return DSM_OK;
+    }
+    // start generating before the main stream gets to the first sweep
+    int prefetch()
+    {
+        if (!active() || filled > 0 || total < 1) return DSM_OK;
+        if (!c->mt_seeded) { dsm_set_error("tau RNG not seeded: call dsm_ctx_seed / dsm_setRNG"); return DSM_ERR_STATE; }
+        return fill_next();
+    }
+    // words of sweep `it` (sweeps must be asked for in order); makes the main stream wait for the chunk at its first sweep
+    int acquire(int it, const uint32_t **u)
+    {
+        *u = nullptr;
+        if (!active()) return DSM_OK;
+        if (!c->mt_seeded) { dsm_set_error("tau RNG not seeded: call dsm_ctx_seed / dsm_setRNG"); return DSM_ERR_STATE; }
+        if (it >= filled) TRY(fill_next());
+        int slot = (it >= first[0] && it < first[0] + len[0] && len[0]) ? 0 : 1;
+        if (!(it >= first[slot] && it < first[slot] + len[slot])) { dsm_set_error("sweep words asked out of order"); return DSM_ERR_STATE; }
+        if (it == first[slot]) {
+            if (filled < total) TRY(fill_next());            // keep one chunk ahead (into the other slot)
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_u_ready[slot], 0));
+        }
+        *u = c->u_raw + (size_t)slot * c->u_chunk_words + (size_t)(it - first[slot]) * c->u_cap;
+        return DSM_OK;
+    }
+    int release(int it)
+    {
+        if (!active()) return DSM_OK;
+        for (int slot = 0; slot < 2; ++slot)
+            if (len[slot] && it == first[slot] + len[slot] - 1) HIP_TRY(hipEventRecord(c->ev_u_free[slot], c->stream));
+        return DSM_OK;
+    }
+};
 
 // ---------------------------------------------------------------- single steps
 extern "C" int dsm_ctx_sample_tau(dsm_ctx *c, int *nchange, double *logp_out)
@@ -542,11 +572,11 @@ extern "C" int dsm_ctx_sample_tau(dsm_ctx *c, int *nchange, double *logp_out)
     const size_t nl = (size_t)c->V * c->G * 4;
     if (logp_out) TRY(d_logp.alloc(nl));
     const uint32_t *u = nullptr;
-    TRY(fill_sweep_uniforms(c, &u));
+    SweepWords words(c, 1);
     HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
-    TRY(await_sweep_uniforms(c, u));
+    TRY(words.acquire(0, &u));
     TRY(k_tau_sweep(c, 1, c->gamma, c->eta, c->eta, nullptr, d_logp, c->iter_ctr++, nullptr, u));
-    TRY(release_sweep_uniforms(c, u));
+    TRY(words.release(0));
     int n = 0;
     HIP_TRY(hipMemcpyAsync(&n, c->nchange, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (logp_out) HIP_TRY(hipMemcpyAsync(logp_out, d_logp, nl * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -696,14 +726,12 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
     TRY(eval_state(c, c->gamma, c->eta, c->tau_trace, 1));
     double *const P[2] = {c->prior, c->prior + (DSM_MAX_S + 4)};
     int nb_prev = 0;
-    const uint32_t *u = nullptr, *u_next = nullptr;
-    if (n_iter > 0) TRY(fill_sweep_uniforms(c, &u));                     // uniforms of sweep 0
+    // the MT19937 words of the sweeps are generated on the side stream, chunks of sweeps ahead (never beyond the last sweep
+    // of the call: the stream position must equal the reference's)
+    SweepWords words(c, n_iter);
+    TRY(words.prefetch());
     for (int it = 0; it < n_iter; ++it) {
         const uint32_t ic = c->iter_ctr++;
-        // the MT19937 words of the NEXT sweep are generated on the side stream one whole iteration
-        // ahead (never beyond the last sweep: the stream position must equal the reference's)
-        u_next = nullptr;
-        if (it + 1 < n_iter) TRY(fill_sweep_uniforms(c, &u_next));
         // sampleMu (:341): spec v2 = stage 1 here, stage 2 inside the Dirichlet launch; spec v1 = the per-read pass
         const bool agg = stats_spec(c) == 2;
         const bool fuse_s2 = agg && c->G < 10;           // many subsets per sample: stage 2 as its own 1024-thread launch
@@ -713,12 +741,12 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
         // launch finalizes iteration it-1 (ll, lp, MAP test :349-353) in one extra workgroup
         TRY(k_dirichlet(c, ic, c->gamma, c->gamma_trace + (size_t)it * sg, c->eta_new, c->eta_trace + (size_t)it * 16,
                         P[it & 1], it - 1, nb_prev, P[(it - 1) & 1], fuse_s2 ? 1 : 0));
-        TRY(await_sweep_uniforms(c, u));
         // tau sweep with (gamma_new, eta_old) (:345) + log-likelihood of the new state with eta_new (:349)
+        const uint32_t *u = nullptr;
+        TRY(words.acquire(it, &u));
         TRY(k_tau_sweep(c, 3, c->gamma, c->eta, c->eta_new, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb_prev, u));
-        TRY(release_sweep_uniforms(c, u));
+        TRY(words.release(it));
         std::swap(c->eta, c->eta_new);                                   // eta_new becomes the chain's eta
-        u = u_next;
     }
     if (n_iter > 0)
         TRY(k_finalize(c, nb_prev, n_iter - 1, 0, P[(n_iter - 1) & 1], c->gamma_trace + (size_t)(n_iter - 1) * sg,
@@ -733,6 +761,8 @@ extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_st
     if (n_iter < 1 || !gamma_store || !eta_store) { dsm_set_error("update_tau: bad arguments"); return DSM_ERR_ARG; }
     BIND(c);
     TRY(alloc_traces(c, n_iter));
+    SweepWords words(c, n_iter);
+    TRY(words.prefetch());
     const size_t sg = (size_t)c->S * c->G;
     if (n_iter > c->in_cap || !c->gamma_in) {            // grow-only, like the traces
         TRY(dev_alloc(&c->gamma_in, (size_t)n_iter * sg));
@@ -757,9 +787,8 @@ extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_st
         const uint32_t ic = c->iter_ctr++;
         const double *g = c->gamma_in + (size_t)it * sg, *e = c->eta_in + (size_t)it * 16;
         const uint32_t *u = nullptr;
-        TRY(fill_sweep_uniforms(c, &u));
+        TRY(words.acquire(it, &u));
         int nb = 0;
-        TRY(await_sweep_uniforms(c, u));
         TauFinalRider rider;
         if (it > 0) {
             rider.nblocks = nb_prev; rider.it = it - 1; rider.prior = c->prior_all + (size_t)(it - 1) * (c->S + 4);
@@ -767,7 +796,7 @@ extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_st
         }
         TRY(k_tau_sweep(c, 3, g, e, e, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb, u, it & 1,
                         it > 0 ? &rider : nullptr));                                                    // :392-393
-        TRY(release_sweep_uniforms(c, u));
+        TRY(words.release(it));
         nb_prev = nb;
     }
     TRY(k_finalize(c, nb_prev, n_iter - 1, 0, c->prior_all + (size_t)(n_iter - 1) * (c->S + 4),

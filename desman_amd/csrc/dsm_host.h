@@ -8,6 +8,7 @@
 #include "../../include/desman_hip.h"
 
 #define DSM_MAX_GRID 4096
+#define DSM_U_CHUNK 8        // MT19937 words are generated in chunks of up to this many sweeps (api.hip: SweepWords)
 
 void dsm_set_error(const char *fmt, ...);
 
@@ -64,9 +65,10 @@ struct dsm_ctx {
     // RNG
     uint32_t *mt_state = nullptr;   // 624 words + position
     bool mt_seeded = false;
-    uint32_t *u_raw = nullptr;      // [2][V*G] raw MT19937 words, double-buffered per sweep
-    int u_slot = 0;
-    size_t u_cap = 0;
+    uint32_t *u_raw = nullptr;      // [2][u_chunk_words] raw MT19937 words: two slots of several sweeps each
+    size_t u_cap = 0;               // words per sweep = V*G
+    size_t u_chunk_words = 0;
+    bool mt_attr_set = false;       // dynamic-LDS limit of the MT19937 kernel raised on this context's device
     uint64_t ctr_seed = 0x243F6A8885A308D3ull;
     uint32_t iter_ctr = 0;          // global iteration counter for counter-based draws
     int tau_rng = DSM_RNG_MT19937;

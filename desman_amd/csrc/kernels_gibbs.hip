@@ -785,7 +785,18 @@ int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n, hipStream_t stream)
     KTimer tm(c, DSM_K_MT, stream);
     static const bool plain = getenv("DESMAN_HIP_MT_PLAIN") != nullptr;        // A/B switch: the 227-words-per-step kernel
     if (plain) hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, stream, c->mt_state, out, n);
-    else hipLaunchKernelGGL(mt_fill_wide_kernel, dim3(1), dim3(1024), 0, stream, c->mt_state, out, n);
+    else {
+        // The generator is one workgroup that runs next to the main stream's kernels.  It asks for (nearly) all of a CU's
+        // LDS, which it does not use, so that no other workgroup is placed on its CU: a workgroup sharing a CU with these
+        // 16 high-priority wavefronts runs 2-3x longer and becomes the tail of its launch (stage 1 of the mu/E pass, whose
+        // wavefronts all get the same number of tasks: 73 -> 57 us; DESMAN_HIP_MT_HOG=0 switches the reservation off).
+        static const int hog = getenv("DESMAN_HIP_MT_HOG") ? atoi(getenv("DESMAN_HIP_MT_HOG")) : 140;   // KB
+        if (hog && !c->mt_attr_set) {                                  // per device, hence per context
+            HIP_TRY(hipFuncSetAttribute((const void *)mt_fill_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, hog * 1024));
+            c->mt_attr_set = true;
+        }
+        hipLaunchKernelGGL(mt_fill_wide_kernel, dim3(1), dim3(1024), (size_t)hog * 1024, stream, c->mt_state, out, n);
+    }
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }

@@ -115,8 +115,8 @@ __device__ __forceinline__ double dsm_log(double x, const double2 *__restrict__ 
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double x)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 #define DSM_DPP_XOR1 0xB1    // quad_perm [1,0,3,2]
@@ -157,6 +157,36 @@ __device__ __forceinline__ void group_allreduce_sum4(double &v0, double &v1, dou
         v1 = __shfl(k, base + 2, 64);
         v2 = __shfl(k, base + 1, 64);
         v3 = __shfl(k, base + 3, 64);
+    }
+}
+
+// Same reduction for groups of W < 64 lanes whose four values were evaluated in a ROTATED candidate order (value i belongs to
+// candidate (rot + i) & 3, rot differs between the groups of a wavefront): the total of candidate a sits in quad lane
+// bitrev2((a - rot) & 3) after the butterfly, so every lane fetches its four totals in base order with one variable-index
+// lane read each -- no select chain (the compiler turned it into divergent branches) after fixed broadcasts.
+template <int W>
+__device__ __forceinline__ void group_allreduce_sum4_unrotate(const double (&cv)[4], int rot, double (&l)[4])
+{
+    static_assert(W < 64, "one group per wavefront: use group_allreduce_sum4");
+    const int lane = __lane_id();
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const double s0 = b0 ? cv[0] : cv[2], s1 = b0 ? cv[1] : cv[3];
+    double k0 = b0 ? cv[2] : cv[0], k1 = b0 ? cv[3] : cv[1];
+    k0 += dpp_mov<DSM_DPP_XOR1>(s0);
+    k1 += dpp_mov<DSM_DPP_XOR1>(s1);
+    const double s = b1 ? k0 : k1;
+    double k = b1 ? k1 : k0;
+    k += dpp_mov<DSM_DPP_XOR2>(s);
+    k += dpp_mov<DSM_DPP_ROR4>(k);
+    k += dpp_mov<DSM_DPP_ROR8>(k);
+#pragma unroll
+    for (int off = 16; off < W; off <<= 1) k += __shfl_xor(k, off, 64);
+    const int lo = __double2loint(k), hi = __double2hiint(k), qbase = (lane & ~3) << 2;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int i = (a - rot) & 3;
+        const int src = qbase | ((((i & 1) << 1) | (i >> 1)) << 2);            // byte address of the source lane
+        l[a] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, hi), __builtin_amdgcn_ds_bpermute(src, lo));
     }
 }
 
@@ -219,7 +249,7 @@ __device__ __forceinline__ T dpp_mov_t(T x)
         const double d = dpp_mov<CTRL>(__builtin_bit_cast(double, x));
         return __builtin_bit_cast(T, d);
     } else {
-        return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+        return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
     }
 }
 

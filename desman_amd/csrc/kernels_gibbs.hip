@@ -665,12 +665,7 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                     for (int i = 0; i < 3; ++i) cv[i] = sweep_candidate<NSL>((rot + i) & 3, xf, st, gg, eS, ltab);
                     cv[3] = 0.0;
                     if (!reuse) cv[3] = sweep_candidate<NSL>(3, xf, st, gg, eS, ltab);       // g == 0: wave-uniform
-                    group_allreduce_sum4<LPV>(cv[0], cv[1], cv[2], cv[3]);
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const int i = (a - rot) & 3;
-                        l[a] = (i == 0) ? cv[0] : (i == 1) ? cv[1] : (i == 2) ? cv[2] : cv[3];
-                    }
+                    group_allreduce_sum4_unrotate<LPV>(cv, rot, l);
                 }
                 if (reuse) {
 #pragma unroll

@@ -839,9 +839,14 @@ __global__ __launch_bounds__(256, 3) void nmft_mfma_kernel(const double *__restr
             const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const double pa = R[e] < DSM_EPS ? DSM_EPS : R[e];
+                const bool tiny = R[e] < DSM_EPS;
+                const double pa = tiny ? DSM_EPS : R[e];
                 const double ratio = nzd(ft[e]) / pa;
-                q2[e] = live[t] ? ((R[e] < DSM_EPS) ? nzd(ft[e]) / nzd(R[e]) : ratio) : 0.0;
+                double qq = ratio;
+                // elop divides by R itself when 0 < R < eps (never with the adjustment on: tau >= eps and the gamma columns
+                // sum to one); a wave-uniform branch keeps that second division out of the common path
+                if (__builtin_amdgcn_ballot_w64(tiny && R[e] != 0.0) != 0ull) { if (tiny) qq = nzd(ft[e]) / nzd(R[e]); }
+                q2[e] = live[t] ? qq : 0.0;
                 if (live[t]) obj += ft[e] * dsm_log(ratio, ltab) - ft[e] + pa;
             }
 #pragma unroll

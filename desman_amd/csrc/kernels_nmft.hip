@@ -659,11 +659,26 @@ int k_nmft_get_tau(dsm_ctx *c, uint64_t *d_packed)
 //   gamma numerators           num_g[g][s] += sum_rows tau_new[row][g] Q2[row][s]: contraction over ROWS, K-block = base e:
 //                              A[m][k] = tau_new[vv = k][e][g = m] (lane m + 16 k), B[k][j] = Q2[vv = k][e][16 t + j] = the L2
 //                              register itself.  The accumulators D[g][s] stay in registers for the whole kernel.
-// No operand ever needs a transposition through LDS.  Shapes: S <= 96 (NT <= 6 tiles), G <= 12 (KB <= 3 K-blocks); beyond
-// four tiles the F tiles are not kept in registers between the halves (KEEPF = false: re-read from L2).  Other shapes
-// run nmft_wave_kernel / the two-pass kernels.
+// No operand ever needs a transposition through LDS.  Shapes: S <= 96 (NT <= 6 tiles), G <= 12 (KB <= 3 K-blocks); from
+// four tiles on the F tiles are not kept in registers between the halves (KEEPF = false: re-read from L2 -- at NT = 4 keeping
+// them costs 96 B/lane of scratch at 3 wavefronts per SIMD: 38 -> 35 us per update at V = 10k, 251 -> 211 us at 50k x 96 x 12);
+// five and six tiles run at 2 wavefronts per SIMD (190 VGPRs, no spills).  Other shapes run nmft_wave_kernel / the two-pass
+// kernels.
 // ===========================================================================
 typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// a / b for the operands of the update (positive, far from the ends of the exponent range): hardware reciprocal, two
+// Newton steps, one residual correction -- 8 instructions / ~50 issue cycles instead of the 11 / ~80 of the IEEE expansion
+// (no v_div_scale / v_div_fmas / v_div_fixup).  The quotient is within 1 ulp of a / b (faithful, not always correctly
+// rounded); the factors stay within the 1e-7 of the reference goldens after 100 updates that the tests ask for.
+__device__ __forceinline__ double fdiv(double a, double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
 #define DSM_DPP_ROW_SHL4 0x104
 #define DSM_DPP_ROW_SHR4 0x114
 
@@ -704,7 +719,7 @@ __device__ __forceinline__ double row16_transpose_reduce(double (&v)[16], int n)
 }
 
 template <int NT, int KB, bool KEEPF>
-__global__ __launch_bounds__(256, 3) void nmft_mfma_kernel(const double *__restrict__ F, double *__restrict__ tau,
+__global__ __launch_bounds__(256, (NT <= 4 ? 3 : 2)) void nmft_mfma_kernel(const double *__restrict__ F, double *__restrict__ tau,
                                                         const double *__restrict__ gam_raw, const double *__restrict__ gam,
                                                         int V, int S, int G, int adjust, int do_update,
                                                         const double *__restrict__ ctl, const double *__restrict__ log_tab,
@@ -791,7 +806,7 @@ __global__ __launch_bounds__(256, 3) void nmft_mfma_kernel(const double *__restr
                 for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_old[kb], braw[(t * KB + kb) * 64 + lane], R, 0, 0, 0);
                 const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qp[t][e] = live[t] ? nzd(ft[e]) / nzd(R[e]) : 0.0;
+                for (int e = 0; e < 4; ++e) qp[t][e] = live[t] ? fdiv(nzd(ft[e]), nzd(R[e])) : 0.0;
             }
 #pragma unroll
             for (int c = 0; c < KB; ++c) {
@@ -810,12 +825,12 @@ __global__ __launch_bounds__(256, 3) void nmft_mfma_kernel(const double *__restr
                 const int g = 4 * c + my_gg;
                 const bool ok = g < G;
                 double tn = 0.0;
-                if (ok) tn = told[(4 * my_e + q) * GP + g] * (nzd(tot_rg) / nzd(t1[g]));       // :171-172
+                if (ok) tn = told[(4 * my_e + q) * GP + g] * fdiv(nzd(tot_rg), nzd(t1[g]));       // :171-172
                 const double t_a0 = dpp_mov<0x00>(tn), t_a1 = dpp_mov<0xAA>(tn);              // e = 0 / 1 live in quad lanes 0 / 2
                 const double t_a2 = dpp_mov<0x55>(tn), t_a3 = dpp_mov<0xFF>(tn);              // e = 2 / 3            quad lanes 1 / 3
                 const double tot = ((t_a0 + t_a1) + t_a2) + t_a3;                              // :176-178
                 if (ok) {
-                    double x = tn / tot;                                                       // :180-181
+                    double x = fdiv(tn, tot);                                                      // :180-181
                     if (adjust && x < DSM_EPS) x = DSM_EPS;                                    // :88-91
                     if (vok) tau[((size_t)(v0 + q) * 4 + my_e) * G + g] = x;
                     tnew[(4 * my_e + q) * GP + g] = vok ? x : 0.0;
@@ -841,11 +856,11 @@ __global__ __launch_bounds__(256, 3) void nmft_mfma_kernel(const double *__restr
             for (int e = 0; e < 4; ++e) {
                 const bool tiny = R[e] < DSM_EPS;
                 const double pa = tiny ? DSM_EPS : R[e];
-                const double ratio = nzd(ft[e]) / pa;
+                const double ratio = fdiv(nzd(ft[e]), pa);
                 double qq = ratio;
                 // elop divides by R itself when 0 < R < eps (never with the adjustment on: tau >= eps and the gamma columns
                 // sum to one); a wave-uniform branch keeps that second division out of the common path
-                if (__builtin_amdgcn_ballot_w64(tiny && R[e] != 0.0) != 0ull) { if (tiny) qq = nzd(ft[e]) / nzd(R[e]); }
+                if (__builtin_amdgcn_ballot_w64(tiny && R[e] != 0.0) != 0ull) { if (tiny) qq = fdiv(nzd(ft[e]), nzd(R[e])); }
                 q2[e] = live[t] ? qq : 0.0;
                 if (live[t]) obj += ft[e] * dsm_log(ratio, ltab) - ft[e] + pa;
             }
@@ -916,7 +931,7 @@ static void launch_mfma(dsm_ctx *c, int adjust, int do_update, int grid)
     constexpr int GP = 4 * KB, SPAD = 16 * NT;
     const size_t sh = (2 * DSM_LOG_TAB_N + (size_t)GP * SPAD + 2 * (size_t)NT * KB * 64 + GP + 4 * 2 * 16 * GP +
                        4 * (size_t)(GP + 2) * SPAD) * sizeof(double);
-    hipLaunchKernelGGL((nmft_mfma_kernel<NT, KB, (NT <= 4)>), dim3(grid), dim3(256), sh, c->stream, c->F, c->ntau, c->ngam_raw, c->ngam,
+    hipLaunchKernelGGL((nmft_mfma_kernel<NT, KB, (NT <= 3)>), dim3(grid), dim3(256), sh, c->stream, c->F, c->ntau, c->ngam_raw, c->ngam,
                        c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart);
 }
 

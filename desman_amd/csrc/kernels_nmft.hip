@@ -911,8 +911,8 @@ static bool mfma_shape(const dsm_ctx *c, int *nt, int *kb)
     *nt = (c->S + 15) / 16;
     *kb = (c->nG + 3) / 4;
     static const bool off = getenv("DESMAN_HIP_NMFT_NO_MFMA") != nullptr;      // A/B switch: the VALU one-pass kernel
-    // measured against the VALU one-pass kernel: 1.0-1.3x at (NT, KB) = (4, 2), 1.64x at (6, 3) [V = 50k, S = 96, G = 12:
-    // 251 vs 413 us per update]; at (8, 4) the 140 KB of LDS leave one workgroup per CU and the VALU kernel wins (449 vs 491 us)
+    // measured against the VALU one-pass kernel: 1.0-1.3x at (NT, KB) = (4, 2), 1.96x at (6, 3) [V = 50k, S = 96, G = 12:
+    // 211 vs 413 us per update]; at (8, 4) the 140 KB of LDS leave one workgroup per CU and the VALU kernel wins (449 vs 491 us)
     return !off && *nt >= 1 && *nt <= 6 && *kb >= 1 && *kb <= 3;          // S <= 96, G <= 12
 }
 

@@ -159,6 +159,11 @@ def main():
     ap.add_argument("--chains-per-gpu", type=int, default=1,
                     help="also time K concurrent chains on the GPU (extra key; the headline stays one chain per GPU)")
     ap.add_argument("--no-nmft", action="store_true")
+    ap.add_argument("--counts-npz", default=None,
+                    help="real data instead of the synthetic tensor: an .npz with `counts` [V,S,4] (tests/golden/cog0015_counts.npz "
+                         "= the reference's complete_example table after its sample filter); V and S come from the file")
+    ap.add_argument("--lrt-filter", action="store_true",
+                    help="with --counts-npz: run the reference's `-f` likelihood-ratio variant filter first (lrt_kernel)")
     ap.add_argument("--workload", choices=["gibbs", "genes"], default="gibbs",
                     help="gibbs = the headline metric (default); genes = the accessory-gene sampler (row f4)")
     ap.add_argument("--genes", type=int, default=2000)
@@ -186,7 +191,22 @@ def main():
     from desman_amd import _lib
     from desman_amd.synth import synth_counts
     V, S, G = args.V, args.S, args.G
-    counts, _, _ = synth_counts(V, S, G, seed=1234 + rank, depth_scale=args.depth_scale)       # one independent chain per GPU
+    data_label = "synthetic"
+    if args.counts_npz:
+        counts = np.ascontiguousarray(np.load(args.counts_npz)["counts"].astype(np.int64))
+        data_label = "real: %s (%d positions)" % (os.path.basename(args.counts_npz), counts.shape[0])
+        if args.lrt_filter:
+            import pandas as pd
+            from numpy.random import RandomState
+            from desman_amd.Variant_Filter import Variant_Filter
+            tab = pd.DataFrame(np.concatenate([np.arange(counts.shape[0])[:, None], counts.reshape(counts.shape[0], -1)], axis=1))
+            flt = Variant_Filter(tab, randomState=RandomState(0), optimise=True, threshold=3.84, min_coverage=5.0, qvalue_cutoff=1.0e-3)
+            flt.device = dev
+            counts = np.ascontiguousarray(flt.get_filtered_VariantsLogRatio().astype(np.int64))
+            data_label += ", -f filter kept %d" % counts.shape[0]
+        V, S = counts.shape[0], counts.shape[1]
+    else:
+        counts, _, _ = synth_counts(V, S, G, seed=1234 + rank, depth_scale=args.depth_scale)   # one independent chain per GPU
     ctx = _lib.Context(dev)
     ctx.set_counts(counts)
     ctx.seed(rank)                                               # sampler seeds 0..N-1 (scripts/runDesman.sh:15-19)
@@ -340,9 +360,9 @@ def main():
             "value": world * V * S * its, "unit": "V*S updates/s",
             "gibbs_it_per_s_per_chain": its, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic V=%d x S=%d, G=%d, full Gibbs iteration, 1 chain per GPU%s%s"
-                                   % (V, S, G, " (configs[2])" if (V, S, G) == (10000, 64, 8) else "",
+            "vs_baseline": None, "dtype": "f64", "data": data_label,
+            "config": {"workload": "%s V=%d x S=%d, G=%d, full Gibbs iteration, 1 chain per GPU%s%s"
+                                   % ("synthetic" if not args.counts_npz else "real", V, S, G, " (configs[2])" if (V, S, G) == (10000, 64, 8) else "",
                                       "" if args.depth_scale == 1.0 else ", read depth x%g" % args.depth_scale),
                        "V": V, "S": S, "G": G, "chains": world, "tau_rng": args.rng, "depth_scale": args.depth_scale},
             "roofline": roofline, "nmft": nmft,

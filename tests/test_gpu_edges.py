@@ -159,3 +159,30 @@ def test_mt19937_device_stream_is_gsl_stream_across_fills_and_handoffs():
     ctx.set_mt_state(_lib.mt_seed_state(99))
     assert np.array_equal(ctx.debug_mt_fill(3000), cbind.MT19937(99).raw(3000))
     ctx.close()
+
+
+def test_mt19937_stream_position_across_chunked_calls():
+    """the sweeps' words are generated in chunks of 1, 2, 3, 4, 6, 8, 8, ... sweeps ahead of their reader, into two slots
+    (api.hip: SweepWords): every sweep of a long updateTau gets exactly its V*G words of the GSL stream (bit-identical
+    haplotypes over 30 sweeps = through the ramp and several reuses of both slots), and the stream position after any mix
+    of calls is the reference's"""
+    V, S, G, n = 150, 8, 3, 30
+    counts, _, _ = synth_counts(V, S, G, seed=90)
+    tau0, gamma0, eta0 = random_state(V, S, G, seed=91)
+    rng = np.random.default_rng(2)
+    gs = np.ascontiguousarray(rng.dirichlet(np.ones(G), size=(n, S)))
+    es = np.ascontiguousarray(np.broadcast_to(eta0, (n, 4, 4)))
+    ctx = _lib.Context(0)
+    ctx.set_counts(counts); ctx.set_state(tau0, gamma0, eta0); ctx.seed(4242)
+    ctx.update_tau(gs, es)
+    mt = cbind.MT19937(4242)
+    ref = tau0.copy()
+    for it in range(n):
+        cbind.sample_tau_u(ref, gs[it], es[it], counts, mt.uniform(V * G))
+        assert np.array_equal(ctx.get_tau_at(it), ref), it
+    # ... a Gibbs call (9 sweeps), one single sweep, and the next raw words
+    ctx.gibbs_update(9)
+    ctx.sample_tau()
+    mt.raw(10 * V * G)
+    assert np.array_equal(ctx.debug_mt_fill(1000), mt.raw(1000))
+    ctx.close()

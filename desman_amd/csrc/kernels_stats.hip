@@ -248,16 +248,27 @@ __global__ __launch_bounds__(256) void binom_test_kernel(int kind, uint32_t n, d
 // =====================================================================
 // host side
 // =====================================================================
-// spec v2 applies when the subset table fits (G <= 16, 2^G * S * 4 B <= 64 MB, every sample's depth < 2^32) and the
-// problem has more than 2^16 cells; the rule depends on the shape (and depth totals) only
+// spec v2 applies when the subset table fits (G <= 16, 2^G * S * 4 B <= 64 MB, every sample's depth < 2^32).  Where both
+// apply the cheaper one runs, by a cost model of the two passes fitted on MI355X (us per iteration, 933 x 64 ... 50k x 96):
+//   per-read pass (v1)   25 + 0.55 per million reads                      -- O(depth)
+//   aggregated pass (v2) 24 + 0.062 per thousand cells + 14               -- O(cells); cells = V x S rounded up to 64 samples
+//                        (lane = sample: a 16-sample table leaves 3/4 of every wavefront idle), + 14 for stage 2 in the
+//                        Dirichlet launch
+// so shallow data (< ~100 reads per cell), tables of a few samples and problems below ~200k cells keep the per-read pass.
+// The rule is a function of the shape and the read totals only: the same on every run and every GPU.
 int stats_spec(const dsm_ctx *c)
 {
     if (c->force_stats_spec == 1) return 1;
     if (c->G < 1 || c->G > 16) return 1;
-    if ((int64_t)c->V * c->S <= 65536 && c->force_stats_spec != 2) return 1;   // small problems: the per-read pass is a single short launch
     if (((size_t)1 << c->G) * (size_t)c->S * 4 > ((size_t)64 << 20)) return 1;
     if (c->max_depth >= ((uint64_t)1 << 32)) return 1;
-    return 2;
+    if (c->force_stats_spec == 2) return 2;
+    double reads = 0.0;
+    for (int64_t d : c->depth) reads += (double)d;
+    const double cells = (double)c->V * (double)(((c->S + 63) / 64) * 64);
+    const double t1 = 25.0 + 0.55e-6 * reads;
+    const double t2 = 38.0 + 0.062e-3 * cells;
+    return t2 < t1 ? 2 : 1;
 }
 
 static int ensure_ntab(dsm_ctx *c)

@@ -42,17 +42,22 @@ __device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t x)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// LPV = lanes per variant: a wavefront works on 64 / LPV (variant, LPV-sample chunk) tasks at a time, so that tables of 16,
+// 32, 48 or 96 samples fill its lanes (lane = sample alone leaves 3/4 of a wavefront idle at S = 16 and 1/4 at S = 96).
+template <int LPV>
 __global__ __launch_bounds__(256) void stats_agg_kernel(StatsAggParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_s[];
+    constexpr int NG = 64 / LPV;
     const int S = p.S, G = p.G, V = p.V;
-    const int NCH = (S + 63) >> 6, SP = NCH << 6;
+    const int NCH = (S + LPV - 1) / LPV, SP = NCH * LPV;
     double *gT = reinterpret_cast<double *>(smem_s);                 // [G][SP] gamma transposed
     double *rcp = gT + (size_t)G * SP;                                // [64]   1/k
     double *es = rcp + DSM_RCP_TAB_N;                                 // [16]   eta
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(es + 16);   // [16]
     uint32_t *eacc = reinterpret_cast<uint32_t *>(acc + 16);          // [16][256] lane-private Esum columns
     const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = lane / LPV, lig = lane % LPV;
     for (int i = tid; i < G * SP; i += 256) {
         const int g = i / SP, s = i - g * SP;
         gT[i] = (s < S) ? p.gamma[(size_t)s * G + g] : 0.0;
@@ -65,27 +70,38 @@ __global__ __launch_bounds__(256) void stats_agg_kernel(StatsAggParams p)
 
     const int nwaves = gridDim.x * 4;
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6));
-    const int ntask = V * NCH;
-    for (int task = wid; task < ntask; task += nwaves) {
-        const int v = task / NCH, j = task - v * NCH;
-        const int s = (j << 6) + lane;
-        const bool active = s < S;
-        const uint64_t t = wave_uniform_u64(p.tau[v]);
+    const int ntask = V * NCH;                                        // (variant, chunk of LPV samples)
+    const int nslot = (ntask + NG - 1) / NG;                          // NG tasks per wavefront pass
+    for (int slot = wid; slot < nslot; slot += nwaves) {
+        const int task = slot * NG + grp;
+        const bool tv = task < ntask;
+        const int v = tv ? task / NCH : 0, j = tv ? task - v * NCH : 0;
+        const int s = j * LPV + lig;
+        const bool active = tv && s < S;
+        uint64_t t = p.tau[v];
         int4 c = make_int4(0, 0, 0, 0);
         if (active) c = reinterpret_cast<const int4 *>(p.cnt_vs)[(size_t)v * S + s];
-        // haplotype sets of the four bases and the abundance each base carries in this sample; t is
-        // wave-uniform, so the base of haplotype g and the branches below are scalar
+        // haplotype sets of the four bases and the abundance each base carries in this sample; t is uniform over a lane
+        // group, so the base of haplotype g and the branches below are scalar -- one group after the other when the
+        // wavefront holds several
         uint32_t H0 = 0, H1 = 0, H2 = 0, H3 = 0;
         double G0 = 0.0, G1 = 0.0, G2 = 0.0, G3 = 0.0;
         const double *gcol = gT + s;
-        for (int g = 0; g < G; ++g) {
-            const int a = (int)((t >> (2 * g)) & 3);
-            const double x = gcol[g * SP];
-            const uint32_t bit = 1u << g;
-            if (a == 0) { H0 |= bit; G0 = G0 + x; }
-            else if (a == 1) { H1 |= bit; G1 = G1 + x; }
-            else if (a == 2) { H2 |= bit; G2 = G2 + x; }
-            else { H3 |= bit; G3 = G3 + x; }
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const uint32_t tlo = __builtin_amdgcn_readlane((uint32_t)t, gi * LPV), thi = __builtin_amdgcn_readlane((uint32_t)(t >> 32), gi * LPV);
+            const uint64_t tg = ((uint64_t)thi << 32) | tlo;
+            if (NG == 1 || grp == gi) {
+                for (int g = 0; g < G; ++g) {
+                    const int a = (int)((tg >> (2 * g)) & 3);
+                    const double x = gcol[g * SP];
+                    const uint32_t bit = 1u << g;
+                    if (a == 0) { H0 |= bit; G0 = G0 + x; }
+                    else if (a == 1) { H1 |= bit; G1 = G1 + x; }
+                    else if (a == 2) { H2 |= bit; G2 = G2 + x; }
+                    else { H3 |= bit; G3 = G3 + x; }
+                }
+            }
         }
         const double Gam[4] = {G0, G1, G2, G3};
         const uint32_t cell = (uint32_t)s * (uint32_t)V + (uint32_t)v;
@@ -251,11 +267,21 @@ __global__ __launch_bounds__(256) void binom_test_kernel(int kind, uint32_t n, d
 // spec v2 applies when the subset table fits (G <= 16, 2^G * S * 4 B <= 64 MB, every sample's depth < 2^32).  Where both
 // apply the cheaper one runs, by a cost model of the two passes fitted on MI355X (us per iteration, 933 x 64 ... 50k x 96):
 //   per-read pass (v1)   25 + 0.55 per million reads                      -- O(depth)
-//   aggregated pass (v2) 24 + 0.062 per thousand cells + 14               -- O(cells); cells = V x S rounded up to 64 samples
-//                        (lane = sample: a 16-sample table leaves 3/4 of every wavefront idle), + 14 for stage 2 in the
-//                        Dirichlet launch
-// so shallow data (< ~100 reads per cell), tables of a few samples and problems below ~200k cells keep the per-read pass.
+//   aggregated pass (v2) 24 + 0.062 per thousand cells + 14 + 0.03 x 3V / 2^G   -- O(cells); cells = V x S rounded up to
+//                        the kernel's lane groups; + 14 for stage 2 in the Dirichlet launch; the last term is the
+//                        same-address contention of the subset-table atomics (3 per cell onto 2^G x S counters: 9 375 per
+//                        counter at V = 50k, G = 4 -> 410 us; 117 at config 3)
+// so shallow data (< ~100 reads per cell), few haplotypes on many positions and problems below ~200k cells keep the
+// per-read pass.
 // The rule is a function of the shape and the read totals only: the same on every run and every GPU.
+// lanes per variant of stats_agg_kernel: the chunk size that pads S least (ties: the larger one)
+static int stats_agg_lpv(int S)
+{
+    int best = 64;
+    for (int l : {32, 16}) if ((S + l - 1) / l * l < (S + best - 1) / best * best) best = l;
+    return best;
+}
+
 int stats_spec(const dsm_ctx *c)
 {
     if (c->force_stats_spec == 1) return 1;
@@ -265,9 +291,10 @@ int stats_spec(const dsm_ctx *c)
     if (c->force_stats_spec == 2) return 2;
     double reads = 0.0;
     for (int64_t d : c->depth) reads += (double)d;
-    const double cells = (double)c->V * (double)(((c->S + 63) / 64) * 64);
+    const int lpv = stats_agg_lpv(c->S);
+    const double cells = (double)c->V * (double)((c->S + lpv - 1) / lpv * lpv);
     const double t1 = 25.0 + 0.55e-6 * reads;
-    const double t2 = 38.0 + 0.062e-3 * cells;
+    const double t2 = 38.0 + 0.062e-3 * cells + 0.03 * 3.0 * (double)c->V / (double)(1u << c->G);
     return t2 < t1 ? 2 : 1;
 }
 
@@ -308,18 +335,21 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     if (r != DSM_OK) return r;
     KTimer tm(c, DSM_K_STATS);
     const int S = c->S, G = c->G, V = c->V;
-    const int NCH = (S + 63) / 64, SP = NCH * 64;
+    const int LPV = stats_agg_lpv(S);
+    const int NCH = (S + LPV - 1) / LPV, SP = NCH * LPV, NG = 64 / LPV;
     const size_t sh = ((size_t)G * SP + DSM_RCP_TAB_N + 16 + 16) * sizeof(double) + 16 * 256 * sizeof(uint32_t);
     if (sh > 160 * 1024) { dsm_set_error("stats_agg: gamma tile (%zu B) exceeds LDS", sh); return DSM_ERR_UNSUPPORTED; }
+    const void *fn = LPV == 16 ? (const void *)stats_agg_kernel<16> : LPV == 32 ? (const void *)stats_agg_kernel<32>
+                                                                              : (const void *)stats_agg_kernel<64>;
     if (c->stats_grid == 0) {
         int occ = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, stats_agg_kernel, 256, sh));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, sh));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, c->device));
         c->stats_grid = std::max(1, occ) * prop.multiProcessorCount;
     }
-    const long ntask = (long)V * NCH;
-    // every wavefront gets the same number of tasks (a task takes ~20 us next to 5 others: a wavefront with one task
+    const long ntask = ((long)V * NCH + NG - 1) / NG;            // wavefront passes (NG lane groups = NG tasks each)
+    // every wavefront gets the same number of passes (a pass takes ~20 us next to 5 others: a wavefront with one
     // more than its neighbours is the whole tail of the launch)
     const long max_waves = (long)c->stats_grid * 4;
     const long per_wave = (ntask + max_waves - 1) / max_waves;
@@ -331,7 +361,9 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
     p.ntab = c->ntab; p.esum = c->esum; p.log_tab = c->log_tab;
     p.big_list = c->big_list; p.big_count = c->big_count;
-    hipLaunchKernelGGL(stats_agg_kernel, dim3(grid), dim3(256), sh, c->stream, p);
+    if (LPV == 16) hipLaunchKernelGGL(stats_agg_kernel<16>, dim3(grid), dim3(256), sh, c->stream, p);
+    else if (LPV == 32) hipLaunchKernelGGL(stats_agg_kernel<32>, dim3(grid), dim3(256), sh, c->stream, p);
+    else hipLaunchKernelGGL(stats_agg_kernel<64>, dim3(grid), dim3(256), sh, c->stream, p);
     // the deferred items (none once the chain has converged on data of ordinary depth: the launch then returns at once)
     const int big_grid = (int)std::max<long>(1, std::min<long>((ntask * 64 * 4 + 255) / 256, 256));
     hipLaunchKernelGGL(stats_big_kernel, dim3(big_grid), dim3(256), 0, c->stream, p);

@@ -268,7 +268,8 @@ __global__ __launch_bounds__(256) void binom_test_kernel(int kind, uint32_t n, d
 // apply the cheaper one runs, by a cost model of the two passes fitted on MI355X (us per iteration, 933 x 64 ... 50k x 96):
 //   per-read pass (v1)   25 + 0.55 per million reads                      -- O(depth)
 //   aggregated pass (v2) 24 + 0.062 per thousand cells + 14 + 0.03 x 3V / 2^G   -- O(cells); cells = V x S rounded up to
-//                        the kernel's lane groups; + 14 for stage 2 in the Dirichlet launch; the last term is the
+//                        the kernel's lane groups; + 14 for stage 2 in the Dirichlet launch (G >= 10: its own launch over
+//                        2^G subsets per sample, + 0.012 x 2^G); the last term is the
 //                        same-address contention of the subset-table atomics (3 per cell onto 2^G x S counters: 9 375 per
 //                        counter at V = 50k, G = 4 -> 410 us; 117 at config 3)
 // so shallow data (< ~100 reads per cell), few haplotypes on many positions and problems below ~200k cells keep the
@@ -294,7 +295,8 @@ int stats_spec(const dsm_ctx *c)
     const int lpv = stats_agg_lpv(c->S);
     const double cells = (double)c->V * (double)((c->S + lpv - 1) / lpv * lpv);
     const double t1 = 25.0 + 0.55e-6 * reads;
-    const double t2 = 38.0 + 0.062e-3 * cells + 0.03 * 3.0 * (double)c->V / (double)(1u << c->G);
+    const double stage2 = 14.0 + (c->G >= 10 ? 0.012 * (double)(1u << c->G) : 0.0);      // its own launch from G = 10: 62 us at G = 12
+    const double t2 = 24.0 + stage2 + 0.062e-3 * cells + 0.03 * 3.0 * (double)c->V / (double)(1u << c->G);
     return t2 < t1 ? 2 : 1;
 }
 

@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "desman_hip.h")
 
 DSM_OK = 0
 RNG_MT19937, RNG_PHILOX = 0, 1
-K_NAMES = ("stats", "dirichlet", "tau", "finalize", "mt", "nmft_a", "nmft_gamma", "nmft_b", "stats2")
+K_NAMES = ("stats", "dirichlet", "tau", "finalize", "mt", "nmft_a", "nmft_gamma", "nmft_b", "stats2", "stats_big")
 
 
 class DesmanHipError(RuntimeError):

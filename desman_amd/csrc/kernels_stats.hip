@@ -335,7 +335,6 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     if (r != DSM_OK) return r;
     r = ensure_big_list(c);
     if (r != DSM_OK) return r;
-    KTimer tm(c, DSM_K_STATS);
     const int S = c->S, G = c->G, V = c->V;
     const int LPV = stats_agg_lpv(S);
     const int NCH = (S + LPV - 1) / LPV, SP = NCH * LPV, NG = 64 / LPV;
@@ -363,9 +362,13 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
     p.ntab = c->ntab; p.esum = c->esum; p.log_tab = c->log_tab;
     p.big_list = c->big_list; p.big_count = c->big_count;
-    if (LPV == 16) hipLaunchKernelGGL(stats_agg_kernel<16>, dim3(grid), dim3(256), sh, c->stream, p);
-    else if (LPV == 32) hipLaunchKernelGGL(stats_agg_kernel<32>, dim3(grid), dim3(256), sh, c->stream, p);
-    else hipLaunchKernelGGL(stats_agg_kernel<64>, dim3(grid), dim3(256), sh, c->stream, p);
+    {
+        KTimer tm(c, DSM_K_STATS);
+        if (LPV == 16) hipLaunchKernelGGL(stats_agg_kernel<16>, dim3(grid), dim3(256), sh, c->stream, p);
+        else if (LPV == 32) hipLaunchKernelGGL(stats_agg_kernel<32>, dim3(grid), dim3(256), sh, c->stream, p);
+        else hipLaunchKernelGGL(stats_agg_kernel<64>, dim3(grid), dim3(256), sh, c->stream, p);
+    }
+    KTimer tm(c, DSM_K_STATSBIG);
     // the deferred items (none once the chain has converged on data of ordinary depth: the launch then returns at once)
     const int big_grid = (int)std::max<long>(1, std::min<long>((ntask * 64 * 4 + 255) / 256, 256));
     hipLaunchKernelGGL(stats_big_kernel, dim3(big_grid), dim3(256), 0, c->stream, p);

@@ -260,7 +260,8 @@ int dsm_kl_assign(int device, const double *cov, const double *delta, double *et
 #define DSM_K_NMFT_G   6
 #define DSM_K_NMFT_B   7
 #define DSM_K_STATS2   8         /* stage 2 of the aggregated mu/E pass       */
-#define DSM_K_COUNT    9
+#define DSM_K_STATSBIG 9         /* deferred stage-1 items (stats_big_kernel) */
+#define DSM_K_COUNT    10
 int dsm_ctx_set_timing(dsm_ctx *ctx, int on);
 int dsm_ctx_get_timing(dsm_ctx *ctx, double *ms_total /*[DSM_K_COUNT]*/,
                        int64_t *launches /*[DSM_K_COUNT]*/);

@@ -1,3 +1,5 @@
+"""updateTau per-sweep wall time with the MT19937 (GSL-order) uniforms vs counter-based Philox uniforms: the difference is what
+the serial stream still costs after chunked generation."""
 import sys, time; sys.path.insert(0, '.')
 import numpy as np
 from desman_amd import _lib

@@ -199,6 +199,10 @@ __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
             for (int j = 0; j < NSL; ++j)
 #pragma unroll
                 for (int bb = 0; bb < 4; ++bb) pre[j][bb] = 0.0;
+            // log-probability of the row's current configuration = the candidate chosen at the previous step that had a
+            // choice (a haplotype without the gene changes nothing): that candidate is not evaluated again (tau_kernel)
+            bool have_cur = false;
+            double l_cur = 0.0;
             for (int g = 0; g < G; ++g) {
                 const int told = (int)((t >> (2 * g)) & 3);
                 uint32_t uw;
@@ -248,10 +252,32 @@ __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
 #pragma unroll
                 for (int j = 0; j < NSL; ++j) gg[j] = gT[g * SP + lig + j * LPV];
                 double l[4];
+                const bool reuse = have_cur;
+                if constexpr (LPV == 64) {
 #pragma unroll
-                for (int a = 0; a < 4; ++a) l[a] = sweep_candidate<NSL>(a, xf, st, gg, eS, ltab);
-                group_allreduce_sum4<LPV>(l[0], l[1], l[2], l[3]);
+                    for (int a = 0; a < 4; ++a) {
+                        l[a] = 0.0;
+                        if (!(reuse && a == told)) l[a] = sweep_candidate<NSL>(a, xf, st, gg, eS, ltab);
+                    }
+                    group_allreduce_sum4<LPV>(l[0], l[1], l[2], l[3]);
+                } else {
+                    // several rows per wavefront, each with its own current base: candidates in the rotated order
+                    // told + 1, told + 2, told + 3; the totals come back in base order (dsm_device.h)
+                    const int rot = reuse ? told + 1 : 0;
+                    double cv[4];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) cv[i] = sweep_candidate<NSL>((rot + i) & 3, xf, st, gg, eS, ltab);
+                    cv[3] = 0.0;
+                    if (!reuse) cv[3] = sweep_candidate<NSL>(3, xf, st, gg, eS, ltab);
+                    group_allreduce_sum4_unrotate<LPV>(cv, rot, l);
+                }
+                if (reuse) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) if (a == told) l[a] = l_cur;
+                }
                 const int tn = sweep_draw(l, uw);
+                l_cur = (tn == 0) ? l[0] : (tn == 1) ? l[1] : (tn == 2) ? l[2] : l[3];
+                have_cur = true;
                 nchg += (lig == 0) & (tn != told);
                 t = (t & ~(3ull << (2 * g))) | ((uint64_t)tn << (2 * g));
                 {                                                   // link g of the chain, with the new base

@@ -673,3 +673,25 @@ def test_reference_stream_chain_with_device_sweep_is_the_reference_trajectory():
     assert np.array_equal(r["tau"], z["tau_final"])
     assert np.array_equal(r["star"]["tau"], z["tau_star"])
     assert r["star"]["lp"] == pytest.approx(float(z["lp_star"]), rel=1e-13)
+
+
+def test_random_shapes_full_iteration_and_stage1():
+    """seeded sweep over odd shapes (V, S, G, iterations drawn at random: ragged lane groups, single samples / haplotypes,
+    chunk boundaries of the sweep-word generator): the whole-iteration oracle composition under both mu/E
+    specifications, and stage 1 of the aggregated pass on shallow / deep data"""
+    rng = np.random.default_rng(20260929)
+    for _ in range(10):
+        V, S, G, n_iter = int(rng.integers(1, 300)), int(rng.integers(1, 140)), int(rng.integers(1, 13)), int(rng.integers(1, 12))
+        for spec in (2, 1):
+            c = _lib.Context(0)
+            try:
+                test_gibbs_update_is_self_consistent_with_oracle(c, V, S, G, n_iter, spec)
+            finally:
+                c.close()
+    for _ in range(8):
+        V, S, G = int(rng.integers(8, 200)), int(rng.integers(1, 150)), int(rng.integers(1, 17))
+        c = _lib.Context(0)
+        try:
+            test_stats_stage1_matches_spec(c, V, S, G, float(rng.choice([0.05, 1.0, 20.0])))
+        finally:
+            c.close()

@@ -66,13 +66,16 @@ __device__ __forceinline__ uint32_t cvt_sat_u32(double v)
     return q;
 }
 
+// b^e by repeated squaring (oracle: pw).  The loop runs to the longest exponent of the wavefront on a scalar condition; a
+// lane that is done keeps squaring a base it no longer uses -- the products it did use are the oracle's, bit for bit
 __device__ __forceinline__ double dsm_pw(double b, uint32_t e)
 {
     double res = 1.0;
-    while (e) {
-        if (e & 1u) res = res * b;
+    while (__builtin_amdgcn_ballot_w64(e != 0u) != 0ull) {
+        const double rb = res * b;
+        res = (e & 1u) ? rb : res;
         e >>= 1;
-        if (e) b = b * b;
+        b = b * b;
     }
     return res;
 }

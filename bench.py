@@ -256,12 +256,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ctx.gibbs_update(args.warmup)
+    fence()                                          # first collective of the job: communicator set-up happens here, not
+    ctx.gibbs_update(args.warmup)                    # between the warm-up steps and the timed ones (an idle GPU clocks down)
     fence()
     t0 = time.perf_counter()
-    ctx.gibbs_update(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
+    ctx.gibbs_update(args.steps)                     # returns after the library's stream has drained
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0                    # this rank: common start (barrier) -> its own K steps done
+    fence()                                          # closing barrier + synchronize; the job's time is the MAX over ranks (below),
+                                                     # i.e. what the closing barrier waits for, without the collective's own latency
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

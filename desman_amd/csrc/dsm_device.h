@@ -253,6 +253,31 @@ __device__ __forceinline__ T dpp_mov_t(T x)
     }
 }
 
+// The same reduction for four fp32 values (the screening pass of the tau sweep): every lane of the group ends with all four
+// totals, in value order.
+template <int W>
+__device__ __forceinline__ void group_allreduce_sum4_f32(float &v0, float &v1, float &v2, float &v3)
+{
+    const int lane = __lane_id();
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const float s0 = b0 ? v0 : v2, s1 = b0 ? v1 : v3;
+    float k0 = b0 ? v2 : v0, k1 = b0 ? v3 : v1;
+    k0 += dpp_mov_t<float, DSM_DPP_XOR1>(s0);
+    k1 += dpp_mov_t<float, DSM_DPP_XOR1>(s1);
+    const float s = b1 ? k0 : k1;
+    float k = b1 ? k1 : k0;
+    k += dpp_mov_t<float, DSM_DPP_XOR2>(s);
+    k += dpp_mov_t<float, DSM_DPP_ROR4>(k);
+    k += dpp_mov_t<float, DSM_DPP_ROR8>(k);
+#pragma unroll
+    for (int off = 16; off < W; off <<= 1) k += __shfl_xor(k, off, 64);
+    // quad lane (b0, b1) holds value 2 b0 + b1: value 0 in quad lane 0, 1 in lane 2, 2 in lane 1, 3 in lane 3
+    v0 = dpp_mov_t<float, 0x00>(k);
+    v1 = dpp_mov_t<float, 0xAA>(k);
+    v2 = dpp_mov_t<float, 0x55>(k);
+    v3 = dpp_mov_t<float, 0xFF>(k);
+}
+
 template <typename T, int NV, int CNT, int OFF>
 __device__ __forceinline__ void transpose_reduce_step(T (&v)[NV], int lane)
 {

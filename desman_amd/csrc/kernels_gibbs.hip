@@ -580,13 +580,22 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
     double *red = eL + 16;                               // [4]
     int *redi = reinterpret_cast<int *>(red + 4);        // [4] (+4 pad)
     double2 *ltab = reinterpret_cast<double2 *>(red + 6);// [256] log table
+    float *gT32 = reinterpret_cast<float *>(ltab + DSM_LOG_TAB_N);   // [G][SP] fp32 copies for the screening pass
+    float *eS32 = gT32 + (size_t)p.G * SP;               // [16] eta_sweep, [4] its column minima
     const int tid = threadIdx.x, G = p.G, S = p.S;
     if (tid < DSM_LOG_TAB_N) ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
     for (int i = tid; i < G * SP; i += 256) {
         const int g = i / SP, s = i % SP;
-        gT[i] = (s < S) ? p.gamma[(size_t)s * G + g] : 1.0;   // pad: p > 0, count = 0
+        const double x = (s < S) ? p.gamma[(size_t)s * G + g] : 1.0;   // pad: p > 0, count = 0
+        gT[i] = x;
+        if (SWEEP) gT32[i] = (float)x;
     }
-    if (tid < 16) { eS[tid] = p.eta_sweep[tid]; eL[tid] = p.eta_ll[tid]; }
+    if (tid < 16) { eS[tid] = p.eta_sweep[tid]; eL[tid] = p.eta_ll[tid]; if (SWEEP) eS32[tid] = (float)p.eta_sweep[tid]; }
+    if (SWEEP && tid < 4) {
+        float m = (float)p.eta_sweep[tid];
+        for (int a = 1; a < 4; ++a) m = fminf(m, (float)p.eta_sweep[a * 4 + tid]);
+        eS32[16 + tid] = m;
+    }
     __syncthreads();
 
     const int grp = tid / LPV, lig = tid % LPV;
@@ -619,7 +628,78 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
             for (int j = 0; j < NSL; ++j)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) pre[j][b] = 0.0;
+            bool have_cur = false;               // l_cur is the log-probability of the current configuration (wave-uniform)
+            const bool screen = p.logp == nullptr;
             for (int g = 0; g < G; ++g) {
+                double gg[NSL];
+#pragma unroll
+                for (int j = 0; j < NSL; ++j) gg[j] = gT[g * SP + lig + j * LPV];
+                const int told = (int)((t >> (2 * g)) & 3);
+                uint32_t uw;
+                const size_t ui = (size_t)v * G + g;
+                if (p.u_raw) {
+                    uw = p.u_raw[ui];
+                } else {
+                    uint32_t r[4];
+                    philox4x32_10((uint32_t)ui, (uint32_t)(ui >> 32), p.iter, DSM_STREAM_TAUU, p.k0, p.k1, r);
+                    uw = r[0];
+                }
+                int tn = 0;
+                bool decided = false;
+                if (screen) {
+                    // ---- screening pass in fp32 (hardware log2): the four candidate log-probabilities to ~1e-6 relative.
+                    // If the best one leads every other by more than 64 + 2^-13 |l| (natural units; the fp32 error is below
+                    // 0.1 + 1e-6 |l|), the fp64 evaluation below would find exp(l_a - l_best) < e^-30 for the others, and its
+                    // draw is then `best` for every uniform word except 0 (sum <= 1 + 3e-13, u <= 1 - 2^-32: u sum < 1 =
+                    // the best candidate's CDF edge; u sum >= the edges below it as soon as u >= 2^-32).  Such a step costs
+                    // ~850 issue cycles instead of ~3700; anything else -- a closer race, a zero word, a mixture component
+                    // outside fp32's normal range, NaN -- is decided by the fp64 code.  More than 99 % of the steps of a
+                    // converged chain and ~97 % right after the NMFT initialisation take the short way.
+                    float s32[NSL][4];
+#pragma unroll
+                    for (int j = 0; j < NSL; ++j)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) s32[j][b] = (float)pre[j][b];
+#pragma unroll 4
+                    for (int h = g + 1; h < G; ++h) {
+                        const float *er = eS32 + (int)((t >> (2 * h)) & 3) * 4;
+                        const float e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
+#pragma unroll
+                        for (int j = 0; j < NSL; ++j) {
+                            const float gm = gT32[h * SP + lig + j * LPV];
+                            s32[j][0] = fmaf(e0, gm, s32[j][0]);
+                            s32[j][1] = fmaf(e1, gm, s32[j][1]);
+                            s32[j][2] = fmaf(e2, gm, s32[j][2]);
+                            s32[j][3] = fmaf(e3, gm, s32[j][3]);
+                        }
+                    }
+                    float g32[NSL], c32[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    float lbmin = 1.0f;
+#pragma unroll
+                    for (int j = 0; j < NSL; ++j) {
+                        g32[j] = gT32[g * SP + lig + j * LPV];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            lbmin = fminf(lbmin, fmaf(eS32[16 + b], g32[j], s32[j][b]));      // smallest mixture value any candidate sees
+                            const float xs = (float)xi[j][b];                                // the reference's (float)count
+#pragma unroll
+                            for (int a = 0; a < 4; ++a)
+                                c32[a] = fmaf(xs, __builtin_amdgcn_logf(fmaf(eS32[a * 4 + b], g32[j], s32[j][b])), c32[a]);
+                        }
+                    }
+                    if (!(lbmin >= 1.0e-30f)) c32[0] = __builtin_nanf("");          // poisons the totals of the whole group
+                    group_allreduce_sum4_f32<LPV>(c32[0], c32[1], c32[2], c32[3]);    // log2 units
+                    int best = 0;
+                    float m = c32[0];
+#pragma unroll
+                    for (int a = 1; a < 4; ++a) if (c32[a] > m) { m = c32[a]; best = a; }
+                    const float need = 93.0f + 1.3e-4f * fabsf(m);                   // (64 + 2^-13 |l|) / ln 2
+                    bool cert = (uw != 0u) && (fabsf(m) < 3.0e38f);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) cert = cert && (a == best || m - c32[a] > need);
+                    if (__builtin_amdgcn_ballot_w64(cert) == __builtin_amdgcn_ballot_w64(true)) { tn = best; decided = true; }
+                }
+                if (!decided) {
                 double st[NSL][4];
 #pragma unroll
                 for (int j = 0; j < NSL; ++j)
@@ -638,14 +718,10 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                         st[j][3] = fma(e3, gm, st[j][3]);
                     }
                 }
-                double gg[NSL];
-#pragma unroll
-                for (int j = 0; j < NSL; ++j) gg[j] = gT[g * SP + lig + j * LPV];
-                const int told = (int)((t >> (2 * g)) & 3);
-                // With one variant per wavefront the candidate a == told is the variant's current
-                // configuration, whose log-probability was already evaluated (it is the candidate
-                // chosen at the previous step): only the three other candidates need their 4*NSL logs.
-                const bool reuse = g > 0;
+                // The candidate a == told is the variant's current configuration; when its log-probability is known from
+                // the previous step (the candidate chosen there, evaluated in fp64) only the three others need their
+                // 4*NSL logs.
+                const bool reuse = have_cur;
                 double l[4];
                 if constexpr (LPV == 64) {
                     // one variant per wavefront: told is wave-uniform, the current candidate is branched around
@@ -664,7 +740,7 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
 #pragma unroll
                     for (int i = 0; i < 3; ++i) cv[i] = sweep_candidate<NSL>((rot + i) & 3, xf, st, gg, eS, ltab);
                     cv[3] = 0.0;
-                    if (!reuse) cv[3] = sweep_candidate<NSL>(3, xf, st, gg, eS, ltab);       // g == 0: wave-uniform
+                    if (!reuse) cv[3] = sweep_candidate<NSL>(3, xf, st, gg, eS, ltab);       // wave-uniform
                     group_allreduce_sum4_unrotate<LPV>(cv, rot, l);
                 }
                 if (reuse) {
@@ -675,17 +751,10 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                     double *o = p.logp + ((size_t)v * G + g) * 4;
                     o[0] = l[0]; o[1] = l[1]; o[2] = l[2]; o[3] = l[3];
                 }
-                uint32_t uw;
-                const size_t ui = (size_t)v * G + g;
-                if (p.u_raw) {
-                    uw = p.u_raw[ui];
-                } else {
-                    uint32_t r[4];
-                    philox4x32_10((uint32_t)ui, (uint32_t)(ui >> 32), p.iter, DSM_STREAM_TAUU, p.k0, p.k1, r);
-                    uw = r[0];
-                }
-                const int tn = sweep_draw(l, uw);
+                tn = sweep_draw(l, uw);
                 l_cur = (tn == 0) ? l[0] : (tn == 1) ? l[1] : (tn == 2) ? l[2] : l[3];
+                }
+                have_cur = !decided;
                 nchg += (lig == 0) & (tn != told);
                 t = (t & ~(3ull << (2 * g))) | ((uint64_t)tn << (2 * g));
                 {                                                   // link g of the chain, with the new base
@@ -1004,7 +1073,8 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
     }
     p.V = V; p.S = S; p.G = G;
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
-    const size_t sh = ((size_t)G * LPV * NSL + 16 + 16 + 6 + 2 * DSM_LOG_TAB_N) * sizeof(double);
+    const size_t sh = ((size_t)G * LPV * NSL + 16 + 16 + 6 + 2 * DSM_LOG_TAB_N) * sizeof(double) +
+                      ((size_t)G * LPV * NSL + 20) * sizeof(float);        // + fp32 copies of gamma / eta for the screening pass
     if (sh > 160 * 1024) { dsm_set_error("gamma tile (%zu B) exceeds LDS", sh); return DSM_ERR_UNSUPPORTED; }
 #define TAU_CASE(L, N) if (LPV == L && NSL == N) launch_tau<L, N>(c, mode, p, grid, sh)
     TAU_CASE(16, 1); TAU_CASE(16, 2); TAU_CASE(16, 3); TAU_CASE(32, 1); TAU_CASE(32, 2); TAU_CASE(32, 3); TAU_CASE(64, 1); TAU_CASE(64, 2); TAU_CASE(64, 3); TAU_CASE(64, 4);

@@ -309,12 +309,17 @@ def main():
     ctx.gibbs_update(20)
     tm = ctx.get_timing()
     ctx.set_timing(False)
+    ctx.sweep_stats(1)                               # (counting is a separate run: it slows the sweep)
+    ctx.gibbs_update(20)
+    sw_steps, sw_exact = ctx.sweep_stats(2)          # wavefront-steps of those sweeps / left to the fp64 code by the fp32 screen
     k_us = {k: 1e3 * ms / max(n, 1) for k, (ms, n) in tm.items() if n}
     spec = ctx.stats_spec()
     # algorithmic HBM bytes per launch: one pass over the int32 count tensor each,
     # plus the tau traffic (u8-equivalent: read for the mu/E pass; read + write + trace for the sweep)
     alg = {"tau": V * S * 16 + 3 * V * G, "stats": V * S * 16 + V * G}
-    n_logs = 12.0 * V * G * S + 4.0 * V * S + 4.0 * V * S          # logs actually evaluated per sweep (+LL)
+    # candidate log-probability terms per sweep, SURVEY sec. 8(d): 16 V G S (+ 4 V S for the likelihood).  Each is evaluated by the
+    # fp32 screening pass (hardware log2); the steps it cannot decide (tau_steps_fp64_frac) are re-evaluated in fp64, 12 of 16
+    n_logs = 16.0 * V * G * S + 4.0 * V * S
     traffic, valu = {}, {}
     tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     stats_kname = "stats_agg_kernel" if spec == 2 else "stats_kernel"
@@ -349,7 +354,8 @@ def main():
                     valu_issue_frac=dk.get("valu_issue_frac"),
                     avg_kernel_us=dk["avg_kernel_us"],
                     algorithmic_bytes_per_launch=dk["algorithmic_bytes_per_launch"],
-                    per_kernel=per_kernel, fp64_logs_per_s_tau_kernel=n_logs / (k_us.get("tau", float("nan")) * 1e-6),
+                    per_kernel=per_kernel, log_terms_per_s_tau_kernel=n_logs / (k_us.get("tau", float("nan")) * 1e-6),
+                    tau_steps_fp64_frac=(sw_exact / sw_steps) if sw_steps else None,
                     stats_spec=spec,
                     note="both Gibbs kernels are VALU-issue bound, not HBM bound (bound_actual; per_kernel.valu_issue_frac, "
                          "PMC traffic ~ algorithmic bytes; profiles/, DESIGN.md sec. 3): the HBM fraction is reported "

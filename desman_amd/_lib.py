@@ -61,6 +61,7 @@ SIGNATURES = {
     "dsm_ctx_sample_tau": (_i, [_vp, C.POINTER(_i), _vp]),
     "dsm_ctx_sample_stats": (_i, [_vp, C.c_uint32, _u64p, _u64p]),
     "dsm_ctx_stats_spec": (_i, [_vp]),
+    "dsm_ctx_sweep_stats": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _i]),
     "dsm_ctx_force_stats_spec": (_i, [_vp, _i]),
     "dsm_ctx_debug_stage1": (_i, [_vp, C.c_uint32, _vp, _u64p]),
     "dsm_ctx_debug_binom": (_i, [_vp, _i, C.c_uint32, _f64p, C.c_uint64, _i, _u32p]),
@@ -266,6 +267,13 @@ class Context:
         E = np.zeros((4, 4), dtype=np.uint64)
         check(self.lib.dsm_ctx_sample_stats(self._h, int(it), mu, E))
         return mu, E
+
+    def sweep_stats(self, mode=0):
+        """(wavefront-steps of the tau sweeps, of which decided by the fp64 code) while counting was on;
+        mode 1 = zero and start counting, 0 = read, 2 = read and stop"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(self.lib.dsm_ctx_sweep_stats(self._h, C.byref(a), C.byref(b), int(mode)))
+        return a.value, b.value
 
     def stats_spec(self):
         """2 = aggregated mu/E sampler (oracle/stats_agg.c), 1 = per-read draws (orc_stats_counter)."""

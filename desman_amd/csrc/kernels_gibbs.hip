@@ -556,6 +556,7 @@ struct TauParams {
     double *ll_partial;       // [gridDim.x]
     const double *log_tab;    // [256][2]
     int *nchange;
+    unsigned long long *sweep_stats;   // [2] wavefront-steps run / decided by the fp64 code (screening evidence; may be null)
     int V, S, G;
     uint32_t k0, k1, iter;
     int do_fin;               // the last workgroup of the launch finalizes the PREVIOUS sweep (updateTau: no launch between
@@ -601,6 +602,7 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
     const int grp = tid / LPV, lig = tid % LPV;
     double ll_acc = 0.0;
     int nchg = 0;
+    int n_steps = 0, n_exact = 0;                        // wave-uniform
 
     for (int v = blockIdx.x * GPB + grp; v < p.V; v += nblk * GPB) {
         uint64_t t = p.tau[v];
@@ -629,6 +631,7 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) pre[j][b] = 0.0;
             bool have_cur = false;               // l_cur is the log-probability of the current configuration (wave-uniform)
+            n_steps += G;
             const bool screen = p.logp == nullptr;
             for (int g = 0; g < G; ++g) {
                 double gg[NSL];
@@ -765,6 +768,7 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                 l_cur = (tn == 0) ? l[0] : (tn == 1) ? l[1] : (tn == 2) ? l[2] : l[3];
                 }
                 have_cur = !decided;
+                n_exact += !decided;
                 nchg += (lig == 0) & (tn != told);
                 t = (t & ~(3ull << (2 * g))) | ((uint64_t)tn << (2 * g));
                 {                                                   // link g of the chain, with the new base
@@ -810,6 +814,10 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
     const int wn = (int)group_allreduce_sum_u32<64>((unsigned)nchg);
     if ((tid & 63) == 0) { red[tid >> 6] = wsum; redi[tid >> 6] = wn; }
     __syncthreads();
+    if (SWEEP && p.sweep_stats && (tid & 63) == 0 && n_steps) {
+        atomicAdd(&p.sweep_stats[0], (unsigned long long)n_steps);
+        if (n_exact) atomicAdd(&p.sweep_stats[1], (unsigned long long)n_exact);
+    }
     if (tid == 0) {
         p.ll_partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
         const int tot = redi[0] + redi[1] + redi[2] + redi[3];
@@ -1075,6 +1083,7 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
     p.gamma = gamma; p.eta_sweep = eta_sweep; p.eta_ll = eta_ll;
     p.u_raw = (c->tau_rng == DSM_RNG_MT19937 && (mode & 1)) ? u_raw : nullptr;
     p.logp = d_logp; p.ll_partial = c->ll_partial + (size_t)slot * DSM_MAX_GRID; p.nchange = c->nchange + slot; p.log_tab = c->log_tab;
+    p.sweep_stats = c->count_sweep_steps ? c->sweep_stats : nullptr;       // off by default: two same-address atomics per wavefront
     p.do_fin = 0;
     memset(&p.fin, 0, sizeof p.fin);
     if (rider) {

@@ -658,58 +658,8 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                     // ~850 issue cycles instead of ~3700; anything else -- a closer race, a zero word, a mixture component
                     // outside fp32's normal range, NaN -- is decided by the fp64 code.  More than 99 % of the steps of a
                     // converged chain and ~97 % right after the NMFT initialisation take the short way.
-                    // (packed fp32 arithmetic: the observed bases go two by two through v_pk_fma_f32)
-                    typedef float f2 __attribute__((ext_vector_type(2)));
-                    f2 s32[NSL][2];
-#pragma unroll
-                    for (int j = 0; j < NSL; ++j)
-#pragma unroll
-                        for (int bp = 0; bp < 2; ++bp) s32[j][bp] = (f2){(float)pre[j][2 * bp], (float)pre[j][2 * bp + 1]};
-#pragma unroll 4
-                    for (int h = g + 1; h < G; ++h) {
-                        const f2 *er = reinterpret_cast<const f2 *>(eS32 + (int)((t >> (2 * h)) & 3) * 4);
-                        const f2 e01 = er[0], e23 = er[1];
-#pragma unroll
-                        for (int j = 0; j < NSL; ++j) {
-                            const float gm = gT32[h * SP + lig + j * LPV];
-                            const f2 gm2 = (f2){gm, gm};
-                            s32[j][0] = __builtin_elementwise_fma(e01, gm2, s32[j][0]);
-                            s32[j][1] = __builtin_elementwise_fma(e23, gm2, s32[j][1]);
-                        }
-                    }
-                    const f2 *e2 = reinterpret_cast<const f2 *>(eS32);               // [a][bp], then the column minima [bp]
-                    f2 acc2[4] = {(f2){0.0f, 0.0f}, (f2){0.0f, 0.0f}, (f2){0.0f, 0.0f}, (f2){0.0f, 0.0f}};
-                    float lbmin = 1.0f;
-#pragma unroll
-                    for (int j = 0; j < NSL; ++j) {
-                        const float g1 = gT32[g * SP + lig + j * LPV];
-                        const f2 g2 = (f2){g1, g1};
-#pragma unroll
-                        for (int bp = 0; bp < 2; ++bp) {
-                            const f2 lb = __builtin_elementwise_fma(e2[8 + bp], g2, s32[j][bp]);     // smallest mixture value any candidate sees
-                            lbmin = fminf(lbmin, fminf(lb.x, lb.y));
-                            const f2 xs = (f2){(float)xi[j][2 * bp], (float)xi[j][2 * bp + 1]};      // the reference's (float)count
-#pragma unroll
-                            for (int a = 0; a < 4; ++a) {
-                                const f2 P = __builtin_elementwise_fma(e2[a * 2 + bp], g2, s32[j][bp]);
-                                const f2 lg = (f2){__builtin_amdgcn_logf(P.x), __builtin_amdgcn_logf(P.y)};
-                                acc2[a] = __builtin_elementwise_fma(xs, lg, acc2[a]);
-                            }
-                        }
-                    }
-                    float c32[4];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) c32[a] = acc2[a].x + acc2[a].y;
-                    if (!(lbmin >= 1.0e-30f)) c32[0] = __builtin_nanf("");          // poisons the totals of the whole group
-                    group_allreduce_sum4_f32<LPV>(c32[0], c32[1], c32[2], c32[3]);    // log2 units
                     int best = 0;
-                    float m = c32[0];
-#pragma unroll
-                    for (int a = 1; a < 4; ++a) if (c32[a] > m) { m = c32[a]; best = a; }
-                    const float need = 93.0f + 1.3e-4f * fabsf(m);                   // (64 + 2^-13 |l|) / ln 2
-                    bool cert = (uw != 0u) && (fabsf(m) < 3.0e38f);
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) cert = cert && (a == best || m - c32[a] > need);
+                    const bool cert = sweep_screen<LPV, NSL>(pre, xi, t, g, G, lig, uw, gT32, eS32, best);
                     if (__builtin_amdgcn_ballot_w64(cert) == __builtin_amdgcn_ballot_w64(true)) { tn = best; decided = true; }
                 }
                 if (!decided) {

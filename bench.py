@@ -305,13 +305,12 @@ def main():
                      unit="V*S updates/s", speedup_vs_one_chain=(K * args.steps / dtk) / (args.steps / dt))
 
     # per-kernel HIP-event timing (on the library's stream) for the roofline object
+    ctx.sweep_stats(reset=True)
     ctx.set_timing(True)
     ctx.gibbs_update(20)
     tm = ctx.get_timing()
     ctx.set_timing(False)
-    ctx.sweep_stats(1)                               # (counting is a separate run: it slows the sweep)
-    ctx.gibbs_update(20)
-    sw_steps, sw_exact = ctx.sweep_stats(2)          # wavefront-steps of those sweeps / left to the fp64 code by the fp32 screen
+    sw_steps, sw_exact = ctx.sweep_stats()           # wavefront-steps of those sweeps / left to the fp64 code by the fp32 screen
     k_us = {k: 1e3 * ms / max(n, 1) for k, (ms, n) in tm.items() if n}
     spec = ctx.stats_spec()
     # algorithmic HBM bytes per launch: one pass over the int32 count tensor each,

@@ -268,11 +268,11 @@ class Context:
         check(self.lib.dsm_ctx_sample_stats(self._h, int(it), mu, E))
         return mu, E
 
-    def sweep_stats(self, mode=0):
-        """(wavefront-steps of the tau sweeps, of which decided by the fp64 code) while counting was on;
-        mode 1 = zero and start counting, 0 = read, 2 = read and stop"""
+    def sweep_stats(self, reset=False):
+        """(wavefront-steps of the tau sweeps so far, of which evaluated in fp64 because the screening pass
+        could not decide them); reset=True also zeroes the totals"""
         a, b = C.c_uint64(0), C.c_uint64(0)
-        check(self.lib.dsm_ctx_sweep_stats(self._h, C.byref(a), C.byref(b), int(mode)))
+        check(self.lib.dsm_ctx_sweep_stats(self._h, C.byref(a), C.byref(b), 1 if reset else 0))
         return a.value, b.value
 
     def stats_spec(self):

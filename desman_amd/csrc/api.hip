@@ -163,6 +163,10 @@ extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
     TRY(dev_alloc(&c->nchange, 2));
     TRY(dev_alloc(&c->sweep_stats, 2));
     HIP_TRY(hipMemsetAsync(c->sweep_stats, 0, 2 * sizeof(unsigned long long), c->stream));
+    TRY(dev_alloc(&c->step_cnt, (size_t)2 * 2 * DSM_MAX_GRID));
+    HIP_TRY(hipMemsetAsync(c->step_cnt, 0, (size_t)2 * 2 * DSM_MAX_GRID * sizeof(uint32_t), c->stream));
+    TRY(dev_alloc(&c->screen_ctl, 4));
+    HIP_TRY(hipMemsetAsync(c->screen_ctl, 0, 4 * sizeof(uint32_t), c->stream));
     TRY(dev_alloc(&c->prior, 2 * (DSM_MAX_S + 4)));
     TRY(dev_alloc(&c->scalars, 8));
     TRY(dev_alloc(&c->star, 2));
@@ -200,7 +204,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     dev_free(&c->blk_tab); dev_free(&c->ntab); dev_free(&c->big_list); dev_free(&c->big_count);
     dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
-    dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->sweep_stats); dev_free(&c->prior); dev_free(&c->prior_all); dev_free(&c->scalars); dev_free(&c->star);
+    dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->sweep_stats); dev_free(&c->step_cnt); dev_free(&c->screen_ctl); dev_free(&c->prior); dev_free(&c->prior_all); dev_free(&c->scalars); dev_free(&c->star);
     dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); dev_free(&c->ngam_raw);
     dev_free(&c->npart); dev_free(&c->nstat);
     for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ev_u_ready[i]); (void)hipEventDestroy(c->ev_u_free[i]); }
@@ -807,19 +811,17 @@ extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_st
     return DSM_OK;
 }
 
-// Evidence for the screening pass of the tau sweep: wavefront-steps run, and wavefront-steps the fp32 screen could not decide
-// (evaluated in fp64), over the sweeps since counting was switched on.  mode 1 = zero the counters and start counting, 0 = read,
-// 2 = read and stop.  Counting is off by default: it costs two same-address atomics per wavefront (the sweep takes ~2x as long).
+// Evidence for the screening pass of the tau sweep: wavefront-steps run, and wavefront-steps the fp32 screen did not decide
+// (evaluated in fp64), summed by every finalize step over the sweeps of the full iterations and of updateTau.  mode 1 = read
+// and zero, 0 = read.
 extern "C" int dsm_ctx_sweep_stats(dsm_ctx *c, uint64_t *steps, uint64_t *exact_steps, int mode)
 {
-    if (!c || mode < 0 || mode > 2) { dsm_set_error("sweep_stats: bad arguments"); return DSM_ERR_ARG; }
+    if (!c || mode < 0 || mode > 1) { dsm_set_error("sweep_stats: bad arguments"); return DSM_ERR_ARG; }
     BIND(c);
     unsigned long long h[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(h, c->sweep_stats, sizeof h, hipMemcpyDeviceToHost, c->stream));
     if (mode == 1) HIP_TRY(hipMemsetAsync(c->sweep_stats, 0, sizeof h, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (mode == 1) c->count_sweep_steps = true;
-    if (mode == 2) c->count_sweep_steps = false;
     if (steps) *steps = h[0];
     if (exact_steps) *exact_steps = h[1];
     return DSM_OK;

@@ -76,7 +76,8 @@ struct dsm_ctx {
     double *ll_partial = nullptr;   // [DSM_MAX_GRID]
     int *nchange = nullptr;         // device counter
     unsigned long long *sweep_stats = nullptr;   // [2] wavefront-steps of the tau sweeps: run / decided by the fp64 code
-    bool count_sweep_steps = false; // collected only on request (dsm_ctx_sweep_stats): the counting costs the sweep ~2x
+    uint32_t *step_cnt = nullptr;   // [2 slots][DSM_MAX_GRID][2] per-workgroup wavefront-steps of a tau launch: run / left to fp64
+    uint32_t *screen_ctl = nullptr; // [4] [0] = sweeps still to run without the screening pass (set by finalize_body)
     double *prior_all = nullptr;    // [n_iter][S + 4] priors of the stored states of updateTau
     double *prior = nullptr;        // [2][DSM_MAX_S + 4] per-row Dirichlet log-prior terms, by iteration parity
     double *scalars = nullptr;      // [8] misc device scalars

@@ -390,6 +390,9 @@ struct FinalParams {
     const double *eta_src; double *eta_star;
     int star_mode;                // 0 = keep the better lp, 1 = force (entry state), 2 = never
     double *scalars;              // [0]=ll [1]=lp of this evaluation
+    const uint32_t *step_cnt;     // [nblocks][2] wavefront-steps of the finalized launch: run / left to the fp64 code (~0: not screened)
+    unsigned long long *sweep_stats;   // [2] running totals of the two
+    uint32_t *screen_ctl;         // [0] sweeps still to run without the screening pass
 };
 
 __device__ void finalize_body(const FinalParams &p, double *red, double *redp, int *flag, int tid, int nthr)
@@ -418,6 +421,33 @@ __device__ void finalize_body(const FinalParams &p, double *red, double *redp, i
     if (*flag) {
         for (int i = tid; i < p.SG; i += nthr) p.gamma_star[i] = p.gamma_src[i];
         if (tid < 16) p.eta_star[tid] = p.eta_src[tid];
+    }
+    // the screening pass of the tau sweep is worth its ~20 % only while it decides most steps: a sweep that
+    // left more than half of its wavefront-steps to the fp64 code (very shallow data, a handful of samples, the first
+    // iterations from a random state) switches it off for the next 15 sweeps, then it is tried again.  Which steps are screened
+    // never changes a result.
+    if (p.step_cnt) {
+        __syncthreads();
+        unsigned long long steps = 0, exact = 0;
+        unsigned plain = 0;
+        for (int i = tid; i < p.nblocks; i += nthr) {
+            const uint32_t a = p.step_cnt[2 * i], b = p.step_cnt[2 * i + 1];
+            steps += a;
+            if (b == 0xFFFFFFFFu) { plain = 1; exact += a; } else exact += b;
+        }
+        red[tid] = (double)steps; redp[tid] = (double)exact;              // < 2^53: exact in fp64
+        __syncthreads();
+        for (int o = nthr / 2; o >= 1; o >>= 1) {
+            if (tid < o) { red[tid] += red[tid + o]; redp[tid] += redp[tid + o]; }
+            __syncthreads();
+        }
+        const unsigned any_plain = __syncthreads_or((int)plain);
+        if (tid == 0 && red[0] > 0.0) {
+            p.sweep_stats[0] += (unsigned long long)red[0];
+            p.sweep_stats[1] += (unsigned long long)redp[0];
+            if (any_plain) { if (p.screen_ctl[0] > 0) p.screen_ctl[0] -= 1; }
+            else if (2.0 * redp[0] > red[0]) p.screen_ctl[0] = 15;
+        }
     }
 }
 
@@ -556,7 +586,9 @@ struct TauParams {
     double *ll_partial;       // [gridDim.x]
     const double *log_tab;    // [256][2]
     int *nchange;
-    unsigned long long *sweep_stats;   // [2] wavefront-steps run / decided by the fp64 code (screening evidence; may be null)
+    uint32_t *step_cnt;                // [gridDim.x][2] this launch's wavefront-steps: run / left to the fp64 code (~0: not screened)
+    const uint32_t *screen_ctl;        // [0] != 0: the screening pass is suspended (finalize_body)
+    int screen;                        // fp32 screening pass allowed (DESMAN_HIP_TAU_NO_SCREEN switches it off for A/B runs)
     int V, S, G;
     uint32_t k0, k1, iter;
     int do_fin;               // the last workgroup of the launch finalizes the PREVIOUS sweep (updateTau: no launch between
@@ -603,6 +635,7 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
     double ll_acc = 0.0;
     int nchg = 0;
     int n_steps = 0, n_exact = 0;                        // wave-uniform
+    const bool screen_on = SWEEP && p.logp == nullptr && p.screen && *p.screen_ctl == 0u;
 
     for (int v = blockIdx.x * GPB + grp; v < p.V; v += nblk * GPB) {
         uint64_t t = p.tau[v];
@@ -632,7 +665,7 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
                 for (int b = 0; b < 4; ++b) pre[j][b] = 0.0;
             bool have_cur = false;               // l_cur is the log-probability of the current configuration (wave-uniform)
             n_steps += G;
-            const bool screen = p.logp == nullptr;
+            const bool screen = screen_on;
             for (int g = 0; g < G; ++g) {
                 double gg[NSL];
 #pragma unroll
@@ -762,13 +795,13 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
     // workgroup reduction, fixed order -> deterministic ll
     const double wsum = group_allreduce_sum<64>(ll_acc);
     const int wn = (int)group_allreduce_sum_u32<64>((unsigned)nchg);
-    if ((tid & 63) == 0) { red[tid >> 6] = wsum; redi[tid >> 6] = wn; }
+    __shared__ uint32_t s_cnt[8];                         // wavefront-steps run / left to the fp64 code, per wavefront
+    if ((tid & 63) == 0) { red[tid >> 6] = wsum; redi[tid >> 6] = wn; s_cnt[tid >> 6] = (uint32_t)n_steps; s_cnt[4 + (tid >> 6)] = (uint32_t)n_exact; }
     __syncthreads();
-    if (SWEEP && p.sweep_stats && (tid & 63) == 0 && n_steps) {
-        atomicAdd(&p.sweep_stats[0], (unsigned long long)n_steps);
-        if (n_exact) atomicAdd(&p.sweep_stats[1], (unsigned long long)n_exact);
-    }
     if (tid == 0) {
+        const uint32_t st_sum = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3], ex_sum = s_cnt[4] + s_cnt[5] + s_cnt[6] + s_cnt[7];
+        p.step_cnt[2 * blockIdx.x] = st_sum;
+        p.step_cnt[2 * blockIdx.x + 1] = screen_on ? ex_sum : (SWEEP ? 0xFFFFFFFFu : 0u);
         p.ll_partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
         const int tot = redi[0] + redi[1] + redi[2] + redi[3];
         if (SWEEP && tot) atomicAdd(p.nchange, tot);
@@ -918,6 +951,7 @@ static FinalParams make_final(dsm_ctx *c, int nblocks, int it, int star_mode, co
     p.star = c->star; p.gamma_src = gamma_src; p.gamma_star = c->gamma_star; p.SG = c->S * c->G;
     p.eta_src = eta_src; p.eta_star = c->eta_star;
     p.star_mode = star_mode; p.scalars = c->scalars;
+    p.step_cnt = c->step_cnt + (size_t)slot * 2 * DSM_MAX_GRID; p.sweep_stats = c->sweep_stats; p.screen_ctl = c->screen_ctl;
     return p;
 }
 
@@ -1033,7 +1067,9 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
     p.gamma = gamma; p.eta_sweep = eta_sweep; p.eta_ll = eta_ll;
     p.u_raw = (c->tau_rng == DSM_RNG_MT19937 && (mode & 1)) ? u_raw : nullptr;
     p.logp = d_logp; p.ll_partial = c->ll_partial + (size_t)slot * DSM_MAX_GRID; p.nchange = c->nchange + slot; p.log_tab = c->log_tab;
-    p.sweep_stats = c->count_sweep_steps ? c->sweep_stats : nullptr;       // off by default: two same-address atomics per wavefront
+    static const bool no_screen = getenv("DESMAN_HIP_TAU_NO_SCREEN") != nullptr;
+    p.screen = no_screen ? 0 : 1;
+    p.step_cnt = c->step_cnt + (size_t)slot * 2 * DSM_MAX_GRID; p.screen_ctl = c->screen_ctl;
     p.do_fin = 0;
     memset(&p.fin, 0, sizeof p.fin);
     if (rider) {

@@ -811,6 +811,14 @@ extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_st
     return DSM_OK;
 }
 
+// A/B switch for tests and measurements: with on = 0 every sweep step is evaluated in fp64 (the results are the same either way)
+extern "C" int dsm_ctx_set_tau_screen(dsm_ctx *c, int on)
+{
+    if (!c) { dsm_set_error("set_tau_screen: null context"); return DSM_ERR_ARG; }
+    c->tau_screen = on != 0;
+    return DSM_OK;
+}
+
 // Evidence for the screening pass of the tau sweep: wavefront-steps run, and wavefront-steps the fp32 screen did not decide
 // (evaluated in fp64), summed by every finalize step over the sweeps of the full iterations and of updateTau.  mode 1 = read
 // and zero, 0 = read.

@@ -78,6 +78,7 @@ struct dsm_ctx {
     unsigned long long *sweep_stats = nullptr;   // [2] wavefront-steps of the tau sweeps: run / decided by the fp64 code
     uint32_t *step_cnt = nullptr;   // [2 slots][DSM_MAX_GRID][2] per-workgroup wavefront-steps of a tau launch: run / left to fp64
     uint32_t *screen_ctl = nullptr; // [4] [0] = sweeps still to run without the screening pass (set by finalize_body)
+    bool tau_screen = true;         // dsm_ctx_set_tau_screen: the fp32 screening pass of the tau sweep may run
     double *prior_all = nullptr;    // [n_iter][S + 4] priors of the stored states of updateTau
     double *prior = nullptr;        // [2][DSM_MAX_S + 4] per-row Dirichlet log-prior terms, by iteration parity
     double *scalars = nullptr;      // [8] misc device scalars

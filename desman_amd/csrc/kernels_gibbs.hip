@@ -1068,7 +1068,7 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
     p.u_raw = (c->tau_rng == DSM_RNG_MT19937 && (mode & 1)) ? u_raw : nullptr;
     p.logp = d_logp; p.ll_partial = c->ll_partial + (size_t)slot * DSM_MAX_GRID; p.nchange = c->nchange + slot; p.log_tab = c->log_tab;
     static const bool no_screen = getenv("DESMAN_HIP_TAU_NO_SCREEN") != nullptr;
-    p.screen = no_screen ? 0 : 1;
+    p.screen = (no_screen || !c->tau_screen) ? 0 : 1;
     p.step_cnt = c->step_cnt + (size_t)slot * 2 * DSM_MAX_GRID; p.screen_ctl = c->screen_ctl;
     p.do_fin = 0;
     memset(&p.fin, 0, sizeof p.fin);

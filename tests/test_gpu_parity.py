@@ -695,3 +695,37 @@ def test_random_shapes_full_iteration_and_stage1():
             test_stats_stage1_matches_spec(c, V, S, G, float(rng.choice([0.05, 1.0, 20.0])))
         finally:
             c.close()
+
+
+@pytest.mark.parametrize("V,S,G,scale", [(3000, 64, 8, 1.0), (2000, 16, 5, 0.2), (1500, 96, 12, 1.0), (800, 40, 3, 3.0)])
+def test_screening_pass_never_changes_a_result(V, S, G, scale):
+    """the fp32 screening pass of the tau sweep against the all-fp64 sweep: identical haplotype trace, change
+    counts, log-likelihoods and MAP record over a burn-in from a random state (many undecided steps, the screen suspends itself)
+    and over a run from the generating state (nearly every step decided by the screen), and the counters that say so"""
+    counts, tau_true, gamma_true = synth_counts(V, S, G, seed=11, depth_scale=scale)
+    for start in ("random", "truth"):
+        if start == "random":
+            tau0, gamma0, eta0 = random_state(V, S, G, seed=12)
+        else:
+            tau0 = cbind.idx_to_onehot(tau_true)
+            gamma0, eta0 = np.ascontiguousarray(gamma_true), 0.96 * np.eye(4) + 0.01
+        out = []
+        for on in (True, False):
+            c = _lib.Context(0)
+            c.set_counts(counts); c.set_state(tau0, gamma0, eta0); c.seed(77, ctr_seed=99)
+            c.set_tau_screen(on)
+            c.sweep_stats(reset=True)
+            c.gibbs_update(25)
+            tr = c.get_trace()
+            taus = [c.get_tau_at(i) for i in (0, 7, 24)]
+            out.append((tr, taus, c.get_star(), c.sweep_stats()))
+            c.close()
+        (tr_a, tau_a, star_a, st_a), (tr_b, tau_b, star_b, st_b) = out
+        assert all(np.array_equal(x, y) for x, y in zip(tau_a, tau_b))
+        for k in ("ll", "lp", "nchange", "gamma", "eta"):
+            assert np.array_equal(tr_a[k], tr_b[k]), k
+        assert star_a["lp"] == star_b["lp"] and np.array_equal(star_a["tau"], star_b["tau"])
+        assert st_b[0] == st_b[1] and st_b[0] > 0                       # switched off: every wavefront-step counted as fp64
+        assert st_a[0] == st_b[0] and st_a[1] <= st_a[0]
+        if start == "truth" and scale >= 1.0:
+            assert st_a[1] < 0.2 * st_a[0]                               # the screen decided most steps

@@ -63,6 +63,7 @@ SIGNATURES = {
     "dsm_ctx_stats_spec": (_i, [_vp]),
     "dsm_ctx_sweep_stats": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _i]),
     "dsm_ctx_set_tau_screen": (_i, [_vp, _i]),
+    "dsm_ctx_debug_log2f": (_i, [_vp, _vp, _vp, C.c_size_t]),
     "dsm_ctx_force_stats_spec": (_i, [_vp, _i]),
     "dsm_ctx_debug_stage1": (_i, [_vp, C.c_uint32, _vp, _u64p]),
     "dsm_ctx_debug_binom": (_i, [_vp, _i, C.c_uint32, _f64p, C.c_uint64, _i, _u32p]),
@@ -268,6 +269,12 @@ class Context:
         E = np.zeros((4, 4), dtype=np.uint64)
         check(self.lib.dsm_ctx_sample_stats(self._h, int(it), mu, E))
         return mu, E
+
+    def debug_log2f(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        check(self.lib.dsm_ctx_debug_log2f(self._h, x.ctypes.data, out.ctypes.data, x.size))
+        return out
 
     def set_tau_screen(self, on):
         """A/B switch: False = every step of the tau sweep in fp64 (same results)"""

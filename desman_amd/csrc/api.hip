@@ -811,6 +811,20 @@ extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_st
     return DSM_OK;
 }
 
+extern "C" int dsm_ctx_debug_log2f(dsm_ctx *c, const float *in, float *out, size_t n)
+{
+    if (!c || !in || !out) { dsm_set_error("debug_log2f: bad arguments"); return DSM_ERR_ARG; }
+    if (n == 0) return DSM_OK;
+    BIND(c);
+    Scratch<float> d_in, d_out;
+    TRY(d_in.alloc(n)); TRY(d_out.alloc(n));
+    HIP_TRY(hipMemcpyAsync(d_in, in, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    TRY(k_log2f_test(c, d_in, d_out, n));
+    HIP_TRY(hipMemcpyAsync(out, d_out, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
 // A/B switch for tests and measurements: with on = 0 every sweep step is evaluated in fp64 (the results are the same either way)
 extern "C" int dsm_ctx_set_tau_screen(dsm_ctx *c, int on)
 {

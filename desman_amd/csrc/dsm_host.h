@@ -128,6 +128,7 @@ int k_unpack_tau(dsm_ctx *c, const uint64_t *d_packed, int64_t *d_onehot, int V,
 int k_tau_sum(dsm_ctx *c, const uint64_t *trace, int n, int64_t *d_sum);
 int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n, hipStream_t stream);
 int k_stats_v1(dsm_ctx *c, uint32_t iter);
+int k_log2f_test(dsm_ctx *c, const float *d_in, float *d_out, size_t n);
 int build_stats_items(dsm_ctx *c);          // api.hip: work list of the per-read pass from the resident tensor
 
 // ---- launchers (kernels_stats.hip)

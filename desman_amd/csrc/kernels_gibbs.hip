@@ -808,6 +808,19 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
     }
 }
 
+// test hook: the hardware log2 the screening pass relies on (its error bound is pinned by tests/test_gpu_edges.py)
+__global__ __launch_bounds__(256) void log2f_test_kernel(const float *__restrict__ in, float *__restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = __builtin_amdgcn_logf(in[i]);
+}
+
+int k_log2f_test(dsm_ctx *c, const float *d_in, float *d_out, size_t n)
+{
+    hipLaunchKernelGGL(log2f_test_kernel, dim3(1024), dim3(256), 0, c->stream, d_in, d_out, n);
+    HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}
+
 // =====================================================================
 // host launchers
 // =====================================================================

@@ -265,6 +265,8 @@ int dsm_kl_assign(int device, const double *cov, const double *delta, double *et
 /* evidence for the screening pass of the tau sweep: wavefront-steps run / left to the fp64 code, over the sweeps
    of dsm_ctx_gibbs_update and dsm_ctx_update_tau so far.  mode 1 = read and zero, 0 = read */
 int dsm_ctx_sweep_stats(dsm_ctx *ctx, uint64_t *steps, uint64_t *exact_steps, int mode);
+/* test hook: out[i] = the hardware log2 (v_log_f32) of in[i], the logarithm of the screening pass */
+int dsm_ctx_debug_log2f(dsm_ctx *ctx, const float *in, float *out, size_t n);
 /* on = 0: every step of the tau sweep in fp64 (A/B switch: the results do not depend on it) */
 int dsm_ctx_set_tau_screen(dsm_ctx *ctx, int on);
 int dsm_ctx_set_timing(dsm_ctx *ctx, int on);

@@ -186,3 +186,20 @@ def test_mt19937_stream_position_across_chunked_calls():
     mt.raw(10 * V * G)
     assert np.array_equal(ctx.debug_mt_fill(1000), mt.raw(1000))
     ctx.close()
+
+
+def test_hardware_log2_error_bound_of_the_screening_pass():
+    """the screening pass of the tau sweep budgets the hardware v_log_f32 at a few ulp; measured here
+    over the whole range it is used on (mixture values in [1e-30, 1]) and around 1, where log2 changes sign"""
+    ctx = _lib.Context(0)
+    rng = np.random.default_rng(5)
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-30), 0.0, 2_000_000)), 1.0 - rng.uniform(0, 1e-3, 200_000),
+                        rng.uniform(0.5, 1.0, 500_000), np.array([1.0, 0.5, 0.25, 1e-30])]).astype(np.float32)
+    got = ctx.debug_log2f(x).astype(np.float64)
+    ref = np.log2(x.astype(np.float64))
+    err = np.abs(got - ref)
+    ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+    # absolute error: <= 2 ulp of the result away from 1, <= 2^-22 where the result is tiny
+    assert np.all(err <= np.maximum(2.0 * ulp, 2.0 ** -22)), float((err / np.maximum(ulp, 2.0 ** -23)).max())
+    assert got[-4] == 0.0 and got[-3] == -1.0 and got[-2] == -2.0
+    ctx.close()

@@ -575,6 +575,10 @@ __global__ __launch_bounds__(256) void prior_kernel(const double *__restrict__ g
 // (float)count * log(p) reduced with an in-register butterfly, every lane
 // normalises and inverts the CDF redundantly (no divergence), and the packed
 // tau word is updated in a register.
+// Each step first runs the fp32 screening pass (dsm_device.h: sweep_screen,
+// DESIGN.md sec. 3d): when the four totals are far enough apart that the fp64
+// draw is certain, the step is decided there; the fp64 evaluation above is the
+// path of the remaining (< 1 % of the) steps.
 // =====================================================================
 struct TauParams {
     const int32_t *cnt_vs;

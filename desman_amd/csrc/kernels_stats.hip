@@ -347,14 +347,15 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, sh));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-        c->stats_grid = std::max(1, occ) * prop.multiProcessorCount;
+        c->stats_grid = std::min(6, std::max(1, occ)) * prop.multiProcessorCount;   // six workgroups per CU: measured optimum (below)
     }
     const long ntask = ((long)V * NCH + NG - 1) / NG;            // wavefront passes (NG lane groups = NG tasks each)
-    // every wavefront gets the same number of passes (a pass takes ~20 us next to 5 others: a wavefront with one
-    // more than its neighbours is the whole tail of the launch)
+    // a persistent grid of six workgroups (24 wavefronts) per CU, passes dealt round-robin: the kernel is issue-bound, and a SIMD
+    // with six wavefronts of one or two passes each keeps its VALU busier than five with exactly two (48 vs 52 us at config 3,
+    // 143 vs 152 at V = 20k); a seventh workgroup per CU or a second partial round costs more than it brings (7168 wavefronts
+    // 53 us, 8192 57 us)
     const long max_waves = (long)c->stats_grid * 4;
-    const long per_wave = (ntask + max_waves - 1) / max_waves;
-    const long waves = (ntask + per_wave - 1) / per_wave;
+    const long waves = std::min<long>(ntask, max_waves);
     const int grid = (int)std::max<long>(1, (waves + 3) / 4);
     StatsAggParams p;
     p.cnt_vs = c->cnt_vs; p.tau = c->tau; p.gamma = c->gamma; p.eta = c->eta;

@@ -634,7 +634,7 @@ extern "C" int dsm_ctx_debug_stage1(dsm_ctx *c, uint32_t iter, uint32_t *ntab, u
     if (esum) HIP_TRY(hipMemcpyAsync(esum, c->esum, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemsetAsync(c->ntab, 0, t.size() * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
-    HIP_TRY(hipMemsetAsync(c->big_count, 0, sizeof(uint32_t), c->stream));     // no stage 2 follows to reset it
+    HIP_TRY(hipMemsetAsync(c->big_count, 0, DSM_BIG_NT * DSM_BIG_NL * DSM_BIG_STRIDE * sizeof(uint32_t), c->stream));     // no stage 2 follows to reset it
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (ntab)
         for (size_t h = 0; h < NH; ++h)

@@ -17,6 +17,7 @@
 #define DSM_BINV_MEAN_CAP 128.0       // inversion while the mean of the rarer outcome is <= 128, BTRS above: on a
                                       // 64-lane wavefront BTRS costs ~1500 instructions (some lane always takes the
                                       // slow path / another attempt), the search 14 per step
+#define DSM_LEAN_CAP 64.0             // stage 1 itself draws the items up to this mean (kernels_stats.hip: lean_cap); not part of the specification
 #define DSM_BINV_MEAN_CAP_S2 16.0      // stage 2: one latency-bound binomial per lane, BTRS is the shorter dependent chain
 #define DSM_BINV_KMAX 255u
 #define DSM_RCP_TAB_N 256             // 1/k for k < 256, staged in LDS by the kernels (entry 0 unused)
@@ -188,7 +189,8 @@ __device__ __forceinline__ uint32_t binom(Xo128 &rng, uint32_t n, double wa, dou
 
 template <bool BIG>
 __device__ __forceinline__ void mult4(Xo128 &rng, uint32_t x, const double (&W)[4], uint32_t (&n)[4], const double *__restrict__ rcp,
-                                      const double2 *__restrict__ ltab, bool &defer)
+                                      const double2 *__restrict__ ltab, bool &defer, double lean_cap = DSM_BINV_MEAN_CAP,
+                                      int *kind = nullptr)
 {
     n[0] = n[1] = n[2] = n[3] = 0;
     if (x == 0) return;
@@ -205,9 +207,13 @@ __device__ __forceinline__ void mult4(Xo128 &rng, uint32_t x, const double (&W)[
     // by read, more (only possible for the items of the compacted kernel, in practice) by two more binomials
     uint32_t m = 0, k[3] = {0, 0, 0};
     if constexpr (!BIG) {
-        m = binom<false>(rng, x, ws, wm, rcp, ltab, defer);
-        if (m > DSM_XS) defer = true;
-        if (defer) return;
+        m = binom<false>(rng, x, ws, wm, rcp, ltab, defer, lean_cap);   // lean_cap <= the cap of the specification: who draws, not what
+        if (defer) {                                        // what the compacted kernel will run for it: BTRS or a long search
+            const double wsm = ws < wm ? ws : wm;
+            if (kind) *kind = ((double)x * wsm > DSM_BINV_MEAN_CAP * (ws + wm)) ? 0 : 1;
+            return;
+        }
+        if (m > DSM_XS) { defer = true; if (kind) *kind = 2; return; }   // ... or a search and two more binomials
     } else {
         uint32_t nn = x;
         double wa = ws, wb = wm;

@@ -8,6 +8,9 @@
 #include "../../include/desman_hip.h"
 
 #define DSM_MAX_GRID 4096
+#define DSM_BIG_NL 64        // sub-lists of deferred stage-1 items (kernels_stats.hip), one counter each ...
+#define DSM_BIG_STRIDE 16    // ... 64 B apart
+#define DSM_BIG_NT 3         // ... for each kind of deferred item (BTRS / long search / search + two more binomials)
 #define DSM_U_CHUNK 8        // MT19937 words are generated in chunks of up to this many sweeps (api.hip: SweepWords)
 
 void dsm_set_error(const char *fmt, ...);
@@ -42,7 +45,7 @@ struct dsm_ctx {
     uint32_t *ntab = nullptr;       // [2^G][S] subset counts of the aggregated mu/E pass (spec v2), zero between passes
     size_t ntab_len = 0;
     unsigned long long *big_list = nullptr;   // stage-1 items deferred to the compacted (BTRS) kernel: cell * 4 + base
-    uint32_t *big_count = nullptr;
+    uint32_t *big_count = nullptr;            // DSM_BIG_NL counters, DSM_BIG_STRIDE words apart
     size_t big_cap = 0;
     int stats_grid = 0;             // resident workgroups of stats_agg_kernel
     int item_stride = 1;            // items per sample row of `items`

@@ -50,7 +50,7 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
     int *n_lo = reinterpret_cast<int *>(leaf + 32);                            // the plan's node arrays (lane-indexed below)
     int *n_hi = n_lo + S2_MAX_NODES, *n_off = n_hi + S2_MAX_NODES, *n_idx = n_off + S2_MAX_NODES, *n_child = n_idx + S2_MAX_NODES;
 
-    if (s == 0 && tid == 0 && p.big_count) *p.big_count = 0u;
+    if (s == 0 && tid < DSM_BIG_NT * DSM_BIG_NL && p.big_count) p.big_count[tid * DSM_BIG_STRIDE] = 0u;
     if (tid < DSM_LOG_TAB_N) ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
     for (int k = tid; k < DSM_RCP_TAB_N; k += nthr) rcp[k] = k ? 1.0 / (double)k : 0.0;
     if (tid < 32) {

@@ -13,8 +13,8 @@
 #include <string.h>
 
 #include "dsm_device.h"
-#include "dsm_stage2.h"
 #include "dsm_host.h"
+#include "dsm_stage2.h"
 #include "log_table.h"
 
 // =====================================================================

@@ -8,9 +8,13 @@
 //                        four observed bases (dsm_binom.h: mult4) -> Esum (lane-private LDS columns) and the
 //                        subset counts N[H_a(v)][s] (one coalesced row of global atomics per true base).
 //                        Cost per cell ~ O(G + errors).  Inversion only: an item whose rarer outcome has a mean
-//                        above 64 is pushed onto a work list instead (lean kernel: 64 VGPRs, no rejection loop).
-//   stats_big_kernel     the listed items, one lane each (compacted: every lane runs BTRS, no idle lanes); cost
-//                        O(1) in the depth.  Items are independent work units (own Philox stream each).
+//                        above 64 (DSM_LEAN_CAP), or more than DSM_XS reads off its heaviest base, is pushed onto a
+//                        work list instead (lean kernel: <= 80 VGPRs, no rejection loop).  The lists: one per kind of
+//                        item (rejection sampler / long search / search + two more binomials) x DSM_BIG_NL, each with
+//                        its own counter -- workgroup b appends to list b mod DSM_BIG_NL of the kind.
+//   stats_big_kernel     the listed items, one lane each (compacted, a wavefront holds items of one kind: no idle
+//                        lanes, no path run for one lane only).  Items are independent work units (own Philox
+//                        stream each): which kernel draws an item does not change the draw.
 //   stats_stage2_kernel  stage 2: one workgroup per sample spreads N[.][s] over the haplotypes by recursive
 //                        halving of the haplotype range (one large-count binomial per (node, subset): BTRS).
 //   stats v1 (per-read draws, kernels_gibbs.hip: stats_kernel) remains for G > 16 / tables above 64 MB.
@@ -32,8 +36,12 @@ struct StatsAggParams {
     uint32_t *ntab;                 // [2^G][S]
     unsigned long long *esum;       // [16]
     const double *log_tab;
-    unsigned long long *big_list;   // deferred items: cell * 4 + observed base
-    uint32_t *big_count;            // [1]
+    unsigned long long *big_list;   // deferred items: cell * 4 + observed base; DSM_BIG_NL sub-lists of big_seg entries each
+    uint32_t *big_count;            // [DSM_BIG_NL] counters, 64 B apart (workgroup b appends to sub-list b % DSM_BIG_NL: one
+                                    // counter took every deferring wavefront's atomic in turn, ~8 ns each -- 35k of them = the
+                                    // whole pass on deep data)
+    size_t big_seg;
+    double lean_cap;                // stage 1 hands an item whose rarer outcome has a mean above this to the compacted kernel
 };
 
 __device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t x)
@@ -123,17 +131,25 @@ __global__ __launch_bounds__(256) void stats_agg_kernel(StatsAggParams p)
                 uint32_t n[4];
                 Xo128 rng = item_seed(cbase, (uint32_t)b, p.k0, p.k1);
                 bool defer = false;
-                mult4<false>(rng, (uint32_t)xb, W, n, rcp, nullptr, defer);
+                int kind = 0;
+                mult4<false>(rng, (uint32_t)xb, W, n, rcp, nullptr, defer, p.lean_cap, &kind);
                 if (__builtin_expect(defer, 0)) {
                     // needs the rejection sampler: the compacted kernel re-does this item from its own stream
                     // (one atomic per wavefront: the deferring lanes take consecutive slots)
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(true);
-                    const int leader = __builtin_ctzll(mask);
-                    uint32_t base = 0;
-                    if (lane == leader) base = atomicAdd(p.big_count, (uint32_t)__builtin_popcountll(mask));
-                    base = __shfl(base, leader, 64);
-                    const uint32_t slot = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                    p.big_list[slot] = (unsigned long long)cell * 4ull + (unsigned long long)b;
+                    // one list per kind of item (and DSM_BIG_NL of each): the wavefronts of the compacted kernel then hold
+                    // items that take the same path; one atomic per wavefront and kind, the deferring lanes take consecutive slots
+#pragma unroll 1
+                    for (int kd = 0; kd < DSM_BIG_NT; ++kd) {
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(kind == kd);
+                        if (mask == 0ull) continue;
+                        const uint32_t sub = (uint32_t)kd * DSM_BIG_NL + blockIdx.x % DSM_BIG_NL;
+                        const int leader = __builtin_ctzll(mask);
+                        uint32_t base = 0;
+                        if (lane == leader) base = atomicAdd(p.big_count + sub * DSM_BIG_STRIDE, (uint32_t)__builtin_popcountll(mask));
+                        base = __builtin_amdgcn_readlane(base, leader);
+                        const uint32_t slot = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                        if (kind == kd) p.big_list[(size_t)sub * p.big_seg + slot] = (unsigned long long)cell * 4ull + (unsigned long long)b;
+                    }
                 } else {
                     uint32_t *erow = eacc + (b * 4) * 256 + tid;           // lane-private column: ds_add_u32, never a conflict
 #pragma unroll
@@ -173,8 +189,10 @@ __global__ __launch_bounds__(256) void stats_big_kernel(StatsAggParams p)
     __shared__ unsigned long long acc[16];
     __shared__ uint32_t eacc[16 * 256];
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t nbig = *p.big_count;
-    if (nbig == 0) return;
+    const uint32_t sub = blockIdx.x % (DSM_BIG_NT * DSM_BIG_NL), bi = blockIdx.x / (DSM_BIG_NT * DSM_BIG_NL), nb = gridDim.x / (DSM_BIG_NT * DSM_BIG_NL);
+    const uint32_t nbig = p.big_count[sub * DSM_BIG_STRIDE];
+    if (bi * 256u >= nbig) return;
+    const unsigned long long *list = p.big_list + (size_t)sub * p.big_seg;
     ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
     for (int k = tid; k < DSM_RCP_TAB_N; k += blockDim.x) rcp[k] = k ? 1.0 / (double)k : 0.0;
     if (tid < 16) { es[tid] = p.eta[tid]; acc[tid] = 0ull; }
@@ -182,8 +200,8 @@ __global__ __launch_bounds__(256) void stats_big_kernel(StatsAggParams p)
     for (int i = 0; i < 16; ++i) eacc[i * 256 + tid] = 0u;
     __syncthreads();
     const int V = p.V, S = p.S, G = p.G;
-    for (uint32_t i = blockIdx.x * 256 + tid; i < nbig; i += gridDim.x * 256) {
-        const unsigned long long item = p.big_list[i];
+    for (uint32_t i = bi * 256u + tid; i < nbig; i += nb * 256u) {
+        const unsigned long long item = list[i];
         const uint32_t cell = (uint32_t)(item >> 2);
         const int b = (int)(item & 3ull);
         const int s = (int)(cell / (uint32_t)V), v = (int)(cell - (uint32_t)s * (uint32_t)V);
@@ -312,28 +330,26 @@ static int ensure_ntab(dsm_ctx *c)
     return DSM_OK;
 }
 
-static int ensure_big_list(dsm_ctx *c)
+static int ensure_big_list(dsm_ctx *c, size_t seg)
 {
-    const size_t need = (size_t)c->V * c->S * 4;
+    const size_t need = seg * DSM_BIG_NT * DSM_BIG_NL;
     if (c->big_list && c->big_cap == need) return DSM_OK;
     if (c->big_list) { (void)hipFree(c->big_list); c->big_list = nullptr; }
     if (!c->big_count) {
-        hipError_t e = hipMalloc((void **)&c->big_count, sizeof(uint32_t));
+        hipError_t e = hipMalloc((void **)&c->big_count, DSM_BIG_NT * DSM_BIG_NL * DSM_BIG_STRIDE * sizeof(uint32_t));
         if (e != hipSuccess) { dsm_set_error("hipMalloc failed: %s", hipGetErrorString(e)); return DSM_ERR_NOMEM; }
     }
     hipError_t e = hipMalloc((void **)&c->big_list, need * sizeof(unsigned long long));
     if (e != hipSuccess) { dsm_set_error("hipMalloc(%zu B) failed: %s", need * 8, hipGetErrorString(e)); return DSM_ERR_NOMEM; }
     c->big_cap = need;
-    // the counter is zero between passes: stage 2 (its consumer-side successor) resets it
-    HIP_TRY(hipMemsetAsync(c->big_count, 0, sizeof(uint32_t), c->stream));
+    // the counters are zero between passes: stage 2 (its consumer-side successor) resets them
+    HIP_TRY(hipMemsetAsync(c->big_count, 0, DSM_BIG_NT * DSM_BIG_NL * DSM_BIG_STRIDE * sizeof(uint32_t), c->stream));
     return DSM_OK;
 }
 
 int k_stats_stage1(dsm_ctx *c, uint32_t iter)
 {
     int r = ensure_ntab(c);
-    if (r != DSM_OK) return r;
-    r = ensure_big_list(c);
     if (r != DSM_OK) return r;
     const int S = c->S, G = c->G, V = c->V;
     const int LPV = stats_agg_lpv(S);
@@ -357,12 +373,26 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     const long max_waves = (long)c->stats_grid * 4;
     const long waves = std::min<long>(ntask, max_waves);
     const int grid = (int)std::max<long>(1, (waves + 3) / 4);
+    // a sub-list holds what its workgroups can defer at most: passes per wavefront x 4 wavefronts x 64 lanes x 4 bases each
+    const long per_wg = ((ntask + waves - 1) / waves) * 4 * 64 * 4;
+    const size_t seg = (size_t)std::min<long>((long)V * S * 4, ((grid + DSM_BIG_NL - 1) / DSM_BIG_NL) * per_wg);
+    r = ensure_big_list(c, seg);
+    if (r != DSM_OK) return r;
     StatsAggParams p;
     p.cnt_vs = c->cnt_vs; p.tau = c->tau; p.gamma = c->gamma; p.eta = c->eta;
-    p.V = V; p.S = S; p.G = G;
+    p.V = V; p.S = S; p.G = G; p.big_seg = seg;
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
     p.ntab = c->ntab; p.esum = c->esum; p.log_tab = c->log_tab;
     p.big_list = c->big_list; p.big_count = c->big_count;
+    {
+        // who draws an item, not what is drawn: an item whose rarer outcome has a mean above lean_cap goes to the compacted
+        // kernel although inversion still applies to it -- its search would hold its 63 neighbours of the wavefront for
+        // ~lean_cap more steps.  Config 3 at 10 x depth (us, this pass + compacted kernel): 128 -> 150 + 35, 64 -> 119 + 53,
+        // 48 -> 105 + 81, 32 -> 86 + 134.  Data of ordinary depth has no such item once the chain has converged.
+        static const char *e = getenv("DESMAN_HIP_LEAN_CAP");
+        p.lean_cap = e ? atof(e) : DSM_LEAN_CAP;
+        if (!(p.lean_cap > 0.0 && p.lean_cap <= DSM_BINV_MEAN_CAP)) p.lean_cap = DSM_LEAN_CAP;
+    }
     {
         KTimer tm(c, DSM_K_STATS);
         if (LPV == 16) hipLaunchKernelGGL(stats_agg_kernel<16>, dim3(grid), dim3(256), sh, c->stream, p);
@@ -371,7 +401,9 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     }
     KTimer tm(c, DSM_K_STATSBIG);
     // the deferred items (none once the chain has converged on data of ordinary depth: the launch then returns at once)
-    const int big_grid = (int)std::max<long>(1, std::min<long>((ntask * 64 * 4 + 255) / 256, 256));
+    // up to 16 workgroups per list = 4096 items of a list per round (a list one item longer than a round doubles the launch:
+    // every wavefront is one long dependent chain); the workgroups of an empty list leave at once
+    const int big_grid = DSM_BIG_NT * DSM_BIG_NL * (int)std::max<long>(1, std::min<long>((ntask * 64 * 4 / DSM_BIG_NL + 255) / 256, 16));
     hipLaunchKernelGGL(stats_big_kernel, dim3(big_grid), dim3(256), 0, c->stream, p);
     HIP_TRY(hipGetLastError());
     return DSM_OK;

@@ -236,7 +236,9 @@ def test_stats_bit_exact_vs_spec(ctx, V, S, G):
 
 
 @pytest.mark.parametrize("V,S,G,scale", [(200, 64, 8, 1.0), (120, 96, 12, 1.0), (150, 16, 5, 1.0), (60, 130, 3, 1.0),
-                                         (80, 64, 8, 20.0), (40, 7, 16, 1.0), (64, 64, 1, 1.0), (50, 300, 6, 0.05),
+                                         (80, 64, 8, 20.0), (40, 7, 16, 1.0),
+                                         # deferred lists of every kind longer than one workgroup of the compacted kernel
+                                         (400, 64, 8, 10.0), (64, 64, 1, 1.0), (50, 300, 6, 0.05),
                                          # lane groups of 16 / 32 lanes with ragged last chunks and a ragged last wavefront pass
                                          (91, 48, 6, 1.0), (77, 33, 4, 1.0), (53, 100, 5, 1.0), (35, 32, 7, 1.0), (9, 20, 2, 1.0)])
 def test_stats_stage1_matches_spec(ctx, V, S, G, scale):

@@ -119,6 +119,32 @@ __device__ __forceinline__ uint32_t binv(Xo128 &rng, uint32_t c, double f0, doub
     return k;
 }
 
+// the same search with nothing but one multiply on the loop-carried path.  A lane that is still searching after t steps has
+// k = t, so 1/k comes from a wave-uniform index and the ratio P(t+1)/P(t) does not depend on the lane's progress; a lane that
+// has stopped stays stopped (`go` is sticky), so its u and f may run on as garbage -- only k, counted while `go` holds, is
+// kept.  The wavefront tests for the end once in four steps.  Same operations in the same order on every lane that is
+// still searching, hence the same k as binv().  A step of binv() on a wavefront that runs alone on its SIMD (the compacted
+// stage-1 kernel, stage 2) is ~170 cycles of dependent latency: compare -> scalar mask -> exec -> branch -> LDS -> fma -> mul.
+__device__ __forceinline__ uint32_t binv_chain(Xo128 &rng, uint32_t c, double f0, double r, const double *__restrict__ rcp)
+{
+    double u = xo_u01(rng), f = f0;
+    const double rc1 = r * ((double)c + 1.0);
+    uint32_t k = 0, t = 0;
+    const uint32_t kend = c < DSM_BINV_KMAX ? c : DSM_BINV_KMAX;
+    bool go = true;
+    do {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            go = go && u >= f && t < kend;
+            k += go ? 1u : 0u;
+            u = u - f;
+            f = f * fma(rc1, rcp[(t + 1u) & (DSM_RCP_TAB_N - 1)], -r);
+            t = t + 1u;
+        }
+    } while (__builtin_amdgcn_ballot_w64(go) != 0ull);
+    return k;
+}
+
 __device__ __forceinline__ double stirling_tail(double k)
 {
     if (k <= 9.0) {
@@ -183,7 +209,8 @@ __device__ __forceinline__ uint32_t binom(Xo128 &rng, uint32_t n, double wa, dou
     if ((double)n * ws > cap * T) {
         if constexpr (BIG) k = btrs(rng.s0, rng.s1, rng.s2, rng.s3, n, ws / T, ltab);
         else { defer = true; return 0; }
-    } else k = binv(rng, n, dsm_pw(wl / T, n), ws / wl, rcp);
+    } else if constexpr (BIG) k = binv_chain(rng, n, dsm_pw(wl / T, n), ws / wl, rcp);   // few, lonely wavefronts: latency
+    else k = binv(rng, n, dsm_pw(wl / T, n), ws / wl, rcp);                                // stage 1: throughput (48 vs 50 us with binv_chain)
     return flip ? n - k : k;
 }
 

@@ -149,7 +149,8 @@ extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
     dsm_ctx *c = new dsm_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    {   // the single-workgroup MT19937 refill must not queue behind a full grid of the main stream
+    if (getenv("DESMAN_HIP_ONE_STREAM")) c->stream_rng = c->stream;      // several chains per GPU: one hardware queue each
+    else {   // the single-workgroup MT19937 refill must not queue behind a full grid of the main stream
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIP_TRY(hipStreamCreateWithPriority(&c->stream_rng, hipStreamNonBlocking, hi));
@@ -208,7 +209,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); dev_free(&c->ngam_raw);
     dev_free(&c->npart); dev_free(&c->nstat);
     for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ev_u_ready[i]); (void)hipEventDestroy(c->ev_u_free[i]); }
-    (void)hipStreamDestroy(c->stream_rng);
+    if (c->stream_rng != c->stream) (void)hipStreamDestroy(c->stream_rng);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return DSM_OK;

@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--depth-scale", type=float, default=1.0, help="multiply the mean read depths of the synthetic tensor")
     ap.add_argument("--chains-per-gpu", type=int, default=1,
                     help="also time K concurrent chains on the GPU (extra key; the headline stays one chain per GPU)")
+    ap.add_argument("--batch", type=int, default=1, help="extra key: K chains of this shape in one set of launches (dsm_batch_gibbs_update)")
     ap.add_argument("--no-nmft", action="store_true")
     ap.add_argument("--counts-npz", default=None,
                     help="real data instead of the synthetic tensor: an .npz with `counts` [V,S,4] (tests/golden/cog0015_counts.npz "
@@ -304,6 +305,33 @@ def main():
         multi = dict(chains=K, ms_per_step_per_chain=1e3 * dtk / args.steps, value=K * V * S * args.steps / dtk,
                      unit="V*S updates/s", speedup_vs_one_chain=(K * args.steps / dtk) / (args.steps / dt))
 
+    # K chains of this shape in ONE set of launches (dsm_batch_gibbs_update): the replicate chains of a G value
+    batch = None
+    if args.batch > 1:
+        K = args.batch
+        ctxs = []
+        for k in range(K):
+            c2 = _lib.Context(dev)
+            c2.set_counts(counts)
+            c2.seed(2000 + k)
+            c2.set_tau_rng(_lib.RNG_MT19937 if args.rng == "mt19937" else _lib.RNG_PHILOX)
+            c2.set_state(tau_init, np.ascontiguousarray(gam.T), eta0)
+            ctxs.append(c2)
+        _lib.Context.batch_gibbs_update(ctxs, max(args.warmup, 5))
+        one = ctxs[0]                                            # the same chain alone, same mu/E specification
+        one.force_stats_spec(2)
+        t0 = time.perf_counter(); one.gibbs_update(args.steps); dt1 = time.perf_counter() - t0
+        one.force_stats_spec(0)
+        t0 = time.perf_counter()
+        _lib.Context.batch_gibbs_update(ctxs, args.steps)
+        dtk = time.perf_counter() - t0
+        for c2 in ctxs:
+            c2.close()
+        batch = dict(chains=K, ms_per_step_batch=1e3 * dtk / args.steps, ms_per_step_per_chain=1e3 * dtk / args.steps / K,
+                     value=K * V * S * args.steps / dtk, unit="V*S updates/s",
+                     speedup_vs_one_chain_same_spec=(K * args.steps / dtk) / (args.steps / dt1),
+                     speedup_vs_headline_chain=(K * args.steps / dtk) / (args.steps / dt))
+
     # per-kernel HIP-event timing (on the library's stream) for the roofline object
     ctx.sweep_stats(reset=True)
     ctx.set_timing(True)
@@ -378,6 +406,8 @@ def main():
         }
         if multi:
             out["chains_per_gpu"] = multi
+        if batch:
+            out["batch"] = batch
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, G)
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]

@@ -49,6 +49,8 @@ class HaploSNP_Sampler:
         self._tau_sum = None
         self._have_trace = False
         self._keyed = False
+        self.mt_state = None            # a GSL stream of the sampler's own (update_batch: several chains in one thread);
+                                        # None = the stream of the sampletau module, as in the reference
 
     def _alloc_stores(self):
         self.gamma_store = np.zeros((self.max_iter, self.S, self.G))
@@ -62,7 +64,7 @@ class HaploSNP_Sampler:
 
     # ---- RNG plumbing: the tau uniforms continue the process-global GSL-compatible stream
     def _bind_rng(self):
-        st = _sampletau.getRNGState()          # raises if initRNG()/setRNG() were not called
+        st = self.mt_state if self.mt_state is not None else _sampletau.getRNGState()   # raises if initRNG()/setRNG() were not called
         if not self._keyed:
             # key the counter-based streams (mu/E, gamma, eta) once per sampler object
             # a function of the stream position only: deterministic whatever else runs in the process
@@ -73,7 +75,10 @@ class HaploSNP_Sampler:
         self._ctx.set_mt_state(st)
 
     def _release_rng(self):
-        _sampletau.setRNGState(self._ctx.get_mt_state())
+        if self.mt_state is not None:
+            self.mt_state = self._ctx.get_mt_state()
+        else:
+            _sampletau.setRNGState(self._ctx.get_mt_state())
 
     def _push_state(self):
         self._ctx.set_state(np.ascontiguousarray(self.tau, dtype=np.int64),
@@ -89,6 +94,25 @@ class HaploSNP_Sampler:
         self._ctx.gibbs_update(self.max_iter)
         self._release_rng()
         self._collect(prefix='nlp')
+
+    @staticmethod
+    def update_batch(samplers, on_chain=None):
+        """update() of several chains of one shape on one device at once: one kernel launch per step of the iteration for
+        all of them (dsm_batch_gibbs_update; the replicate chains of a G value, scripts/runDesman.sh:15-21).  Every sampler
+        needs a GSL stream of its own (``mt_state``).  The mu/E pass of a batch is the aggregated sampler."""
+        samplers = list(samplers)
+        n = samplers[0].max_iter
+        if any(s.max_iter != n for s in samplers) or any(s.mt_state is None for s in samplers):
+            raise ValueError("update_batch: samplers need equal max_iter and a GSL stream each (mt_state)")
+        for s in samplers:
+            s._push_state()
+            s._bind_rng()
+        _lib.Context.batch_gibbs_update([s._ctx for s in samplers], n)
+        for s in samplers:
+            if on_chain is not None:
+                on_chain(s)
+            s._release_rng()
+            s._collect(prefix='nlp')
 
     def updateTau(self):
         """tau-only sweeps driven by gamma_store / eta_store (HaploSNP_Sampler.py:383-407)."""

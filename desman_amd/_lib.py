@@ -70,6 +70,7 @@ SIGNATURES = {
     "dsm_ctx_draw_gamma_eta": (_i, [_vp, C.c_uint32, _u64p, _u64p, _f64p, _f64p]),
     "dsm_ctx_loglik": (_i, [_vp, C.POINTER(_d), C.POINTER(_d)]),
     "dsm_ctx_gibbs_update": (_i, [_vp, _i]),
+    "dsm_batch_gibbs_update": (_i, [C.POINTER(_vp), _i, _i]),
     "dsm_ctx_update_tau": (_i, [_vp, _i, _f64p, _f64p]),
     "dsm_ctx_get_trace": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "dsm_ctx_get_star": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_d), C.POINTER(_i)]),
@@ -326,6 +327,16 @@ class Context:
     def gibbs_update(self, n_iter):
         check(self.lib.dsm_ctx_gibbs_update(self._h, int(n_iter)))
         self.n_trace = int(n_iter)
+
+    @staticmethod
+    def batch_gibbs_update(ctxs, n_iter):
+        """n_iter Gibbs iterations of every chain in ``ctxs`` (contexts of one shape on one device, at most 8), one launch
+        per kernel of the iteration for all of them (include/desman_hip.h: dsm_batch_gibbs_update)."""
+        ctxs = list(ctxs)
+        arr = (_vp * len(ctxs))(*[c._h.value for c in ctxs])
+        check(load().dsm_batch_gibbs_update(arr, len(ctxs), int(n_iter)))
+        for c in ctxs:
+            c.n_trace = int(n_iter)
 
     def update_tau(self, gamma_store, eta_store):
         g = np.ascontiguousarray(gamma_store, dtype=np.float64)

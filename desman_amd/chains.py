@@ -48,7 +48,22 @@ def sweep_specs(g_values, n_reps, V, S):
     return specs
 
 
-def run_chains(specs, run_fn, dist=None, device=None, concurrency=1):
+def group_units(specs, batch):
+    """chain ids grouped into the units that are scheduled together: with batch > 1 the replicate chains of a G value, at
+    most `batch` per unit (they share every kernel launch of the Gibbs loop: dsm_batch_gibbs_update), else one chain each"""
+    if batch <= 1:
+        return [[i] for i in range(len(specs))]
+    by_g = {}
+    for i, sp in enumerate(specs):
+        by_g.setdefault(sp.get("G"), []).append(i)
+    units = []
+    for g in sorted(by_g, key=lambda x: (x is None, x)):
+        ids = by_g[g]
+        units += [ids[j:j + batch] for j in range(0, len(ids), batch)]
+    return units
+
+
+def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=None, batch=1):
     """Run `run_fn(spec) -> dict(REC_FIELDS...)` for this rank's share of `specs` and gather
     every chain's record on all ranks.  `dist` = an initialised torch.distributed module
     (or None for a single process).  `concurrency` chains of a rank run at the same time in
@@ -64,7 +79,9 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1):
     import torch
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
-    bins = lpt_assign([s["cost"] for s in specs], world)
+    units = group_units(specs, batch if batch_fn is not None else 1)
+    unit_bins = lpt_assign([sum(specs[i]["cost"] for i in u) for u in units], world)
+    bins = [[i for ui in ub for i in units[ui]] for ub in unit_bins]          # chain ids per rank, unit by unit
 
     import logging
     log = logging.getLogger("desman_amd.chains")
@@ -89,7 +106,29 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1):
                    mean_dev=np.nan, iters=0, wall_s=np.nan, failed=1.0)
         return [float(rec[k]) for k in REC_FIELDS]
 
-    if concurrency > 1 and len(bins[rank]) > 1:
+    if batch_fn is not None and batch > 1:
+        # the units of this rank one after the other, each as one batched run; a unit whose batched run raises falls back to
+        # its chains one by one (and those to the re-queue / failed-record rule below)
+        first = []
+        for ui in unit_bins[rank]:
+            ids = units[ui]
+            recs = None
+            if len(ids) > 1:
+                t0 = time.perf_counter()
+                try:
+                    recs = [dict(r) for r in batch_fn([specs[i] for i in ids])]
+                except Exception as e:                       # noqa: BLE001
+                    log.warning("batched unit %s failed on rank %d (%s: %s): its chains run one by one", ids, rank, type(e).__name__, e)
+                    recs = None
+                if recs is not None:
+                    for cid, rec in zip(ids, recs):
+                        rec.setdefault("wall_s", (time.perf_counter() - t0) / len(ids))
+                        rec["chain"] = cid
+                        rec.setdefault("failed", 0.0)
+                        first.append([float(rec[k]) for k in REC_FIELDS])
+            if recs is None:
+                first += [one(cid) for cid in ids]
+    elif concurrency > 1 and len(bins[rank]) > 1:
         from concurrent.futures import ThreadPoolExecutor
         os.environ.setdefault("DESMAN_HIP_NMFT_GRAPH", "1")      # replayed NMFT batches: see api.hip (dsm_nmft_factorize)
         with ThreadPoolExecutor(max_workers=concurrency) as pool:
@@ -133,6 +172,12 @@ class _ThreadLogRouter(__import__("logging").Handler):
         import threading
         with self._lock:
             self._files[threading.get_ident()] = open(path, "w")
+
+    def switch(self, handle):
+        """make an open file the current one of this thread (a batch of chains run by one thread)"""
+        import threading
+        with self._lock:
+            self._files[threading.get_ident()] = handle
 
     def close_current(self):
         import threading
@@ -180,6 +225,32 @@ def gibbs_chain_runner(variant_file, n_iter, device, out_stub, extra_args=()):
         _, gt, ht, lp, dev = open(os.path.join(d, "fit.txt")).read().strip().split(",")
         return dict(G=G, seed=seed, G_final=int(ht), lp_star=float(lp), mean_dev=float(dev), iters=2 * n_iter,
                     wall_s=time.perf_counter() - t0)
+
+    def run_batch(group):
+        """the same for the replicate chains of one G value, their Gibbs iterations batched (cli.main_replicates)"""
+        dirs, argvs, logs = [], [], []
+        for spec in group:
+            d = "%s_%d_%d" % (out_stub, spec["G"], spec["seed"])
+            os.makedirs(d, exist_ok=True)
+            dirs.append(d)
+            argvs.append([variant_file, "-g", str(spec["G"]), "-s", str(spec["seed"]), "-i", str(n_iter), "-o", d,
+                          "--device", str(device)] + list(extra_args))
+            logs.append(open(os.path.join(d, "log_file.txt"), "w"))
+        sampletau.use_thread_local_rng(True)
+        try:
+            cli.main_replicates(argvs, on_chain=lambda k: router.switch(logs[k]))
+        finally:
+            router.close_current()
+            for f in logs:
+                if not f.closed:
+                    f.close()
+            sampletau.use_thread_local_rng(False)
+        recs = []
+        for spec, d in zip(group, dirs):
+            _, gt, ht, lp, dev = open(os.path.join(d, "fit.txt")).read().strip().split(",")
+            recs.append(dict(G=spec["G"], seed=spec["seed"], G_final=int(ht), lp_star=float(lp), mean_dev=float(dev), iters=2 * n_iter))
+        return recs
+    run.batch = run_batch
     return run
 
 
@@ -205,6 +276,8 @@ def main(argv=None):
     ap.add_argument("-r", "--random_select", type=int, default=None)
     ap.add_argument("-o", "--output_stub", default="sweep")
     ap.add_argument("-c", "--concurrency", type=int, default=4, help="chains running at the same time per GPU")
+    ap.add_argument("-b", "--batch", type=int, default=1, help="replicate chains of a G value (up to 8) share every kernel "
+                    "launch of the Gibbs loop instead of running as separate chains (small tables: several times the throughput)")
     args = ap.parse_args(argv)
     import pandas as p
     import torch
@@ -219,8 +292,9 @@ def main(argv=None):
     V, S = frame.shape[0], (frame.shape[1] - 1) // 4
     specs = sweep_specs(range(args.gmin, args.gmax + 1), args.reps, V, S)
     extra = ["-m", str(args.min_coverage)] + (["-r", str(args.random_select)] if args.random_select else [])
-    recs = run_chains(specs, gibbs_chain_runner(args.variant_file, args.no_iter, local, args.output_stub, extra), dist,
-                      device=torch.device("cuda", local) if dist is not None else None, concurrency=args.concurrency)
+    runner = gibbs_chain_runner(args.variant_file, args.no_iter, local, args.output_stub, extra)
+    recs = run_chains(specs, runner, dist, device=torch.device("cuda", local) if dist is not None else None,
+                      concurrency=args.concurrency, batch_fn=runner.batch if args.batch > 1 else None, batch=min(args.batch, 8))
     if dist is None or dist.get_rank() == 0:
         write_dev_csv(args.output_stub + "_Dev.csv", recs)
         print(json.dumps(recs))

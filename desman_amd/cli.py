@@ -159,5 +159,68 @@ def main(argv=None):
     sampletau.freeRNG()
 
 
+def main_replicates(argv_list, on_chain=None):
+    """The `desman` runs of several replicate chains (argv lists that differ in -s / -o only) with their Gibbs iterations
+    batched: one set of kernel launches per iteration for all of them (HaploSNP_Sampler.update_batch).  Loading, the NMF
+    start, the degenerate-haplotype merge and the result files are per chain, as in main(); replicates whose haplotype
+    counts differ after the merge finish one by one.  ``on_chain(k)`` is called before chain k's own work (log routing).
+    The mu/E pass of a batch is the aggregated sampler whatever the table size, so a chain's draws are those of a
+    single run only where that run takes the aggregated pass too (same law either way)."""
+    from . import _lib
+    tell = on_chain if on_chain is not None else (lambda k: None)
+    runs = []
+    for k, argv in enumerate(argv_list):
+        tell(k)
+        opts = build_parser().parse_args(argv)
+        if opts.assign_file is not None:
+            sys.exit('desman: -a/--assign_file is not supported (dead in the reference: bin/desman:213-214)')
+        report = Output_Results(opts.output_dir)
+        table, flt, subsample = _load(opts, report)
+        logging.info('sampler seed %d', opts.random_seed)
+        rng = RandomState(opts.random_seed)
+        nmft = Init_NMFT(flt.snps_filter, opts.genomes, rng, device=opts.device)
+        logging.info('NMF-tensor initialisation')
+        nmft.factorize()
+        chain = HaploSNP_Sampler(flt.snps_filter, opts.genomes, rng, max_iter=opts.no_iter, device=opts.device, ctx=nmft._ctx)
+        chain.mt_state = _lib.mt_seed_state(opts.random_seed)       # what initRNG(); setRNG(seed) leave in the module's stream
+        chain.tau = np.copy(nmft.get_tau(), order='C')
+        chain.updateTauIndices()
+        chain.gamma = np.copy(nmft.get_gamma(), order='C')
+        chain.eta = np.copy(flt.eta, order='C')
+        runs.append(dict(opts=opts, report=report, table=table, flt=flt, subsample=subsample, chain=chain))
+    chains = [r["chain"] for r in runs]
+
+    def together(group):
+        shapes = {(c.V, c.S, c.G) for c in group}
+        if len(group) > 1 and len(shapes) == 1:
+            HaploSNP_Sampler.update_batch(group, on_chain=lambda c: tell(chains.index(c)))
+        else:
+            for c in group:
+                tell(chains.index(c))
+                c.update()
+    for k in range(len(runs)):
+        tell(k)
+        logging.info('Gibbs burn-in (batch of %d chains)' % len(runs))
+    together(chains)
+    for k, c in enumerate(chains):
+        tell(k)
+        c.removeDegenerate()
+        logging.info('Gibbs sampling')
+    by_g = {}
+    for c in chains:
+        by_g.setdefault(c.G, []).append(c)
+    for group in by_g.values():
+        together(group)
+    for k, r in enumerate(runs):
+        tell(k)
+        _report(r["report"], r["table"], r["flt"], r["chain"], r["opts"].genomes)
+        if r["subsample"] is not None:
+            sampletau.initRNG()
+            sampletau.setRNGState(r["chain"].mt_state)              # the tau-only sweeps continue the chain's GSL stream
+            _assign_rest(r["opts"], r["report"], r["table"], r["flt"], r["chain"])
+            sampletau.freeRNG()
+    return chains
+
+
 if __name__ == "__main__":
     main()

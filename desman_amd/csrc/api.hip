@@ -38,6 +38,8 @@ static const char *const k_names[DSM_K_COUNT] = {"stats_kernel", "dirichlet_kern
 extern "C" const char *dsm_kernel_name(int k) { return (k >= 0 && k < DSM_K_COUNT) ? k_names[k] : "?"; }
 
 // ---------------------------------------------------------------- timing
+thread_local BatchCtl g_batch;
+
 KTimer::KTimer(dsm_ctx *ctx, int kid, hipStream_t stream) : c(ctx), k(kid), st(stream ? stream : ctx->stream)
 {
     c->k_launches[k]++;
@@ -759,6 +761,97 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
         TRY(k_finalize(c, nb_prev, n_iter - 1, 0, P[(n_iter - 1) & 1], c->gamma_trace + (size_t)(n_iter - 1) * sg,
                        c->eta_trace + (size_t)(n_iter - 1) * 16));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
+// K chains of one shape (same device, V, S, G, tau RNG), one launch per kernel of the iteration for all of them (chain =
+// blockIdx.y): on tables that leave most of the GPU idle -- a few hundred to a few thousand positions, the usual DESMAN
+// input -- the replicate chains of a G value (scripts/runDesman.sh:15-21) then cost little more than one.  Every chain ends
+// in the state dsm_ctx_gibbs_update would leave it in under the aggregated mu/E pass (spec v2, which the batch always uses:
+// its fixed costs are what a batch amortises; G <= 16).
+extern "C" int dsm_batch_gibbs_update(dsm_ctx *const *ctxs, int K, int n_iter)
+{
+    if (!ctxs || K < 1 || K > DSM_MAX_BATCH) { dsm_set_error("batch of %d chains (1..%d)", K, DSM_MAX_BATCH); return DSM_ERR_ARG; }
+    if (n_iter < 0) { dsm_set_error("n_iter < 0"); return DSM_ERR_ARG; }
+    for (int k = 0; k < K; ++k) {
+        TRY(need(ctxs[k], true, true));
+        const dsm_ctx *a = ctxs[0], *b = ctxs[k];
+        if (b->device != a->device || b->V != a->V || b->S != a->S || b->G != a->G || b->tau_rng != a->tau_rng) {
+            dsm_set_error("batch: chain %d differs from chain 0 in device, shape or tau RNG", k);
+            return DSM_ERR_ARG;
+        }
+        for (int j = 0; j < k; ++j) if (ctxs[j] == ctxs[k]) { dsm_set_error("batch: chain %d listed twice", k); return DSM_ERR_ARG; }
+    }
+    dsm_ctx *const lead = ctxs[0];
+    BIND(lead);
+    // every chain on the leader's streams for the duration of the call; spec v2 of the mu/E pass
+    struct Saved { hipStream_t st, rng; int force; bool timing; };
+    std::vector<Saved> saved(K);
+    for (int k = 0; k < K; ++k) {
+        dsm_ctx *c = ctxs[k];
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream_rng));
+        saved[k] = Saved{c->stream, c->stream_rng, c->force_stats_spec, c->timing};
+        c->stream = lead->stream; c->stream_rng = lead->stream_rng; c->force_stats_spec = 2; c->timing = false;
+    }
+    auto restore = [&]() {
+        g_batch = BatchCtl{};
+        for (int k = 0; k < K; ++k) {
+            dsm_ctx *c = ctxs[k];
+            c->stream = saved[k].st; c->stream_rng = saved[k].rng; c->force_stats_spec = saved[k].force; c->timing = saved[k].timing;
+        }
+    };
+#define BTRY(expr) do { int _r = (expr); if (_r != DSM_OK) { (void)hipStreamSynchronize(lead->stream); (void)hipStreamSynchronize(lead->stream_rng); restore(); return _r; } } while (0)
+#define BHIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { dsm_set_error("%s failed: %s", #expr, hipGetErrorString(_e)); (void)hipStreamSynchronize(lead->stream); restore(); return DSM_ERR_HIP; } } while (0)
+    for (int k = 0; k < K; ++k)
+        if (stats_spec(ctxs[k]) != 2) { dsm_set_error("batch: the aggregated mu/E pass does not apply to this shape (G <= 16)"); restore(); return DSM_ERR_UNSUPPORTED; }
+    const size_t sg = (size_t)lead->S * lead->G;
+    std::vector<SweepWords> words;
+    words.reserve(K);
+    std::vector<int> nb_prev(K, 0);
+    for (int k = 0; k < K; ++k) {                                  // entry states, chain by chain (once per call)
+        dsm_ctx *c = ctxs[k];
+        BTRY(alloc_traces(c, n_iter));
+        BHIP(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
+        BTRY(eval_state(c, c->gamma, c->eta, c->tau_trace, 1));
+        words.emplace_back(c, n_iter);
+    }
+    g_batch.K = K;
+    for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(words[k].prefetch()); }
+    const bool fuse_s2 = lead->G < 10;
+    std::vector<uint32_t> ic(K);
+    std::vector<const uint32_t *> u(K, nullptr);
+    for (int it = 0; it < n_iter; ++it) {
+        for (int k = 0; k < K; ++k) { g_batch.k = k; ic[k] = ctxs[k]->iter_ctr++; BTRY(k_stats_stage1(ctxs[k], ic[k])); }
+        if (!fuse_s2) for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_stats_stage2(ctxs[k], ic[k])); }
+        for (int k = 0; k < K; ++k) {
+            dsm_ctx *c = ctxs[k];
+            double *const P[2] = {c->prior, c->prior + (DSM_MAX_S + 4)};
+            g_batch.k = k;
+            BTRY(k_dirichlet(c, ic[k], c->gamma, c->gamma_trace + (size_t)it * sg, c->eta_new, c->eta_trace + (size_t)it * 16,
+                             P[it & 1], it - 1, nb_prev[k], P[(it - 1) & 1], fuse_s2 ? 1 : 0));
+        }
+        for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(words[k].acquire(it, &u[k])); }
+        for (int k = 0; k < K; ++k) {
+            dsm_ctx *c = ctxs[k];
+            g_batch.k = k;
+            BTRY(k_tau_sweep(c, 3, c->gamma, c->eta, c->eta_new, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic[k], &nb_prev[k], u[k]));
+        }
+        for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(words[k].release(it)); std::swap(ctxs[k]->eta, ctxs[k]->eta_new); }
+    }
+    g_batch = BatchCtl{};
+    if (n_iter > 0)
+        for (int k = 0; k < K; ++k) {
+            dsm_ctx *c = ctxs[k];
+            double *const P[2] = {c->prior, c->prior + (DSM_MAX_S + 4)};
+            BTRY(k_finalize(c, nb_prev[k], n_iter - 1, 0, P[(n_iter - 1) & 1], c->gamma_trace + (size_t)(n_iter - 1) * sg,
+                            c->eta_trace + (size_t)(n_iter - 1) * 16));
+        }
+    BHIP(hipStreamSynchronize(lead->stream));
+    BHIP(hipStreamSynchronize(lead->stream_rng));
+#undef BTRY
+#undef BHIP
+    restore();
     return DSM_OK;
 }
 

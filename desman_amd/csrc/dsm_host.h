@@ -13,7 +13,27 @@
 #define DSM_BIG_NT 3         // ... for each kind of deferred item (BTRS / long search / search + two more binomials)
 #define DSM_U_CHUNK 8        // MT19937 words are generated in chunks of up to this many sweeps (api.hip: SweepWords)
 
+#define DSM_MAX_BATCH 8      // chains of one shape that share every launch of the Gibbs loop (api.hip: dsm_batch_gibbs_update)
+
 void dsm_set_error(const char *fmt, ...);
+
+// ---- batched launches: K chains of the same shape, one launch per kernel of the iteration with the chain in blockIdx.y.
+// A launcher called while g_batch.K > 0 stores its parameter block in slot g_batch.k and launches -- on the K-th call -- the
+// _b form of its kernel, whose argument is the array of parameter blocks (kernarg, indexed by blockIdx.y).  The chains of a
+// batch share the leader's streams for the duration of the call.
+struct BatchCtl { int K = 0, k = 0; };
+extern thread_local BatchCtl g_batch;
+template <class P> struct BatchArgs { P p[DSM_MAX_BATCH]; };
+// inside a launcher: LAUNCH_OR_COLLECT(params type, param block, normal launch statement, batched launch statement using `acc` and `K`)
+#define LAUNCH_OR_COLLECT(PT, P, NORMAL, BATCHED)                                          \
+    do {                                                                                    \
+        if (g_batch.K == 0) { NORMAL; }                                                     \
+        else {                                                                              \
+            static thread_local BatchArgs<PT> acc;                                          \
+            acc.p[g_batch.k] = (P);                                                         \
+            if (g_batch.k == g_batch.K - 1) { const int K = g_batch.K; (void)K; BATCHED; }  \
+        }                                                                                   \
+    } while (0)
 
 #define HIP_TRY(expr)                                                                       \
     do {                                                                                    \

@@ -30,8 +30,7 @@ struct Stage2Params {
     int S, G;
     uint32_t k0, k1, iter;
     uint32_t *big_count;            // work-list counter of stage 1: consumed by now, reset here for the next pass (or null)
-    S2Plan plan;
-};
+};                                  // the plan of the halving tree (a function of G) travels beside it: one per launch
 
 S2Plan make_stage2_plan(int G);     // kernels_stats.hip
 
@@ -39,7 +38,7 @@ S2Plan make_stage2_plan(int G);     // kernels_stats.hip
 
 // leaf counts end in LDS (returned pointer, [G] u32, valid after the function's final barrier); to_global also adds
 // them to p.sum_mu[s][.]
-__device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, int s, char *smem, bool to_global)
+__device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, const S2Plan &pl, int s, char *smem, bool to_global)
 {
     const int G = p.G, S = p.S, tid = threadIdx.x, nthr = blockDim.x;      // 256 (fused form) or 1024 (many subsets)
     double2 *ltab = reinterpret_cast<double2 *>(smem);                         // [256]
@@ -55,13 +54,12 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
     for (int k = tid; k < DSM_RCP_TAB_N; k += nthr) rcp[k] = k ? 1.0 / (double)k : 0.0;
     if (tid < 32) {
         gs[tid] = (tid < G) ? p.gamma[(size_t)s * G + tid] : 0.0; leaf[tid] = 0u;
-        n_lo[tid] = p.plan.lo[tid]; n_hi[tid] = p.plan.hi[tid]; n_off[tid] = p.plan.off[tid]; n_idx[tid] = p.plan.idx[tid];
-        n_child[tid] = p.plan.child[tid];
+        n_lo[tid] = pl.lo[tid]; n_hi[tid] = pl.hi[tid]; n_off[tid] = pl.off[tid]; n_idx[tid] = pl.idx[tid];
+        n_child[tid] = pl.child[tid];
     }
     for (int i = tid; i < S2_TAB_ENTRIES; i += nthr) tab[i] = 0u;
     __syncthreads();
 
-    const S2Plan &pl = p.plan;
     for (int level = 0; level < pl.nlevels; ++level) {
         // all (node, subset) pairs of the level at once: the tables of a level are contiguous in `tab`, so entry j of
         // the level belongs to the node whose table covers it (root: the 2^G words of this sample in HBM)

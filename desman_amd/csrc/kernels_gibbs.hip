@@ -187,7 +187,7 @@ __device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b)
     return (y >> 1) ^ ((b & 1u) ? 0x9908b0dfu : 0u);
 }
 
-__global__ __launch_bounds__(1024) void mt_fill_wide_kernel(uint32_t *__restrict__ state, uint32_t *__restrict__ out, size_t n)
+__device__ __forceinline__ void mt_fill_wide_body(uint32_t *__restrict__ state, uint32_t *__restrict__ out, size_t n)
 {
     __shared__ uint32_t ring[4096];                 // raw word with absolute index a (block start = 0) at ring[a & 4095]
     __builtin_amdgcn_s_setprio(3);                  // a latency chain on one CU: do not queue behind the co-resident sweep / mu-E waves
@@ -233,6 +233,18 @@ __global__ __launch_bounds__(1024) void mt_fill_wide_kernel(uint32_t *__restrict
     const size_t B = R - 624;
     for (int i = tid; i < 624; i += 1024) state[i] = ring[(B + (size_t)i) & 4095];
     if (tid == 0) state[624] = (uint32_t)(E - B);
+}
+
+struct MtArgs { uint32_t *state, *out; size_t n; };
+__global__ __launch_bounds__(1024) void mt_fill_wide_kernel(uint32_t *__restrict__ state, uint32_t *__restrict__ out, size_t n)
+{
+    mt_fill_wide_body(state, out, n);
+}
+// the generators of K chains, one workgroup each (blockIdx.x = chain)
+__global__ __launch_bounds__(1024) void mt_fill_wide_kernel_b(BatchArgs<MtArgs> b)
+{
+    const MtArgs &a = b.p[blockIdx.x];
+    mt_fill_wide_body(a.state, a.out, a.n);
 }
 
 // =====================================================================
@@ -501,17 +513,31 @@ __device__ double gamma_variate(double shape, uint32_t idx, uint32_t iter, uint3
 // fixed order).  Rows are independent, so the launch fills S+4 CUs instead of one.
 // do_s2: the gamma rows first run stage 2 of the aggregated mu/E pass for their sample (dsm_stage2.h, all 256 threads): the
 // sums the draw needs never leave the workgroup's LDS and the iteration has one launch less.
-__global__ __launch_bounds__(256) void dirichlet_kernel(unsigned long long *__restrict__ sum_mu,
-                                                       unsigned long long *__restrict__ esum, int S, int G,
-                                                       double alpha, double delta, double epsilon,
-                                                       double lgc_gamma, double lgc_eta, uint32_t k0,
-                                                       uint32_t k1, uint32_t iter, int zero_after,
-                                                       double *__restrict__ gamma_out,
-                                                       double *__restrict__ gamma_trace,
-                                                       double *__restrict__ eta_out, double *__restrict__ eta_trace,
-                                                       double *__restrict__ rowprior, int do_fin, FinalParams fin,
-                                                       int do_s2, Stage2Params s2)
+struct DirParams {
+    unsigned long long *sum_mu, *esum;
+    int S, G;
+    double alpha, delta, epsilon, lgc_gamma, lgc_eta;
+    uint32_t k0, k1, iter;
+    int zero_after;
+    double *gamma_out, *gamma_trace, *eta_out, *eta_trace, *rowprior;
+    int do_fin;
+    FinalParams fin;
+    int do_s2;
+    Stage2Params s2;
+};
+
+__device__ __forceinline__ void dirichlet_body(const DirParams &q, const S2Plan &plan)
 {
+    unsigned long long *__restrict__ sum_mu = q.sum_mu, *__restrict__ esum = q.esum;
+    const int S = q.S, G = q.G;
+    const double alpha = q.alpha, delta = q.delta, epsilon = q.epsilon, lgc_gamma = q.lgc_gamma, lgc_eta = q.lgc_eta;
+    const uint32_t k0 = q.k0, k1 = q.k1, iter = q.iter;
+    const int zero_after = q.zero_after;
+    double *__restrict__ gamma_out = q.gamma_out, *__restrict__ gamma_trace = q.gamma_trace;
+    double *__restrict__ eta_out = q.eta_out, *__restrict__ eta_trace = q.eta_trace, *__restrict__ rowprior = q.rowprior;
+    const int do_fin = q.do_fin, do_s2 = q.do_s2;
+    const FinalParams &fin = q.fin;
+    const Stage2Params &s2 = q.s2;
     __shared__ __attribute__((aligned(16))) char smem_d[S2_SMEM_BYTES];   // stage 2 / finalize scratch (never both)
     if (do_fin && (int)blockIdx.x == S + 4) {            // extra workgroup: finalize the PREVIOUS iteration
         double *red = reinterpret_cast<double *>(smem_d), *redp = red + 256;
@@ -522,7 +548,7 @@ __global__ __launch_bounds__(256) void dirichlet_kernel(unsigned long long *__re
     const int row = blockIdx.x;
     const bool is_gamma = row < S;
     const uint32_t *leaf = nullptr;
-    if (do_s2 && is_gamma) leaf = stage2_sample(s2, row, smem_d, false);      // workgroup-uniform branch; ends with a barrier
+    if (do_s2 && is_gamma) leaf = stage2_sample(s2, plan, row, smem_d, false);      // workgroup-uniform branch; ends with a barrier
     if (threadIdx.x >= 64) return;                       // the draw needs one wavefront (no workgroup barriers below)
     const int lane = threadIdx.x;
     const int n = is_gamma ? G : 4;
@@ -550,6 +576,11 @@ __global__ __launch_bounds__(256) void dirichlet_kernel(unsigned long long *__re
         else { eta_out[(row - S) * 4 + lane] = x; if (eta_trace) eta_trace[(row - S) * 4 + lane] = x; }
     }
 }
+
+struct DirBatch { DirParams p[DSM_MAX_BATCH]; S2Plan plan; };        // chains of a batch have one G, hence one plan
+__global__ __launch_bounds__(256) void dirichlet_kernel(DirParams q, S2Plan plan) { dirichlet_body(q, plan); }
+__global__ __launch_bounds__(256) void dirichlet_kernel_b(DirBatch b) { dirichlet_body(b.p[blockIdx.y], b.plan); }
+static_assert(sizeof(DirBatch) <= 4096, "kernarg segment");
 
 // Dirichlet log-priors of a given (gamma, eta) -- entry state of update()
 __global__ __launch_bounds__(256) void prior_kernel(const double *__restrict__ gamma, const double *__restrict__ eta,
@@ -600,7 +631,7 @@ struct TauParams {
 };
 
 template <int LPV, int NSL, bool SWEEP, bool LL>
-__global__ __launch_bounds__(256) void tau_kernel(TauParams p)
+__device__ __forceinline__ void tau_body(const TauParams &p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_t[];
     const int nblk = (int)gridDim.x - p.do_fin;
@@ -812,6 +843,13 @@ __global__ __launch_bounds__(256) void tau_kernel(TauParams p)
     }
 }
 
+template <int LPV, int NSL, bool SWEEP, bool LL>
+__global__ __launch_bounds__(256) void tau_kernel(TauParams p) { tau_body<LPV, NSL, SWEEP, LL>(p); }
+// K chains of one shape, chain = blockIdx.y (dsm_host.h: BatchCtl)
+template <int LPV, int NSL, bool SWEEP, bool LL>
+__global__ __launch_bounds__(256) void tau_kernel_b(BatchArgs<TauParams> b) { tau_body<LPV, NSL, SWEEP, LL>(b.p[blockIdx.y]); }
+static_assert(sizeof(BatchArgs<TauParams>) <= 4096, "kernarg segment");
+
 // test hook: the hardware log2 the screening pass relies on (its error bound is pinned by tests/test_gpu_edges.py)
 __global__ __launch_bounds__(256) void log2f_test_kernel(const float *__restrict__ in, float *__restrict__ out, size_t n)
 {
@@ -877,7 +915,13 @@ int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n, hipStream_t stream)
             HIP_TRY(hipFuncSetAttribute((const void *)mt_fill_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, hog * 1024));
             c->mt_attr_set = true;
         }
-        hipLaunchKernelGGL(mt_fill_wide_kernel, dim3(1), dim3(1024), (size_t)hog * 1024, stream, c->mt_state, out, n);
+        if (g_batch.K) {
+            static thread_local BatchArgs<MtArgs> acc;
+            acc.p[g_batch.k] = MtArgs{c->mt_state, out, n};
+            if (g_batch.k == g_batch.K - 1)          // no CU reservation here: small tables, K generators
+                hipLaunchKernelGGL(mt_fill_wide_kernel_b, dim3(g_batch.K), dim3(1024), 0, stream, acc);
+        } else
+            hipLaunchKernelGGL(mt_fill_wide_kernel, dim3(1), dim3(1024), (size_t)hog * 1024, stream, c->mt_state, out, n);
     }
     HIP_TRY(hipGetLastError());
     return DSM_OK;
@@ -992,11 +1036,24 @@ int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trac
         s2.ntab = c->ntab; s2.gamma = c->gamma; s2.sum_mu = c->sum_mu; s2.log_tab = c->log_tab;
         s2.S = c->S; s2.G = c->G; s2.k0 = k0; s2.k1 = k1; s2.iter = iter;
         s2.big_count = c->big_count;
-        s2.plan = make_stage2_plan(c->G);
     }
-    hipLaunchKernelGGL(dirichlet_kernel, dim3(c->S + 4 + do_fin), dim3(256), 0, c->stream, c->sum_mu, c->esum, c->S, c->G,
-                       c->alpha, c->delta, c->epsilon, lg, le, k0, k1, iter, 1, gamma_out, gamma_trace, eta_out, eta_trace,
-                       prior_out, do_fin, fin, do_s2, s2);
+    DirParams q;
+    q.sum_mu = c->sum_mu; q.esum = c->esum; q.S = c->S; q.G = c->G;
+    q.alpha = c->alpha; q.delta = c->delta; q.epsilon = c->epsilon; q.lgc_gamma = lg; q.lgc_eta = le;
+    q.k0 = k0; q.k1 = k1; q.iter = iter; q.zero_after = 1;
+    q.gamma_out = gamma_out; q.gamma_trace = gamma_trace; q.eta_out = eta_out; q.eta_trace = eta_trace; q.rowprior = prior_out;
+    q.do_fin = do_fin; q.fin = fin; q.do_s2 = do_s2; q.s2 = s2;
+    if (g_batch.K == 0) {
+        const S2Plan plan = do_s2 ? make_stage2_plan(c->G) : S2Plan{};
+        hipLaunchKernelGGL(dirichlet_kernel, dim3(c->S + 4 + do_fin), dim3(256), 0, c->stream, q, plan);
+    } else {
+        static thread_local DirBatch acc;
+        acc.p[g_batch.k] = q;
+        if (g_batch.k == g_batch.K - 1) {
+            acc.plan = do_s2 ? make_stage2_plan(c->G) : S2Plan{};
+            hipLaunchKernelGGL(dirichlet_kernel_b, dim3(c->S + 4 + do_fin, g_batch.K), dim3(256), 0, c->stream, acc);
+        }
+    }
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }
@@ -1049,6 +1106,13 @@ template <int LPV, int NSL>
 static void launch_tau(dsm_ctx *c, int mode, const TauParams &p, int grid, size_t sh)
 {
     const int g2 = grid + p.do_fin;
+    if (g_batch.K) {                                     // the Gibbs loop's sweep (mode 3) of K chains in one launch
+        static thread_local BatchArgs<TauParams> acc;
+        acc.p[g_batch.k] = p;
+        if (g_batch.k == g_batch.K - 1)
+            hipLaunchKernelGGL((tau_kernel_b<LPV, NSL, true, true>), dim3(g2, g_batch.K), dim3(256), sh, c->stream, acc);
+        return;
+    }
     if (mode == 3) hipLaunchKernelGGL((tau_kernel<LPV, NSL, true, true>), dim3(g2), dim3(256), sh, c->stream, p);
     else if (mode == 1) hipLaunchKernelGGL((tau_kernel<LPV, NSL, true, false>), dim3(g2), dim3(256), sh, c->stream, p);
     else hipLaunchKernelGGL((tau_kernel<LPV, NSL, false, true>), dim3(g2), dim3(256), sh, c->stream, p);

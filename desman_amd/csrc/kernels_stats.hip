@@ -53,7 +53,7 @@ __device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t x)
 // LPV = lanes per variant: a wavefront works on 64 / LPV (variant, LPV-sample chunk) tasks at a time, so that tables of 16,
 // 32, 48 or 96 samples fill its lanes (lane = sample alone leaves 3/4 of a wavefront idle at S = 16 and 1/4 at S = 96).
 template <int LPV>
-__global__ __launch_bounds__(256) void stats_agg_kernel(StatsAggParams p)
+__device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_s[];
     constexpr int NG = 64 / LPV;
@@ -176,12 +176,17 @@ __global__ __launch_bounds__(256) void stats_agg_kernel(StatsAggParams p)
     if (tid < 16 && acc[tid]) atomicAdd(&p.esum[tid], acc[tid]);
 }
 
+template <int LPV>
+__global__ __launch_bounds__(256) void stats_agg_kernel(StatsAggParams p) { stats_agg_body<LPV>(p); }
+template <int LPV>
+__global__ __launch_bounds__(256) void stats_agg_kernel_b(BatchArgs<StatsAggParams> b) { stats_agg_body<LPV>(b.p[blockIdx.y]); }
+
 // ---------------------------------------------------------------------------------------------------
 // the deferred items (rarer outcome with a mean above 64: burn-in states, very deep data), one lane per item:
 // the same arithmetic as stats_agg_kernel with the full sampler (BTRS).  tau_v differs from lane to lane here,
 // so the haplotype sets / abundances are built with vector selects.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stats_big_kernel(StatsAggParams p)
+__device__ __forceinline__ void stats_big_body(const StatsAggParams &p)
 {
     __shared__ double2 ltab[DSM_LOG_TAB_N];
     __shared__ double rcp[DSM_RCP_TAB_N];
@@ -247,12 +252,21 @@ __global__ __launch_bounds__(256) void stats_big_kernel(StatsAggParams p)
     if (tid < 16 && acc[tid]) atomicAdd(&p.esum[tid], acc[tid]);
 }
 
+__global__ __launch_bounds__(256) void stats_big_kernel(StatsAggParams p) { stats_big_body(p); }
+__global__ __launch_bounds__(256) void stats_big_kernel_b(BatchArgs<StatsAggParams> b) { stats_big_body(b.p[blockIdx.y]); }
+
 #include "dsm_stage2.h"
 
-__global__ __launch_bounds__(1024) void stats_stage2_kernel(Stage2Params p)
+struct Stage2Batch { Stage2Params p[DSM_MAX_BATCH]; S2Plan plan; };
+__global__ __launch_bounds__(1024) void stats_stage2_kernel(Stage2Params p, S2Plan plan)
 {
     __shared__ __attribute__((aligned(16))) char smem2[S2_SMEM_BYTES];
-    stage2_sample(p, blockIdx.x, smem2, true);
+    stage2_sample(p, plan, blockIdx.x, smem2, true);
+}
+__global__ __launch_bounds__(1024) void stats_stage2_kernel_b(Stage2Batch b)
+{
+    __shared__ __attribute__((aligned(16))) char smem2[S2_SMEM_BYTES];
+    stage2_sample(b.p[blockIdx.y], b.plan, blockIdx.x, smem2, true);
 }
 
 // test hook: variate i of a sampler from the stream Philox({i, 0, 0, 'TEST'})  (oracle: orc_binom_test / orc_mult4_test)
@@ -303,11 +317,16 @@ static int stats_agg_lpv(int S)
 
 int stats_spec(const dsm_ctx *c)
 {
-    if (c->force_stats_spec == 1) return 1;
+    int force = c->force_stats_spec;
+    if (force == 0) {                       // DESMAN_HIP_STATS_SPEC=1|2: the choice for every context that has none of its own
+        const char *e = getenv("DESMAN_HIP_STATS_SPEC");   // (2 = the draws of a batched run, also for chains run one by one)
+        if (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) force = e[0] - '0';
+    }
+    if (force == 1) return 1;
     if (c->G < 1 || c->G > 16) return 1;
     if (((size_t)1 << c->G) * (size_t)c->S * 4 > ((size_t)64 << 20)) return 1;
     if (c->max_depth >= ((uint64_t)1 << 32)) return 1;
-    if (c->force_stats_spec == 2) return 2;
+    if (force == 2) return 2;
     double reads = 0.0;
     for (int64_t d : c->depth) reads += (double)d;
     const int lpv = stats_agg_lpv(c->S);
@@ -370,7 +389,7 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     // with six wavefronts of one or two passes each keeps its VALU busier than five with exactly two (48 vs 52 us at config 3,
     // 143 vs 152 at V = 20k); a seventh workgroup per CU or a second partial round costs more than it brings (7168 wavefronts
     // 53 us, 8192 57 us)
-    const long max_waves = (long)c->stats_grid * 4;
+    const long max_waves = (long)c->stats_grid * 4 / (g_batch.K ? g_batch.K : 1);   // the chains of a batch share the persistent grid
     const long waves = std::min<long>(ntask, max_waves);
     const int grid = (int)std::max<long>(1, (waves + 3) / 4);
     // a sub-list holds what its workgroups can defer at most: passes per wavefront x 4 wavefronts x 64 lanes x 4 bases each
@@ -393,6 +412,21 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
         p.lean_cap = e ? atof(e) : DSM_LEAN_CAP;
         if (!(p.lean_cap > 0.0 && p.lean_cap <= DSM_BINV_MEAN_CAP)) p.lean_cap = DSM_LEAN_CAP;
     }
+    const int big_grid = DSM_BIG_NT * DSM_BIG_NL * (int)std::max<long>(1, std::min<long>((ntask * 64 * 4 / DSM_BIG_NL + 255) / 256, 16));
+    if (g_batch.K) {
+        // two launches of the chain's pass, each collected on its own: stage 1, then the deferred items
+        static thread_local BatchArgs<StatsAggParams> acc;
+        acc.p[g_batch.k] = p;
+        if (g_batch.k == g_batch.K - 1) {
+            const dim3 g(grid, g_batch.K);
+            if (LPV == 16) hipLaunchKernelGGL(stats_agg_kernel_b<16>, g, dim3(256), sh, c->stream, acc);
+            else if (LPV == 32) hipLaunchKernelGGL(stats_agg_kernel_b<32>, g, dim3(256), sh, c->stream, acc);
+            else hipLaunchKernelGGL(stats_agg_kernel_b<64>, g, dim3(256), sh, c->stream, acc);
+            hipLaunchKernelGGL(stats_big_kernel_b, dim3(big_grid, g_batch.K), dim3(256), 0, c->stream, acc);
+        }
+        HIP_TRY(hipGetLastError());
+        return DSM_OK;
+    }
     {
         KTimer tm(c, DSM_K_STATS);
         if (LPV == 16) hipLaunchKernelGGL(stats_agg_kernel<16>, dim3(grid), dim3(256), sh, c->stream, p);
@@ -400,10 +434,9 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
         else hipLaunchKernelGGL(stats_agg_kernel<64>, dim3(grid), dim3(256), sh, c->stream, p);
     }
     KTimer tm(c, DSM_K_STATSBIG);
-    // the deferred items (none once the chain has converged on data of ordinary depth: the launch then returns at once)
+    // the deferred items (none once the chain has converged on data of ordinary depth: the launch then returns at once);
     // up to 16 workgroups per list = 4096 items of a list per round (a list one item longer than a round doubles the launch:
     // every wavefront is one long dependent chain); the workgroups of an empty list leave at once
-    const int big_grid = DSM_BIG_NT * DSM_BIG_NL * (int)std::max<long>(1, std::min<long>((ntask * 64 * 4 / DSM_BIG_NL + 255) / 256, 16));
     hipLaunchKernelGGL(stats_big_kernel, dim3(big_grid), dim3(256), 0, c->stream, p);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
@@ -443,10 +476,18 @@ int k_stats_stage2(dsm_ctx *c, uint32_t iter)
     p.ntab = c->ntab; p.gamma = c->gamma; p.sum_mu = c->sum_mu; p.log_tab = c->log_tab;
     p.S = c->S; p.G = c->G;
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
-    p.plan = make_stage2_plan(c->G);
     p.big_count = c->big_count;
     // 2^G subsets per sample at the root: 256 threads up to G = 9, 1024 above
-    hipLaunchKernelGGL(stats_stage2_kernel, dim3(c->S), dim3(c->G >= 10 ? 1024 : 256), 0, c->stream, p);
+    const int nthr = c->G >= 10 ? 1024 : 256;
+    if (g_batch.K == 0) hipLaunchKernelGGL(stats_stage2_kernel, dim3(c->S), dim3(nthr), 0, c->stream, p, make_stage2_plan(c->G));
+    else {
+        static thread_local Stage2Batch acc;
+        acc.p[g_batch.k] = p;
+        if (g_batch.k == g_batch.K - 1) {
+            acc.plan = make_stage2_plan(c->G);
+            hipLaunchKernelGGL(stats_stage2_kernel_b, dim3(c->S, g_batch.K), dim3(nthr), 0, c->stream, acc);
+        }
+    }
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }

@@ -144,6 +144,12 @@ int dsm_ctx_loglik(dsm_ctx *ctx, double *ll, double *lp);
 /* A6: HaploSNP_Sampler.update (HaploSNP_Sampler.py:334-365): n_iter full Gibbs
  * iterations with MAP tracking and traces, all on the device.                */
 int dsm_ctx_gibbs_update(dsm_ctx *ctx, int n_iter);
+/* The same for n_ctx (1..8) chains of one shape -- same device, V, S, G, tau RNG; typically the replicate chains of one
+ * G value (scripts/runDesman.sh:15-21) -- with one kernel launch per step of the iteration for all of them.  On tables
+ * that leave most of the GPU idle the batch costs little more than one chain.  The mu/E pass of a batch is always the
+ * aggregated sampler (dsm_ctx_stats_spec 2; needs G <= 16): every chain ends in the state dsm_ctx_gibbs_update leaves
+ * it in after dsm_ctx_force_stats_spec(ctx, 2).                                                                        */
+int dsm_batch_gibbs_update(dsm_ctx *const *ctxs, int n_ctx, int n_iter);
 /* HaploSNP_Sampler.updateTau (HaploSNP_Sampler.py:383-407): tau-only sweeps
  * driven by host traces gamma_store [n][S][G], eta_store [n][4][4].          */
 int dsm_ctx_update_tau(dsm_ctx *ctx, int n_iter, const double *gamma_store,

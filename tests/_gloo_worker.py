@@ -38,6 +38,21 @@ if __name__ == "__main__":
             json.dump(dict(recs=recs, calls={"%d_%d" % k: v for k, v in _calls.items()}), f)
         dist.destroy_process_group()
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "batch":
+        # replicate chains scheduled and run as units of up to 2; the unit of G = 4 fails as a batch and falls back to its
+        # chains one by one
+        units_run = []
+
+        def fake_batch(group):
+            units_run.append([(sp["G"], sp["seed"]) for sp in group])
+            if group[0]["G"] == 4:
+                raise RuntimeError("injected batch failure")
+            return [fake_run(sp) for sp in group]
+        recs = chains.run_chains(specs, fake_run, dist, batch_fn=fake_batch, batch=2)
+        with open(os.path.join(sys.argv[1], "batch%d.json" % dist.get_rank()), "w") as f:
+            json.dump(dict(recs=recs, units=units_run), f)
+        dist.destroy_process_group()
+        sys.exit(0)
     recs = chains.run_chains(specs, fake_run, dist)
     bins = chains.lpt_assign([s["cost"] for s in specs], dist.get_world_size())
     out = dict(rank=dist.get_rank(), recs=recs, mine=bins[dist.get_rank()])

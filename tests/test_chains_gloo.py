@@ -76,6 +76,27 @@ def test_two_rank_gloo_failed_chain_is_requeued_and_never_strands_the_gather(tmp
     assert len(open(d).read().strip().split("\n")) == 15              # header + 14 chains: the failed one is skipped
 
 
+def test_group_units_and_two_rank_gloo_batched_units(tmp_path):
+    """--batch: replicate chains of a G value are scheduled (LPT over units) and run together; a unit whose batched run
+    fails falls back to its chains one by one; the gather is what the unbatched run gives"""
+    specs = chains.sweep_specs(range(2, 7), 3, V=1000, S=16)
+    assert chains.group_units(specs, 1) == [[i] for i in range(15)]
+    assert chains.group_units(specs, 2) == [[0, 1], [2], [3, 4], [5], [6, 7], [8], [9, 10], [11], [12, 13], [14]]
+    assert chains.group_units(specs, 8) == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11], [12, 13, 14]]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29667", os.path.join(HERE, "_gloo_worker.py"), str(tmp_path), "batch"]
+    subprocess.run(cmd, check=True, env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r0 = json.load(open(tmp_path / "batch0.json"))
+    r1 = json.load(open(tmp_path / "batch1.json"))
+    assert r0["recs"] == r1["recs"] and [int(r["chain"]) for r in r0["recs"]] == list(range(15))
+    for r, s in zip(r0["recs"], specs):
+        assert (r["G"], r["seed"], r["failed"]) == (s["G"], s["seed"], 0.0) and r["lp_star"] == -1000.0 * s["G"] - s["seed"]
+    units = sorted(tuple(map(tuple, u)) for u in r0["units"] + r1["units"])
+    assert units == sorted([((g, 0), (g, 1)) for g in range(2, 7)])       # pairs batched, the third replicate runs alone
+    assert not {tuple(map(tuple, u)) for u in r0["units"]} & {tuple(map(tuple, u)) for u in r1["units"]}
+
+
 def test_single_process_failure_handling():
     n = {"k": 0}
 

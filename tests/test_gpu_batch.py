@@ -1,0 +1,81 @@
+"""Batched Gibbs loop (include/desman_hip.h: dsm_batch_gibbs_update): K chains of one shape share every launch of the
+iteration.  Each chain of the batch must end exactly where dsm_ctx_gibbs_update leaves it (aggregated mu/E pass)."""
+import numpy as np
+import pytest
+
+from desman_amd import _lib
+from desman_amd.synth import synth_counts, random_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _chain(counts, state, seed, ctr_seed):
+    c = _lib.Context(0)
+    c.set_counts(counts)
+    c.set_state(*state)
+    c.set_tau_rng(_lib.RNG_MT19937)
+    c.seed(seed, ctr_seed=ctr_seed)
+    return c
+
+
+def _snapshot(c):
+    tr = c.get_trace()
+    star = c.get_star()
+    out = dict(state=c.get_state(), mt=c.get_mt_state(), lp_star=star["lp"])
+    out.update({k: tr[k] for k in ("ll", "lp", "nchange", "gamma", "eta")})
+    out["tau_last"] = c.get_tau_at(len(tr["ll"]) - 1)
+    return out
+
+
+def _same(a, b):
+    for k in a:
+        if k == "state":
+            assert all(np.array_equal(x, y) for x, y in zip(a[k], b[k])), k
+        elif k == "lp_star":
+            assert a[k] == b[k]
+        else:
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+
+
+# shapes: fused stage 2 (G < 10) with lane groups of 16 / 32 / 64, the stand-alone stage-2 launch (G >= 10), several
+# MT19937 chunks (n_iter > 1 + 2 + 3), a second call on the same contexts (stream positions, buffers kept)
+@pytest.mark.parametrize("V,S,G,K,n_iter", [(300, 16, 5, 3, 12), (200, 64, 8, 5, 9), (150, 40, 3, 8, 7), (90, 20, 11, 2, 5), (64, 100, 4, 4, 6)])
+def test_batch_equals_chains_run_one_by_one(V, S, G, K, n_iter):
+    counts, _, _ = synth_counts(V, S, G, seed=500 + V)
+    states = [random_state(V, S, G, seed=600 + k) for k in range(K)]
+    single, batch = [], []
+    for k in range(K):
+        a = _chain(counts, states[k], 1000 + k, 0xB47C4000 + k)
+        a.force_stats_spec(2)
+        a.gibbs_update(n_iter)
+        first = _snapshot(a)
+        a.gibbs_update(3)
+        single.append((first, _snapshot(a)))
+        a.close()
+    ctxs = [_chain(counts, states[k], 1000 + k, 0xB47C4000 + k) for k in range(K)]
+    _lib.Context.batch_gibbs_update(ctxs, n_iter)
+    for k in range(K):
+        _same(single[k][0], _snapshot(ctxs[k]))
+    _lib.Context.batch_gibbs_update(ctxs, 3)
+    for k in range(K):
+        _same(single[k][1], _snapshot(ctxs[k]))
+    # a context of the batch goes on alone afterwards, on its own streams
+    ctxs[0].force_stats_spec(2)
+    ctxs[0].gibbs_update(2)
+    assert np.isfinite(ctxs[0].get_trace()["lp"]).all()
+    for c in ctxs:
+        c.close()
+
+
+def test_batch_argument_checks():
+    counts, _, _ = synth_counts(50, 8, 3, seed=1)
+    a = _chain(counts, random_state(50, 8, 3, seed=2), 1, 2)
+    b = _chain(counts[:40], random_state(40, 8, 3, seed=3), 1, 2)
+    with pytest.raises(_lib.DesmanHipError):
+        _lib.Context.batch_gibbs_update([a, b], 2)             # shapes differ
+    with pytest.raises(_lib.DesmanHipError):
+        _lib.Context.batch_gibbs_update([a, a], 2)             # the same chain twice
+    with pytest.raises(_lib.DesmanHipError):
+        _lib.Context.batch_gibbs_update([a] * 9, 2)            # more than 8
+    _lib.Context.batch_gibbs_update([a], 2)                    # a batch of one is allowed
+    a.close(); b.close()

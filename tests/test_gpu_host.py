@@ -223,3 +223,25 @@ def test_config1_real_data_replays_the_recorded_reference_run():
     assert dg.max() < 0.06 and dg.mean() < 0.01
     np.testing.assert_allclose(smp.eta_star, z["eta_star"], atol=0.01)
     sampletau.freeRNG()
+
+
+def test_gsweep_with_batched_replicates_equals_chains_run_one_by_one(tmp_path, monkeypatch):
+    """desman-sweep -b K: the replicate chains of a G value share every launch of the Gibbs loop (dsm_batch_gibbs_update,
+    cli.main_replicates).  File for file what the chains give one by one under the same mu/E specification (a batch always
+    takes the aggregated pass; DESMAN_HIP_STATS_SPEC=2 makes single chains take it on this small table too)."""
+    from desman_amd import chains
+    V, S, G = 160, 12, 3
+    counts, _, _ = synth_counts(V, S, G, seed=99)
+    freq = str(tmp_path / "syn.freq")
+    _write_freq(freq, counts)
+    monkeypatch.setenv("DESMAN_HIP_STATS_SPEC", "2")
+    one, bat = str(tmp_path / "one"), str(tmp_path / "bat")
+    chains.main([freq, "--gmin", "2", "--gmax", "4", "--reps", "3", "-i", "30", "-r", "100", "-o", one, "-c", "1"])
+    chains.main([freq, "--gmin", "2", "--gmax", "4", "--reps", "3", "-i", "30", "-r", "100", "-o", bat, "-b", "3"])
+    assert open(one + "_Dev.csv").read() == open(bat + "_Dev.csv").read()
+    for g in range(2, 5):
+        for r in range(3):
+            for f in ("fit.txt", "fitP.txt", "Filtered_Tau_star.csv", "Gamma_mean.csv", "Eta_star.csv", "Collated_Tau_star.csv"):
+                assert open("%s_%d_%d/%s" % (one, g, r, f)).read() == open("%s_%d_%d/%s" % (bat, g, r, f)).read(), (g, r, f)
+            log = open("%s_%d_%d/log_file.txt" % (bat, g, r)).read()
+            assert "Gibbs Iter" in log and "sampler seed %d" % r in log

@@ -412,7 +412,9 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
         p.lean_cap = e ? atof(e) : DSM_LEAN_CAP;
         if (!(p.lean_cap > 0.0 && p.lean_cap <= DSM_BINV_MEAN_CAP)) p.lean_cap = DSM_LEAN_CAP;
     }
-    const int big_grid = DSM_BIG_NT * DSM_BIG_NL * (int)std::max<long>(1, std::min<long>((ntask * 64 * 4 / DSM_BIG_NL + 255) / 256, 16));
+    // (a batch: fewer workgroups per list, the launch holds K times as many lists)
+    const int big_grid = DSM_BIG_NT * DSM_BIG_NL *
+        (int)std::max<long>(1, std::min<long>((ntask * 64 * 4 / DSM_BIG_NL + 255) / 256, g_batch.K ? std::max(2, 16 / g_batch.K) : 16));
     if (g_batch.K) {
         // two launches of the chain's pass, each collected on its own: stage 1, then the deferred items
         static thread_local BatchArgs<StatsAggParams> acc;

@@ -104,6 +104,22 @@ class Init_NMFT:
             self.div_trace = tr
             self._log_trace(tr)
 
+    @staticmethod
+    def factorize_batch(objs):
+        """factorize() of several objects of one shape at once (replicate chains): shared launches on the device, the
+        stop test per chain (dsm_batch_nmft_factorize).  Same factors as factorize() on each."""
+        objs = list(objs)
+        if any(o.n_run != 1 for o in objs) or len({(o.max_iter, o.min_change) for o in objs}) != 1:
+            raise ValueError("factorize_batch: n_run = 1 and equal max_iter / min_change expected")
+        for o in objs:
+            o.random_initialize()
+            o._push()
+        res = _lib.Context.batch_nmft_factorize([o._ctx for o in objs], objs[0].max_iter, objs[0].min_change, fix_gamma=False)
+        for o, (n, tr) in zip(objs, res):
+            o._pull()
+            o.div_trace = tr
+        return res
+
     def factorize_tau(self):
         for _ in range(self.n_run):
             self.random_initialize_tau()

@@ -71,6 +71,7 @@ SIGNATURES = {
     "dsm_ctx_loglik": (_i, [_vp, C.POINTER(_d), C.POINTER(_d)]),
     "dsm_ctx_gibbs_update": (_i, [_vp, _i]),
     "dsm_batch_gibbs_update": (_i, [C.POINTER(_vp), _i, _i]),
+    "dsm_batch_nmft_factorize": (_i, [C.POINTER(_vp), _i, _i, _d, _i, C.POINTER(_i), _vp]),
     "dsm_ctx_update_tau": (_i, [_vp, _i, _f64p, _f64p]),
     "dsm_ctx_get_trace": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "dsm_ctx_get_star": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_d), C.POINTER(_i)]),
@@ -389,6 +390,18 @@ class Context:
         check(self.lib.dsm_nmft_factorize(self._h, int(max_iter), float(min_change), int(bool(fix_gamma)),
                                           C.byref(n), _ptr(tr)))
         return n.value, tr[: n.value + 1]
+
+    @staticmethod
+    def batch_nmft_factorize(ctxs, max_iter=5000, min_change=1e-5, fix_gamma=False):
+        """nmft_factorize of every context in ``ctxs`` (one shape, one device, at most 8) with shared launches
+        (include/desman_hip.h: dsm_batch_nmft_factorize) -> [(updates run, objective trace), ...]"""
+        ctxs = list(ctxs)
+        arr = (_vp * len(ctxs))(*[c._h.value for c in ctxs])
+        n = (_i * len(ctxs))()
+        tr = np.full((len(ctxs), max_iter + 1), np.nan)
+        check(load().dsm_batch_nmft_factorize(arr, len(ctxs), int(max_iter), float(min_change), int(bool(fix_gamma)), n,
+                                              tr.ctypes.data_as(_vp)))
+        return [(int(n[k]), tr[k, : n[k] + 1].copy()) for k in range(len(ctxs))]
 
     def nmft_objective(self):
         d = _d(0)

@@ -109,9 +109,9 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
     if batch_fn is not None and batch > 1:
         # the units of this rank one after the other, each as one batched run; a unit whose batched run raises falls back to
         # its chains one by one (and those to the re-queue / failed-record rule below)
-        first = []
-        for ui in unit_bins[rank]:
+        def unit(ui):
             ids = units[ui]
+            out = []
             recs = None
             if len(ids) > 1:
                 t0 = time.perf_counter()
@@ -125,9 +125,16 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
                         rec.setdefault("wall_s", (time.perf_counter() - t0) / len(ids))
                         rec["chain"] = cid
                         rec.setdefault("failed", 0.0)
-                        first.append([float(rec[k]) for k in REC_FIELDS])
+                        out.append([float(rec[k]) for k in REC_FIELDS])
             if recs is None:
-                first += [one(cid) for cid in ids]
+                out += [one(cid) for cid in ids]
+            return out
+        if concurrency > 1 and len(unit_bins[rank]) > 1:         # units (different G) side by side: their host work overlaps
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=concurrency) as pool:
+                first = [r for rs in pool.map(unit, unit_bins[rank]) for r in rs]
+        else:
+            first = [r for ui in unit_bins[rank] for r in unit(ui)]
     elif concurrency > 1 and len(bins[rank]) > 1:
         from concurrent.futures import ThreadPoolExecutor
         os.environ.setdefault("DESMAN_HIP_NMFT_GRAPH", "1")      # replayed NMFT batches: see api.hip (dsm_nmft_factorize)

@@ -179,15 +179,32 @@ def main_replicates(argv_list, on_chain=None):
         logging.info('sampler seed %d', opts.random_seed)
         rng = RandomState(opts.random_seed)
         nmft = Init_NMFT(flt.snps_filter, opts.genomes, rng, device=opts.device)
+        runs.append(dict(opts=opts, report=report, table=table, flt=flt, subsample=subsample, rng=rng, nmft=nmft))
+    # the NMF starts: together where the batched kernels apply (one shape, S <= 96, G <= 12), else one by one
+    nm = [r["nmft"] for r in runs]
+    done = False
+    if len(nm) > 1 and len({(o.V, o.S, o.G) for o in nm}) == 1:
+        try:
+            Init_NMFT.factorize_batch(nm)
+            done = True
+        except _lib.DesmanHipError as e:
+            logging.info('batched NMF start not available (%s): one by one' % e)
+    for k, r in enumerate(runs):
+        tell(k)
         logging.info('NMF-tensor initialisation')
-        nmft.factorize()
+        if done:
+            r["nmft"]._log_trace(r["nmft"].div_trace)
+        else:
+            r["nmft"].factorize()
+    for k, r in enumerate(runs):
+        opts, flt, rng, nmft = r["opts"], r["flt"], r["rng"], r["nmft"]
         chain = HaploSNP_Sampler(flt.snps_filter, opts.genomes, rng, max_iter=opts.no_iter, device=opts.device, ctx=nmft._ctx)
         chain.mt_state = _lib.mt_seed_state(opts.random_seed)       # what initRNG(); setRNG(seed) leave in the module's stream
         chain.tau = np.copy(nmft.get_tau(), order='C')
         chain.updateTauIndices()
         chain.gamma = np.copy(nmft.get_gamma(), order='C')
         chain.eta = np.copy(flt.eta, order='C')
-        runs.append(dict(opts=opts, report=report, table=table, flt=flt, subsample=subsample, chain=chain))
+        r["chain"] = chain
     chains = [r["chain"] for r in runs]
 
     def together(group):

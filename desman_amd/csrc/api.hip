@@ -1115,6 +1115,84 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     return DSM_OK;
 }
 
+// Init_NMFT.factorize / factorize_tau of K chains of one shape at once: every update is one launch of each of its three
+// kernels for all of them (chain = blockIdx.y).  The stop test is per chain, on the device; a chain that has stopped costs
+// nothing but its workgroups' first instruction.  Matrix-core path only (S <= 96, G <= 12).  n_done [K];
+// div_traces [K][max_iter + 1] or null.
+extern "C" int dsm_batch_nmft_factorize(dsm_ctx *const *ctxs, int K, int max_iter, double min_change, int fix_gamma,
+                                        int *n_done, double *div_traces)
+{
+    if (!ctxs || K < 1 || K > DSM_MAX_BATCH) { dsm_set_error("batch of %d chains (1..%d)", K, DSM_MAX_BATCH); return DSM_ERR_ARG; }
+    if (max_iter < 0) { dsm_set_error("max_iter < 0"); return DSM_ERR_ARG; }
+    for (int k = 0; k < K; ++k) {
+        TRY(need(ctxs[k], true, false));
+        const dsm_ctx *a = ctxs[0], *b = ctxs[k];
+        if (!b->ntau) { dsm_set_error("nmft_factorize: call dsm_nmft_set first (chain %d)", k); return DSM_ERR_STATE; }
+        if (b->device != a->device || b->V != a->V || b->S != a->S || b->nG != a->nG) {
+            dsm_set_error("batch: chain %d differs from chain 0 in device or shape", k);
+            return DSM_ERR_ARG;
+        }
+        for (int j = 0; j < k; ++j) if (ctxs[j] == ctxs[k]) { dsm_set_error("batch: chain %d listed twice", k); return DSM_ERR_ARG; }
+        if (!nmft_use_mfma(b)) { dsm_set_error("batch: the matrix-core NMFT kernel does not apply to this shape (S <= 96, G <= 12)"); return DSM_ERR_UNSUPPORTED; }
+    }
+    dsm_ctx *const lead = ctxs[0];
+    BIND(lead);
+    const int G = lead->nG, S = lead->S;
+    struct Saved { hipStream_t st; bool timing; };
+    std::vector<Saved> saved(K);
+    std::vector<Scratch<double>> traces(K);
+    for (int k = 0; k < K; ++k) {
+        dsm_ctx *c = ctxs[k];
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        saved[k] = Saved{c->stream, c->timing};
+        c->stream = lead->stream; c->timing = false;
+    }
+    auto restore = [&]() {
+        g_batch = BatchCtl{};
+        for (int k = 0; k < K; ++k) { ctxs[k]->stream = saved[k].st; ctxs[k]->timing = saved[k].timing; ctxs[k]->ndiv_trace = nullptr; }
+    };
+#define BTRY(expr) do { int _r = (expr); if (_r != DSM_OK) { (void)hipStreamSynchronize(lead->stream); restore(); return _r; } } while (0)
+#define BHIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { dsm_set_error("%s failed: %s", #expr, hipGetErrorString(_e)); (void)hipStreamSynchronize(lead->stream); restore(); return DSM_ERR_HIP; } } while (0)
+    const int adjust = fix_gamma ? 0 : 1;
+    auto ctl_of = [&](dsm_ctx *c) { return c->nstat + (size_t)G * S + 2 * G; };
+    for (int k = 0; k < K; ++k) {                                  // per chain, once: control words, _adjustment, first statistics
+        dsm_ctx *c = ctxs[k];
+        BTRY(traces[k].alloc((size_t)max_iter + 1));
+        c->ndiv_trace = traces[k];
+        BHIP(hipMemsetAsync(ctl_of(c), 0, 16 * sizeof(double), c->stream));
+        if (adjust) BTRY(k_nmft_clamp(c));
+    }
+    g_batch.K = K;
+    for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_wave(ctxs[k], adjust, 0)); }
+    const int BATCH = 64;
+    std::vector<double> h((size_t)K * 7, 0.0);
+    for (int launched = 0; launched <= max_iter;) {
+        for (int i = 0; i < BATCH && launched <= max_iter; ++i, ++launched) {
+            for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_gamma(ctxs[k], max_iter, min_change, fix_gamma, adjust)); }
+            for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_wave(ctxs[k], adjust, 1)); }
+        }
+        for (int k = 0; k < K; ++k)
+            BHIP(hipMemcpyAsync(h.data() + (size_t)k * 7, ctl_of(ctxs[k]), 7 * sizeof(double), hipMemcpyDeviceToHost, lead->stream));
+        BHIP(hipStreamSynchronize(lead->stream));
+        bool all = true;
+        for (int k = 0; k < K; ++k) all = all && h[(size_t)k * 7 + 2] != 0.0;
+        if (all) break;
+    }
+    g_batch = BatchCtl{};
+    for (int k = 0; k < K; ++k) {
+        const int done = (int)h[(size_t)k * 7 + 3];
+        if (n_done) n_done[k] = done;
+        if (div_traces)
+            BHIP(hipMemcpyAsync(div_traces + (size_t)k * ((size_t)max_iter + 1), traces[k], ((size_t)done + 1) * sizeof(double),
+                                hipMemcpyDeviceToHost, lead->stream));
+    }
+    BHIP(hipStreamSynchronize(lead->stream));
+#undef BTRY
+#undef BHIP
+    restore();
+    return DSM_OK;
+}
+
 extern "C" int dsm_nmft_objective(dsm_ctx *c, double *div)
 {
     TRY(need(c, true, false));

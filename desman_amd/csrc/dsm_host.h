@@ -182,5 +182,6 @@ int k_nmft_pass_b(dsm_ctx *c, int adjust);
 int k_nmft_get_tau(dsm_ctx *c, uint64_t *d_packed);
 int nmft_grid(dsm_ctx *c);
 bool nmft_use_wave(const dsm_ctx *c);
+bool nmft_use_mfma(const dsm_ctx *c);
 int nmft_wave_grid(const dsm_ctx *c);
 int k_nmft_wave(dsm_ctx *c, int adjust, int do_update);

@@ -154,9 +154,12 @@ __global__ __launch_bounds__(NMFT_A_THREADS) void nmft_pass_a_kernel(const doubl
 // reduction of the transposed partials: one wavefront per output, coalesced
 // reads, fixed-order butterfly -> stat[out].
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nmft_reduce_kernel(const double *__restrict__ partial, int nblk, int nout,
-                                                          const double *__restrict__ ctl, double *__restrict__ stat)
+struct NmftReduceParams { const double *partial; int nblk, nout; const double *ctl; double *stat; };
+__device__ __forceinline__ void nmft_reduce_body(const NmftReduceParams &q)
 {
+    const double *__restrict__ partial = q.partial, *__restrict__ ctl = q.ctl;
+    double *__restrict__ stat = q.stat;
+    const int nblk = q.nblk, nout = q.nout;
     if (ctl[2] != 0.0) return;
     const int out = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (out >= nout) return;
@@ -165,17 +168,24 @@ __global__ __launch_bounds__(256) void nmft_reduce_kernel(const double *__restri
     a = group_allreduce_sum<64>(a);
     if (lane == 0) stat[out] = a;
 }
+__global__ __launch_bounds__(256) void nmft_reduce_kernel(NmftReduceParams q) { nmft_reduce_body(q); }
+__global__ __launch_bounds__(256) void nmft_reduce_kernel_b(BatchArgs<NmftReduceParams> b) { nmft_reduce_body(b.p[blockIdx.y]); }
 
 // ---------------------------------------------------------------------------
 // gamma / control kernel (one workgroup): the stop test of the factorize loop
 // (Init_NMFT.py:106) on the device, then the gamma update (:163-168).
 // ctl: [0] div  [2] done  [3] updates run  [4 + (it&1)] div of iteration it  [6] iteration counter.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void nmft_gamma_kernel(const double *__restrict__ stat, int S, int G,
-                                                          int max_iter, double min_change, int fix_gamma, int adjust,
-                                                          double *__restrict__ gam, double *__restrict__ gam_raw,
-                                                          double *__restrict__ ctl, double *__restrict__ div_trace)
+struct NmftGammaParams {
+    const double *stat; int S, G, max_iter; double min_change; int fix_gamma, adjust;
+    double *gam, *gam_raw, *ctl, *div_trace;
+};
+__device__ __forceinline__ void nmft_gamma_body(const NmftGammaParams &q)
 {
+    const double *__restrict__ stat = q.stat;
+    const int S = q.S, G = q.G, max_iter = q.max_iter, fix_gamma = q.fix_gamma, adjust = q.adjust;
+    const double min_change = q.min_change;
+    double *__restrict__ gam = q.gam, *__restrict__ gam_raw = q.gam_raw, *__restrict__ ctl = q.ctl, *__restrict__ div_trace = q.div_trace;
     extern __shared__ __attribute__((aligned(16))) char smem_g[];
     double *val = reinterpret_cast<double *>(smem_g);          // [G][SC] one chunk of sample columns
     __shared__ int go;
@@ -218,6 +228,8 @@ __global__ __launch_bounds__(1024) void nmft_gamma_kernel(const double *__restri
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(1024) void nmft_gamma_kernel(NmftGammaParams q) { nmft_gamma_body(q); }
+__global__ __launch_bounds__(1024) void nmft_gamma_kernel_b(BatchArgs<NmftGammaParams> b) { nmft_gamma_body(b.p[blockIdx.y]); }
 
 // ---------------------------------------------------------------------------
 // pass B.  A workgroup takes VT variants (4*VT rows) at a time:
@@ -555,10 +567,21 @@ int k_nmft_gamma(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int
 {
     KTimer tm(c, DSM_K_NMFT_G);
     const int nout = c->nG * c->S + c->nG + 1;
-    hipLaunchKernelGGL(nmft_reduce_kernel, dim3((nout + 3) / 4), dim3(256), 0, c->stream, c->npart, c->npart_cols, nout,
-                       NMFT_CTL(c), c->nstat);
-    hipLaunchKernelGGL(nmft_gamma_kernel, dim3(1), dim3(1024), (size_t)1024 * sizeof(double), c->stream, c->nstat, c->S,
-                       c->nG, max_iter, min_change, fix_gamma, adjust, c->ngam, c->ngam_raw, NMFT_CTL(c), c->ndiv_trace);
+    const NmftReduceParams r{c->npart, c->npart_cols, nout, NMFT_CTL(c), c->nstat};
+    const NmftGammaParams g{c->nstat, c->S, c->nG, max_iter, min_change, fix_gamma, adjust, c->ngam, c->ngam_raw, NMFT_CTL(c), c->ndiv_trace};
+    if (g_batch.K) {                                         // both launches of K chains at once (dsm_host.h: BatchCtl)
+        static thread_local BatchArgs<NmftReduceParams> ar;
+        static thread_local BatchArgs<NmftGammaParams> ag;
+        ar.p[g_batch.k] = r; ag.p[g_batch.k] = g;
+        if (g_batch.k == g_batch.K - 1) {
+            hipLaunchKernelGGL(nmft_reduce_kernel_b, dim3((nout + 3) / 4, g_batch.K), dim3(256), 0, c->stream, ar);
+            hipLaunchKernelGGL(nmft_gamma_kernel_b, dim3(1, g_batch.K), dim3(1024), (size_t)1024 * sizeof(double), c->stream, ag);
+        }
+        HIP_TRY(hipGetLastError());
+        return DSM_OK;
+    }
+    hipLaunchKernelGGL(nmft_reduce_kernel, dim3((nout + 3) / 4), dim3(256), 0, c->stream, r);
+    hipLaunchKernelGGL(nmft_gamma_kernel, dim3(1), dim3(1024), (size_t)1024 * sizeof(double), c->stream, g);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }
@@ -718,13 +741,18 @@ __device__ __forceinline__ double row16_transpose_reduce(double (&v)[16], int n)
     return v[0];
 }
 
+struct NmftMfmaParams {
+    const double *F; double *tau; const double *gam_raw, *gam;
+    int V, S, G, adjust, do_update;
+    const double *ctl, *log_tab; double *partial;
+};
 template <int NT, int KB, bool KEEPF>
-__global__ __launch_bounds__(256, (NT <= 4 ? 3 : 2)) void nmft_mfma_kernel(const double *__restrict__ F, double *__restrict__ tau,
-                                                        const double *__restrict__ gam_raw, const double *__restrict__ gam,
-                                                        int V, int S, int G, int adjust, int do_update,
-                                                        const double *__restrict__ ctl, const double *__restrict__ log_tab,
-                                                        double *__restrict__ partial)
+__device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
 {
+    const double *__restrict__ F = prm.F, *__restrict__ gam_raw = prm.gam_raw, *__restrict__ gam = prm.gam;
+    double *__restrict__ tau = prm.tau, *__restrict__ partial = prm.partial;
+    const double *__restrict__ ctl = prm.ctl, *__restrict__ log_tab = prm.log_tab;
+    const int V = prm.V, S = prm.S, G = prm.G, adjust = prm.adjust, do_update = prm.do_update;
     extern __shared__ __attribute__((aligned(16))) char smem_m[];
     if (ctl[2] != 0.0) return;
     constexpr int GP = 4 * KB, SPAD = 16 * NT;
@@ -924,6 +952,13 @@ int nmft_mfma_grid(const dsm_ctx *c)
     if (g > 768) g = 768;
     return g < 1 ? 1 : g;
 }
+template <int NT, int KB, bool KEEPF>
+__global__ __launch_bounds__(256, (NT <= 4 ? 3 : 2)) void nmft_mfma_kernel(NmftMfmaParams q) { nmft_mfma_body<NT, KB, KEEPF>(q); }
+template <int NT, int KB, bool KEEPF>
+__global__ __launch_bounds__(256, (NT <= 4 ? 3 : 2)) void nmft_mfma_kernel_b(BatchArgs<NmftMfmaParams> b)
+{
+    nmft_mfma_body<NT, KB, KEEPF>(b.p[blockIdx.y]);
+}
 
 template <int NT, int KB>
 static void launch_mfma(dsm_ctx *c, int adjust, int do_update, int grid)
@@ -931,8 +966,10 @@ static void launch_mfma(dsm_ctx *c, int adjust, int do_update, int grid)
     constexpr int GP = 4 * KB, SPAD = 16 * NT;
     const size_t sh = (2 * DSM_LOG_TAB_N + (size_t)GP * SPAD + 2 * (size_t)NT * KB * 64 + GP + 4 * 2 * 16 * GP +
                        4 * (size_t)(GP + 2) * SPAD) * sizeof(double);
-    hipLaunchKernelGGL((nmft_mfma_kernel<NT, KB, (NT <= 3)>), dim3(grid), dim3(256), sh, c->stream, c->F, c->ntau, c->ngam_raw, c->ngam,
-                       c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart);
+    const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart};
+    LAUNCH_OR_COLLECT(NmftMfmaParams, q,
+                      hipLaunchKernelGGL((nmft_mfma_kernel<NT, KB, (NT <= 3)>), dim3(grid), dim3(256), sh, c->stream, q),
+                      hipLaunchKernelGGL((nmft_mfma_kernel_b<NT, KB, (NT <= 3)>), dim3(grid, K), dim3(256), sh, c->stream, acc));
 }
 
 int k_nmft_mfma(dsm_ctx *c, int adjust, int do_update)

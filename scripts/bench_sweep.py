@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wall time of a G-sweep (g = 2..8 x 5 seeds = 35 chains, the fan-out of scripts/runDesman.sh) on ONE GPU
-for several values of the per-GPU chain concurrency.  usage: bench_sweep.py [V] [S] [iters]"""
+for several values of the per-GPU chain concurrency, and with the replicates of a G value batched.  usage: bench_sweep.py [V] [S] [iters]"""
 import json
 import os
 import sys
@@ -34,4 +34,19 @@ with tempfile.TemporaryDirectory() as d:
         finally:
             sys.stdout = sys.__stdout__
         out["concurrency_%d_wall_s" % c] = time.perf_counter() - t0
+    # the replicates of each G as one batched unit (dsm_batch_gibbs_update)
+    t0 = time.perf_counter()
+    sys.stdout = open(os.devnull, "w")
+    try:
+        chains.main([freq, "--gmin", "2", "--gmax", "8", "--reps", "5", "-i", str(I), "-o", os.path.join(d, "b5"), "-b", "5", "-c", "1"])
+    finally:
+        sys.stdout = sys.__stdout__
+    out["batch_5_wall_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sys.stdout = open(os.devnull, "w")
+    try:
+        chains.main([freq, "--gmin", "2", "--gmax", "8", "--reps", "5", "-i", str(I), "-o", os.path.join(d, "b5c2"), "-b", "5", "-c", "2"])
+    finally:
+        sys.stdout = sys.__stdout__
+    out["batch_5_two_units_at_a_time_wall_s"] = time.perf_counter() - t0
 print(json.dumps(dict(V=V, S=S, iters=I, chains=35, **out)))

@@ -79,3 +79,36 @@ def test_batch_argument_checks():
         _lib.Context.batch_gibbs_update([a] * 9, 2)            # more than 8
     _lib.Context.batch_gibbs_update([a], 2)                    # a batch of one is allowed
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("V,S,G,K", [(120, 16, 4, 3), (300, 64, 8, 5), (90, 96, 12, 2), (50, 7, 1, 4)])
+def test_batched_nmft_factorize_equals_one_by_one(V, S, G, K):
+    """dsm_batch_nmft_factorize: same factors, update counts and objective traces as dsm_nmft_factorize per chain (the
+    chains stop at different updates)"""
+    counts, _, _ = synth_counts(V, S, max(G, 2), seed=700 + V)
+    rs = np.random.RandomState(5)
+    starts = []
+    for k in range(K):
+        gam0 = np.ascontiguousarray(rs.dirichlet(np.full(G, 0.3), size=S).T) if G > 1 else np.ones((1, S))
+        d = rs.dirichlet(np.full(4, 0.3), size=V * G).reshape(V, G, 4)
+        tau0 = np.ascontiguousarray(np.transpose(d, (2, 0, 1)).reshape(4 * V, G))
+        starts.append((tau0, gam0))
+    max_iter = 300
+    for mc in (1e-3, 1e-7):                                  # chains that stop early at different updates / run to max_iter
+        singles = []
+        for tau0, gam0 in starts:
+            c = _lib.Context(0); c.set_counts(counts); c.nmft_set(tau0, gam0)
+            n, tr = c.nmft_factorize(max_iter, mc)
+            singles.append((n, tr, c.nmft_get(), c.nmft_get_tau()))
+            c.close()
+        ctxs = []
+        for tau0, gam0 in starts:
+            c = _lib.Context(0); c.set_counts(counts); c.nmft_set(tau0, gam0)
+            ctxs.append(c)
+        res = _lib.Context.batch_nmft_factorize(ctxs, max_iter, mc)
+        for c, (n, tr), (n1, tr1, fac1, tau1) in zip(ctxs, res, singles):
+            assert n == n1 and np.array_equal(tr, tr1)
+            fac = c.nmft_get()
+            assert np.array_equal(fac[0], fac1[0]) and np.array_equal(fac[1], fac1[1])
+            assert np.array_equal(c.nmft_get_tau(), tau1)
+            c.close()

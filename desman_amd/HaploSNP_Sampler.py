@@ -114,6 +114,26 @@ class HaploSNP_Sampler:
             s._release_rng()
             s._collect(prefix='nlp')
 
+    @staticmethod
+    def updateTau_batch(samplers, on_chain=None):
+        """updateTau() of several chains of one shape at once (dsm_batch_update_tau); a GSL stream each (mt_state)"""
+        samplers = list(samplers)
+        n = samplers[0].max_iter
+        if any(s.max_iter != n for s in samplers) or any(s.mt_state is None for s in samplers):
+            raise ValueError("updateTau_batch: samplers need equal max_iter and a GSL stream each (mt_state)")
+        for s in samplers:
+            s._push_state()
+            s._bind_rng()
+        _lib.Context.batch_update_tau([s._ctx for s in samplers], [s.gamma_store[:n] for s in samplers],
+                                      [s.eta_store[:n] for s in samplers])
+        for s in samplers:
+            if on_chain is not None:
+                on_chain(s)
+            s._release_rng()
+            gs, es = s.gamma_store, s.eta_store
+            s._collect(prefix='nll', keep_gamma_eta=True)
+            s.gamma_store, s.eta_store = gs, es
+
     def updateTau(self):
         """tau-only sweeps driven by gamma_store / eta_store (HaploSNP_Sampler.py:383-407)."""
         self._push_state()

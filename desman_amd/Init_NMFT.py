@@ -120,6 +120,21 @@ class Init_NMFT:
             o.div_trace = tr
         return res
 
+    @staticmethod
+    def factorize_tau_batch(objs):
+        """factorize_tau() (gamma fixed) of several objects of one shape at once; same factors as one by one"""
+        objs = list(objs)
+        if any(o.n_run != 1 for o in objs) or len({(o.max_iter, o.min_change) for o in objs}) != 1:
+            raise ValueError("factorize_tau_batch: n_run = 1 and equal max_iter / min_change expected")
+        for o in objs:
+            o.random_initialize_tau()
+            o._push()
+        res = _lib.Context.batch_nmft_factorize([o._ctx for o in objs], objs[0].max_iter, objs[0].min_change, fix_gamma=True)
+        for o, (n, tr) in zip(objs, res):
+            o._pull()
+            o.div_trace = tr
+        return res
+
     def factorize_tau(self):
         for _ in range(self.n_run):
             self.random_initialize_tau()

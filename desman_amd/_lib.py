@@ -71,6 +71,7 @@ SIGNATURES = {
     "dsm_ctx_loglik": (_i, [_vp, C.POINTER(_d), C.POINTER(_d)]),
     "dsm_ctx_gibbs_update": (_i, [_vp, _i]),
     "dsm_batch_gibbs_update": (_i, [C.POINTER(_vp), _i, _i]),
+    "dsm_batch_update_tau": (_i, [C.POINTER(_vp), _i, _i, C.POINTER(_vp), C.POINTER(_vp)]),
     "dsm_batch_nmft_factorize": (_i, [C.POINTER(_vp), _i, _i, _d, _i, C.POINTER(_i), _vp]),
     "dsm_ctx_update_tau": (_i, [_vp, _i, _f64p, _f64p]),
     "dsm_ctx_get_trace": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
@@ -390,6 +391,23 @@ class Context:
         check(self.lib.dsm_nmft_factorize(self._h, int(max_iter), float(min_change), int(bool(fix_gamma)),
                                           C.byref(n), _ptr(tr)))
         return n.value, tr[: n.value + 1]
+
+    @staticmethod
+    def batch_update_tau(ctxs, gamma_stores, eta_stores):
+        """update_tau of every context in ``ctxs`` with shared launches (dsm_batch_update_tau); one (gamma_store, eta_store)
+        pair of equal length per context"""
+        ctxs = list(ctxs)
+        gs = [np.ascontiguousarray(g, dtype=np.float64) for g in gamma_stores]
+        es = [np.ascontiguousarray(e, dtype=np.float64) for e in eta_stores]
+        n = gs[0].shape[0]
+        if any(g.shape[0] != n for g in gs) or any(e.shape[0] != n for e in es):
+            raise ValueError("batch_update_tau: traces of equal length expected")
+        arr = (_vp * len(ctxs))(*[c._h.value for c in ctxs])
+        gp = (_vp * len(ctxs))(*[g.ctypes.data for g in gs])
+        ep = (_vp * len(ctxs))(*[e.ctypes.data for e in es])
+        check(load().dsm_batch_update_tau(arr, len(ctxs), int(n), gp, ep))
+        for c in ctxs:
+            c.n_trace = int(n)
 
     @staticmethod
     def batch_nmft_factorize(ctxs, max_iter=5000, min_change=1e-5, fix_gamma=False):

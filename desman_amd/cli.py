@@ -139,6 +139,44 @@ def _assign_rest(opts, report, table, flt, chain):
     report.output_collated_Tau(other, table)
 
 
+def _assign_rest_batch(runs, tell):
+    """_assign_rest of several replicate chains with their NMF fits and tau-only sweeps batched (equal shapes assumed)"""
+    from . import _lib
+    others, nm = [], []
+    for k, r in enumerate(runs):
+        tell(k)
+        opts, flt, chain = r["opts"], r["flt"], r["chain"]
+        rest = flt.snps_filter_original[~np.asarray(flt.selected, dtype=bool), :]
+        nmft = Init_NMFT(rest, chain.G, chain.randomState, device=opts.device)
+        nmft.gamma = np.transpose(chain.gamma)
+        logging.info('NMF-tensor initialisation of the %d remaining positions (gamma fixed)' % rest.shape[0])
+        nm.append(nmft)
+    Init_NMFT.factorize_tau_batch(nm)
+    for k, (r, nmft) in enumerate(zip(runs, nm)):
+        tell(k)
+        nmft._log_trace(nmft.div_trace)
+        opts, flt, chain = r["opts"], r["flt"], r["chain"]
+        rest = flt.snps_filter_original[~np.asarray(flt.selected, dtype=bool), :]
+        other = HaploSNP_Sampler(rest, chain.G, chain.randomState, max_iter=opts.no_iter, device=opts.device, ctx=nmft._ctx)
+        other.mt_state = chain.mt_state                          # the tau-only sweeps continue the chain's GSL stream
+        other.tau = nmft.get_tau()
+        other.updateTauIndices()
+        other.gamma_star = np.copy(chain.gammaMean(), order='C')
+        other.eta_star = np.copy(chain.etaMean(), order='C')
+        other.gamma_store = np.copy(chain.gamma_store, order='C')
+        other.eta_store = np.copy(chain.eta_store, order='C')
+        others.append(other)
+    for phase in ('burn-in', 'sampling'):
+        for k in range(len(runs)):
+            tell(k)
+            logging.info('tau-only %s' % phase)
+        HaploSNP_Sampler.updateTau_batch(others, on_chain=lambda o: tell(others.index(o)))
+    for k, (r, other) in enumerate(zip(runs, others)):
+        tell(k)
+        r["report"].outPredFit(other, r["opts"].genomes)
+        r["report"].output_collated_Tau(other, r["table"])
+
+
 def main(argv=None):
     opts = build_parser().parse_args(argv)
     if opts.assign_file is not None:
@@ -231,11 +269,28 @@ def main_replicates(argv_list, on_chain=None):
     for k, r in enumerate(runs):
         tell(k)
         _report(r["report"], r["table"], r["flt"], r["chain"], r["opts"].genomes)
-        if r["subsample"] is not None:
-            sampletau.initRNG()
-            sampletau.setRNGState(r["chain"].mt_state)              # the tau-only sweeps continue the chain's GSL stream
-            _assign_rest(r["opts"], r["report"], r["table"], r["flt"], r["chain"])
-            sampletau.freeRNG()
+    # -r: the positions left out of the fit -- batched where the replicates still agree in shape
+    rest_runs = [r for r in runs if r["subsample"] is not None]
+    idx = {id(r): k for k, r in enumerate(runs)}
+    groups = {}
+    for r in rest_runs:
+        n_rest = int((~np.asarray(r["flt"].selected, dtype=bool)).sum())
+        groups.setdefault((r["chain"].G, n_rest, r["chain"].S), []).append(r)
+    for group in groups.values():
+        batched = False
+        if len(group) > 1:
+            try:
+                _assign_rest_batch(group, lambda j, g=group: tell(idx[id(g[j])]))
+                batched = True
+            except _lib.DesmanHipError as e:
+                logging.info('batched -r path not available (%s): one by one' % e)
+        if not batched:
+            for r in group:
+                tell(idx[id(r)])
+                sampletau.initRNG()
+                sampletau.setRNGState(r["chain"].mt_state)          # the tau-only sweeps continue the chain's GSL stream
+                _assign_rest(r["opts"], r["report"], r["table"], r["flt"], r["chain"])
+                sampletau.freeRNG()
     return chains
 
 

@@ -905,6 +905,98 @@ extern "C" int dsm_ctx_update_tau(dsm_ctx *c, int n_iter, const double *gamma_st
     return DSM_OK;
 }
 
+// updateTau of K chains of one shape at once (the -r path of replicate chains): one tau_kernel launch per sweep for all of
+// them.  gamma_stores[k] [n][S][G], eta_stores[k] [n][4][4]: chain k's traces.
+extern "C" int dsm_batch_update_tau(dsm_ctx *const *ctxs, int K, int n_iter, const double *const *gamma_stores,
+                                    const double *const *eta_stores)
+{
+    if (!ctxs || K < 1 || K > DSM_MAX_BATCH) { dsm_set_error("batch of %d chains (1..%d)", K, DSM_MAX_BATCH); return DSM_ERR_ARG; }
+    if (n_iter < 1 || !gamma_stores || !eta_stores) { dsm_set_error("update_tau: bad arguments"); return DSM_ERR_ARG; }
+    for (int k = 0; k < K; ++k) {
+        TRY(need(ctxs[k], true, true));
+        const dsm_ctx *a = ctxs[0], *b = ctxs[k];
+        if (!gamma_stores[k] || !eta_stores[k]) { dsm_set_error("update_tau: bad arguments"); return DSM_ERR_ARG; }
+        if (b->device != a->device || b->V != a->V || b->S != a->S || b->G != a->G || b->tau_rng != a->tau_rng) {
+            dsm_set_error("batch: chain %d differs from chain 0 in device, shape or tau RNG", k);
+            return DSM_ERR_ARG;
+        }
+        for (int j = 0; j < k; ++j) if (ctxs[j] == ctxs[k]) { dsm_set_error("batch: chain %d listed twice", k); return DSM_ERR_ARG; }
+    }
+    dsm_ctx *const lead = ctxs[0];
+    BIND(lead);
+    struct Saved { hipStream_t st, rng; bool timing; };
+    std::vector<Saved> saved(K);
+    for (int k = 0; k < K; ++k) {
+        dsm_ctx *c = ctxs[k];
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream_rng));
+        saved[k] = Saved{c->stream, c->stream_rng, c->timing};
+        c->stream = lead->stream; c->stream_rng = lead->stream_rng; c->timing = false;
+    }
+    auto restore = [&]() {
+        g_batch = BatchCtl{};
+        for (int k = 0; k < K; ++k) { ctxs[k]->stream = saved[k].st; ctxs[k]->stream_rng = saved[k].rng; ctxs[k]->timing = saved[k].timing; }
+    };
+#define BTRY(expr) do { int _r = (expr); if (_r != DSM_OK) { (void)hipStreamSynchronize(lead->stream); (void)hipStreamSynchronize(lead->stream_rng); restore(); return _r; } } while (0)
+#define BHIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { dsm_set_error("%s failed: %s", #expr, hipGetErrorString(_e)); (void)hipStreamSynchronize(lead->stream); restore(); return DSM_ERR_HIP; } } while (0)
+    const size_t sg = (size_t)lead->S * lead->G;
+    std::vector<SweepWords> words;
+    words.reserve(K);
+    for (int k = 0; k < K; ++k) {                                  // per chain, once: traces in, entry state, all log-priors
+        dsm_ctx *c = ctxs[k];
+        BTRY(alloc_traces(c, n_iter));
+        if (n_iter > c->in_cap || !c->gamma_in) {
+            BTRY(dev_alloc(&c->gamma_in, (size_t)n_iter * sg));
+            BTRY(dev_alloc(&c->eta_in, (size_t)n_iter * 16));
+            BTRY(dev_alloc(&c->prior_all, (size_t)n_iter * (c->S + 4)));
+            c->in_cap = n_iter;
+        }
+        BHIP(hipMemcpyAsync(c->gamma_in, gamma_stores[k], (size_t)n_iter * sg * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        BHIP(hipMemcpyAsync(c->eta_in, eta_stores[k], (size_t)n_iter * 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        BHIP(hipMemcpyAsync(c->gamma_trace, c->gamma_in, (size_t)n_iter * sg * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        BHIP(hipMemcpyAsync(c->eta_trace, c->eta_in, (size_t)n_iter * 16 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        BHIP(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
+        BTRY(eval_state(c, c->gamma_in, c->eta_in, c->tau_trace, 1));
+        BTRY(k_prior_batch(c, c->gamma_in, c->eta_in, n_iter, c->prior_all));
+        BHIP(hipMemsetAsync(c->nchange, 0, 2 * sizeof(int), c->stream));
+        words.emplace_back(c, n_iter);
+    }
+    g_batch.K = K;
+    for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(words[k].prefetch()); }
+    std::vector<int> nb_prev(K, 0);
+    std::vector<const uint32_t *> u(K, nullptr);
+    for (int it = 0; it < n_iter; ++it) {
+        for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(words[k].acquire(it, &u[k])); }
+        for (int k = 0; k < K; ++k) {
+            dsm_ctx *c = ctxs[k];
+            const uint32_t ic = c->iter_ctr++;
+            const double *g = c->gamma_in + (size_t)it * sg, *e = c->eta_in + (size_t)it * 16;
+            int nb = 0;
+            TauFinalRider rider;
+            if (it > 0) {
+                rider.nblocks = nb_prev[k]; rider.it = it - 1; rider.prior = c->prior_all + (size_t)(it - 1) * (c->S + 4);
+                rider.gamma_src = c->gamma_in + (size_t)(it - 1) * sg; rider.eta_src = c->eta_in + (size_t)(it - 1) * 16;
+            }
+            g_batch.k = k;
+            BTRY(k_tau_sweep(c, 3, g, e, e, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb, u[k], it & 1, it > 0 ? &rider : nullptr));
+            nb_prev[k] = nb;
+        }
+        for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(words[k].release(it)); }
+    }
+    g_batch = BatchCtl{};
+    for (int k = 0; k < K; ++k) {
+        dsm_ctx *c = ctxs[k];
+        BTRY(k_finalize(c, nb_prev[k], n_iter - 1, 0, c->prior_all + (size_t)(n_iter - 1) * (c->S + 4),
+                        c->gamma_in + (size_t)(n_iter - 1) * sg, c->eta_in + (size_t)(n_iter - 1) * 16, (n_iter - 1) & 1));
+    }
+    BHIP(hipStreamSynchronize(lead->stream));
+    BHIP(hipStreamSynchronize(lead->stream_rng));
+#undef BTRY
+#undef BHIP
+    restore();
+    return DSM_OK;
+}
+
 extern "C" int dsm_ctx_debug_log2f(dsm_ctx *c, const float *in, float *out, size_t n)
 {
     if (!c || !in || !out) { dsm_set_error("debug_log2f: bad arguments"); return DSM_ERR_ARG; }

@@ -154,6 +154,10 @@ int dsm_batch_gibbs_update(dsm_ctx *const *ctxs, int n_ctx, int n_iter);
  * driven by host traces gamma_store [n][S][G], eta_store [n][4][4].          */
 int dsm_ctx_update_tau(dsm_ctx *ctx, int n_iter, const double *gamma_store,
                        const double *eta_store);
+/* ... and for n_ctx (1..8) chains of one shape at once (the -r path of replicate chains): one launch per sweep for all of
+ * them; gamma_stores[k] / eta_stores[k] are chain k's traces.                                                          */
+int dsm_batch_update_tau(dsm_ctx *const *ctxs, int n_ctx, int n_iter, const double *const *gamma_stores,
+                         const double *const *eta_stores);
 
 /* results of the last update call.  Any pointer may be NULL.                 */
 int dsm_ctx_get_trace(dsm_ctx *ctx, double *ll, double *lp, int32_t *nchange,

@@ -112,3 +112,28 @@ def test_batched_nmft_factorize_equals_one_by_one(V, S, G, K):
             assert np.array_equal(fac[0], fac1[0]) and np.array_equal(fac[1], fac1[1])
             assert np.array_equal(c.nmft_get_tau(), tau1)
             c.close()
+
+
+@pytest.mark.parametrize("V,S,G,K,n", [(400, 24, 4, 3, 14), (128, 64, 8, 6, 9)])
+def test_batched_update_tau_equals_one_by_one(V, S, G, K, n):
+    """dsm_batch_update_tau (the -r path): tau-only sweeps of K chains over their own (gamma, eta) traces"""
+    counts, _, _ = synth_counts(V, S, G, seed=900 + V)
+    rs = np.random.RandomState(3)
+    stores = [(np.ascontiguousarray(rs.dirichlet(np.ones(G), size=(n, S))),
+               np.ascontiguousarray(rs.dirichlet(np.ones(4), size=(n, 4)) * 0.08 + 0.92 * np.eye(4))) for _ in range(K)]
+    states = [random_state(V, S, G, seed=910 + k) for k in range(K)]
+    singles = []
+    for k in range(K):
+        c = _chain(counts, states[k], 70 + k, 0xABC0 + k)
+        c.update_tau(*stores[k])
+        first = _snapshot(c)
+        c.update_tau(*stores[k])
+        singles.append((first, _snapshot(c)))
+        c.close()
+    ctxs = [_chain(counts, states[k], 70 + k, 0xABC0 + k) for k in range(K)]
+    for rnd in range(2):
+        _lib.Context.batch_update_tau(ctxs, [g for g, _ in stores], [e for _, e in stores])
+        for k in range(K):
+            _same(singles[k][rnd], _snapshot(ctxs[k]))
+    for c in ctxs:
+        c.close()

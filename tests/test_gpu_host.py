@@ -244,4 +244,5 @@ def test_gsweep_with_batched_replicates_equals_chains_run_one_by_one(tmp_path, m
             for f in ("fit.txt", "fitP.txt", "Filtered_Tau_star.csv", "Gamma_mean.csv", "Eta_star.csv", "Collated_Tau_star.csv"):
                 assert open("%s_%d_%d/%s" % (one, g, r, f)).read() == open("%s_%d_%d/%s" % (bat, g, r, f)).read(), (g, r, f)
             log = open("%s_%d_%d/log_file.txt" % (bat, g, r)).read()
-            assert "Gibbs Iter" in log and "sampler seed %d" % r in log
+            assert "Gibbs Iter" in log and "sampler seed %d" % r in log and "tau-only sampling" in log
+            assert "one by one" not in log                         # every batched stage ran batched

@@ -632,7 +632,7 @@ extern "C" int dsm_ctx_debug_stage1(dsm_ctx *c, uint32_t iter, uint32_t *ntab, u
     HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
     TRY(k_stats_stage1(c, iter));
     const size_t NH = (size_t)1 << c->G, S = (size_t)c->S;
-    std::vector<uint32_t> t(NH * S);
+    std::vector<uint32_t> t((size_t)c->ntab_rep * NH * S);
     HIP_TRY(hipMemcpyAsync(t.data(), c->ntab, t.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     if (esum) HIP_TRY(hipMemcpyAsync(esum, c->esum, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemsetAsync(c->ntab, 0, t.size() * sizeof(uint32_t), c->stream));
@@ -641,7 +641,11 @@ extern "C" int dsm_ctx_debug_stage1(dsm_ctx *c, uint32_t iter, uint32_t *ntab, u
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (ntab)
         for (size_t h = 0; h < NH; ++h)
-            for (size_t s = 0; s < S; ++s) ntab[s * NH + h] = t[h * S + s];       // device [H][S] -> [S][H]
+            for (size_t s = 0; s < S; ++s) {                                       // device [rep][H][S] -> [S][H], copies summed
+                uint32_t v = 0;
+                for (int r = 0; r < c->ntab_rep; ++r) v += t[((size_t)r * NH + h) * S + s];
+                ntab[s * NH + h] = v;
+            }
     return DSM_OK;
 }
 

@@ -64,6 +64,7 @@ struct dsm_ctx {
     int force_stats_spec = 0;       // test hook: 1 = per-read pass even where spec v2 applies, 2 = spec v2 on small problems too
     uint32_t *ntab = nullptr;       // [2^G][S] subset counts of the aggregated mu/E pass (spec v2), zero between passes
     size_t ntab_len = 0;
+    int ntab_rep = 1;               // copies of the table (few subsets x many positions: kernels_stats.hip, stats_ntab_rep)
     unsigned long long *big_list = nullptr;   // stage-1 items deferred to the compacted (BTRS) kernel: cell * 4 + base
     uint32_t *big_count = nullptr;            // DSM_BIG_NL counters, DSM_BIG_STRIDE words apart
     size_t big_cap = 0;
@@ -155,6 +156,7 @@ int k_log2f_test(dsm_ctx *c, const float *d_in, float *d_out, size_t n);
 int build_stats_items(dsm_ctx *c);          // api.hip: work list of the per-read pass from the resident tensor
 
 // ---- launchers (kernels_stats.hip)
+int stats_ntab_rep(const dsm_ctx *c);       // copies of the subset table the stage-1 atomics are spread over
 int stats_spec(const dsm_ctx *c);           // 2 = aggregated sampler (oracle/stats_agg.c), 1 = per-read (orc_stats_counter)
 int k_stats(dsm_ctx *c, uint32_t iter);
 int k_stats_stage1(dsm_ctx *c, uint32_t iter);

@@ -23,7 +23,8 @@ struct S2Plan {
 };
 
 struct Stage2Params {
-    uint32_t *ntab;                 // [2^G][S], zeroed after reading
+    uint32_t *ntab;                 // [rep][2^G][S], zeroed after reading
+    int rep;                        // copies of the table (their sum is the count)
     const double *gamma;            // [S][G]
     unsigned long long *sum_mu;     // [S][G] accumulated into (stand-alone kernel)
     const double *log_tab;
@@ -77,6 +78,11 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
                 uint32_t *cell = p.ntab + (size_t)Hs * S + s;
                 n = *cell;
                 if (n) *cell = 0u;
+                const size_t cstride = ((size_t)1 << G) * S;
+                for (int r = 1; r < p.rep; ++r) {               // few subsets, many positions: the atomics of stage 1 were spread over copies
+                    const uint32_t m = cell[r * cstride];
+                    if (m) { cell[r * cstride] = 0u; n += m; }
+                }
             } else n = tab[base + j];
             if (w == 1) {                                   // leaf: Hs == 1
                 leaf[lo] = n;

@@ -33,7 +33,8 @@ struct StatsAggParams {
     const double *gamma, *eta;
     int V, S, G;
     uint32_t k0, k1, iter;
-    uint32_t *ntab;                 // [2^G][S]
+    uint32_t *ntab;                 // [rep][2^G][S]; workgroup b adds to copy b mod rep
+    int rep;
     unsigned long long *esum;       // [16]
     const double *log_tab;
     unsigned long long *big_list;   // deferred items: cell * 4 + observed base; DSM_BIG_NL sub-lists of big_seg entries each
@@ -158,10 +159,11 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
             }
         }
         // N[H_a(v)][s] += reads whose true base is a: adjacent lanes -> adjacent words of one table row
-        if (nacc[0]) atomicAdd(p.ntab + (size_t)H0 * S + s, nacc[0]);
-        if (nacc[1]) atomicAdd(p.ntab + (size_t)H1 * S + s, nacc[1]);
-        if (nacc[2]) atomicAdd(p.ntab + (size_t)H2 * S + s, nacc[2]);
-        if (nacc[3]) atomicAdd(p.ntab + (size_t)H3 * S + s, nacc[3]);
+        uint32_t *const nt = p.ntab + (size_t)(blockIdx.x % (unsigned)p.rep) * (((size_t)1 << G) * S);
+        if (nacc[0]) atomicAdd(nt + (size_t)H0 * S + s, nacc[0]);
+        if (nacc[1]) atomicAdd(nt + (size_t)H1 * S + s, nacc[1]);
+        if (nacc[2]) atomicAdd(nt + (size_t)H2 * S + s, nacc[2]);
+        if (nacc[3]) atomicAdd(nt + (size_t)H3 * S + s, nacc[3]);
     }
     // Esum: lane-private columns -> one transposing butterfly per wavefront -> one global atomic per workgroup and counter
     {
@@ -237,7 +239,7 @@ __device__ __forceinline__ void stats_big_body(const StatsAggParams &p)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             erow[a * 256] += n[a];
-            if (n[a]) atomicAdd(p.ntab + (size_t)H[a] * S + s, n[a]);
+            if (n[a]) atomicAdd(p.ntab + (size_t)(blockIdx.x % (unsigned)p.rep) * (((size_t)1 << G) * S) + (size_t)H[a] * S + s, n[a]);
         }
     }
     {
@@ -299,13 +301,13 @@ __global__ __launch_bounds__(256) void binom_test_kernel(int kind, uint32_t n, d
 // spec v2 applies when the subset table fits (G <= 16, 2^G * S * 4 B <= 64 MB, every sample's depth < 2^32).  Where both
 // apply the cheaper one runs, by a cost model of the two passes fitted on MI355X (us per iteration, 933 x 64 ... 50k x 96):
 //   per-read pass (v1)   25 + 0.55 per million reads                      -- O(depth)
-//   aggregated pass (v2) 24 + 0.062 per thousand cells + 14 + 0.03 x 3V / 2^G   -- O(cells); cells = V x S rounded up to
+//   aggregated pass (v2) 24 + 0.062 per thousand cells + 14 + 0.03 x 3V / (2^G rep)   -- O(cells); cells = V x S rounded up to
 //                        the kernel's lane groups; + 14 for stage 2 in the Dirichlet launch (G >= 10: its own launch over
 //                        2^G subsets per sample, + 0.012 x 2^G); the last term is the
 //                        same-address contention of the subset-table atomics (3 per cell onto 2^G x S counters: 9 375 per
-//                        counter at V = 50k, G = 4 -> 410 us; 117 at config 3)
-// so shallow data (< ~100 reads per cell), few haplotypes on many positions and problems below ~200k cells keep the
-// per-read pass.
+//                        counter at V = 50k, G = 4 -> 410 us; 117 at config 3), spread over rep copies of the table
+//                        (stats_ntab_rep below)
+// so shallow data (< ~100 reads per cell) and problems below ~200k cells keep the per-read pass.
 // The rule is a function of the shape and the read totals only: the same on every run and every GPU.
 // lanes per variant of stats_agg_kernel: the chunk size that pads S least (ties: the larger one)
 static int stats_agg_lpv(int S)
@@ -333,13 +335,26 @@ int stats_spec(const dsm_ctx *c)
     const double cells = (double)c->V * (double)((c->S + lpv - 1) / lpv * lpv);
     const double t1 = 25.0 + 0.55e-6 * reads;
     const double stage2 = 14.0 + (c->G >= 10 ? 0.012 * (double)(1u << c->G) : 0.0);      // its own launch from G = 10: 62 us at G = 12
-    const double t2 = 24.0 + stage2 + 0.062e-3 * cells + 0.03 * 3.0 * (double)c->V / (double)(1u << c->G);
+    const double t2 = 24.0 + stage2 + 0.062e-3 * cells + 0.03 * 3.0 * (double)c->V / ((double)(1u << c->G) * stats_ntab_rep(c));
     return t2 < t1 ? 2 : 1;
+}
+
+// Few subsets and many positions put thousands of atomics on every counter of the subset table (3 V / 2^G each: 9 375 at
+// V = 50k, G = 4 -- 410 us of same-address serialisation).  The table is then kept in `rep` copies, workgroup b adds to copy
+// b mod rep and stage 2 reads their sum: integers, so nothing changes but the time.  rep = 1 from ~256 atomics per counter down
+// (config 3: 117, config 5: 37).
+int stats_ntab_rep(const dsm_ctx *c)
+{
+    const double per = 3.0 * (double)c->V / (double)((size_t)1 << c->G);
+    int rep = 1;
+    while (per / rep > 256.0 && rep < 64 && (size_t)(2 * rep) * ((size_t)1 << c->G) * (size_t)c->S * 4 <= ((size_t)64 << 20)) rep *= 2;
+    return rep;
 }
 
 static int ensure_ntab(dsm_ctx *c)
 {
-    const size_t need = ((size_t)1 << c->G) * (size_t)c->S;
+    c->ntab_rep = stats_ntab_rep(c);
+    const size_t need = (size_t)c->ntab_rep * ((size_t)1 << c->G) * (size_t)c->S;
     if (c->ntab && c->ntab_len == need) return DSM_OK;
     if (c->ntab) { (void)hipFree(c->ntab); c->ntab = nullptr; }
     hipError_t e = hipMalloc((void **)&c->ntab, need * sizeof(uint32_t));
@@ -401,7 +416,7 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     p.cnt_vs = c->cnt_vs; p.tau = c->tau; p.gamma = c->gamma; p.eta = c->eta;
     p.V = V; p.S = S; p.G = G; p.big_seg = seg;
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
-    p.ntab = c->ntab; p.esum = c->esum; p.log_tab = c->log_tab;
+    p.ntab = c->ntab; p.rep = c->ntab_rep; p.esum = c->esum; p.log_tab = c->log_tab;
     p.big_list = c->big_list; p.big_count = c->big_count;
     {
         // who draws an item, not what is drawn: an item whose rarer outcome has a mean above lean_cap goes to the compacted
@@ -475,7 +490,7 @@ int k_stats_stage2(dsm_ctx *c, uint32_t iter)
 {
     KTimer tm(c, DSM_K_STATS2);
     Stage2Params p;
-    p.ntab = c->ntab; p.gamma = c->gamma; p.sum_mu = c->sum_mu; p.log_tab = c->log_tab;
+    p.ntab = c->ntab; p.rep = c->ntab_rep; p.gamma = c->gamma; p.sum_mu = c->sum_mu; p.log_tab = c->log_tab;
     p.S = c->S; p.G = c->G;
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
     p.big_count = c->big_count;

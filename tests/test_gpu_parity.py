@@ -238,7 +238,9 @@ def test_stats_bit_exact_vs_spec(ctx, V, S, G):
 @pytest.mark.parametrize("V,S,G,scale", [(200, 64, 8, 1.0), (120, 96, 12, 1.0), (150, 16, 5, 1.0), (60, 130, 3, 1.0),
                                          (80, 64, 8, 20.0), (40, 7, 16, 1.0),
                                          # deferred lists of every kind longer than one workgroup of the compacted kernel
-                                         (400, 64, 8, 10.0), (64, 64, 1, 1.0), (50, 300, 6, 0.05),
+                                         (400, 64, 8, 10.0),
+                                         # few subsets, many positions: the subset table in 4 / 8 copies (stats_ntab_rep)
+                                         (800, 20, 2, 1.0), (2500, 12, 3, 1.0), (64, 64, 1, 1.0), (50, 300, 6, 0.05),
                                          # lane groups of 16 / 32 lanes with ragged last chunks and a ragged last wavefront pass
                                          (91, 48, 6, 1.0), (77, 33, 4, 1.0), (53, 100, 5, 1.0), (35, 32, 7, 1.0), (9, 20, 2, 1.0)])
 def test_stats_stage1_matches_spec(ctx, V, S, G, scale):
@@ -426,7 +428,7 @@ def test_gibbs_chain_recovers_asymmetric_eta(spec_ctx):
 
 # ---------------------------------------------------------------- A6 full iteration
 @pytest.mark.parametrize("spec", [2, 1])
-@pytest.mark.parametrize("V,S,G,n_iter", [(400, 16, 5, 12), (600, 64, 8, 8), (150, 96, 3, 6), (200, 20, 11, 4)])
+@pytest.mark.parametrize("V,S,G,n_iter", [(400, 16, 5, 12), (600, 64, 8, 8), (150, 96, 3, 6), (200, 20, 11, 4), (900, 10, 2, 4)])
 def test_gibbs_update_is_self_consistent_with_oracle(ctx, V, S, G, n_iter, spec):
     """every piece of every iteration of the device loop against the oracle, in the reference's order
     (HaploSNP_Sampler.py:341-358): the mu/E sums + gamma/eta draws from the restated counter-based specs (spec 2:

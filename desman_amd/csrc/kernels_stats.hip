@@ -341,13 +341,16 @@ int stats_spec(const dsm_ctx *c)
 
 // Few subsets and many positions put thousands of atomics on every counter of the subset table (3 V / 2^G each: 9 375 at
 // V = 50k, G = 4 -- 410 us of same-address serialisation).  The table is then kept in `rep` copies, workgroup b adds to copy
-// b mod rep and stage 2 reads their sum: integers, so nothing changes but the time.  rep = 1 from ~256 atomics per counter down
-// (config 3: 117, config 5: 37).
+// b mod rep and stage 2 reads their sum: integers, so nothing changes but the time.  rep = 1 up to 128 atomics per counter
+// (config 3: 117, config 5: 37); the cost is not linear in that number -- V = 20k, S = 64, G = 8 (234 per counter) takes 145 us
+// with one table and 88 with two, config 3 the same 48 us with one or two -- and every copy is one more read per subset for
+// stage 2's root level (config 3 with 8 copies: Dirichlet launch 21 -> 25 us).  DESMAN_HIP_NTAB_PER overrides the 128.
 int stats_ntab_rep(const dsm_ctx *c)
 {
     const double per = 3.0 * (double)c->V / (double)((size_t)1 << c->G);
     int rep = 1;
-    while (per / rep > 256.0 && rep < 64 && (size_t)(2 * rep) * ((size_t)1 << c->G) * (size_t)c->S * 4 <= ((size_t)64 << 20)) rep *= 2;
+    static const double lim = getenv("DESMAN_HIP_NTAB_PER") ? atof(getenv("DESMAN_HIP_NTAB_PER")) : 128.0;
+    while (per / rep > lim && rep < 64 && (size_t)(2 * rep) * ((size_t)1 << c->G) * (size_t)c->S * 4 <= ((size_t)64 << 20)) rep *= 2;
     return rep;
 }
 

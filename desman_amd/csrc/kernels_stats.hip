@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void binom_test_kernel(int kind, uint32_t n, d
 // =====================================================================
 // spec v2 applies when the subset table fits (G <= 16, 2^G * S * 4 B <= 64 MB, every sample's depth < 2^32).  Where both
 // apply the cheaper one runs, by a cost model of the two passes fitted on MI355X (us per iteration, 933 x 64 ... 50k x 96):
-//   per-read pass (v1)   25 + 0.069 G per million reads                   -- O(depth x G): 0.55 at G = 8, 0.83 at G = 12
+//   per-read pass (v1)   25 + (0.25 + 0.02 G + 0.0029 G^2) per million reads   -- O(depth x G): 0.30 at G = 2, 0.60 at 8, 1.31 at 16
 //   aggregated pass (v2) 24 + 0.062 per thousand cells + 14 + 0.03 x 3V / (2^G rep)   -- O(cells); cells = V x S rounded up to
 //                        the kernel's lane groups; + 14 for stage 2 in the Dirichlet launch (G >= 10: its own launch over
 //                        2^G subsets per sample, + 0.012 x 2^G); the last term is the
@@ -333,7 +333,8 @@ int stats_spec(const dsm_ctx *c)
     for (int64_t d : c->depth) reads += (double)d;
     const int lpv = stats_agg_lpv(c->S);
     const double cells = (double)c->V * (double)((c->S + lpv - 1) / lpv * lpv);
-    const double t1 = 25.0 + 0.069e-6 * reads * (double)std::max(c->G, 2);        // G - 1 threshold tests per read: 0.55 per million at G = 8
+    const double g = (double)c->G;
+    const double t1 = 25.0 + (0.25 + 0.02 * g + 0.0029 * g * g) * 1e-6 * reads;    // per read: its uniform + G - 1 threshold tests (0.30 / 0.60 / 1.31 at G = 2 / 8 / 16)
     const double stage2 = 14.0 + (c->G >= 10 ? 0.012 * (double)(1u << c->G) : 0.0);      // its own launch from G = 10: 62 us at G = 12
     const double t2 = 24.0 + stage2 + 0.062e-3 * cells + 0.03 * 3.0 * (double)c->V / ((double)(1u << c->G) * stats_ntab_rep(c));
     return t2 < t1 ? 2 : 1;

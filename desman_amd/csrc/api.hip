@@ -1173,10 +1173,10 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     // it takes the host (and the runtime's launch lock) out of the loop: 35-chain sweep at V=1000, 4 chains at a
     // time: 4.2 s eager -> 2.2 s replayed.  desman_amd.chains opts in through DESMAN_HIP_NMFT_GRAPH=1.
     // (Timing mode records events per launch -> eager.)
-    auto enqueue_iteration = [&]() -> int {
+    auto enqueue_iteration = [&](int n) -> int {                                     // n = launch number of this call (parity slot)
         if (!wave) TRY(k_nmft_pass_a(c));
         // the control kernel decides ON THE DEVICE whether this update runs at all (Init_NMFT.py:106)
-        TRY(k_nmft_gamma(c, max_iter, min_change, fix_gamma, adjust));              // also records div_trace[it]
+        TRY(k_nmft_gamma(c, max_iter, min_change, fix_gamma, adjust, n & 1));       // also records div_trace[it]
         TRY(wave ? k_nmft_wave(c, adjust, 1) : k_nmft_pass_b(c, adjust));           // exits at once when stopped
         return DSM_OK;
     };
@@ -1188,7 +1188,7 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     if (use_graph) {
         HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         int rc = DSM_OK;
-        for (int k = 0; k < BATCH && rc == DSM_OK; ++k) rc = enqueue_iteration();
+        for (int k = 0; k < BATCH && rc == DSM_OK; ++k) rc = enqueue_iteration(k);      // BATCH is even: node k keeps its parity in every replay
         hipError_t e = hipStreamEndCapture(c->stream, &graph);
         if (rc != DSM_OK) return rc;
         HIP_TRY(e);
@@ -1197,7 +1197,7 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     // iterations 0..max_iter inclusive evaluate the objective; the last one can only stop
     for (int launched = 0; launched <= max_iter;) {
         if (use_graph) { HIP_TRY(hipGraphLaunch(gexec, c->stream)); launched += BATCH; }
-        else { for (int k = 0; k < BATCH && launched <= max_iter; ++k, ++launched) TRY(enqueue_iteration()); }
+        else { for (int k = 0; k < BATCH && launched <= max_iter; ++k, ++launched) TRY(enqueue_iteration(launched)); }
         HIP_TRY(hipMemcpyAsync(h, ctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (h[2] != 0.0) break;
@@ -1264,7 +1264,7 @@ extern "C" int dsm_batch_nmft_factorize(dsm_ctx *const *ctxs, int K, int max_ite
     std::vector<double> h((size_t)K * 7, 0.0);
     for (int launched = 0; launched <= max_iter;) {
         for (int i = 0; i < BATCH && launched <= max_iter; ++i, ++launched) {
-            for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_gamma(ctxs[k], max_iter, min_change, fix_gamma, adjust)); }
+            for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_gamma(ctxs[k], max_iter, min_change, fix_gamma, adjust, launched & 1)); }
             for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_wave(ctxs[k], adjust, 1)); }
         }
         for (int k = 0; k < K; ++k)
@@ -1298,7 +1298,7 @@ extern "C" int dsm_nmft_objective(dsm_ctx *c, double *div)
     double *ctl = c->nstat + (size_t)G * S + 2 * G;
     HIP_TRY(hipMemsetAsync(ctl, 0, 16 * sizeof(double), c->stream));
     TRY(nmft_use_wave(c) ? k_nmft_wave(c, 0, 0) : k_nmft_pass_a(c));
-    TRY(k_nmft_gamma(c, 0, 0.0, 1, 0));        // max_iter = 0: reduce + record div only
+    TRY(k_nmft_gamma(c, 0, 0.0, 1, 0, 0));     // max_iter = 0: reduce + record div only
     HIP_TRY(hipMemcpyAsync(div, ctl, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSM_OK;

@@ -179,7 +179,7 @@ int k_finalize(dsm_ctx *c, int nblocks, int it, int star_mode, const double *pri
 int k_nmft_freq(dsm_ctx *c);
 int k_nmft_clamp(dsm_ctx *c);
 int k_nmft_pass_a(dsm_ctx *c);
-int k_nmft_gamma(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int adjust);
+int k_nmft_gamma(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int adjust, int parity);   // parity = launch number & 1 since the control words were zeroed
 int k_nmft_pass_b(dsm_ctx *c, int adjust);
 int k_nmft_get_tau(dsm_ctx *c, uint64_t *d_packed);
 int nmft_grid(dsm_ctx *c);

@@ -232,6 +232,89 @@ __global__ __launch_bounds__(1024) void nmft_gamma_kernel(NmftGammaParams q) { n
 __global__ __launch_bounds__(1024) void nmft_gamma_kernel_b(BatchArgs<NmftGammaParams> b) { nmft_gamma_body(b.p[blockIdx.y]); }
 
 // ---------------------------------------------------------------------------
+// reduce + gamma / control in ONE launch of NMFT_RG_WGS workgroups (an update is then two dependent launches, not three).
+// Workgroup b owns the sample columns [b cw, (b+1) cw): it sums the workgroup partials of the statistics it needs -- its
+// own G x cw numerators, the G row sums and the objective -- exactly as nmft_reduce_kernel does (lane-strided partial sums,
+// fixed-order butterfly: the same bits), runs the stop test (every workgroup for itself, from words nobody writes in this
+// launch) and updates its columns of gamma.  Control words: the iteration index and the previous objective live in two
+// parity slots; launch number n reads slot n & 1 and workgroup 0 writes slot 1 - (n & 1) for the next launch, so the launch
+// has no reader of a word it writes.  The parity is a kernel argument (a captured batch of 64 iterations replays with the
+// same arguments per node).
+//   ctl: [0] div  [2] done  [3] updates run  [4 + p] previous div  [6 + p] iteration index
+// ---------------------------------------------------------------------------
+#define NMFT_RG_WGS 8
+struct NmftRgParams {
+    const double *partial; int nblk;
+    double *stat; int S, G, max_iter; double min_change; int fix_gamma, adjust, parity;
+    double *gam, *gam_raw, *ctl, *div_trace;
+};
+__device__ __forceinline__ void nmft_rg_body(const NmftRgParams &q)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_g[];
+    double *red = reinterpret_cast<double *>(smem_g);              // [G cw] numerators of the own columns, [G] row sums, [1] objective
+    const double *__restrict__ partial = q.partial;
+    double *__restrict__ ctl = q.ctl;
+    if (ctl[2] != 0.0) return;                                     // stopped in an earlier launch (set in this one only when
+                                                                   // no workgroup has anything left to do)
+    const int S = q.S, G = q.G, nblk = q.nblk, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nwg = (int)gridDim.x, cw = (S + nwg - 1) / nwg, s_lo = (int)blockIdx.x * cw;
+    const int ncol = s_lo < S ? (S - s_lo < cw ? S - s_lo : cw) : 0;
+    const int nown = G * ncol, nneed = nown + G + 1;
+    for (int i = wv; i < nneed; i += 16) {
+        // statistic number `out` of the update kernels' partial table: numerator (g, s) = g S + s, row sum g = G S + g,
+        // objective = G S + G
+        int out;
+        if (i < nown) { const int g = i / ncol, s = s_lo + i % ncol; out = g * S + s; }
+        else out = G * S + (i - nown);
+        double a = 0.0;
+        for (int b = lane; b < nblk; b += 64) a += partial[(size_t)out * nblk + b];
+        a = group_allreduce_sum<64>(a);
+        if (lane == 0) {
+            red[i] = a;
+            if (i < nown || blockIdx.x == 0) q.stat[out] = a;
+        }
+    }
+    __syncthreads();
+    const int p = q.parity & 1;
+    const int it = (int)ctl[6 + p];
+    const double div = red[nown + G];
+    const double prev = (it == 0) ? 0.0 : ctl[4 + p];
+    const bool go = (it < q.max_iter) && (fabs(prev - div) > q.min_change);      // Init_NMFT.py:106
+    if (blockIdx.x == 0 && tid == 0) {
+        ctl[0] = div;
+        ctl[4 + (1 - p)] = div;
+        ctl[6 + (1 - p)] = (double)(it + 1);
+        ctl[3] = (double)it;
+        if (!go) ctl[2] = 1.0;
+        if (q.div_trace) q.div_trace[it] = div;
+    }
+    if (!go || q.fix_gamma) return;                                               // uniform over the workgroup
+    double *val = red + nneed;                                                    // [G][SC] one chunk of the own columns
+    const int SC = 1024 / G;                                                      // columns per chunk (all G values of a column at once)
+    for (int c0 = 0; c0 < ncol; c0 += SC) {
+        const int g = tid / SC, cc = tid % SC, c = c0 + cc, s = s_lo + c;
+        const bool live = g < G && c < ncol;
+        double v = 1.0;                                                           // :168
+        if (live && G > 1) v = q.gam[(size_t)g * S + s] * (nzd(red[g * ncol + c]) / nzd(red[nown + g]));   // :163
+        if (g < G) val[g * SC + cc] = v;
+        __syncthreads();
+        if (live) {
+            if (G > 1) {
+                double tot = 0.0;
+                for (int k = 0; k < G; ++k) tot += val[k * SC + cc];              // :165
+                v = v / tot;                                                      // :166
+            }
+            q.gam_raw[(size_t)g * S + s] = v;                // the tau update of this iteration sees it unclamped
+            if (q.adjust && v < DSM_EPS) v = DSM_EPS;        // _adjustment follows the whole div_update (:88-91,:108)
+            q.gam[(size_t)g * S + s] = v;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void nmft_rg_kernel(NmftRgParams q) { nmft_rg_body(q); }
+__global__ __launch_bounds__(1024) void nmft_rg_kernel_b(BatchArgs<NmftRgParams> b) { nmft_rg_body(b.p[blockIdx.y]); }
+
+// ---------------------------------------------------------------------------
 // pass B.  A workgroup takes VT variants (4*VT rows) at a time:
 //   step 1  threads <-> (row, s):  Q'[row][s] = F (/) (tau.gamma)        -> LDS
 //   step 2  threads <-> (row, g):  num[row][g] = sum_s Q'[row][s] gamma[g][s]
@@ -563,10 +646,27 @@ int k_nmft_pass_a(dsm_ctx *c)
     return DSM_OK;
 }
 
-int k_nmft_gamma(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int adjust)
+int k_nmft_gamma(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int adjust, int parity)
 {
     KTimer tm(c, DSM_K_NMFT_G);
     const int nout = c->nG * c->S + c->nG + 1;
+    // Few workgroup partials (V <= ~2000 positions, where a chain's ~4 500 updates are most of its run): reduce + gamma /
+    // control as ONE launch of up to 32 workgroups (nmft_rg_kernel) -- V = 1000, S = 32, G = 4: 12.7 instead of 16.8 us per
+    // update.  More partials: the reduction as its own launch over all its outputs, then the one-workgroup gamma / control
+    // launch (config 3: 34 us per update; fused, with one workgroup per sample column, 35).
+    static const bool no_fuse = getenv("DESMAN_HIP_NMFT_NO_FUSED_REDUCE") != nullptr;
+    if (c->npart_cols <= 128 && !no_fuse) {
+        const int nwg = std::min(c->S, 32);
+        const int cw = (c->S + nwg - 1) / nwg;
+        const size_t sh = ((size_t)c->nG * cw + c->nG + 1 + 1024) * sizeof(double);
+        const NmftRgParams q{c->npart, c->npart_cols, c->nstat, c->S, c->nG, max_iter, min_change, fix_gamma, adjust, parity,
+                             c->ngam, c->ngam_raw, NMFT_CTL(c), c->ndiv_trace};
+        LAUNCH_OR_COLLECT(NmftRgParams, q,
+                          hipLaunchKernelGGL(nmft_rg_kernel, dim3(nwg), dim3(1024), sh, c->stream, q),
+                          hipLaunchKernelGGL(nmft_rg_kernel_b, dim3(nwg, K), dim3(1024), sh, c->stream, acc));
+        HIP_TRY(hipGetLastError());
+        return DSM_OK;
+    }
     const NmftReduceParams r{c->npart, c->npart_cols, nout, NMFT_CTL(c), c->nstat};
     const NmftGammaParams g{c->nstat, c->S, c->nG, max_iter, min_change, fix_gamma, adjust, c->ngam, c->ngam_raw, NMFT_CTL(c), c->ndiv_trace};
     if (g_batch.K) {                                         // both launches of K chains at once (dsm_host.h: BatchCtl)

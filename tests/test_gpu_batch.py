@@ -39,7 +39,8 @@ def _same(a, b):
 
 # shapes: fused stage 2 (G < 10) with lane groups of 16 / 32 / 64, the stand-alone stage-2 launch (G >= 10), several
 # MT19937 chunks (n_iter > 1 + 2 + 3), a second call on the same contexts (stream positions, buffers kept)
-@pytest.mark.parametrize("V,S,G,K,n_iter", [(300, 16, 5, 3, 12), (200, 64, 8, 5, 9), (150, 40, 3, 8, 7), (90, 20, 11, 2, 5), (64, 100, 4, 4, 6)])
+@pytest.mark.parametrize("V,S,G,K,n_iter", [(300, 16, 5, 3, 12), (200, 64, 8, 5, 9), (150, 40, 3, 8, 7), (90, 20, 11, 2, 5), (64, 100, 4, 4, 6),
+                                             (900, 10, 2, 3, 5)])      # the last: subset table in 8 copies
 def test_batch_equals_chains_run_one_by_one(V, S, G, K, n_iter):
     counts, _, _ = synth_counts(V, S, G, seed=500 + V)
     states = [random_state(V, S, G, seed=600 + k) for k in range(K)]

@@ -246,3 +246,32 @@ def test_gsweep_with_batched_replicates_equals_chains_run_one_by_one(tmp_path, m
             log = open("%s_%d_%d/log_file.txt" % (bat, g, r)).read()
             assert "Gibbs Iter" in log and "sampler seed %d" % r in log and "tau-only sampling" in log
             assert "one by one" not in log                         # every batched stage ran batched
+
+
+def test_batched_replicates_whose_haplotype_counts_diverge_finish_in_groups(tmp_path, monkeypatch):
+    """cli.main_replicates: a replicate that loses a haplotype in removeDegenerate no longer has the shape of the others;
+    it finishes on its own, the rest stay batched, and every chain still writes its complete set of files"""
+    from desman_amd import cli
+    from desman_amd.HaploSNP_Sampler import HaploSNP_Sampler
+    V, S, G = 150, 10, 4
+    counts, _, _ = synth_counts(V, S, G, seed=77)
+    freq = str(tmp_path / "syn.freq")
+    _write_freq(freq, counts)
+    real = HaploSNP_Sampler.removeDegenerate
+    seen = []
+
+    def degenerate_second_chain(self):
+        seen.append(self)
+        if len(seen) == 2:                                   # the second replicate: make haplotype 1 a copy of haplotype 0
+            self.tau[:, 1, :] = self.tau[:, 0, :]
+            self.updateTauIndices()
+        return real(self)
+    monkeypatch.setattr(HaploSNP_Sampler, "removeDegenerate", degenerate_second_chain)
+    outs = [str(tmp_path / ("rep%d" % k)) for k in range(3)]
+    chains_ = cli.main_replicates([[freq, "-g", str(G), "-s", str(k), "-i", "25", "-r", "90", "-o", outs[k]] for k in range(3)])
+    assert [c.G for c in chains_] == [G, G - 1, G]
+    for k, o in enumerate(outs):
+        fit = open(os.path.join(o, "fit.txt")).read().strip().split(",")
+        assert int(fit[1]) == G and int(fit[2]) == (G - 1 if k == 1 else G)
+        for f in ("Filtered_Tau_star.csv", "Gamma_mean.csv", "Eta_star.csv", "Collated_Tau_star.csv", "fitP.txt"):
+            assert os.path.exists(os.path.join(o, f)), (k, f)

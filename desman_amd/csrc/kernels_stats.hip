@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void binom_test_kernel(int kind, uint32_t n, d
 // spec v2 applies when the subset table fits (G <= 16, 2^G * S * 4 B <= 64 MB, every sample's depth < 2^32).  Where both
 // apply the cheaper one runs, by a cost model of the two passes fitted on MI355X (us per iteration, 933 x 64 ... 50k x 96):
 //   per-read pass (v1)   25 + (0.25 + 0.02 G + 0.0029 G^2) per million reads   -- O(depth x G): 0.30 at G = 2, 0.60 at 8, 1.31 at 16
-//   aggregated pass (v2) 24 + 0.062 per thousand cells + 14 + 0.03 x 3V / (2^G rep)   -- O(cells); cells = V x S rounded up to
+//   aggregated pass (v2) 24 + 0.062 per thousand cells + 14 + 0.03 x 3V / 2^G (one table; ~0 with copies)   -- O(cells); cells = V x S rounded up to
 //                        the kernel's lane groups; + 14 for stage 2 in the Dirichlet launch (G >= 10: its own launch over
 //                        2^G subsets per sample, + 0.012 x 2^G); the last term is the
 //                        same-address contention of the subset-table atomics (3 per cell onto 2^G x S counters: 9 375 per
@@ -336,22 +336,30 @@ int stats_spec(const dsm_ctx *c)
     const double g = (double)c->G;
     const double t1 = 25.0 + (0.25 + 0.02 * g + 0.0029 * g * g) * 1e-6 * reads;    // per read: its uniform + G - 1 threshold tests (0.30 / 0.60 / 1.31 at G = 2 / 8 / 16)
     const double stage2 = 14.0 + (c->G >= 10 ? 0.012 * (double)(1u << c->G) : 0.0);      // its own launch from G = 10: 62 us at G = 12
-    const double t2 = 24.0 + stage2 + 0.062e-3 * cells + 0.03 * 3.0 * (double)c->V / ((double)(1u << c->G) * stats_ntab_rep(c));
+    const int rep = stats_ntab_rep(c);
+    const double per = 3.0 * (double)c->V / (double)(1u << c->G);                // atomics per counter of the subset table
+    const double t2 = 24.0 + stage2 + 0.062e-3 * cells + (rep == 1 ? 0.03 * per : 0.003 * per / rep);   // with copies: no measurable penalty
     return t2 < t1 ? 2 : 1;
 }
 
 // Few subsets and many positions put thousands of atomics on every counter of the subset table (3 V / 2^G each: 9 375 at
 // V = 50k, G = 4 -- 410 us of same-address serialisation).  The table is then kept in `rep` copies, workgroup b adds to copy
-// b mod rep and stage 2 reads their sum: integers, so nothing changes but the time.  rep = 1 up to 128 atomics per counter
-// (config 3: 117, config 5: 37); the cost is not linear in that number -- V = 20k, S = 64, G = 8 (234 per counter) takes 145 us
-// with one table and 88 with two, config 3 the same 48 us with one or two -- and every copy is one more read per subset for
-// stage 2's root level (config 3 with 8 copies: Dirichlet launch 21 -> 25 us).  DESMAN_HIP_NTAB_PER overrides the 128.
+// b mod rep and stage 2 reads their sum: integers, so nothing changes but the time.  What decides is the rate of atomics per
+// 64 B line of the table(s): stage 1 issues 3 per cell and takes ~0.06 us per thousand cells, so the rate is ~48 000 /
+// (lines x rep) per us whatever V is, and the measurements (scripts/shape_scan.py) put the knee at
+// lines x rep ~ 300: V = 100k, S = 64, G = 2 (16 lines) 585 us with 16 copies, 304 with 32; V = 50k, S = 96, G = 5 (192 lines)
+// 472 us with one table, 300 with two; V = 20k, S = 32, G = 5 (64 lines) 0.127 ms per iteration with two copies, 0.094 with
+// sixteen.  So: one table while a counter takes <= 128 atomics (config 3: 117, config 5: 37); otherwise at least two copies
+// (V = 20k, S = 64, G = 8: 145 -> 88 us) and as many as bring lines x rep to 384 -- every copy is one more read per subset at
+// stage 2's root (64 copies: +20 us on the Dirichlet launch).  DESMAN_HIP_NTAB_LINES overrides the 384.
 int stats_ntab_rep(const dsm_ctx *c)
 {
+    static const double want = getenv("DESMAN_HIP_NTAB_LINES") ? atof(getenv("DESMAN_HIP_NTAB_LINES")) : 384.0;
     const double per = 3.0 * (double)c->V / (double)((size_t)1 << c->G);
-    int rep = 1;
-    static const double lim = getenv("DESMAN_HIP_NTAB_PER") ? atof(getenv("DESMAN_HIP_NTAB_PER")) : 128.0;
-    while (per / rep > lim && rep < 64 && (size_t)(2 * rep) * ((size_t)1 << c->G) * (size_t)c->S * 4 <= ((size_t)64 << 20)) rep *= 2;
+    if (per <= 128.0) return 1;
+    const double lines = (double)((((size_t)1 << c->G) * (size_t)c->S * 4 + 63) / 64);
+    int rep = 2;
+    while (lines * rep < want && rep < 64 && (size_t)(2 * rep) * ((size_t)1 << c->G) * (size_t)c->S * 4 <= ((size_t)64 << 20)) rep *= 2;
     return rep;
 }
 

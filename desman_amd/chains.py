@@ -21,9 +21,10 @@ REC_FIELDS = ("chain", "G", "seed", "G_final", "lp_star", "mean_dev", "iters", "
 
 
 def chain_cost(V, S, G):
-    """relative cost of one Gibbs iteration: the per-read pass is ~linear in G, the tau
-    sweep does G sequential draws each touching G haplotypes."""
-    return float(V) * float(S) * (4.0 * G + 1.0 * G * G)
+    """relative cost of one Gibbs iteration, as measured on MI355X (profiles/r02_shape_scan.txt: V = 50k, S = 96 takes
+    0.32 / 0.41 / 0.45 / 0.73 ms at G = 2 / 4 / 5 / 12, i.e. ~0.25 + 0.04 G): the mu/E pass costs the same per cell
+    whatever G is, the tau sweep grows with G.  (Round 1's 4 G + G^2 over-weighted the large-G chains 7-fold.)"""
+    return float(V) * float(S) * (6.0 + float(G))
 
 
 def lpt_assign(costs, n_ranks):

@@ -132,6 +132,7 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
             return out
         if concurrency > 1 and len(unit_bins[rank]) > 1:         # units (different G) side by side: their host work overlaps
             from concurrent.futures import ThreadPoolExecutor
+            os.environ.setdefault("DESMAN_HIP_ONE_STREAM", "1")  # one hardware queue per chain (see below)
             with ThreadPoolExecutor(max_workers=concurrency) as pool:
                 first = [r for rs in pool.map(unit, unit_bins[rank]) for r in rs]
         else:
@@ -139,6 +140,9 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
     elif concurrency > 1 and len(bins[rank]) > 1:
         from concurrent.futures import ThreadPoolExecutor
         os.environ.setdefault("DESMAN_HIP_NMFT_GRAPH", "1")      # replayed NMFT batches: see api.hip (dsm_nmft_factorize)
+        # more than four live hardware queues stretch every small kernel to ~55 us: the MT19937 refill of
+        # a chain then runs on the chain's own stream (35-chain sweep at V = 1000, 8 at a time: 4.2 -> 2.6 s)
+        os.environ.setdefault("DESMAN_HIP_ONE_STREAM", "1")
         with ThreadPoolExecutor(max_workers=concurrency) as pool:
             first = list(pool.map(one, bins[rank]))          # LPT order: longest chains start first
     else:

@@ -7,7 +7,7 @@ for V in (2000, 20000, 100000):
             if V * S > 100000 * 128: continue
             steps = 40 if V * S > 2e6 else 100
             out = subprocess.run([sys.executable, "bench.py", "--V", str(V), "--S", str(S), "--G", str(G), "--steps", str(steps),
-                                  "--warmup", "10", "--no-cpu-baseline"], capture_output=True, text=True).stdout.strip().split("\n")[-1]
+                                  "--warmup", "10", "--no-cpu-baseline", "--batch", "0"], capture_output=True, text=True).stdout.strip().split("\n")[-1]
             try:
                 d = json.loads(out)
                 k = d["roofline"]["kernels_us"]

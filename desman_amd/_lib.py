@@ -63,6 +63,7 @@ SIGNATURES = {
     "dsm_ctx_stats_spec": (_i, [_vp]),
     "dsm_ctx_sweep_stats": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _i]),
     "dsm_ctx_set_tau_screen": (_i, [_vp, _i]),
+    "dsm_ctx_set_nmft_fused": (_i, [_vp, _i]),
     "dsm_ctx_debug_log2f": (_i, [_vp, _vp, _vp, C.c_size_t]),
     "dsm_ctx_force_stats_spec": (_i, [_vp, _i]),
     "dsm_ctx_debug_stage1": (_i, [_vp, C.c_uint32, _vp, _u64p]),
@@ -282,6 +283,10 @@ class Context:
     def set_tau_screen(self, on):
         """A/B switch: False = every step of the tau sweep in fp64 (same results)"""
         check(self.lib.dsm_ctx_set_tau_screen(self._h, 1 if on else 0))
+
+    def set_nmft_fused(self, mode=-1):
+        """reduce + gamma/control of an NMFT update: -1 = by size, 0 = two launches, 1 = one fused launch (same results)"""
+        check(self.lib.dsm_ctx_set_nmft_fused(self._h, int(mode)))
 
     def sweep_stats(self, reset=False):
         """(wavefront-steps of the tau sweeps so far, of which evaluated in fp64 because the screening pass

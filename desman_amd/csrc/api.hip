@@ -32,9 +32,10 @@ extern "C" int dsm_device_count(void)
     return n;
 }
 
-static const char *const k_names[DSM_K_COUNT] = {"stats_kernel", "dirichlet_kernel", "tau_kernel", "finalize_kernel",
-                                                 "mt_fill_kernel", "nmft_pass_a", "nmft_gamma", "nmft_pass_b",
-                                                 "stats_stage2_kernel"};
+static const char *const k_names[] = {"stats_kernel", "dirichlet_kernel", "tau_kernel", "finalize_kernel",
+                                      "mt_fill_kernel", "nmft_pass_a", "nmft_gamma", "nmft_pass_b",
+                                      "stats_stage2_kernel", "stats_big_kernel"};
+static_assert(sizeof(k_names) / sizeof(k_names[0]) == DSM_K_COUNT, "one name per DSM_K_* id");
 extern "C" const char *dsm_kernel_name(int k) { return (k >= 0 && k < DSM_K_COUNT) ? k_names[k] : "?"; }
 
 // ---------------------------------------------------------------- timing
@@ -151,6 +152,7 @@ extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
     dsm_ctx *c = new dsm_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (getenv("DESMAN_HIP_NMFT_NO_FUSED_REDUCE")) c->nmft_fused = 0;    // A/B switch, see dsm_ctx_set_nmft_fused
     if (getenv("DESMAN_HIP_ONE_STREAM")) c->stream_rng = c->stream;      // several chains per GPU: one hardware queue each
     else {   // the single-workgroup MT19937 refill must not queue behind a full grid of the main stream
         int lo = 0, hi = 0;
@@ -1015,6 +1017,15 @@ extern "C" int dsm_ctx_debug_log2f(dsm_ctx *c, const float *in, float *out, size
     return DSM_OK;
 }
 
+// Which form of the reduce + gamma/control step of an NMFT update runs (kernels_nmft.hip: k_nmft_gamma): -1 = by the number of
+// workgroup partials (the default), 0 = reduction and control as two launches, 1 = the fused launch.  Same factors bit for bit.
+extern "C" int dsm_ctx_set_nmft_fused(dsm_ctx *c, int mode)
+{
+    if (!c || mode < -1 || mode > 1) { dsm_set_error("set_nmft_fused: mode -1, 0 or 1"); return DSM_ERR_ARG; }
+    c->nmft_fused = mode;
+    return DSM_OK;
+}
+
 // A/B switch for tests and measurements: with on = 0 every sweep step is evaluated in fp64 (the results are the same either way)
 extern "C" int dsm_ctx_set_tau_screen(dsm_ctx *c, int on)
 {
@@ -1234,18 +1245,21 @@ extern "C" int dsm_batch_nmft_factorize(dsm_ctx *const *ctxs, int K, int max_ite
     dsm_ctx *const lead = ctxs[0];
     BIND(lead);
     const int G = lead->nG, S = lead->S;
-    struct Saved { hipStream_t st; bool timing; };
+    struct Saved { hipStream_t st; bool timing; int fused; };
     std::vector<Saved> saved(K);
     std::vector<Scratch<double>> traces(K);
     for (int k = 0; k < K; ++k) {
         dsm_ctx *c = ctxs[k];
         HIP_TRY(hipStreamSynchronize(c->stream));
-        saved[k] = Saved{c->stream, c->timing};
-        c->stream = lead->stream; c->timing = false;
+        saved[k] = Saved{c->stream, c->timing, c->nmft_fused};
+        c->stream = lead->stream; c->timing = false; c->nmft_fused = saved[0].fused;   // one launch form for the whole batch: the leader's
     }
     auto restore = [&]() {
         g_batch = BatchCtl{};
-        for (int k = 0; k < K; ++k) { ctxs[k]->stream = saved[k].st; ctxs[k]->timing = saved[k].timing; ctxs[k]->ndiv_trace = nullptr; }
+        for (int k = 0; k < K; ++k) {
+            ctxs[k]->stream = saved[k].st; ctxs[k]->timing = saved[k].timing; ctxs[k]->nmft_fused = saved[k].fused;
+            ctxs[k]->ndiv_trace = nullptr;
+        }
     };
 #define BTRY(expr) do { int _r = (expr); if (_r != DSM_OK) { (void)hipStreamSynchronize(lead->stream); restore(); return _r; } } while (0)
 #define BHIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { dsm_set_error("%s failed: %s", #expr, hipGetErrorString(_e)); (void)hipStreamSynchronize(lead->stream); restore(); return DSM_ERR_HIP; } } while (0)

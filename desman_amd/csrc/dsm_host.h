@@ -131,6 +131,7 @@ struct dsm_ctx {
     double *ndiv_trace = nullptr;   // objective after every update of the running factorize (or null)
     int nG = 0;
     int nmft_blocks = 0;
+    int nmft_fused = -1;            // reduce + gamma/control of an update as one launch: -1 = by size (<= 128 partials), 0 = never, 1 = always
     // timing
     bool timing = false;
     std::vector<TimedSpan> spans;

@@ -654,8 +654,9 @@ int k_nmft_gamma(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int
     // control as ONE launch of up to 32 workgroups (nmft_rg_kernel) -- V = 1000, S = 32, G = 4: 12.7 instead of 16.8 us per
     // update.  More partials: the reduction as its own launch over all its outputs, then the one-workgroup gamma / control
     // launch (config 3: 34 us per update; fused, with one workgroup per sample column, 35).
-    static const bool no_fuse = getenv("DESMAN_HIP_NMFT_NO_FUSED_REDUCE") != nullptr;
-    if (c->npart_cols <= 128 && !no_fuse) {
+    // dsm_ctx_set_nmft_fused overrides the size rule per context (tests assert that the two forms agree bit for bit).
+    const bool fuse = c->nmft_fused < 0 ? c->npart_cols <= 128 : c->nmft_fused != 0;
+    if (fuse) {
         const int nwg = std::min(c->S, 32);
         const int cw = (c->S + nwg - 1) / nwg;
         const size_t sh = ((size_t)c->nG * cw + c->nG + 1 + 1024) * sizeof(double);

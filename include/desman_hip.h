@@ -120,8 +120,10 @@ int dsm_ctx_sample_tau(dsm_ctx *ctx, int *nchange, double *logp_out);
  * :266,:276): sum_mu [S][G], esum [4][4] = [observed][true].                 */
 int dsm_ctx_sample_stats(dsm_ctx *ctx, uint32_t iter, uint64_t *sum_mu, uint64_t *esum);
 /* which counter-based specification dsm_ctx_sample_stats / dsm_ctx_gibbs_update follow for the resident
- * shape: 2 = aggregated sampler (oracle/stats_agg.c; G <= 16, a subset table of at most 64 MB, V*S > 65536),
- * 1 = per-read draws (oracle/desman_oracle.c: orc_stats_counter).  dsm_ctx_force_stats_spec: 0 = that rule,
+ * shape: 2 = aggregated sampler (oracle/stats_agg.c; needs G <= 16, a subset table of at most 64 MB and every sample's
+ * depth < 2^32), 1 = per-read draws (oracle/desman_oracle.c: orc_stats_counter).  Where both apply the cheaper pass runs,
+ * by a cost model over the read total, the cells V x S (padded to the kernel's lane groups) and the atomics per subset
+ * counter (kernels_stats.hip: stats_spec) -- a function of the shape and the read totals only, the same on every run.  dsm_ctx_force_stats_spec: 0 = that rule,
  * 1 = always spec 1, 2 = spec 2 also on small problems (G <= 16 still required).                     */
 int dsm_ctx_stats_spec(dsm_ctx *ctx);
 int dsm_ctx_force_stats_spec(dsm_ctx *ctx, int spec);
@@ -282,6 +284,10 @@ int dsm_kl_assign(int device, const double *cov, const double *delta, double *et
 int dsm_ctx_sweep_stats(dsm_ctx *ctx, uint64_t *steps, uint64_t *exact_steps, int mode);
 /* test hook: out[i] = the hardware log2 (v_log_f32) of in[i], the logarithm of the screening pass */
 int dsm_ctx_debug_log2f(dsm_ctx *ctx, const float *in, float *out, size_t n);
+/* reduce + gamma/control step of an NMFT update (Init_NMFT.py:163-168 and the stop test :106): -1 = one fused launch while the
+   update kernel leaves <= 128 workgroup partials, two launches above (default); 0 = always two; 1 = always fused.  The factors,
+   update counts and objective traces do not depend on it (tests/test_gpu_fullsize.py asserts bit-equality). */
+int dsm_ctx_set_nmft_fused(dsm_ctx *ctx, int mode);
 /* on = 0: every step of the tau sweep in fp64 (A/B switch: the results do not depend on it) */
 int dsm_ctx_set_tau_screen(dsm_ctx *ctx, int on);
 int dsm_ctx_set_timing(dsm_ctx *ctx, int on);

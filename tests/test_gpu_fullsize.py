@@ -61,3 +61,116 @@ def test_full_size_sweep_loglik_and_stats_invariants(V, S, G):
     assert tr["ll"][-1] == pytest.approx(cbind.loglik(cbind.onehot_to_idx(t), g, e, counts), rel=1e-12)
     np.testing.assert_allclose(g.sum(axis=1), 1.0, rtol=1e-12)
     ctx.close()
+
+
+# ---------------------------------------------------------------- A10/A11 at BASELINE sizes
+# Init_NMFT.factorize (/root/reference/desman/Init_NMFT.py:98-115), div_update (:158-181), factorize_tau / div_update_tau
+# (:134-149, :192-205), get_tau (:230-245) on tables that take the product path of configs 3-5: more than 128 workgroup
+# partials (nmft_reduce_kernel + nmft_gamma_kernel as their own launches) and, above V = 12 288, the grid-stride loop of
+# nmft_mfma_body.  V = 3000 crosses the 128-partial switch from above, V = 2000 sits right below it.
+def _nmft_case(V, S, G, seed=1234):
+    from oracle import ref_numpy as rn
+    counts, _, _ = synth_counts(V, S, G, seed=seed)
+    tau0, gam0 = rn.nmft_random_initialize(np.random.RandomState(seed + 1), V, S, G)
+    return counts, tau0, gam0, cbind.nmft_freq(counts)
+
+
+def _nmft_run(counts, tau0, gam0, fused, fix_gamma, max_iter=20):
+    c = _lib.Context(0)
+    c.set_counts(counts)
+    c.set_nmft_fused(fused)
+    c.nmft_set(tau0, gam0)
+    n, tr = c.nmft_factorize(max_iter=max_iter, min_change=1e-5, fix_gamma=fix_gamma)
+    tau, gam = c.nmft_get()
+    onehot = c.nmft_get_tau()
+    div = c.nmft_objective()
+    c.close()
+    return n, tr, tau, gam, onehot, div
+
+
+@pytest.mark.parametrize("V,S,G", [(10000, 64, 8), (50000, 96, 12), (3000, 64, 8), (2000, 32, 5), (13000, 40, 3)])
+def test_full_size_nmft_factorize_matches_oracle(V, S, G):
+    counts, tau0, gam0, F = _nmft_case(V, S, G)
+    for fix_gamma in (False, True):
+        tc, gc = tau0.copy(), gam0.copy()
+        if fix_gamma:
+            n_ref, tr_ref = cbind.nmft_factorize_tau(F, tc, gc, max_iter=20, min_change=1e-5)
+        else:
+            n_ref, tr_ref = cbind.nmft_factorize(F, tc, gc, max_iter=20, min_change=1e-5)
+        runs = {f: _nmft_run(counts, tau0, gam0, f, fix_gamma) for f in (-1, 0, 1)}
+        n, tr, tau, gam, onehot, div = runs[-1]
+        assert n == n_ref == 20
+        np.testing.assert_allclose(tr, tr_ref, rtol=1e-9)                 # the whole objective trace
+        np.testing.assert_allclose(tau, tc, rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(gam, gc, rtol=1e-6, atol=1e-12)
+        if fix_gamma:
+            assert np.array_equal(gam, gam0)                              # factorize_tau never touches gamma
+        # arg-max of the factor: the oracle's one-hot wherever the device's own factor is not within rounding of a tie
+        ref_idx = cbind.nmft_get_tau(tc, G)
+        own_idx = cbind.nmft_get_tau(tau, G)
+        assert np.array_equal(onehot, cbind.idx_to_onehot(own_idx))       # get_tau of the device = get_tau of its own factor
+        assert (own_idx != ref_idx).mean() < 1e-5
+        assert div == pytest.approx(cbind.nmft_objective(F, tc, gc), rel=1e-9)
+        # fused and two-launch forms of the reduce + gamma/control step: the same bits, on either side of the size rule
+        for f in (0, 1):
+            m, tr_f, tau_f, gam_f, onehot_f, div_f = runs[f]
+            assert m == n and np.array_equal(tr_f, tr) and np.array_equal(tau_f, tau) and np.array_equal(gam_f, gam)
+            assert np.array_equal(onehot_f, onehot) and div_f == div
+
+
+def test_full_size_nmft_stop_rule_fires_at_the_oracles_update():
+    """the |delta div| <= min_change stop (Init_NMFT.py:106) on the two-launch control path: a loose threshold so
+    that the loop stops by itself well before max_iter at V = 10 000."""
+    counts, tau0, gam0, F = _nmft_case(10000, 64, 8, seed=77)
+    tc, gc = tau0.copy(), gam0.copy()
+    n_ref, tr_ref = cbind.nmft_factorize(F, tc, gc, max_iter=200, min_change=30.0)
+    assert 3 < n_ref < 200
+    for fused in (-1, 1):
+        c = _lib.Context(0)
+        c.set_counts(counts)
+        c.set_nmft_fused(fused)
+        c.nmft_set(tau0, gam0)
+        n, tr = c.nmft_factorize(max_iter=200, min_change=30.0)
+        assert n == n_ref and len(tr) == len(tr_ref)
+        np.testing.assert_allclose(tr, tr_ref, rtol=1e-9)
+        tau, gam = c.nmft_get()
+        np.testing.assert_allclose(tau, tc, rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(gam, gc, rtol=1e-6, atol=1e-12)
+        c.close()
+
+
+@pytest.mark.parametrize("V,S,G,K", [(10000, 64, 8, 3), (3000, 48, 5, 2), (13000, 96, 12, 2)])
+def test_full_size_batched_nmft_equals_one_by_one_and_oracle(V, S, G, K):
+    """dsm_batch_nmft_factorize above 128 workgroup partials (nmft_reduce_kernel_b / nmft_gamma_kernel_b and the
+    grid-stride loop of nmft_mfma_kernel_b): chain k ends bit for bit where dsm_nmft_factorize leaves it, and chain 0
+    agrees with the oracle."""
+    from oracle import ref_numpy as rn
+    counts, _, _ = synth_counts(V, S, G, seed=4321)
+    starts = [rn.nmft_random_initialize(np.random.RandomState(100 + k), V, S, G) for k in range(K)]
+    for fix_gamma in (False, True):
+        singles = []
+        for tau0, gam0 in starts:
+            c = _lib.Context(0); c.set_counts(counts); c.nmft_set(tau0, gam0)
+            n, tr = c.nmft_factorize(12, 1e-5, fix_gamma)
+            singles.append((n, tr, c.nmft_get(), c.nmft_get_tau()))
+            c.close()
+        for fused in (-1, 1):
+            ctxs = []
+            for tau0, gam0 in starts:
+                c = _lib.Context(0); c.set_counts(counts); c.nmft_set(tau0, gam0); c.set_nmft_fused(fused)
+                ctxs.append(c)
+            res = _lib.Context.batch_nmft_factorize(ctxs, 12, 1e-5, fix_gamma)
+            for c, (n, tr), (n1, tr1, fac1, oh1) in zip(ctxs, res, singles):
+                fac = c.nmft_get()
+                assert n == n1 and np.array_equal(tr, tr1)
+                assert np.array_equal(fac[0], fac1[0]) and np.array_equal(fac[1], fac1[1])
+                assert np.array_equal(c.nmft_get_tau(), oh1)
+                c.close()
+        F = cbind.nmft_freq(counts)
+        tc, gc = starts[0][0].copy(), starts[0][1].copy()
+        fn = cbind.nmft_factorize_tau if fix_gamma else cbind.nmft_factorize
+        n_ref, tr_ref = fn(F, tc, gc, max_iter=12, min_change=1e-5)
+        assert singles[0][0] == n_ref
+        np.testing.assert_allclose(singles[0][1], tr_ref, rtol=1e-9)
+        np.testing.assert_allclose(singles[0][2][0], tc, rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(singles[0][2][1], gc, rtol=1e-6, atol=1e-12)

@@ -13,6 +13,8 @@ from desman_amd import _lib
 from desman_amd.synth import synth_counts, random_state
 from oracle import cbind, ref_numpy as rn
 
+from _law import LAW_CASES, assert_same_law, law_case, reference_draws
+
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -307,33 +309,31 @@ def test_binomial_and_multinomial_samplers_match_spec(ctx, kind, n, w):
     assert np.array_equal(got, ref)
 
 
-def test_stats_law_matches_reference_sampleMu(spec_ctx):
-    """the one-stage counter-based draw and the reference's two-stage numpy draw
-    (HaploSNP_Sampler.py:284-309) have the same mean: z-test on sum_mu / Esum."""
+@pytest.mark.parametrize("name", sorted(LAW_CASES))
+def test_stats_law_matches_reference_sampleMu(spec_ctx, name):
+    """the counter-based device draws of (sum_mu, Esum) and the reference's two-stage numpy draw
+    (HaploSNP_Sampler.py:284-309, oracle/ref_numpy.py: sample_mu) have the same law: two-sample chi-square on every
+    per-(s,g) marginal of sum_mu and every entry of Esum (2000 draws a side), means and variances; cases: the small
+    shape, G = 10 and 12 (stage 2 as its own launch), x 15 depth (BTRS, deferred lists, stats_big_kernel), and a
+    converged state with eta ~ 0.97 I (rare-outcome inversion).  tests/test_law_cpu.py does the same for the oracle twins."""
     ctx = spec_ctx
-    V, S, G = 30, 6, 3
-    counts, _, _ = synth_counts(V, S, G, seed=40)
-    tau, gamma, eta = random_state(V, S, G, seed=41)
+    counts, tau, gamma, eta = law_case(name)
     _load(ctx, counts, tau, gamma, eta)
     ctx.seed(1, ctr_seed=5)
     idx = cbind.onehot_to_idx(tau)
-    e_mu, v_mu, e_E = cbind.stats_expect(idx, gamma, eta, counts)
-    n = 400
-    acc = np.zeros((S, G)); accE = np.zeros((4, 4))
+    n = 2000
+    mus, es = [], []
     for it in range(n):
         mu, E = ctx.sample_stats(it)
-        acc += mu; accE += E
-    z = (acc / n - e_mu) / np.sqrt(v_mu / n + 1e-12)
-    assert np.abs(z).max() < 4.5
-    rs = np.random.RandomState(3)
-    m = 30
-    ref = np.zeros((S, G))
-    for _ in range(m):
-        E_r, mu_r = rn.sample_mu(rs, tau, gamma, eta, counts)
-        ref += mu_r.sum(axis=(0, 2))
-    z2 = (acc / n - ref / m) / np.sqrt(v_mu / n + v_mu / m + 1e-12)
-    assert np.abs(z2).max() < 4.5
-    np.testing.assert_allclose(accE / n, e_E, rtol=0.03, atol=3.0)
+        mus.append(mu.astype(np.int64)); es.append(E.astype(np.int64))
+    mus, es = np.array(mus), np.array(es)
+    assert (mus.sum(axis=2) == counts.sum(axis=(0, 2))[None, :]).all()
+    mu_r, E_r = reference_draws(name, n)
+    assert_same_law(mus, es, mu_r, E_r, name)
+    e_mu, v_mu, e_E = cbind.stats_expect(idx, gamma, eta, counts)
+    z = (mus.mean(axis=0) - e_mu) / np.sqrt(v_mu / n + 1e-12)
+    assert np.abs(z).max() < 5.0
+    np.testing.assert_allclose(es.mean(axis=0), e_E, rtol=0.02, atol=5.0 * np.sqrt(e_E.max() / n) + 0.5)
 
 
 # ---------------------------------------------------------------- A3/A4 Dirichlet draws

@@ -111,10 +111,18 @@ class Init_NMFT:
         objs = list(objs)
         if any(o.n_run != 1 for o in objs) or len({(o.max_iter, o.min_change) for o in objs}) != 1:
             raise ValueError("factorize_batch: n_run = 1 and equal max_iter / min_change expected")
-        for o in objs:
-            o.random_initialize()
-            o._push()
-        res = _lib.Context.batch_nmft_factorize([o._ctx for o in objs], objs[0].max_iter, objs[0].min_change, fix_gamma=False)
+        # a batch the kernels do not take (S > 96, G > 12, more than 8 chains) must leave every chain's numpy stream where
+        # it was: the caller falls back to factorize(), which draws the same initial factors again
+        states = [o.randomState.get_state() for o in objs]
+        try:
+            for o in objs:
+                o.random_initialize()
+                o._push()
+            res = _lib.Context.batch_nmft_factorize([o._ctx for o in objs], objs[0].max_iter, objs[0].min_change, fix_gamma=False)
+        except _lib.DesmanHipError:
+            for o, st in zip(objs, states):
+                o.randomState.set_state(st)
+            raise
         for o, (n, tr) in zip(objs, res):
             o._pull()
             o.div_trace = tr
@@ -126,10 +134,16 @@ class Init_NMFT:
         objs = list(objs)
         if any(o.n_run != 1 for o in objs) or len({(o.max_iter, o.min_change) for o in objs}) != 1:
             raise ValueError("factorize_tau_batch: n_run = 1 and equal max_iter / min_change expected")
-        for o in objs:
-            o.random_initialize_tau()
-            o._push()
-        res = _lib.Context.batch_nmft_factorize([o._ctx for o in objs], objs[0].max_iter, objs[0].min_change, fix_gamma=True)
+        states = [o.randomState.get_state() for o in objs]          # as in factorize_batch
+        try:
+            for o in objs:
+                o.random_initialize_tau()
+                o._push()
+            res = _lib.Context.batch_nmft_factorize([o._ctx for o in objs], objs[0].max_iter, objs[0].min_change, fix_gamma=True)
+        except _lib.DesmanHipError:
+            for o, st in zip(objs, states):
+                o.randomState.set_state(st)
+            raise
         for o, (n, tr) in zip(objs, res):
             o._pull()
             o.div_trace = tr

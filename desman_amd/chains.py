@@ -92,7 +92,8 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
         t0 = time.perf_counter()
         try:
             rec = dict(run_fn(specs[cid]))
-        except Exception as e:                               # noqa: BLE001 -- any failure of one chain is contained
+        except (Exception, SystemExit) as e:                 # noqa: BLE001 -- any failure of one chain is contained (the CLI
+            #                                                  reports bad input through sys.exit: a BaseException)
             log.warning("chain %d (G=%s, seed=%s) failed on rank %d: %s: %s", cid, specs[cid].get("G"), specs[cid].get("seed"),
                         rank, type(e).__name__, e)
             return e
@@ -118,7 +119,9 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
                 t0 = time.perf_counter()
                 try:
                     recs = [dict(r) for r in batch_fn([specs[i] for i in ids])]
-                except Exception as e:                       # noqa: BLE001
+                    if len(recs) != len(ids):
+                        raise RuntimeError("batch_fn returned %d records for %d chains" % (len(recs), len(ids)))
+                except (Exception, SystemExit) as e:         # noqa: BLE001
                     log.warning("batched unit %s failed on rank %d (%s: %s): its chains run one by one", ids, rank, type(e).__name__, e)
                     recs = None
                 if recs is not None:
@@ -149,9 +152,9 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
         first = [one(cid) for cid in bins[rank]]
     mine = []
     for cid, res in zip(bins[rank], first):
-        if isinstance(res, Exception):                       # second and last attempt, alone on the device
+        if isinstance(res, BaseException):                   # second and last attempt, alone on the device
             res = one(cid)
-            if isinstance(res, Exception):
+            if isinstance(res, BaseException):
                 res = failed_record(cid)
         mine.append(res)
     width = max(len(b) for b in bins) if specs else 0
@@ -304,6 +307,10 @@ def main(argv=None):
     V, S = frame.shape[0], (frame.shape[1] - 1) // 4
     specs = sweep_specs(range(args.gmin, args.gmax + 1), args.reps, V, S)
     extra = ["-m", str(args.min_coverage)] + (["-r", str(args.random_select)] if args.random_select else [])
+    if args.batch > 1:
+        # batched units draw mu/E from the aggregated specification; chains of this sweep that run one by one (a unit of one
+        # chain, the fallback of a failed unit) follow it too, so that a (G, seed) gives the same draws whatever -b is
+        os.environ["DESMAN_HIP_STATS_SPEC"] = "2"
     runner = gibbs_chain_runner(args.variant_file, args.no_iter, local, args.output_stub, extra)
     recs = run_chains(specs, runner, dist, device=torch.device("cuda", local) if dist is not None else None,
                       concurrency=args.concurrency, batch_fn=runner.batch if args.batch > 1 else None, batch=min(args.batch, 8))

@@ -237,6 +237,10 @@ def main_replicates(argv_list, on_chain=None):
     for k, r in enumerate(runs):
         opts, flt, rng, nmft = r["opts"], r["flt"], r["rng"], r["nmft"]
         chain = HaploSNP_Sampler(flt.snps_filter, opts.genomes, rng, max_iter=opts.no_iter, device=opts.device, ctx=nmft._ctx)
+        # a batch always takes the aggregated mu/E pass; a replicate that ends up alone (its haplotype count changed in
+        # removeDegenerate, a failed batched unit) must keep drawing from the same specification, so that a chain's draws
+        # depend on its own seed and shape only -- not on what the other replicates did
+        chain._ctx.force_stats_spec(2)
         chain.mt_state = _lib.mt_seed_state(opts.random_seed)       # what initRNG(); setRNG(seed) leave in the module's stream
         chain.tau = np.copy(nmft.get_tau(), order='C')
         chain.updateTauIndices()
@@ -279,10 +283,14 @@ def main_replicates(argv_list, on_chain=None):
     for group in groups.values():
         batched = False
         if len(group) > 1:
+            # whatever the batched attempt drew from the chains' numpy streams before it gave up is handed back
+            states = [r["chain"].randomState.get_state() for r in group]
             try:
                 _assign_rest_batch(group, lambda j, g=group: tell(idx[id(g[j])]))
                 batched = True
             except _lib.DesmanHipError as e:
+                for r, st in zip(group, states):
+                    r["chain"].randomState.set_state(st)
                 logging.info('batched -r path not available (%s): one by one' % e)
         if not batched:
             for r in group:

@@ -21,6 +21,8 @@ _u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
 
 
 def build(force=False):
+    if os.environ.get("DESMAN_ORACLE_SO"):          # e.g. the sanitizer build (`make -C oracle asan-test`)
+        return os.environ["DESMAN_ORACLE_SO"]
     srcs = [os.path.join(_HERE, f) for f in ("desman_oracle.c", "stats_agg.c", "orc_log_table.h")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
@@ -30,8 +32,7 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_SO)
+        L = C.CDLL(build())
         L.orc_mt_seed.argtypes = [C.c_void_p, C.c_ulong]
         L.orc_mt_u32.argtypes = [C.c_void_p]
         L.orc_mt_u32.restype = C.c_uint32

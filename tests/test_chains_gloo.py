@@ -109,6 +109,37 @@ def test_single_process_failure_handling():
     assert [r["failed"] for r in recs] == [0.0, 1.0, 0.0] and n["k"] == 4
 
 
+def test_sys_exit_of_a_chain_is_contained_and_short_batches_are_rejected():
+    """the CLI reports bad input through sys.exit (a BaseException): such a chain must become a failed record, not kill the
+    rank before the gather; a batch_fn that returns fewer records than chains must not misalign them"""
+    import sys as _sys
+    calls = {"one": 0, "batch": 0}
+
+    def run(spec):
+        calls["one"] += 1
+        if spec["seed"] == 0:
+            _sys.exit("desman: no samples above the coverage cut")
+        return dict(G=spec["G"], seed=spec["seed"], G_final=spec["G"], lp_star=-1.0, mean_dev=2.0, iters=1)
+    recs = chains.run_chains(chains.sweep_specs([2], 3, 10, 4), run)
+    assert [r["failed"] for r in recs] == [1.0, 0.0, 0.0] and calls["one"] == 4
+    for conc in (1, 2):
+        calls["one"] = 0
+        recs = chains.run_chains(chains.sweep_specs([2], 3, 10, 4), run, concurrency=conc)
+        assert [r["failed"] for r in recs] == [1.0, 0.0, 0.0] and calls["one"] == 4
+
+    def short_batch(group):
+        calls["batch"] += 1
+        if group[0]["G"] == 3:
+            _sys.exit("bad unit")
+        return [dict(G=sp["G"], seed=sp["seed"], G_final=sp["G"], lp_star=-7.0, mean_dev=2.0, iters=1) for sp in group[:-1]]
+    calls["one"] = 0
+    recs = chains.run_chains(chains.sweep_specs([2, 3], 2, 10, 4), run, batch_fn=short_batch, batch=2)
+    assert calls["batch"] == 2
+    # both units fell back to one by one (short result / sys.exit): records come from run(), seed 0 fails twice
+    assert [(int(r["G"]), int(r["seed"]), r["failed"], r["lp_star"] == -1.0) for r in recs] == \
+        [(2, 0, 1.0, False), (2, 1, 0.0, True), (3, 0, 1.0, False), (3, 1, 0.0, True)]
+
+
 # ---------------------------------------------------------------- row f4: genes sharded over ranks
 def test_gene_partition_properties():
     from desman_amd.gene_shards import partition_genes

@@ -99,7 +99,7 @@ def test_full_size_nmft_factorize_matches_oracle(V, S, G):
             n_ref, tr_ref = cbind.nmft_factorize(F, tc, gc, max_iter=20, min_change=1e-5)
         runs = {f: _nmft_run(counts, tau0, gam0, f, fix_gamma) for f in (-1, 0, 1)}
         n, tr, tau, gam, onehot, div = runs[-1]
-        assert n == n_ref == 20
+        assert n == n_ref and (fix_gamma or n_ref == 20)           # factorize_tau may stop by itself (13 updates at 13000 x 40 x 3)
         np.testing.assert_allclose(tr, tr_ref, rtol=1e-9)                 # the whole objective trace
         np.testing.assert_allclose(tau, tc, rtol=1e-6, atol=1e-12)
         np.testing.assert_allclose(gam, gc, rtol=1e-6, atol=1e-12)

@@ -85,6 +85,61 @@ def cpu_baseline(S, G):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+TRAFFIC_DB = os.path.join(ROOT, "profiles", "pmc_traffic_by_shape.json")
+
+
+def shape_key(V, S, G, depth):
+    return "%d,%d,%d,%g" % (V, S, G, depth)
+
+
+def pmc_passes(V, S, G, depth, iters=30):
+    """`bench.py --pmc`: HBM-side traffic and VALU instruction counts per launch of this workload's kernels, measured now: three
+    separate `rocprofv3 --pmc` passes (FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU -- one counter group per pass, kernel trace only, as
+    MI355X_MICROARCH.md prescribes; FETCH_SIZE x 2 is its gfx950 correction for wide coalesced reads) over scripts/prof_gibbs.py,
+    the benchmark's chain at this shape.  Returns {kernel name: {bytes_per_launch, read_bytes_corrected, write_bytes, valu_insts}}
+    and stores it in profiles/pmc_traffic_by_shape.json under the shape key, where runs without --pmc find it."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    env = dict(os.environ, TMPDIR="/tmp")
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    work = tempfile.mkdtemp(prefix="dsm_pmc_", dir="/tmp")
+    try:
+        for ctr in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES"]):
+            d = os.path.join(work, ctr[0])
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + ctr + ["--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.join(ROOT, "scripts", "prof_gibbs.py"), str(iters), str(V), str(S), str(G), str(depth)]
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd="/tmp", timeout=900)
+            if r.returncode != 0:
+                raise RuntimeError("rocprofv3 pass %s failed: %s" % (ctr, r.stderr[-1500:]))
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    agg[row["Kernel_Name"].split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    out = {}
+    for k, dd in agg.items():
+        mean = {c: sum(v) / len(v) for c, v in dd.items()}
+        fe, wr = mean.get("FETCH_SIZE", 0.0), mean.get("WRITE_SIZE", 0.0)            # KiB per launch
+        out[k] = dict(fetch_kib_raw=fe, write_kib_raw=wr, read_bytes_corrected=2.0 * fe * 1024.0, write_bytes=wr * 1024.0,
+                      bytes_per_launch=2.0 * fe * 1024.0 + wr * 1024.0, valu_insts=mean.get("SQ_INSTS_VALU"),
+                      valu_active_cycles=mean.get("SQ_ACTIVE_INST_VALU"), dispatches=max(len(v) for v in dd.values()))
+    db = {}
+    if os.path.exists(TRAFFIC_DB):
+        db = json.load(open(TRAFFIC_DB))
+    db[shape_key(V, S, G, depth)] = out
+    for path in (TRAFFIC_DB, os.path.join(ROOT, "gpurun_out", "pmc_traffic_by_shape.json")):
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            json.dump(db, open(path, "w"), indent=1, sort_keys=True)
+        except OSError:
+            pass
+    return out
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -161,6 +216,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="extra key `batch`: K chains of this shape in one set of launches "
                     "(dsm_batch_gibbs_update); default 4 chains x at most 100 steps on a single-GPU run, 0/1 = off")
     ap.add_argument("--no-nmft", action="store_true")
+    ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic now: three extra rocprofv3 --pmc passes of this "
+                    "workload (about a minute); without it the figure recorded for this shape in profiles/pmc_traffic_by_shape.json is used")
     ap.add_argument("--counts-npz", default=None,
                     help="real data instead of the synthetic tensor: an .npz with `counts` [V,S,4] (tests/golden/cog0015_counts.npz "
                          "= the reference's complete_example table after its sample filter); V and S come from the file")
@@ -331,7 +388,7 @@ def main():
             ctxs = []
     if args.batch > 1 and ctxs:
         one = ctxs[0]                                            # the same chain alone, same mu/E specification
-        one.force_stats_spec(2)
+        one.force_stats_spec(_lib.STATS_AGG)
         one.gibbs_update(batch_steps)
         t0 = time.perf_counter(); one.gibbs_update(batch_steps); dt1 = time.perf_counter() - t0
         one.force_stats_spec(0)
@@ -361,10 +418,19 @@ def main():
     # fp32 screening pass (hardware log2); the steps it cannot decide (tau_steps_fp64_frac) are re-evaluated in fp64, 12 of 16
     n_logs = 16.0 * V * G * S + 4.0 * V * S
     traffic, valu = {}, {}
-    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    stats_kname = "stats_agg_kernel" if spec == 2 else "stats_kernel"
-    if os.path.exists(tpath) and (V, S, G) == (10000, 64, 8) and args.depth_scale == 1.0:
-        tj = json.load(open(tpath))                               # PMC passes are separate rocprofv3 runs (profiles/)
+    stats_kname = "stats_agg_kernel" if spec >= 2 else "stats_kernel"
+    tj, traffic_source = None, None
+    if not args.counts_npz:
+        if args.pmc and rank == 0:
+            tj = pmc_passes(V, S, G, args.depth_scale)
+            traffic_source = ("measured by this run: three separate rocprofv3 --pmc passes (FETCH_SIZE x 2 per the gfx950 correction + "
+                              "WRITE_SIZE; SQ_INSTS_VALU) of scripts/prof_gibbs.py at this shape")
+        elif os.path.exists(TRAFFIC_DB):
+            tj = json.load(open(TRAFFIC_DB)).get(shape_key(V, S, G, args.depth_scale))
+            traffic_source = ("profiles/pmc_traffic_by_shape.json[%s]: recorded by `bench.py --pmc` at this shape (separate rocprofv3 "
+                              "--pmc passes: FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE), not measured in this run"
+                              % shape_key(V, S, G, args.depth_scale))
+    if tj:
         for key, rec in tj.items():
             # the sweep + likelihood instantiation (tau_kernel<LPV, NSL, true, true>) and the stage-1 mu/E kernel
             name = "tau" if (key.startswith("void tau_kernel<") and key.endswith("true, true>")) else \
@@ -383,19 +449,24 @@ def main():
             # average, SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU) over the 1024 SIMDs x duration x 2.4 GHz issue slots
             per_kernel[kname].update(valu_insts_pmc=valu[name],
                                      valu_issue_frac=valu[name] * 4.0 / (1024 * us * 1e-6 * 2.4e9))
+    launched, resident = ctx.tau_launch_info()
+    rounds = launched / max(resident, 1)
+    tau_launch = dict(launched_workgroups=launched, resident_workgroups=resident, rounds=rounds,
+                      tail_frac=1.0 - rounds / float(np.ceil(rounds)) if rounds > 0 else None)
     dom = "stats" if k_us.get("stats", 0) >= k_us.get("tau", 0) else "tau"
     dk = per_kernel[(stats_kname if dom == "stats" else "tau_kernel")]
     roofline = dict(bound="hbm", bound_actual="valu_issue", kernel=(stats_kname if dom == "stats" else "tau_kernel"),
                     achieved=dk["achieved_GBps"], peak=8000.0, unit="GB/s",
                     frac=dk["frac_of_8TBps"], traffic=dk["traffic_bytes_pmc"],
-                    traffic_source=("profiles/r02_pmc_traffic.json: separate rocprofv3 --pmc passes of this workload "
-                                    "(FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE), not measured in this run"
-                                    if dk["traffic_bytes_pmc"] else None),
+                    traffic_source=(traffic_source if dk["traffic_bytes_pmc"] else None),
                     valu_issue_frac=dk.get("valu_issue_frac"),
                     avg_kernel_us=dk["avg_kernel_us"],
                     algorithmic_bytes_per_launch=dk["algorithmic_bytes_per_launch"],
                     per_kernel=per_kernel, log_terms_per_s_tau_kernel=n_logs / (k_us.get("tau", float("nan")) * 1e-6),
                     tau_steps_fp64_frac=(sw_exact / sw_steps) if sw_steps else None,
+                    # workgroups a sweep launches / workgroups of tau_kernel resident at once: the launch runs as `rounds` waves of
+                    # workgroups and the last, partly filled one is its tail (tail_frac = idle share of the slots of those rounds)
+                    tau_launch=tau_launch,
                     stats_spec=spec,
                     note="both Gibbs kernels are VALU-issue bound, not HBM bound (bound_actual; per_kernel.valu_issue_frac, "
                          "PMC traffic ~ algorithmic bytes; profiles/, DESIGN.md sec. 3): the HBM fraction is reported "

@@ -15,6 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "desman_hip.h")
 
 DSM_OK = 0
 RNG_MT19937, RNG_PHILOX = 0, 1
+STATS_AGG = 2        # version of the aggregated mu/E specification that runs by default (oracle/stats_agg.c); 3 = the table exp / log variant
 K_NAMES = ("stats", "dirichlet", "tau", "finalize", "mt", "nmft_a", "nmft_gamma", "nmft_b", "stats2", "stats_big")
 
 
@@ -64,10 +65,11 @@ SIGNATURES = {
     "dsm_ctx_sweep_stats": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _i]),
     "dsm_ctx_set_tau_screen": (_i, [_vp, _i]),
     "dsm_ctx_set_nmft_fused": (_i, [_vp, _i]),
+    "dsm_ctx_tau_launch_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "dsm_ctx_debug_log2f": (_i, [_vp, _vp, _vp, C.c_size_t]),
     "dsm_ctx_force_stats_spec": (_i, [_vp, _i]),
     "dsm_ctx_debug_stage1": (_i, [_vp, C.c_uint32, _vp, _u64p]),
-    "dsm_ctx_debug_binom": (_i, [_vp, _i, C.c_uint32, _f64p, C.c_uint64, _i, _u32p]),
+    "dsm_ctx_debug_binom": (_i, [_vp, _i, C.c_uint32, _f64p, C.c_uint64, _i, _u32p, _i]),
     "dsm_ctx_draw_gamma_eta": (_i, [_vp, C.c_uint32, _u64p, _u64p, _f64p, _f64p]),
     "dsm_ctx_loglik": (_i, [_vp, C.POINTER(_d), C.POINTER(_d)]),
     "dsm_ctx_gibbs_update": (_i, [_vp, _i]),
@@ -284,6 +286,12 @@ class Context:
         """A/B switch: False = every step of the tau sweep in fp64 (same results)"""
         check(self.lib.dsm_ctx_set_tau_screen(self._h, 1 if on else 0))
 
+    def tau_launch_info(self):
+        """(workgroups a tau sweep launches, workgroups of that kernel resident on the device at once)"""
+        a, b = _i(0), _i(0)
+        check(self.lib.dsm_ctx_tau_launch_info(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_nmft_fused(self, mode=-1):
         """reduce + gamma/control of an NMFT update: -1 = by size, 0 = two launches, 1 = one fused launch (same results)"""
         check(self.lib.dsm_ctx_set_nmft_fused(self._h, int(mode)))
@@ -296,14 +304,15 @@ class Context:
         return a.value, b.value
 
     def stats_spec(self):
-        """2 = aggregated mu/E sampler (oracle/stats_agg.c), 1 = per-read draws (orc_stats_counter)."""
+        """3 / 2 = aggregated mu/E sampler (oracle/stats_agg.c, current / first version), 1 = per-read draws (orc_stats_counter)."""
         r = self.lib.dsm_ctx_stats_spec(self._h)
         if r < 0:
             check(r)
         return r
 
     def force_stats_spec(self, spec=0):
-        """0 = shape rule, 1 = per-read draws everywhere, 2 = aggregated sampler on small problems too (G <= 16)."""
+        """0 = shape rule, 1 = per-read draws everywhere, 2 (STATS_AGG) / 3 = that version of the aggregated sampler on small
+        problems too (G <= 16)."""
         check(self.lib.dsm_ctx_force_stats_spec(self._h, int(spec)))
 
     def debug_stage1(self, it):
@@ -312,11 +321,11 @@ class Context:
         check(self.lib.dsm_ctx_debug_stage1(self._h, int(it), nt.ctypes.data, E))
         return nt, E
 
-    def debug_binom(self, kind, n, w, seed, nsamp):
+    def debug_binom(self, kind, n, w, seed, nsamp, spec=STATS_AGG):
         w4 = np.zeros(4)
         w4[:len(w)] = w
         out = np.zeros((nsamp, 4) if kind == 2 else nsamp, dtype=np.uint32)
-        check(self.lib.dsm_ctx_debug_binom(self._h, int(kind), int(n), w4, int(seed), int(nsamp), out.reshape(-1)))
+        check(self.lib.dsm_ctx_debug_binom(self._h, int(kind), int(n), w4, int(seed), int(nsamp), out.reshape(-1), int(spec)))
         return out
 
     def draw_gamma_eta(self, it, sum_mu, esum):

@@ -240,7 +240,7 @@ def main_replicates(argv_list, on_chain=None):
         # a batch always takes the aggregated mu/E pass; a replicate that ends up alone (its haplotype count changed in
         # removeDegenerate, a failed batched unit) must keep drawing from the same specification, so that a chain's draws
         # depend on its own seed and shape only -- not on what the other replicates did
-        chain._ctx.force_stats_spec(2)
+        chain._ctx.force_stats_spec(_lib.STATS_AGG)
         chain.mt_state = _lib.mt_seed_state(opts.random_seed)       # what initRNG(); setRNG(seed) leave in the module's stream
         chain.tau = np.copy(nmft.get_tau(), order='C')
         chain.updateTauIndices()

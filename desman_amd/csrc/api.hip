@@ -179,8 +179,9 @@ extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
     TRY(dev_alloc(&c->eta_new, 16));
     TRY(dev_alloc(&c->eta_star, 16));
     TRY(dev_alloc(&c->esum, 16));
-    TRY(dev_alloc(&c->log_tab, 2 * DSM_LOG_TAB_N));
+    TRY(dev_alloc(&c->log_tab, 2 * DSM_LOG_TAB_N + DSM_EXP_TAB_N));           // log table, then the exp table of spec 3
     HIP_TRY(hipMemcpyAsync(c->log_tab, dsm_log_table_host, sizeof dsm_log_table_host, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->log_tab + 2 * DSM_LOG_TAB_N, dsm_exp_table_host, sizeof dsm_exp_table_host, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->nchange, 0, 2 * sizeof(int), c->stream));
     HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -621,7 +622,7 @@ extern "C" int dsm_ctx_stats_spec(dsm_ctx *c)
 
 extern "C" int dsm_ctx_force_stats_spec(dsm_ctx *c, int spec)
 {
-    if (!c || spec < 0 || spec > 2) return DSM_ERR_ARG;
+    if (!c || spec < 0 || spec > 3) { dsm_set_error("force_stats_spec: 0 (rule), 1, 2 or 3"); return DSM_ERR_ARG; }
     c->force_stats_spec = spec;
     return DSM_OK;
 }
@@ -629,7 +630,7 @@ extern "C" int dsm_ctx_force_stats_spec(dsm_ctx *c, int spec)
 extern "C" int dsm_ctx_debug_stage1(dsm_ctx *c, uint32_t iter, uint32_t *ntab, uint64_t *esum)
 {
     TRY(need(c, true, true));
-    if (stats_spec(c) != 2) { dsm_set_error("debug_stage1: spec v2 does not apply to this shape"); return DSM_ERR_UNSUPPORTED; }
+    if (stats_spec(c) < 2) { dsm_set_error("debug_stage1: the aggregated specification does not apply to this shape (force it with dsm_ctx_force_stats_spec)"); return DSM_ERR_UNSUPPORTED; }
     BIND(c);
     HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
     TRY(k_stats_stage1(c, iter));
@@ -651,14 +652,14 @@ extern "C" int dsm_ctx_debug_stage1(dsm_ctx *c, uint32_t iter, uint32_t *ntab, u
     return DSM_OK;
 }
 
-extern "C" int dsm_ctx_debug_binom(dsm_ctx *c, int kind, uint32_t n, const double *w4, uint64_t seed, int nsamp, uint32_t *out)
+extern "C" int dsm_ctx_debug_binom(dsm_ctx *c, int kind, uint32_t n, const double *w4, uint64_t seed, int nsamp, uint32_t *out, int spec)
 {
-    if (!c || !w4 || !out || nsamp < 1 || kind < 0 || kind > 2) { dsm_set_error("debug_binom: bad arguments"); return DSM_ERR_ARG; }
+    if (!c || !w4 || !out || nsamp < 1 || kind < 0 || kind > 2 || spec < 2 || spec > 3) { dsm_set_error("debug_binom: bad arguments"); return DSM_ERR_ARG; }
     BIND(c);
     const size_t len = (size_t)nsamp * (kind == 2 ? 4 : 1);
     Scratch<uint32_t> d;
     TRY(d.alloc(len));
-    TRY(k_binom_test(c, kind, n, w4, seed, nsamp, d));
+    TRY(k_binom_test(c, kind, n, w4, seed, nsamp, d, spec));
     HIP_TRY(hipMemcpyAsync(out, d, len * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSM_OK;
@@ -748,7 +749,7 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
     for (int it = 0; it < n_iter; ++it) {
         const uint32_t ic = c->iter_ctr++;
         // sampleMu (:341): spec v2 = stage 1 here, stage 2 inside the Dirichlet launch; spec v1 = the per-read pass
-        const bool agg = stats_spec(c) == 2;
+        const bool agg = stats_spec(c) >= 2;
         const bool fuse_s2 = agg && c->G < 10;           // many subsets per sample: stage 2 as its own 1024-thread launch
         TRY(agg ? k_stats_stage1(c, ic) : k_stats_v1(c, ic));
         if (agg && !fuse_s2) TRY(k_stats_stage2(c, ic));
@@ -798,7 +799,8 @@ extern "C" int dsm_batch_gibbs_update(dsm_ctx *const *ctxs, int K, int n_iter)
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream_rng));
         saved[k] = Saved{c->stream, c->stream_rng, c->force_stats_spec, c->timing};
-        c->stream = lead->stream; c->stream_rng = lead->stream_rng; c->force_stats_spec = 2; c->timing = false;
+        // one version of the aggregated specification for the whole batch: the leader's choice if it made one, else the default
+        c->stream = lead->stream; c->stream_rng = lead->stream_rng; c->force_stats_spec = (saved[0].force >= 2) ? saved[0].force : DSM_STATS_AGG; c->timing = false;
     }
     auto restore = [&]() {
         g_batch = BatchCtl{};
@@ -810,7 +812,7 @@ extern "C" int dsm_batch_gibbs_update(dsm_ctx *const *ctxs, int K, int n_iter)
 #define BTRY(expr) do { int _r = (expr); if (_r != DSM_OK) { (void)hipStreamSynchronize(lead->stream); (void)hipStreamSynchronize(lead->stream_rng); restore(); return _r; } } while (0)
 #define BHIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { dsm_set_error("%s failed: %s", #expr, hipGetErrorString(_e)); (void)hipStreamSynchronize(lead->stream); restore(); return DSM_ERR_HIP; } } while (0)
     for (int k = 0; k < K; ++k)
-        if (stats_spec(ctxs[k]) != 2) { dsm_set_error("batch: the aggregated mu/E pass does not apply to this shape (G <= 16)"); restore(); return DSM_ERR_UNSUPPORTED; }
+        if (stats_spec(ctxs[k]) < 2) { dsm_set_error("batch: the aggregated mu/E pass does not apply to this shape (G <= 16)"); restore(); return DSM_ERR_UNSUPPORTED; }
     const size_t sg = (size_t)lead->S * lead->G;
     std::vector<SweepWords> words;
     words.reserve(K);
@@ -1015,6 +1017,15 @@ extern "C" int dsm_ctx_debug_log2f(dsm_ctx *c, const float *in, float *out, size
     HIP_TRY(hipMemcpyAsync(out, d_out, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSM_OK;
+}
+
+// workgroups of one tau sweep: launched, and resident at once on this device (occupancy x compute units)
+extern "C" int dsm_ctx_tau_launch_info(dsm_ctx *c, int *launched, int *resident)
+{
+    TRY(need(c, true, true));
+    if (!launched || !resident) { dsm_set_error("tau_launch_info: null argument"); return DSM_ERR_ARG; }
+    BIND(c);
+    return tau_launch_info(c, launched, resident);
 }
 
 // Which form of the reduce + gamma/control step of an NMFT update runs (kernels_nmft.hip: k_nmft_gamma): -1 = by the number of

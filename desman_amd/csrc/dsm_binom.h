@@ -1,6 +1,9 @@
-// dsm_binom.h -- device-side samplers of the aggregated mu/E pass (spec v2, restated in
+// dsm_binom.h -- device-side samplers of the aggregated mu/E pass (specs 2 and 3, restated in
 // oracle/stats_agg.c: every function here has a twin there with the same operation order; the library
 // is built with -ffp-contract=off, division and sqrt are IEEE, so the two agree bit for bit).
+// SPEC = 2: (1-q)^n by repeated squaring, two divisions, item streams three Philox rounds off the cell's block.
+// SPEC = 3 (default): f0 = exp(-n ln(1 + r)), r = q/(1-q) the one division, table log + table exp (dsm_texp) -- a fixed
+//           ~35 instructions instead of a loop over the bits of n to the deepest lane; item streams two rounds.
 //
 //   draw_reads<K>   x reads over K categories, read by read against 32-bit thresholds (x <= DSM_XS)
 //   binom           Binomial(n, p): sequential-search inversion on the rarer outcome while its mean is <= 128
@@ -9,6 +12,7 @@
 //                   others read by read
 #pragma once
 #include "dsm_device.h"
+#include "log_table.h"
 
 #define DSM_STREAM_STA1 0x53544131u   // 'STA1'  stage-1 cell streams
 #define DSM_STREAM_STA2 0x53544132u   // 'STA2'  stage-2 binomial streams
@@ -41,12 +45,13 @@ __device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_
 
 // stream of the item (cell, observed base b): base = Philox4x32-10({cell, 0, iter, 'STA1'}) is shared by the four items
 // of the cell; three more rounds keyed by the base make the item's xoshiro state (oracle: item_seed)
+template <int SPEC>
 __device__ __forceinline__ Xo128 item_seed(const uint32_t (&base)[4], uint32_t b, uint32_t key0, uint32_t key1)
 {
     uint32_t c0 = base[0], c1 = base[1], c2 = base[2], c3 = base[3];
     uint32_t k0 = key0 ^ (0x9E3779B9u * (b + 1u)), k1 = key1 ^ (0xBB67AE85u * (b + 1u));
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    for (int i = 0; i < (SPEC >= 3 ? 2 : 3); ++i) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
     Xo128 r{c0, c1, c2, c3};
     if ((r.s0 | r.s1 | r.s2 | r.s3) == 0u) r.s0 = 1u;
     return r;
@@ -79,6 +84,25 @@ __device__ __forceinline__ double dsm_pw(double b, uint32_t e)
         b = b * b;
     }
     return res;
+}
+
+// exp(y), y <= 0 (oracle: orc_texp): y = (32 k + j) ln2/32 + r, exp(r) - 1 by a degree-6 polynomial, 2^(j/32) from the
+// 32-entry table `etab` (LDS copy of dsm_exp_table_host), 2^k by v_ldexp_f64
+__device__ __forceinline__ double dsm_texp(double y, const double *__restrict__ etab)
+{
+    const double kd = __builtin_rint(y * DSM_EXP_INV_LN2_32);
+    const int ki = (int)kd;
+    double r = fma(kd, -DSM_EXP_LN2_32_HI, y);
+    r = fma(kd, -DSM_EXP_LN2_32_LO, r);
+    double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
+    p = fma(r, p, 1.0 / 24.0);
+    p = fma(r, p, 1.0 / 6.0);
+    p = fma(r, p, 0.5);
+    p = fma(r, p, 1.0);
+    p = r * p;
+    const double t = etab[ki & 31];
+    const double v = ldexp(fma(t, p, t), ki >> 5);
+    return (y > -700.0) ? v : 0.0;
 }
 
 template <int K>
@@ -196,7 +220,8 @@ __device__ __forceinline__ uint32_t btrs(uint32_t &s0, uint32_t &s1, uint32_t &s
 
 // successes among n trials with success : failure odds wa : wb.  BIG = false is the inversion-only form of the
 // lean stage-1 kernel: a draw that needs BTRS sets `defer` instead (the item is re-done by the compacted kernel).
-template <bool BIG>
+// ltab / etab: LDS copies of the log and exp tables (etab = ltab + DSM_LOG_TAB_N doubles further: one staged block)
+template <bool BIG, int SPEC>
 __device__ __forceinline__ uint32_t binom(Xo128 &rng, uint32_t n, double wa, double wb, const double *__restrict__ rcp,
                                           const double2 *__restrict__ ltab, bool &defer, double cap = DSM_BINV_MEAN_CAP)
 {
@@ -209,12 +234,19 @@ __device__ __forceinline__ uint32_t binom(Xo128 &rng, uint32_t n, double wa, dou
     if ((double)n * ws > cap * T) {
         if constexpr (BIG) k = btrs(rng.s0, rng.s1, rng.s2, rng.s3, n, ws / T, ltab);
         else { defer = true; return 0; }
-    } else if constexpr (BIG) k = binv_chain(rng, n, dsm_pw(wl / T, n), ws / wl, rcp);   // few, lonely wavefronts: latency
-    else k = binv(rng, n, dsm_pw(wl / T, n), ws / wl, rcp);                                // stage 1: throughput (48 vs 50 us with binv_chain)
+    } else {
+        double f0, r;
+        if constexpr (SPEC >= 3) {
+            r = ws / wl;                                                                   // q / (1 - q); 1 - q = 1 / (1 + r)
+            f0 = dsm_texp(-((double)n * dsm_log_core(1.0 + r, ltab)), reinterpret_cast<const double *>(ltab + DSM_LOG_TAB_N));
+        } else { f0 = dsm_pw(wl / T, n); r = ws / wl; }
+        if constexpr (BIG) k = binv_chain(rng, n, f0, r, rcp);                             // few, lonely wavefronts: latency
+        else k = binv(rng, n, f0, r, rcp);                                                 // stage 1: throughput (48 vs 50 us with binv_chain)
+    }
     return flip ? n - k : k;
 }
 
-template <bool BIG>
+template <bool BIG, int SPEC>
 __device__ __forceinline__ void mult4(Xo128 &rng, uint32_t x, const double (&W)[4], uint32_t (&n)[4], const double *__restrict__ rcp,
                                       const double2 *__restrict__ ltab, bool &defer, double lean_cap = DSM_BINV_MEAN_CAP,
                                       int *kind = nullptr)
@@ -234,7 +266,7 @@ __device__ __forceinline__ void mult4(Xo128 &rng, uint32_t x, const double (&W)[
     // by read, more (only possible for the items of the compacted kernel, in practice) by two more binomials
     uint32_t m = 0, k[3] = {0, 0, 0};
     if constexpr (!BIG) {
-        m = binom<false>(rng, x, ws, wm, rcp, ltab, defer, lean_cap);   // lean_cap <= the cap of the specification: who draws, not what
+        m = binom<false, SPEC>(rng, x, ws, wm, rcp, ltab, defer, lean_cap);   // lean_cap <= the cap of the specification: who draws, not what
         if (defer) {                                        // what the compacted kernel will run for it: BTRS or a long search
             const double wsm = ws < wm ? ws : wm;
             if (kind) *kind = ((double)x * wsm > DSM_BINV_MEAN_CAP * (ws + wm)) ? 0 : 1;
@@ -247,7 +279,7 @@ __device__ __forceinline__ void mult4(Xo128 &rng, uint32_t x, const double (&W)[
         int nst = 1;
 #pragma unroll 1
         for (int st = 0; st < nst; ++st) {                  // ONE binomial site (the sampler is a large piece of code)
-            const uint32_t kk = binom<true>(rng, nn, wa, wb, rcp, ltab, defer);
+            const uint32_t kk = binom<true, SPEC>(rng, nn, wa, wb, rcp, ltab, defer);
             if (st == 0) {
                 m = kk;
                 if (m > DSM_XS) { nst = 3; nn = m; wa = wo[0]; wb = wo[1] + wo[2]; }

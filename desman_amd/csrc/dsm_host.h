@@ -13,6 +13,8 @@
 #define DSM_BIG_NT 3         // ... for each kind of deferred item (BTRS / long search / search + two more binomials)
 #define DSM_U_CHUNK 8        // MT19937 words are generated in chunks of up to this many sweeps (api.hip: SweepWords)
 
+#define DSM_STATS_AGG 2      // the version of the aggregated mu/E specification that runs by default (oracle/stats_agg.c); version 3 (table
+                             // exp / log instead of the squaring loop) is selectable: measured 2 us slower in stage 1 at config 3
 #define DSM_MAX_BATCH 8      // chains of one shape that share every launch of the Gibbs loop (api.hip: dsm_batch_gibbs_update)
 
 void dsm_set_error(const char *fmt, ...);
@@ -61,7 +63,8 @@ struct dsm_ctx {
     int max_items = 0;
     bool items_built = false;       // the work list of the per-read pass (spec v1) is built on first use
     uint64_t max_depth = 0;         // largest per-sample read total
-    int force_stats_spec = 0;       // test hook: 1 = per-read pass even where spec v2 applies, 2 = spec v2 on small problems too
+    int force_stats_spec = 0;       // 0 = by the shape rule (1 or DSM_STATS_AGG); 1 = per-read pass everywhere; 2 / 3 = that version of
+                                    // the aggregated pass wherever it applies, small problems too
     uint32_t *ntab = nullptr;       // [2^G][S] subset counts of the aggregated mu/E pass (spec v2), zero between passes
     size_t ntab_len = 0;
     int ntab_rep = 1;               // copies of the table (few subsets x many positions: kernels_stats.hip, stats_ntab_rep)
@@ -69,6 +72,7 @@ struct dsm_ctx {
     uint32_t *big_count = nullptr;            // DSM_BIG_NL counters, DSM_BIG_STRIDE words apart
     size_t big_cap = 0;
     int stats_grid = 0;             // resident workgroups of stats_agg_kernel
+    int stats_grid_key = -1;        // ... of which instantiation (specification x register-gamma form)
     int item_stride = 1;            // items per sample row of `items`
     bool chunked = false;           // items carry reads | chunk << 12 (small problems, see dsm_ctx_set_counts)
     int32_t *blk_tab = nullptr;     // [blk_n][3] workgroup -> {sample, j, n_j} of the mu/E pass
@@ -162,7 +166,7 @@ int stats_spec(const dsm_ctx *c);           // 2 = aggregated sampler (oracle/st
 int k_stats(dsm_ctx *c, uint32_t iter);
 int k_stats_stage1(dsm_ctx *c, uint32_t iter);
 int k_stats_stage2(dsm_ctx *c, uint32_t iter);
-int k_binom_test(dsm_ctx *c, int kind, uint32_t n, const double *w, uint64_t seed, int nsamp, uint32_t *d_out);
+int k_binom_test(dsm_ctx *c, int kind, uint32_t n, const double *w, uint64_t seed, int nsamp, uint32_t *d_out, int spec);
 int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trace, double *eta_out, double *eta_trace,
                 double *prior_out, int fin_it, int fin_nblocks, const double *fin_prior, int do_s2 = 0);
 int k_prior(dsm_ctx *c, const double *gamma, const double *eta, double *prior_out);
@@ -173,6 +177,7 @@ struct TauFinalRider { int nblocks, it; const double *prior, *gamma_src, *eta_sr
 int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_sweep,
                 const double *eta_ll, uint64_t *trace_slot, double *d_logp, uint32_t iter, int *nblocks,
                 const uint32_t *u_raw, int slot = 0, const TauFinalRider *rider = nullptr);
+int tau_launch_info(dsm_ctx *c, int *launched, int *resident);
 int k_finalize(dsm_ctx *c, int nblocks, int it, int star_mode, const double *prior, const double *gamma_src,
                const double *eta_src, int slot = 0);
 

@@ -35,15 +35,17 @@ struct Stage2Params {
 
 S2Plan make_stage2_plan(int G);     // kernels_stats.hip
 
-#define S2_SMEM_BYTES (DSM_LOG_TAB_N * 16 + DSM_RCP_TAB_N * 8 + 32 * 8 + S2_TAB_ENTRIES * 4 + 32 * 4 + 5 * S2_MAX_NODES * 4)
+#define S2_SMEM_BYTES (DSM_LOG_TAB_N * 16 + DSM_EXP_TAB_N * 8 + DSM_RCP_TAB_N * 8 + 32 * 8 + S2_TAB_ENTRIES * 4 + 32 * 4 + 5 * S2_MAX_NODES * 4)
 
 // leaf counts end in LDS (returned pointer, [G] u32, valid after the function's final barrier); to_global also adds
 // them to p.sum_mu[s][.]
+template <int SPEC>
 __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, const S2Plan &pl, int s, char *smem, bool to_global)
 {
     const int G = p.G, S = p.S, tid = threadIdx.x, nthr = blockDim.x;      // 256 (fused form) or 1024 (many subsets)
-    double2 *ltab = reinterpret_cast<double2 *>(smem);                         // [256]
-    double *rcp = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);            // [256]
+    double2 *ltab = reinterpret_cast<double2 *>(smem);                         // [256] log table, then [64] exp table
+    double *etab = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);
+    double *rcp = etab + DSM_EXP_TAB_N;                                        // [256]
     double *gs = rcp + DSM_RCP_TAB_N;                                          // [32]
     uint32_t *tab = reinterpret_cast<uint32_t *>(gs + 32);                     // [S2_TAB_ENTRIES] tables of all nodes below the root
     uint32_t *leaf = tab + S2_TAB_ENTRIES;                                     // [32]
@@ -52,6 +54,7 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
 
     if (s == 0 && tid < DSM_BIG_NT * DSM_BIG_NL && p.big_count) p.big_count[tid * DSM_BIG_STRIDE] = 0u;
     if (tid < DSM_LOG_TAB_N) ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
+    if (tid < DSM_EXP_TAB_N) etab[tid] = p.log_tab[2 * DSM_LOG_TAB_N + tid];
     for (int k = tid; k < DSM_RCP_TAB_N; k += nthr) rcp[k] = k ? 1.0 / (double)k : 0.0;
     if (tid < 32) {
         gs[tid] = (tid < G) ? p.gamma[(size_t)s * G + tid] : 0.0; leaf[tid] = 0u;
@@ -102,7 +105,7 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
             Xo128 rng = xo_seed(Hs, (uint32_t)s | ((uint32_t)n_idx[i] << 16) | ((uint32_t)level << 24), p.iter, DSM_STREAM_STA2,
                                 p.k0, p.k1);
             bool dummy = false;
-            const uint32_t k = binom<true>(rng, n, wL, wR, rcp, ltab, dummy, DSM_BINV_MEAN_CAP_S2);
+            const uint32_t k = binom<true, SPEC>(rng, n, wL, wR, rcp, ltab, dummy, DSM_BINV_MEAN_CAP_S2);
             if (k) atomicAdd(&L[HL], k);
             if (n - k) atomicAdd(&R[HR], n - k);
         }

@@ -522,7 +522,7 @@ struct DirParams {
     double *gamma_out, *gamma_trace, *eta_out, *eta_trace, *rowprior;
     int do_fin;
     FinalParams fin;
-    int do_s2;
+    int do_s2;                       // 0, or the version (2 / 3) of the aggregated specification stage 2 follows
     Stage2Params s2;
 };
 
@@ -548,7 +548,8 @@ __device__ __forceinline__ void dirichlet_body(const DirParams &q, const S2Plan 
     const int row = blockIdx.x;
     const bool is_gamma = row < S;
     const uint32_t *leaf = nullptr;
-    if (do_s2 && is_gamma) leaf = stage2_sample(s2, plan, row, smem_d, false);      // workgroup-uniform branch; ends with a barrier
+    if (do_s2 && is_gamma)                                                          // workgroup-uniform branches; both end with a barrier
+        leaf = do_s2 >= 3 ? stage2_sample<3>(s2, plan, row, smem_d, false) : stage2_sample<2>(s2, plan, row, smem_d, false);
     if (threadIdx.x >= 64) return;                       // the draw needs one wavefront (no workgroup barriers below)
     const int lane = threadIdx.x;
     const int n = is_gamma ? G : 4;
@@ -1042,7 +1043,7 @@ int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trac
     q.alpha = c->alpha; q.delta = c->delta; q.epsilon = c->epsilon; q.lgc_gamma = lg; q.lgc_eta = le;
     q.k0 = k0; q.k1 = k1; q.iter = iter; q.zero_after = 1;
     q.gamma_out = gamma_out; q.gamma_trace = gamma_trace; q.eta_out = eta_out; q.eta_trace = eta_trace; q.rowprior = prior_out;
-    q.do_fin = do_fin; q.fin = fin; q.do_s2 = do_s2; q.s2 = s2;
+    q.do_fin = do_fin; q.fin = fin; q.do_s2 = do_s2 ? stats_spec(c) : 0; q.s2 = s2;
     if (g_batch.K == 0) {
         const S2Plan plan = do_s2 ? make_stage2_plan(c->G) : S2Plan{};
         hipLaunchKernelGGL(dirichlet_kernel, dim3(c->S + 4 + do_fin), dim3(256), 0, c->stream, q, plan);
@@ -1118,12 +1119,9 @@ static void launch_tau(dsm_ctx *c, int mode, const TauParams &p, int grid, size_
     else hipLaunchKernelGGL((tau_kernel<LPV, NSL, false, true>), dim3(g2), dim3(256), sh, c->stream, p);
 }
 
-int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_sweep, const double *eta_ll,
-                uint64_t *trace_slot, double *d_logp, uint32_t iter, int *nblocks, const uint32_t *u_raw, int slot,
-                const TauFinalRider *rider)
+// lanes per variant and sample slots per lane of the sweep kernel for a table of S samples
+static int tau_shape(int S, int *lpv, int *nsl)
 {
-    KTimer tm(c, DSM_K_TAU);
-    const int S = c->S, G = c->G, V = c->V;
     int LPV, NSL;
     if (S <= 16) { LPV = 16; NSL = 1; }
     else if (S <= 32) { LPV = 16; NSL = 2; }            // four variants per wavefront (77.8 vs 94.5 us as 32 x 1 at V=20k, S=32, G=8)
@@ -1139,6 +1137,23 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
         NSL = need <= 4 ? need : (need <= 6 ? 6 : 8);
         if (need > 8) { dsm_set_error("S=%d exceeds DSM_MAX_S=%d", S, DSM_MAX_S); return DSM_ERR_UNSUPPORTED; }
     }
+    *lpv = LPV; *nsl = NSL;
+    return DSM_OK;
+}
+static size_t tau_lds_bytes(int G, int LPV, int NSL)
+{
+    return ((size_t)G * LPV * NSL + 16 + 16 + 6 + 2 * DSM_LOG_TAB_N) * sizeof(double) +
+           ((size_t)G * LPV * NSL + 20) * sizeof(float);                  // + fp32 copies of gamma / eta for the screening pass
+}
+
+int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_sweep, const double *eta_ll,
+                uint64_t *trace_slot, double *d_logp, uint32_t iter, int *nblocks, const uint32_t *u_raw, int slot,
+                const TauFinalRider *rider)
+{
+    KTimer tm(c, DSM_K_TAU);
+    const int S = c->S, G = c->G, V = c->V;
+    int LPV, NSL;
+    { const int rc = tau_shape(S, &LPV, &NSL); if (rc != DSM_OK) return rc; }
     const int gpb = 256 / LPV;
     int grid = (V + gpb - 1) / gpb;
     if (grid > DSM_MAX_GRID) grid = DSM_MAX_GRID;
@@ -1159,8 +1174,7 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
     }
     p.V = V; p.S = S; p.G = G;
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
-    const size_t sh = ((size_t)G * LPV * NSL + 16 + 16 + 6 + 2 * DSM_LOG_TAB_N) * sizeof(double) +
-                      ((size_t)G * LPV * NSL + 20) * sizeof(float);        // + fp32 copies of gamma / eta for the screening pass
+    const size_t sh = tau_lds_bytes(G, LPV, NSL);
     if (sh > 160 * 1024) { dsm_set_error("gamma tile (%zu B) exceeds LDS", sh); return DSM_ERR_UNSUPPORTED; }
 #define TAU_CASE(L, N) if (LPV == L && NSL == N) launch_tau<L, N>(c, mode, p, grid, sh)
     TAU_CASE(16, 1); TAU_CASE(16, 2); TAU_CASE(16, 3); TAU_CASE(32, 1); TAU_CASE(32, 2); TAU_CASE(32, 3); TAU_CASE(64, 1); TAU_CASE(64, 2); TAU_CASE(64, 3); TAU_CASE(64, 4);
@@ -1168,6 +1182,27 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
 #undef TAU_CASE
     HIP_TRY(hipGetLastError());
     if (nblocks) *nblocks = grid;
+    return DSM_OK;
+}
+
+// workgroups one sweep launches and workgroups of that kernel the device holds at once (occupancy x compute units): the
+// launch runs as launched / resident rounds, and the last, partly filled round is its tail (bench.py: roofline.tail_frac)
+int tau_launch_info(dsm_ctx *c, int *launched, int *resident)
+{
+    int LPV, NSL;
+    { const int rc = tau_shape(c->S, &LPV, &NSL); if (rc != DSM_OK) return rc; }
+    const int gpb = 256 / LPV;
+    int grid = (c->V + gpb - 1) / gpb;
+    if (grid > DSM_MAX_GRID) grid = DSM_MAX_GRID;
+    const size_t sh = tau_lds_bytes(c->G, LPV, NSL);
+    int per_cu = 0, cus = 0;
+#define TAU_CASE(L, N) if (LPV == L && NSL == N) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tau_kernel<L, N, true, true>, 256, sh))
+    TAU_CASE(16, 1); TAU_CASE(16, 2); TAU_CASE(16, 3); TAU_CASE(32, 1); TAU_CASE(32, 2); TAU_CASE(32, 3); TAU_CASE(64, 1); TAU_CASE(64, 2); TAU_CASE(64, 3); TAU_CASE(64, 4);
+    TAU_CASE(64, 6); TAU_CASE(64, 8);
+#undef TAU_CASE
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    *launched = grid;
+    *resident = per_cu * cus;
     return DSM_OK;
 }
 

@@ -43,6 +43,9 @@ struct StatsAggParams {
                                     // whole pass on deep data)
     size_t big_seg;
     double lean_cap;                // stage 1 hands an item whose rarer outcome has a mean above this to the compacted kernel
+    int xcd;                        // 1: the table has a copy per XCD (rep = 8 k); a workgroup adds to a copy of ITS XCD (HW_REG_XCC_ID) with
+                                    // workgroup-scope atomics, which execute in that XCD's L2 instead of at the memory side
+    int dbg;                        // timing experiments only (DESMAN_HIP_STATS_DBG): bit 0 no draws, 1 no item seeding, 2 no E/N atomics, 3 no cell Philox
 };
 
 __device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t x)
@@ -53,32 +56,49 @@ __device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t x)
 
 // LPV = lanes per variant: a wavefront works on 64 / LPV (variant, LPV-sample chunk) tasks at a time, so that tables of 16,
 // 32, 48 or 96 samples fill its lanes (lane = sample alone leaves 3/4 of a wavefront idle at S = 16 and 1/4 at S = 96).
-template <int LPV>
+// SPEC: 2 or 3 (dsm_binom.h).  REGG: S <= LPV and G <= 8 -- a lane keeps its sample for the whole launch, so its G abundances
+// live in registers (no LDS tile of gamma: the 4 KB it took at config 3 now hold the log / exp tables of spec 3 at the same six
+// workgroups per CU) and the haplotype loop of a cell is scalar compares + one add per haplotype, no LDS read.
+template <int LPV, int SPEC, bool REGG>
 __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_s[];
     constexpr int NG = 64 / LPV;
+    constexpr int NTAB = SPEC >= 3 ? (2 * DSM_LOG_TAB_N + DSM_EXP_TAB_N) : 0;      // doubles: log table, then exp table
     const int S = p.S, G = p.G, V = p.V;
     const int NCH = (S + LPV - 1) / LPV, SP = NCH * LPV;
-    double *gT = reinterpret_cast<double *>(smem_s);                 // [G][SP] gamma transposed
-    double *rcp = gT + (size_t)G * SP;                                // [64]   1/k
+    double *tabs = reinterpret_cast<double *>(smem_s);                // [NTAB]
+    double *gT = tabs + NTAB;                                         // [G][SP] gamma transposed (not with REGG)
+    double *rcp = gT + (REGG ? 0 : (size_t)G * SP);                   // [256]  1/k
     double *es = rcp + DSM_RCP_TAB_N;                                 // [16]   eta
-    unsigned long long *acc = reinterpret_cast<unsigned long long *>(es + 16);   // [16]
-    uint32_t *eacc = reinterpret_cast<uint32_t *>(acc + 16);          // [16][256] lane-private Esum columns
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(rcp);       // [16] overlays the 1/k table once the passes are done
+    uint32_t *eacc = reinterpret_cast<uint32_t *>(es + 16);           // [16][256] lane-private Esum columns
+    const double2 *ltab = reinterpret_cast<const double2 *>(tabs);
     const int tid = threadIdx.x, lane = tid & 63;
     const int grp = lane / LPV, lig = lane % LPV;
-    for (int i = tid; i < G * SP; i += 256) {
-        const int g = i / SP, s = i - g * SP;
-        gT[i] = (s < S) ? p.gamma[(size_t)s * G + g] : 0.0;
+    if constexpr (!REGG) {
+        for (int i = tid; i < G * SP; i += 256) {
+            const int g = i / SP, s = i - g * SP;
+            gT[i] = (s < S) ? p.gamma[(size_t)s * G + g] : 0.0;
+        }
     }
+    if constexpr (SPEC >= 3) { for (int i = tid; i < NTAB; i += 256) tabs[i] = p.log_tab[i]; }
     for (int k = tid; k < DSM_RCP_TAB_N; k += blockDim.x) rcp[k] = k ? 1.0 / (double)k : 0.0;
-    if (tid < 16) { es[tid] = p.eta[tid]; acc[tid] = 0ull; }
+    if (tid < 16) es[tid] = p.eta[tid];
 #pragma unroll
     for (int i = 0; i < 16; ++i) eacc[i * 256 + tid] = 0u;
+    double gr[REGG ? 8 : 1];
+    if constexpr (REGG) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) gr[g] = (g < G && lig < S) ? p.gamma[(size_t)lig * G + g] : 0.0;
+    }
     __syncthreads();
 
     const int nwaves = gridDim.x * 4;
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6));
+    // which copy of the subset table this workgroup adds to
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;                // HW_REG_XCC_ID[3:0] (gfx942 / gfx950)
+    const unsigned copy = p.xcd ? xcc + 8u * ((blockIdx.x >> 3) % (unsigned)(p.rep >> 3)) : blockIdx.x % (unsigned)p.rep;
     const int ntask = V * NCH;                                        // (variant, chunk of LPV samples)
     const int nslot = (ntask + NG - 1) / NG;                          // NG tasks per wavefront pass
     for (int slot = wid; slot < nslot; slot += nwaves) {
@@ -101,21 +121,36 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
             const uint32_t tlo = __builtin_amdgcn_readlane((uint32_t)t, gi * LPV), thi = __builtin_amdgcn_readlane((uint32_t)(t >> 32), gi * LPV);
             const uint64_t tg = ((uint64_t)thi << 32) | tlo;
             if (NG == 1 || grp == gi) {
-                for (int g = 0; g < G; ++g) {
-                    const int a = (int)((tg >> (2 * g)) & 3);
-                    const double x = gcol[g * SP];
-                    const uint32_t bit = 1u << g;
-                    if (a == 0) { H0 |= bit; G0 = G0 + x; }
-                    else if (a == 1) { H1 |= bit; G1 = G1 + x; }
-                    else if (a == 2) { H2 |= bit; G2 = G2 + x; }
-                    else { H3 |= bit; G3 = G3 + x; }
+                if constexpr (REGG) {
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        if (g < G) {
+                            const int a = (int)((tlo >> (2 * g)) & 3);
+                            const uint32_t bit = 1u << g;
+                            if (a == 0) { H0 |= bit; G0 = G0 + gr[g]; }
+                            else if (a == 1) { H1 |= bit; G1 = G1 + gr[g]; }
+                            else if (a == 2) { H2 |= bit; G2 = G2 + gr[g]; }
+                            else { H3 |= bit; G3 = G3 + gr[g]; }
+                        }
+                    }
+                } else {
+                    for (int g = 0; g < G; ++g) {
+                        const int a = (int)((tg >> (2 * g)) & 3);
+                        const double x = gcol[g * SP];
+                        const uint32_t bit = 1u << g;
+                        if (a == 0) { H0 |= bit; G0 = G0 + x; }
+                        else if (a == 1) { H1 |= bit; G1 = G1 + x; }
+                        else if (a == 2) { H2 |= bit; G2 = G2 + x; }
+                        else { H3 |= bit; G3 = G3 + x; }
+                    }
                 }
             }
         }
         const double Gam[4] = {G0, G1, G2, G3};
         const uint32_t cell = (uint32_t)s * (uint32_t)V + (uint32_t)v;
         uint32_t cbase[4];
-        philox4x32_10(cell, 0u, p.iter, DSM_STREAM_STA1, p.k0, p.k1, cbase);         // one Philox-10 per cell
+        if (p.dbg & 8) { cbase[0] = cell; cbase[1] = p.iter; cbase[2] = p.k0; cbase[3] = p.k1; }
+        else philox4x32_10(cell, 0u, p.iter, DSM_STREAM_STA1, p.k0, p.k1, cbase);         // one Philox-10 per cell
         uint32_t nacc[4] = {0, 0, 0, 0};
 #pragma unroll 1
         for (int b = 0; b < 4; ++b) {
@@ -130,10 +165,11 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
                     for (int a = 0; a < 4; ++a) W[a] = Gam[a];
                 }
                 uint32_t n[4];
-                Xo128 rng = item_seed(cbase, (uint32_t)b, p.k0, p.k1);
+                Xo128 rng = (p.dbg & 2) ? Xo128{cbase[0] + b, cbase[1], cbase[2], cbase[3] | 1u} : item_seed<SPEC>(cbase, (uint32_t)b, p.k0, p.k1);
                 bool defer = false;
                 int kind = 0;
-                mult4<false>(rng, (uint32_t)xb, W, n, rcp, nullptr, defer, p.lean_cap, &kind);
+                if (p.dbg & 1) { n[0] = (uint32_t)xb + (uint32_t)(W[0] > W[1]) + rng.s0; n[1] = n[2] = n[3] = 0; }
+                else mult4<false, SPEC>(rng, (uint32_t)xb, W, n, rcp, ltab, defer, p.lean_cap, &kind);
                 if (__builtin_expect(defer, 0)) {
                     // needs the rejection sampler: the compacted kernel re-does this item from its own stream
                     // (one atomic per wavefront: the deferring lanes take consecutive slots)
@@ -151,6 +187,9 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
                         const uint32_t slot = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
                         if (kind == kd) p.big_list[(size_t)sub * p.big_seg + slot] = (unsigned long long)cell * 4ull + (unsigned long long)b;
                     }
+                } else if (p.dbg & (4 | 16)) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) nacc[a] += n[a];
                 } else {
                     uint32_t *erow = eacc + (b * 4) * 256 + tid;           // lane-private column: ds_add_u32, never a conflict
 #pragma unroll
@@ -159,13 +198,30 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
             }
         }
         // N[H_a(v)][s] += reads whose true base is a: adjacent lanes -> adjacent words of one table row
-        uint32_t *const nt = p.ntab + (size_t)(blockIdx.x % (unsigned)p.rep) * (((size_t)1 << G) * S);
-        if (nacc[0]) atomicAdd(nt + (size_t)H0 * S + s, nacc[0]);
-        if (nacc[1]) atomicAdd(nt + (size_t)H1 * S + s, nacc[1]);
-        if (nacc[2]) atomicAdd(nt + (size_t)H2 * S + s, nacc[2]);
-        if (nacc[3]) atomicAdd(nt + (size_t)H3 * S + s, nacc[3]);
+        uint32_t *const nt = p.ntab + (size_t)copy * (((size_t)1 << G) * S);
+        if (p.dbg & (4 | 32)) { if ((nacc[0] ^ nacc[1] ^ nacc[2] ^ nacc[3] ^ H0 ^ H1 ^ H2 ^ H3) == 0x12345u) atomicAdd(nt + s, 1u); continue; }
+        if (p.dbg & 64) {        // plain stores instead of atomics (wrong sums; what the adds cost beyond a store)
+            nt[(size_t)H0 * S + s] = nacc[0]; nt[(size_t)H1 * S + s] = nacc[1]; nt[(size_t)H2 * S + s] = nacc[2]; nt[(size_t)H3 * S + s] = nacc[3];
+            continue;
+        }
+        if (p.xcd) {
+            // this XCD's copy: every adder of the copy shares the L2 the atomic executes in (relaxed, workgroup scope: no sc1, the
+            // line stays in L2); the kernel boundary writes the lines back for stage 2, which sums the copies
+            if (nacc[0]) __hip_atomic_fetch_add(nt + (size_t)H0 * S + s, nacc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (nacc[1]) __hip_atomic_fetch_add(nt + (size_t)H1 * S + s, nacc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (nacc[2]) __hip_atomic_fetch_add(nt + (size_t)H2 * S + s, nacc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (nacc[3]) __hip_atomic_fetch_add(nt + (size_t)H3 * S + s, nacc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            if (nacc[0]) atomicAdd(nt + (size_t)H0 * S + s, nacc[0]);
+            if (nacc[1]) atomicAdd(nt + (size_t)H1 * S + s, nacc[1]);
+            if (nacc[2]) atomicAdd(nt + (size_t)H2 * S + s, nacc[2]);
+            if (nacc[3]) atomicAdd(nt + (size_t)H3 * S + s, nacc[3]);
+        }
     }
     // Esum: lane-private columns -> one transposing butterfly per wavefront -> one global atomic per workgroup and counter
+    __syncthreads();                                                  // every wavefront is done with the 1/k table: acc takes its place
+    if (tid < 16) acc[tid] = 0ull;
+    __syncthreads();
     {
         uint32_t e[16];
 #pragma unroll
@@ -178,19 +234,21 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
     if (tid < 16 && acc[tid]) atomicAdd(&p.esum[tid], acc[tid]);
 }
 
-template <int LPV>
-__global__ __launch_bounds__(256) void stats_agg_kernel(StatsAggParams p) { stats_agg_body<LPV>(p); }
-template <int LPV>
-__global__ __launch_bounds__(256) void stats_agg_kernel_b(BatchArgs<StatsAggParams> b) { stats_agg_body<LPV>(b.p[blockIdx.y]); }
+// six wavefronts per SIMD (the persistent grid's six workgroups per CU): the register allocation must leave room for them
+template <int LPV, int SPEC, bool REGG>
+__global__ __launch_bounds__(256, 6) void stats_agg_kernel(StatsAggParams p) { stats_agg_body<LPV, SPEC, REGG>(p); }
+template <int LPV, int SPEC, bool REGG>
+__global__ __launch_bounds__(256, 6) void stats_agg_kernel_b(BatchArgs<StatsAggParams> b) { stats_agg_body<LPV, SPEC, REGG>(b.p[blockIdx.y]); }
 
 // ---------------------------------------------------------------------------------------------------
 // the deferred items (rarer outcome with a mean above 64: burn-in states, very deep data), one lane per item:
 // the same arithmetic as stats_agg_kernel with the full sampler (BTRS).  tau_v differs from lane to lane here,
 // so the haplotype sets / abundances are built with vector selects.
 // ---------------------------------------------------------------------------------------------------
+template <int SPEC>
 __device__ __forceinline__ void stats_big_body(const StatsAggParams &p)
 {
-    __shared__ double2 ltab[DSM_LOG_TAB_N];
+    __shared__ double2 ltab[DSM_LOG_TAB_N + DSM_EXP_TAB_N / 2];          // log table, then the exp table (dsm_binom.h: binom)
     __shared__ double rcp[DSM_RCP_TAB_N];
     __shared__ double es[16];
     __shared__ unsigned long long acc[16];
@@ -201,6 +259,7 @@ __device__ __forceinline__ void stats_big_body(const StatsAggParams &p)
     if (bi * 256u >= nbig) return;
     const unsigned long long *list = p.big_list + (size_t)sub * p.big_seg;
     ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
+    if (tid < DSM_EXP_TAB_N / 2) ltab[DSM_LOG_TAB_N + tid] = reinterpret_cast<const double2 *>(p.log_tab)[DSM_LOG_TAB_N + tid];
     for (int k = tid; k < DSM_RCP_TAB_N; k += blockDim.x) rcp[k] = k ? 1.0 / (double)k : 0.0;
     if (tid < 16) { es[tid] = p.eta[tid]; acc[tid] = 0ull; }
 #pragma unroll
@@ -232,9 +291,9 @@ __device__ __forceinline__ void stats_big_body(const StatsAggParams &p)
         }
         uint32_t n[4], cbase[4];
         philox4x32_10(cell, 0u, p.iter, DSM_STREAM_STA1, p.k0, p.k1, cbase);
-        Xo128 rng = item_seed(cbase, (uint32_t)b, p.k0, p.k1);
+        Xo128 rng = item_seed<SPEC>(cbase, (uint32_t)b, p.k0, p.k1);
         bool defer = false;
-        mult4<true>(rng, (uint32_t)xb, W, n, rcp, ltab, defer);
+        mult4<true, SPEC>(rng, (uint32_t)xb, W, n, rcp, ltab, defer);
         uint32_t *erow = eacc + (b * 4) * 256 + tid;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -254,43 +313,49 @@ __device__ __forceinline__ void stats_big_body(const StatsAggParams &p)
     if (tid < 16 && acc[tid]) atomicAdd(&p.esum[tid], acc[tid]);
 }
 
-__global__ __launch_bounds__(256) void stats_big_kernel(StatsAggParams p) { stats_big_body(p); }
-__global__ __launch_bounds__(256) void stats_big_kernel_b(BatchArgs<StatsAggParams> b) { stats_big_body(b.p[blockIdx.y]); }
+template <int SPEC>
+__global__ __launch_bounds__(256) void stats_big_kernel(StatsAggParams p) { stats_big_body<SPEC>(p); }
+template <int SPEC>
+__global__ __launch_bounds__(256) void stats_big_kernel_b(BatchArgs<StatsAggParams> b) { stats_big_body<SPEC>(b.p[blockIdx.y]); }
 
 #include "dsm_stage2.h"
 
 struct Stage2Batch { Stage2Params p[DSM_MAX_BATCH]; S2Plan plan; };
+template <int SPEC>
 __global__ __launch_bounds__(1024) void stats_stage2_kernel(Stage2Params p, S2Plan plan)
 {
     __shared__ __attribute__((aligned(16))) char smem2[S2_SMEM_BYTES];
-    stage2_sample(p, plan, blockIdx.x, smem2, true);
+    stage2_sample<SPEC>(p, plan, blockIdx.x, smem2, true);
 }
+template <int SPEC>
 __global__ __launch_bounds__(1024) void stats_stage2_kernel_b(Stage2Batch b)
 {
     __shared__ __attribute__((aligned(16))) char smem2[S2_SMEM_BYTES];
-    stage2_sample(b.p[blockIdx.y], b.plan, blockIdx.x, smem2, true);
+    stage2_sample<SPEC>(b.p[blockIdx.y], b.plan, blockIdx.x, smem2, true);
 }
 
 // test hook: variate i of a sampler from the stream Philox({i, 0, 0, 'TEST'})  (oracle: orc_binom_test / orc_mult4_test)
+template <int SPEC>
 __global__ __launch_bounds__(256) void binom_test_kernel(int kind, uint32_t n, double wa, double wb, double w2, double w3,
                                                          uint32_t k0, uint32_t k1, int nsamp, const double *log_tab,
                                                          uint32_t *out)
 {
-    __shared__ double2 ltab[DSM_LOG_TAB_N];
+    __shared__ double2 ltab[DSM_LOG_TAB_N + DSM_EXP_TAB_N / 2];
     __shared__ double rcp[DSM_RCP_TAB_N];
     const int tid = threadIdx.x;
     ltab[tid] = reinterpret_cast<const double2 *>(log_tab)[tid];
+    if (tid < DSM_EXP_TAB_N / 2) ltab[DSM_LOG_TAB_N + tid] = reinterpret_cast<const double2 *>(log_tab)[DSM_LOG_TAB_N + tid];
     for (int k = tid; k < DSM_RCP_TAB_N; k += blockDim.x) rcp[k] = k ? 1.0 / (double)k : 0.0;
     __syncthreads();
     const int i = blockIdx.x * 256 + tid;
     if (i >= nsamp) return;
     Xo128 rng = xo_seed((uint32_t)i, 0u, 0u, DSM_STREAM_TEST, k0, k1);
     bool dummy = false;
-    if (kind != 2) out[i] = binom<true>(rng, n, wa, wb, rcp, ltab, dummy, kind == 0 ? DSM_BINV_MEAN_CAP : DSM_BINV_MEAN_CAP_S2);
+    if (kind != 2) out[i] = binom<true, SPEC>(rng, n, wa, wb, rcp, ltab, dummy, kind == 0 ? DSM_BINV_MEAN_CAP : DSM_BINV_MEAN_CAP_S2);
     else {
         const double W[4] = {wa, wb, w2, w3};
         uint32_t m[4];
-        mult4<true>(rng, n, W, m, rcp, ltab, dummy);
+        mult4<true, SPEC>(rng, n, W, m, rcp, ltab, dummy);
         out[i * 4 + 0] = m[0]; out[i * 4 + 1] = m[1]; out[i * 4 + 2] = m[2]; out[i * 4 + 3] = m[3];
     }
 }
@@ -322,13 +387,13 @@ int stats_spec(const dsm_ctx *c)
     int force = c->force_stats_spec;
     if (force == 0) {                       // DESMAN_HIP_STATS_SPEC=1|2: the choice for every context that has none of its own
         const char *e = getenv("DESMAN_HIP_STATS_SPEC");   // (2 = the draws of a batched run, also for chains run one by one)
-        if (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) force = e[0] - '0';
+        if (e && (e[0] == '1' || e[0] == '2' || e[0] == '3') && e[1] == 0) force = e[0] - '0';
     }
     if (force == 1) return 1;
     if (c->G < 1 || c->G > 16) return 1;
     if (((size_t)1 << c->G) * (size_t)c->S * 4 > ((size_t)64 << 20)) return 1;
     if (c->max_depth >= ((uint64_t)1 << 32)) return 1;
-    if (force == 2) return 2;
+    if (force >= 2) return force;                        // 2 = the first version of the aggregated draws, 3 = the current one
     double reads = 0.0;
     for (int64_t d : c->depth) reads += (double)d;
     const int lpv = stats_agg_lpv(c->S);
@@ -339,7 +404,7 @@ int stats_spec(const dsm_ctx *c)
     const int rep = stats_ntab_rep(c);
     const double per = 3.0 * (double)c->V / (double)(1u << c->G);                // atomics per counter of the subset table
     const double t2 = 24.0 + stage2 + 0.062e-3 * cells + (rep == 1 ? 0.03 * per : 0.003 * per / rep);   // with copies: no measurable penalty
-    return t2 < t1 ? 2 : 1;
+    return t2 < t1 ? DSM_STATS_AGG : 1;
 }
 
 // Few subsets and many positions put thousands of atomics on every counter of the subset table (3 V / 2^G each: 9 375 at
@@ -363,9 +428,19 @@ int stats_ntab_rep(const dsm_ctx *c)
     return rep;
 }
 
+// a copy of the table per XCD (stats_agg_body: the atomics of stage 1 then execute in the XCD's L2) while 8 copies stay below 64 MB
+static bool stats_ntab_xcd(const dsm_ctx *c)
+{
+    // measured at config 3 (rocprofv3 kernel trace of the Gibbs loop): stage 1 47.9 -> 46.1 us, but the root of stage 2 then reads
+    // eight copies: Dirichlet launch 19.2 -> 22.7 us.  Off by default.
+    static const int env = getenv("DESMAN_HIP_NTAB_XCD") ? atoi(getenv("DESMAN_HIP_NTAB_XCD")) : 0;      // A/B switch
+    return env != 0 && (size_t)8 * ((size_t)1 << c->G) * (size_t)c->S * 4 <= ((size_t)64 << 20);
+}
+
 static int ensure_ntab(dsm_ctx *c)
 {
     c->ntab_rep = stats_ntab_rep(c);
+    if (stats_ntab_xcd(c)) c->ntab_rep = std::max(8, (c->ntab_rep + 7) / 8 * 8);
     const size_t need = (size_t)c->ntab_rep * ((size_t)1 << c->G) * (size_t)c->S;
     if (c->ntab && c->ntab_len == need) return DSM_OK;
     if (c->ntab) { (void)hipFree(c->ntab); c->ntab = nullptr; }
@@ -400,16 +475,30 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     const int S = c->S, G = c->G, V = c->V;
     const int LPV = stats_agg_lpv(S);
     const int NCH = (S + LPV - 1) / LPV, SP = NCH * LPV, NG = 64 / LPV;
-    const size_t sh = ((size_t)G * SP + DSM_RCP_TAB_N + 16 + 16) * sizeof(double) + 16 * 256 * sizeof(uint32_t);
+    const int spec = stats_spec(c);                       // 2 or 3 (the caller checked that the aggregated pass applies)
+    static const int regg_env = getenv("DESMAN_HIP_STATS_REGG") ? atoi(getenv("DESMAN_HIP_STATS_REGG")) : -1;   // A/B switch
+    // (gamma in registers where a lane keeps its sample, instead of the LDS tile: measured slower -- 87-91 VGPRs, i.e. five
+    // wavefronts per SIMD, or spills at six: 54-57 us against 48-49; kept as an A/B switch)
+    const bool regg = NCH == 1 && G <= 8 && regg_env == 1;
+    const size_t sh = ((regg ? 0 : (size_t)G * SP) + (spec >= 3 ? 2 * DSM_LOG_TAB_N + DSM_EXP_TAB_N : 0) + DSM_RCP_TAB_N + 16) * sizeof(double) +
+                      16 * 256 * sizeof(uint32_t);
     if (sh > 160 * 1024) { dsm_set_error("stats_agg: gamma tile (%zu B) exceeds LDS", sh); return DSM_ERR_UNSUPPORTED; }
-    const void *fn = LPV == 16 ? (const void *)stats_agg_kernel<16> : LPV == 32 ? (const void *)stats_agg_kernel<32>
-                                                                              : (const void *)stats_agg_kernel<64>;
-    if (c->stats_grid == 0) {
+    // the instantiation of this shape and specification: {single, batched}
+    const void *fn = nullptr, *fn_b = nullptr;
+#define AGG_CASE(L, SP_, R)                                                                                               \
+    if (LPV == L && spec == SP_ && regg == R) { fn = (const void *)stats_agg_kernel<L, SP_, R>; fn_b = (const void *)stats_agg_kernel_b<L, SP_, R>; }
+    AGG_CASE(16, 2, false) AGG_CASE(16, 2, true) AGG_CASE(32, 2, false) AGG_CASE(32, 2, true) AGG_CASE(64, 2, false) AGG_CASE(64, 2, true)
+    AGG_CASE(16, 3, false) AGG_CASE(16, 3, true) AGG_CASE(32, 3, false) AGG_CASE(32, 3, true) AGG_CASE(64, 3, false) AGG_CASE(64, 3, true)
+#undef AGG_CASE
+    if (!fn) { dsm_set_error("stats_agg: no kernel for spec %d", spec); return DSM_ERR_UNSUPPORTED; }
+    if (c->stats_grid == 0 || c->stats_grid_key != (spec * 2 + (regg ? 1 : 0))) {
         int occ = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, sh));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-        c->stats_grid = std::min(6, std::max(1, occ)) * prop.multiProcessorCount;   // six workgroups per CU: measured optimum (below)
+        static const int wgs_env = getenv("DESMAN_HIP_STATS_WGS") ? atoi(getenv("DESMAN_HIP_STATS_WGS")) : 6;   // A/B switch
+        c->stats_grid = std::min(wgs_env, std::max(1, occ)) * prop.multiProcessorCount;   // six workgroups per CU: measured optimum (below)
+        c->stats_grid_key = spec * 2 + (regg ? 1 : 0);
     }
     const long ntask = ((long)V * NCH + NG - 1) / NG;            // wavefront passes (NG lane groups = NG tasks each)
     // a persistent grid of six workgroups (24 wavefronts) per CU, passes dealt round-robin: the kernel is issue-bound, and a SIMD
@@ -429,6 +518,7 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     p.V = V; p.S = S; p.G = G; p.big_seg = seg;
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
     p.ntab = c->ntab; p.rep = c->ntab_rep; p.esum = c->esum; p.log_tab = c->log_tab;
+    p.xcd = stats_ntab_xcd(c) ? 1 : 0;
     p.big_list = c->big_list; p.big_count = c->big_count;
     {
         // who draws an item, not what is drawn: an item whose rarer outcome has a mean above lean_cap goes to the compacted
@@ -437,6 +527,8 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
         // 48 -> 105 + 81, 32 -> 86 + 134.  Data of ordinary depth has no such item once the chain has converged.
         static const char *e = getenv("DESMAN_HIP_LEAN_CAP");
         p.lean_cap = e ? atof(e) : DSM_LEAN_CAP;
+        static const int dbg = getenv("DESMAN_HIP_STATS_DBG") ? atoi(getenv("DESMAN_HIP_STATS_DBG")) : 0;
+        p.dbg = dbg;
         if (!(p.lean_cap > 0.0 && p.lean_cap <= DSM_BINV_MEAN_CAP)) p.lean_cap = DSM_LEAN_CAP;
     }
     // (a batch: fewer workgroups per list, the launch holds K times as many lists)
@@ -448,25 +540,25 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
         acc.p[g_batch.k] = p;
         if (g_batch.k == g_batch.K - 1) {
             const dim3 g(grid, g_batch.K);
-            if (LPV == 16) hipLaunchKernelGGL(stats_agg_kernel_b<16>, g, dim3(256), sh, c->stream, acc);
-            else if (LPV == 32) hipLaunchKernelGGL(stats_agg_kernel_b<32>, g, dim3(256), sh, c->stream, acc);
-            else hipLaunchKernelGGL(stats_agg_kernel_b<64>, g, dim3(256), sh, c->stream, acc);
-            hipLaunchKernelGGL(stats_big_kernel_b, dim3(big_grid, g_batch.K), dim3(256), 0, c->stream, acc);
+            void *args[] = {(void *)&acc};
+            HIP_TRY(hipLaunchKernel(fn_b, g, dim3(256), args, sh, c->stream));
+            if (spec >= 3) hipLaunchKernelGGL(stats_big_kernel_b<3>, dim3(big_grid, g_batch.K), dim3(256), 0, c->stream, acc);
+            else hipLaunchKernelGGL(stats_big_kernel_b<2>, dim3(big_grid, g_batch.K), dim3(256), 0, c->stream, acc);
         }
         HIP_TRY(hipGetLastError());
         return DSM_OK;
     }
     {
         KTimer tm(c, DSM_K_STATS);
-        if (LPV == 16) hipLaunchKernelGGL(stats_agg_kernel<16>, dim3(grid), dim3(256), sh, c->stream, p);
-        else if (LPV == 32) hipLaunchKernelGGL(stats_agg_kernel<32>, dim3(grid), dim3(256), sh, c->stream, p);
-        else hipLaunchKernelGGL(stats_agg_kernel<64>, dim3(grid), dim3(256), sh, c->stream, p);
+        void *args[] = {(void *)&p};
+        HIP_TRY(hipLaunchKernel(fn, dim3(grid), dim3(256), args, sh, c->stream));
     }
     KTimer tm(c, DSM_K_STATSBIG);
     // the deferred items (none once the chain has converged on data of ordinary depth: the launch then returns at once);
     // up to 16 workgroups per list = 4096 items of a list per round (a list one item longer than a round doubles the launch:
     // every wavefront is one long dependent chain); the workgroups of an empty list leave at once
-    hipLaunchKernelGGL(stats_big_kernel, dim3(big_grid), dim3(256), 0, c->stream, p);
+    if (spec >= 3) hipLaunchKernelGGL(stats_big_kernel<3>, dim3(big_grid), dim3(256), 0, c->stream, p);
+    else hipLaunchKernelGGL(stats_big_kernel<2>, dim3(big_grid), dim3(256), 0, c->stream, p);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }
@@ -508,23 +600,27 @@ int k_stats_stage2(dsm_ctx *c, uint32_t iter)
     p.big_count = c->big_count;
     // 2^G subsets per sample at the root: 256 threads up to G = 9, 1024 above
     const int nthr = c->G >= 10 ? 1024 : 256;
-    if (g_batch.K == 0) hipLaunchKernelGGL(stats_stage2_kernel, dim3(c->S), dim3(nthr), 0, c->stream, p, make_stage2_plan(c->G));
-    else {
+    const bool v3 = stats_spec(c) >= 3;
+    if (g_batch.K == 0) {
+        if (v3) hipLaunchKernelGGL(stats_stage2_kernel<3>, dim3(c->S), dim3(nthr), 0, c->stream, p, make_stage2_plan(c->G));
+        else hipLaunchKernelGGL(stats_stage2_kernel<2>, dim3(c->S), dim3(nthr), 0, c->stream, p, make_stage2_plan(c->G));
+    } else {
         static thread_local Stage2Batch acc;
         acc.p[g_batch.k] = p;
         if (g_batch.k == g_batch.K - 1) {
             acc.plan = make_stage2_plan(c->G);
-            hipLaunchKernelGGL(stats_stage2_kernel_b, dim3(c->S, g_batch.K), dim3(nthr), 0, c->stream, acc);
+            if (v3) hipLaunchKernelGGL(stats_stage2_kernel_b<3>, dim3(c->S, g_batch.K), dim3(nthr), 0, c->stream, acc);
+            else hipLaunchKernelGGL(stats_stage2_kernel_b<2>, dim3(c->S, g_batch.K), dim3(nthr), 0, c->stream, acc);
         }
     }
     HIP_TRY(hipGetLastError());
     return DSM_OK;
 }
 
-// A2 for the resident state: spec v2 where it applies, else the per-read pass (spec v1)
+// A2 for the resident state: the aggregated pass (spec 3, or 2 when forced) where it applies, else the per-read pass (spec 1)
 int k_stats(dsm_ctx *c, uint32_t iter)
 {
-    if (stats_spec(c) == 2) {
+    if (stats_spec(c) >= 2) {
         int r = k_stats_stage1(c, iter);
         if (r != DSM_OK) return r;
         return k_stats_stage2(c, iter);
@@ -532,9 +628,11 @@ int k_stats(dsm_ctx *c, uint32_t iter)
     return k_stats_v1(c, iter);
 }
 
-int k_binom_test(dsm_ctx *c, int kind, uint32_t n, const double *w, uint64_t seed, int nsamp, uint32_t *d_out)
+int k_binom_test(dsm_ctx *c, int kind, uint32_t n, const double *w, uint64_t seed, int nsamp, uint32_t *d_out, int spec)
 {
-    hipLaunchKernelGGL(binom_test_kernel, dim3((nsamp + 255) / 256), dim3(256), 0, c->stream, kind, n, w[0], w[1], w[2], w[3],
+    if (spec >= 3) hipLaunchKernelGGL(binom_test_kernel<3>, dim3((nsamp + 255) / 256), dim3(256), 0, c->stream, kind, n, w[0], w[1], w[2], w[3],
+                                      (uint32_t)seed, (uint32_t)(seed >> 32), nsamp, c->log_tab, d_out);
+    else hipLaunchKernelGGL(binom_test_kernel<2>, dim3((nsamp + 255) / 256), dim3(256), 0, c->stream, kind, n, w[0], w[1], w[2], w[3],
                        (uint32_t)seed, (uint32_t)(seed >> 32), nsamp, c->log_tab, d_out);
     HIP_TRY(hipGetLastError());
     return DSM_OK;

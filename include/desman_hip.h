@@ -119,20 +119,25 @@ int dsm_ctx_sample_tau(dsm_ctx *ctx, int *nchange, double *logp_out);
 /* A2: one draw of the auxiliary-count sums (HaploSNP_Sampler.py:284-309 via
  * :266,:276): sum_mu [S][G], esum [4][4] = [observed][true].                 */
 int dsm_ctx_sample_stats(dsm_ctx *ctx, uint32_t iter, uint64_t *sum_mu, uint64_t *esum);
-/* which counter-based specification dsm_ctx_sample_stats / dsm_ctx_gibbs_update follow for the resident
- * shape: 2 = aggregated sampler (oracle/stats_agg.c; needs G <= 16, a subset table of at most 64 MB and every sample's
- * depth < 2^32), 1 = per-read draws (oracle/desman_oracle.c: orc_stats_counter).  Where both apply the cheaper pass runs,
- * by a cost model over the read total, the cells V x S (padded to the kernel's lane groups) and the atomics per subset
- * counter (kernels_stats.hip: stats_spec) -- a function of the shape and the read totals only, the same on every run.  dsm_ctx_force_stats_spec: 0 = that rule,
- * 1 = always spec 1, 2 = spec 2 also on small problems (G <= 16 still required).                     */
+/* which counter-based specification dsm_ctx_sample_stats / dsm_ctx_gibbs_update follow for the resident shape:
+ * 2 = aggregated sampler (oracle/stats_agg.c, spec 2; needs G <= 16, a subset table of at most 64 MB and every sample's
+ * depth < 2^32), 3 = a variant of it (same law; the start of the inversion search from a table exp / log instead of
+ * repeated squaring, item streams two Philox rounds off the cell's block instead of three -- selectable, not the default:
+ * measured no faster), 1 = per-read draws (oracle/desman_oracle.c: orc_stats_counter).  Where the aggregated pass applies
+ * the cheaper of it and the per-read pass runs, by a cost model over the read total, the cells V x S (padded to the
+ * kernel's lane groups) and the atomics per subset counter (kernels_stats.hip: stats_spec) -- a function of the shape and
+ * the read totals only, the same on every run.  dsm_ctx_force_stats_spec: 0 = that rule, 1 = always spec 1, 2 / 3 = that
+ * version of the aggregated sampler wherever it applies, small problems too (environment: DESMAN_HIP_STATS_SPEC=1|2|3 for
+ * contexts without a choice of their own).  A batch (dsm_batch_gibbs_update) always takes the aggregated sampler: spec 2,
+ * or 3 if its first chain asks.  */
 int dsm_ctx_stats_spec(dsm_ctx *ctx);
 int dsm_ctx_force_stats_spec(dsm_ctx *ctx, int spec);
-/* test hooks of spec 2: stage 1 only (subset counts ntab [S][2^G] u32 and esum), and nsamp variates of one
- * sampler (kind 0 binom_small, 1 binom_big: out [nsamp]; 2 mult4 with weights w[0..3]: out [nsamp][4])
- * exactly as oracle/stats_agg.c: orc_binom_test / orc_mult4_test draw them.                          */
+/* test hooks of the aggregated sampler: stage 1 only (subset counts ntab [S][2^G] u32 and esum), and nsamp variates of one
+ * sampler (kind 0 binom_small, 1 binom_big: out [nsamp]; 2 mult4 with weights w[0..3]: out [nsamp][4]) of version
+ * spec (2 / 3) exactly as oracle/stats_agg.c: orc_binom_test / orc_mult4_test draw them.                          */
 int dsm_ctx_debug_stage1(dsm_ctx *ctx, uint32_t iter, uint32_t *ntab, uint64_t *esum);
 int dsm_ctx_debug_binom(dsm_ctx *ctx, int kind, uint32_t n, const double *w4, uint64_t seed, int nsamp,
-                        uint32_t *out);
+                        uint32_t *out, int spec);
 
 /* A3+A4: gamma ~ Dir(alpha + sum_mu[s,:]) clamped/renormalised, eta[a,:] ~
  * Dir(delta + esum[:,a]) (HaploSNP_Sampler.py:263-281) from given sums.      */
@@ -290,6 +295,9 @@ int dsm_ctx_debug_log2f(dsm_ctx *ctx, const float *in, float *out, size_t n);
 int dsm_ctx_set_nmft_fused(dsm_ctx *ctx, int mode);
 /* on = 0: every step of the tau sweep in fp64 (A/B switch: the results do not depend on it) */
 int dsm_ctx_set_tau_screen(dsm_ctx *ctx, int on);
+/* workgroups one tau sweep of the resident shape launches, and how many of them the device holds at once (occupancy of the
+   kernel x compute units): launched / resident = rounds of the launch, the partly filled last one being its tail */
+int dsm_ctx_tau_launch_info(dsm_ctx *ctx, int *launched, int *resident);
 int dsm_ctx_set_timing(dsm_ctx *ctx, int on);
 int dsm_ctx_get_timing(dsm_ctx *ctx, double *ms_total /*[DSM_K_COUNT]*/,
                        int64_t *launches /*[DSM_K_COUNT]*/);

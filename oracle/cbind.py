@@ -70,12 +70,14 @@ def lib():
         L.orc_stats_expect.argtypes = [_u8p, _f64p, _f64p, _i64p, C.c_int, C.c_int, C.c_int,
                                        _f64p, _f64p, _f64p]
         L.orc_stats_agg.argtypes = [_u8p, _f64p, _f64p, _i64p, C.c_int, C.c_int, C.c_int,
-                                    C.c_uint64, C.c_uint32, _u64p, _u64p, C.c_void_p]
+                                    C.c_uint64, C.c_uint32, _u64p, _u64p, C.c_void_p, C.c_int]
         L.orc_stats_agg.restype = C.c_int
-        L.orc_binom_test.argtypes = [C.c_int, C.c_uint32, C.c_double, C.c_double, C.c_uint64, C.c_int, _u32p]
-        L.orc_mult4_test.argtypes = [C.c_uint32, _f64p, C.c_uint64, C.c_int, _u32p]
+        L.orc_binom_test.argtypes = [C.c_int, C.c_uint32, C.c_double, C.c_double, C.c_uint64, C.c_int, _u32p, C.c_int]
+        L.orc_mult4_test.argtypes = [C.c_uint32, _f64p, C.c_uint64, C.c_int, _u32p, C.c_int]
         L.orc_tlog.argtypes = [C.c_double]
         L.orc_tlog.restype = C.c_double
+        L.orc_texp.argtypes = [C.c_double]
+        L.orc_texp.restype = C.c_double
         L.orc_dirichlet_counter.argtypes = [_u64p, _u64p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                             C.c_uint64, C.c_uint32, _f64p, _f64p, _f64p]
         _lib = L
@@ -237,31 +239,38 @@ def dirichlet_counter(sum_mu, esum, seed, it, alpha=0.1, delta=0.1, epsilon=1e-6
     return g, e, rp
 
 
-def stats_agg(tau_idx, gamma, eta, variants, seed, it, want_ntab=False):
-    """spec v2 of the mu/E sums (oracle/stats_agg.c): (sum_mu [S,G], Esum [4,4][, ntab [S,2^G]])."""
+STATS_AGG = 2          # the aggregated specification the product runs by default (3 = the table exp / log variant, selectable)
+
+
+def stats_agg(tau_idx, gamma, eta, variants, seed, it, want_ntab=False, spec=STATS_AGG):
+    """the aggregated specification of the mu/E sums (oracle/stats_agg.c; spec 2 or 3): (sum_mu [S,G], Esum [4,4][, ntab [S,2^G]])."""
     V, S, _ = variants.shape
     G = tau_idx.shape[1]
     mu = np.zeros((S, G), dtype=np.uint64)
     E = np.zeros((4, 4), dtype=np.uint64)
     nt = np.zeros((S, 1 << G), dtype=np.uint32) if want_ntab else None
     rc = lib().orc_stats_agg(tau_idx, gamma, eta, variants, V, G, S, int(seed), int(it), mu, E,
-                             nt.ctypes.data if want_ntab else None)
+                             nt.ctypes.data if want_ntab else None, int(spec))
     if rc != 0:
-        raise ValueError("orc_stats_agg: G outside 1..16")
+        raise ValueError("orc_stats_agg: G outside 1..16 or spec not 2 / 3")
     return (mu, E, nt) if want_ntab else (mu, E)
 
 
-def binom_test(kind, n, wa, wb, seed, nsamp):
+def binom_test(kind, n, wa, wb, seed, nsamp, spec=STATS_AGG):
     out = np.empty(nsamp, dtype=np.uint32)
-    lib().orc_binom_test(int(kind), int(n), float(wa), float(wb), int(seed), int(nsamp), out)
+    lib().orc_binom_test(int(kind), int(n), float(wa), float(wb), int(seed), int(nsamp), out, int(spec))
     return out
 
 
-def mult4_test(x, W, seed, nsamp):
+def mult4_test(x, W, seed, nsamp, spec=STATS_AGG):
     out = np.empty((nsamp, 4), dtype=np.uint32)
-    lib().orc_mult4_test(int(x), np.ascontiguousarray(W, dtype=np.float64), int(seed), int(nsamp), out)
+    lib().orc_mult4_test(int(x), np.ascontiguousarray(W, dtype=np.float64), int(seed), int(nsamp), out, int(spec))
     return out
 
 
 def tlog(x):
     return lib().orc_tlog(float(x))
+
+
+def texp(y):
+    return lib().orc_texp(float(y))

@@ -38,6 +38,17 @@
  *   All arithmetic is IEEE double with the operation order written here (-ffp-contract=off), the
  *   logarithm of BTRS is the table-driven orc_tlog (same table and FMA sequence as the device's
  *   dsm_log), so the kernels reproduce this file bit for bit.
+ *
+ *   Two versions of the draws, selected by `spec` (same law; tests/test_law_cpu.py pins both to the exact pmf and to the
+ *   reference's sampleMu).  The product runs spec 2 by default; spec 3 was written to shorten stage 1 and measured no
+ *   faster on MI355X -- it stays selectable and tested:
+ *     spec 2   as above: (1-q)^n by repeated squaring, q/(1-q) and 1-q by two divisions, item streams three Philox
+ *              rounds off the cell's Philox-10 block;
+ *     spec 3   the start of the inversion search is f0 = exp(-n ln(1 + r)), r = q/(1-q) the ONE division of the
+ *              draw, with the table logarithm orc_tlog and a table exponential orc_texp (32-entry 2^(j/32) table,
+ *              degree-6 polynomial: |relative error| < 1e-15, hence < 1e-13 on f0) -- a fixed ~35 instructions
+ *              instead of a loop over the bits of n that runs to the deepest lane of the wavefront; item streams
+ *              two Philox rounds off the cell's block.  Everything else is spec 2.
  */
 #include <math.h>
 #include <stdint.h>
@@ -87,11 +98,12 @@ static void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1)
 
 /* stream of the item (cell, observed base b): `base` = Philox4x32-10({cell, 0, iter, 'STA1'}) of the cell, then three
  * rounds with the key (key + (b + 1) * Weyl constants), bumped per round as in Philox */
-static void item_seed(xo_t *r, const uint32_t base[4], uint32_t b, const uint32_t key[2])
+static void item_seed(xo_t *r, const uint32_t base[4], uint32_t b, const uint32_t key[2], int spec)
 {
     uint32_t c[4] = { base[0], base[1], base[2], base[3] };
     uint32_t k0 = key[0] ^ (0x9E3779B9u * (b + 1u)), k1 = key[1] ^ (0xBB67AE85u * (b + 1u));
-    for (int i = 0; i < 3; i++) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    const int rounds = spec >= 3 ? 2 : 3;            /* two rounds put every output word behind a keyed multiplication */
+    for (int i = 0; i < rounds; i++) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
     memcpy(r->s, c, sizeof c);
     if ((r->s[0] | r->s[1] | r->s[2] | r->s[3]) == 0) r->s[0] = 1;
 }
@@ -126,6 +138,25 @@ double orc_tlog(double x)
     const double w = fma(ed, 0x1.62e42fefa3800p-1, logc);
     const double lo = fma(ed, 0x1.ef35793c76730p-45, (r * r) * p);
     return (w + r) + lo;
+}
+
+/* exp(y) for y <= 0 (the device's dsm_texp restated): y = (32 k + j) ln2/32 + r, |r| <= ln2/64;
+ * exp(r) - 1 by a degree-6 polynomial (next term r^7/5040 < 4e-18), 2^(j/32) from the table, 2^k by ldexp. */
+double orc_texp(double y)
+{
+    if (!(y > -700.0)) return 0.0;
+    const double kd = rint(y * ORC_EXP_INV_LN2_32);
+    const int ki = (int)kd;
+    double r = fma(kd, -ORC_EXP_LN2_32_HI, y);
+    r = fma(kd, -ORC_EXP_LN2_32_LO, r);
+    double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
+    p = fma(r, p, 1.0 / 24.0);
+    p = fma(r, p, 1.0 / 6.0);
+    p = fma(r, p, 0.5);
+    p = fma(r, p, 1.0);
+    p = r * p;                                       /* exp(r) - 1 */
+    const double t = orc_exp_table[ki & 31];
+    return ldexp(fma(t, p, t), ki >> 5);             /* arithmetic shift: floor(ki / 32) */
 }
 
 /* v >= 0 -> floor(v) saturated to 2^32-1 (what v_cvt_u32_f64 does); NaN -> 0 */
@@ -225,7 +256,7 @@ static uint32_t btrs(xo_t *rng, uint32_t n, double q)
 }
 
 /* successes among n trials with success : failure odds wa : wb */
-static uint32_t binom(xo_t *rng, uint32_t n, double wa, double wb, double cap)
+static uint32_t binom(xo_t *rng, uint32_t n, double wa, double wb, double cap, int spec)
 {
     if (n == 0 || !(wa > 0.0)) return 0;
     if (!(wb > 0.0)) return n;
@@ -234,12 +265,15 @@ static uint32_t binom(xo_t *rng, uint32_t n, double wa, double wb, double cap)
     const double T = ws + wl;
     uint32_t k;
     if ((double)n * ws > cap * T) k = btrs(rng, n, ws / T);
-    else k = binv(rng, n, pw(wl / T, n), ws / wl);
+    else if (spec >= 3) {
+        const double r = ws / wl;                                /* q / (1 - q); 1 - q = 1 / (1 + r) */
+        k = binv(rng, n, orc_texp(-((double)n * orc_tlog(1.0 + r))), r);
+    } else k = binv(rng, n, pw(wl / T, n), ws / wl);
     return flip ? n - k : k;
 }
 
 /* x reads of one (cell, observed base) over the four true bases with weights W */
-static void mult4(xo_t *rng, uint32_t x, const double W[4], uint32_t n[4])
+static void mult4(xo_t *rng, uint32_t x, const double W[4], uint32_t n[4], int spec)
 {
     n[0] = n[1] = n[2] = n[3] = 0;
     if (x == 0) return;
@@ -249,21 +283,21 @@ static void mult4(xo_t *rng, uint32_t x, const double W[4], uint32_t n[4])
     for (int a = 0; a < 4; a++) if (a != am) o[j++] = a;
     const double wo[3] = { W[o[0]], W[o[1]], W[o[2]] };
     const double ws = (wo[0] + wo[1]) + wo[2];
-    const uint32_t m = binom(rng, x, ws, W[am], BINV_MEAN_CAP);                  /* reads NOT of the heaviest base */
+    const uint32_t m = binom(rng, x, ws, W[am], BINV_MEAN_CAP, spec);            /* reads NOT of the heaviest base */
     n[am] = x - m;
     if (m == 0) return;
     uint32_t k[3];
     if (m <= XS) draw_reads(rng, m, wo, 3, k);
     else {
-        k[0] = binom(rng, m, wo[0], wo[1] + wo[2], BINV_MEAN_CAP);
-        k[1] = binom(rng, m - k[0], wo[1], wo[2], BINV_MEAN_CAP);
+        k[0] = binom(rng, m, wo[0], wo[1] + wo[2], BINV_MEAN_CAP, spec);
+        k[1] = binom(rng, m - k[0], wo[1], wo[2], BINV_MEAN_CAP, spec);
         k[2] = m - k[0] - k[1];
     }
     n[o[0]] = k[0]; n[o[1]] = k[1]; n[o[2]] = k[2];
 }
 /* stage 1 for all cells: esum [4,4] ([observed][true]) accumulated, ntab [S][2^G] (subset counts) accumulated */
 static void stage1(const uint8_t *tau_idx, const double *gamma, const double *eta, const int64_t *variants,
-                   int V, int G, int S, const uint32_t key[2], uint32_t iter, uint64_t *esum, uint32_t *ntab)
+                   int V, int G, int S, const uint32_t key[2], uint32_t iter, uint64_t *esum, uint32_t *ntab, int spec)
 {
     const size_t NH = (size_t)1 << G;
     for (int v = 0; v < V; v++) {
@@ -286,8 +320,8 @@ static void stage1(const uint8_t *tau_idx, const double *gamma, const double *et
                 if (!(Wt > 0.0)) for (int a = 0; a < 4; a++) W[a] = Gam[a];     /* degenerate eta: fall back to abundance */
                 uint32_t n[4];
                 xo_t rng;
-                item_seed(&rng, cbase, (uint32_t)b, key);
-                mult4(&rng, (uint32_t)x[b], W, n);
+                item_seed(&rng, cbase, (uint32_t)b, key, spec);
+                mult4(&rng, (uint32_t)x[b], W, n, spec);
                 for (int a = 0; a < 4; a++) { esum[b * 4 + a] += n[a]; nacc[a] += n[a]; }
             }
             for (int a = 0; a < 4; a++) if (nacc[a]) ntab[(size_t)s * NH + H[a]] += nacc[a];
@@ -300,7 +334,7 @@ static void stage1(const uint8_t *tau_idx, const double *gamma, const double *et
 typedef struct { int lo, hi; uint32_t *tab; } node_t;
 
 static void stage2_sample(int s, int G, const double *gam_s, const uint32_t *T0, const uint32_t key[2], uint32_t iter,
-                          uint64_t *sum_mu_s)
+                          uint64_t *sum_mu_s, int spec)
 {
     node_t *cur = (node_t *)malloc(sizeof(node_t) * 64), *nxt = (node_t *)malloc(sizeof(node_t) * 64);
     int ncur = 1;
@@ -329,7 +363,7 @@ static void stage2_sample(int s, int G, const double *gam_s, const uint32_t *T0,
                 for (int j = 0; j < wh; j++) if (HR >> j & 1u) wR = wR + gam_s[mid + j];
                 xo_t rng;
                 xo_seed(&rng, Hs, (uint32_t)s | ((uint32_t)idx_cur[i] << 16) | ((uint32_t)level << 24), iter, STREAM_STA2, key);
-                const uint32_t k = binom(&rng, n, wL, wR, BINV_MEAN_CAP_S2);
+                const uint32_t k = binom(&rng, n, wL, wR, BINV_MEAN_CAP_S2, spec);
                 L[HL] += k; R[HR] += n - k;
             }
             free(T);
@@ -344,41 +378,41 @@ static void stage2_sample(int s, int G, const double *gam_s, const uint32_t *T0,
 }
 
 /* sum_mu [S,G] and esum [4,4] are ACCUMULATED into.  G <= 16.  ntab_out (optional, [S][2^G]) receives the
- * stage-1 subset counts.  Returns 0, or -1 if G is out of range / out of memory. */
+ * stage-1 subset counts.  spec = 2 or 3 (header).  Returns 0, or -1 if G / spec is out of range / out of memory. */
 int orc_stats_agg(const uint8_t *tau_idx, const double *gamma, const double *eta, const int64_t *variants,
                   int V, int G, int S, uint64_t seed, uint32_t iter, uint64_t *sum_mu, uint64_t *esum,
-                  uint32_t *ntab_out)
+                  uint32_t *ntab_out, int spec)
 {
-    if (G < 1 || G > 16) return -1;
+    if (G < 1 || G > 16 || spec < 2 || spec > 3) return -1;
     const uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
     const size_t NH = (size_t)1 << G;
     uint32_t *ntab = (uint32_t *)calloc((size_t)S * NH, sizeof(uint32_t));
     if (!ntab) return -1;
-    stage1(tau_idx, gamma, eta, variants, V, G, S, key, iter, esum, ntab);
+    stage1(tau_idx, gamma, eta, variants, V, G, S, key, iter, esum, ntab, spec);
     if (ntab_out) memcpy(ntab_out, ntab, (size_t)S * NH * sizeof(uint32_t));
     for (int s = 0; s < S; s++)
-        stage2_sample(s, G, gamma + (size_t)s * G, ntab + (size_t)s * NH, key, iter, sum_mu + (size_t)s * G);
+        stage2_sample(s, G, gamma + (size_t)s * G, ntab + (size_t)s * NH, key, iter, sum_mu + (size_t)s * G, spec);
     free(ntab);
     return 0;
 }
 
 /* test hooks: nsamp variates of one sampler, variate i from the stream Philox({i, 0, 0, 'TEST'}, seed) */
-void orc_binom_test(int kind, uint32_t n, double wa, double wb, uint64_t seed, int nsamp, uint32_t *out)
+void orc_binom_test(int kind, uint32_t n, double wa, double wb, uint64_t seed, int nsamp, uint32_t *out, int spec)
 {
     const uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
     for (int i = 0; i < nsamp; i++) {
         xo_t rng;
         xo_seed(&rng, (uint32_t)i, 0u, 0u, STREAM_TEST, key);
-        out[i] = binom(&rng, n, wa, wb, kind == 0 ? BINV_MEAN_CAP : BINV_MEAN_CAP_S2);
+        out[i] = binom(&rng, n, wa, wb, kind == 0 ? BINV_MEAN_CAP : BINV_MEAN_CAP_S2, spec);
     }
 }
 
-void orc_mult4_test(uint32_t x, const double *W, uint64_t seed, int nsamp, uint32_t *out /* [nsamp][4] */)
+void orc_mult4_test(uint32_t x, const double *W, uint64_t seed, int nsamp, uint32_t *out /* [nsamp][4] */, int spec)
 {
     const uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
     for (int i = 0; i < nsamp; i++) {
         xo_t rng;
         xo_seed(&rng, (uint32_t)i, 0u, 0u, STREAM_TEST, key);
-        mult4(&rng, x, W, out + (size_t)i * 4);
+        mult4(&rng, x, W, out + (size_t)i * 4, spec);
     }
 }

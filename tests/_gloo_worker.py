@@ -32,6 +32,27 @@ def flaky_run(spec):
 if __name__ == "__main__":
     dist.init_process_group("gloo")
     specs = chains.sweep_specs(range(2, 7), 3, V=1000, S=16)
+    if len(sys.argv) > 2 and sys.argv[2] == "cfg5":
+        # BASELINE config 5 on a full node: 55 chains (g = 2..12 x 5 seeds) at V = 50k, S = 96 over 8 ranks, unbatched and
+        # with the replicates of a G value as batched units; every rank records which chains it was given
+        specs = chains.sweep_specs(range(2, 13), 5, V=50000, S=96)
+        ran = []
+
+        def rec_run(spec):
+            ran.append(spec["chain"])
+            return fake_run(spec)
+
+        def rec_batch(group):
+            ran.extend(sp["chain"] for sp in group)
+            return [fake_run(sp) for sp in group]
+        recs = chains.run_chains(specs, rec_run, dist)
+        one = list(ran)
+        del ran[:]
+        recs_b = chains.run_chains(specs, rec_run, dist, batch_fn=rec_batch, batch=5)
+        with open(os.path.join(sys.argv[1], "cfg5_%d.json" % dist.get_rank()), "w") as f:
+            json.dump(dict(recs=recs, recs_b=recs_b, one=one, batched=list(ran)), f)
+        dist.destroy_process_group()
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "flaky":
         recs = chains.run_chains(specs, flaky_run, dist)
         with open(os.path.join(sys.argv[1], "flaky%d.json" % dist.get_rank()), "w") as f:

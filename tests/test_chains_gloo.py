@@ -109,6 +109,33 @@ def test_single_process_failure_handling():
     assert [r["failed"] for r in recs] == [0.0, 1.0, 0.0] and n["k"] == 4
 
 
+def test_eight_rank_gloo_config5_plan(tmp_path):
+    """the 8-GPU plan of BASELINE config 5 (55 chains, V = 50k, S = 96) walked by 8 real ranks (gloo): every rank runs exactly
+    the chains the LPT plan gives it -- chain by chain and as batched units of the five replicates of a G value -- and every
+    rank ends with all 55 records; the plan's predicted imbalance is the one scripts/bench_config5.py checks against measured
+    chain times (profiles/r03_config5.json)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+           "--master-addr", "127.0.0.1", "--master-port", "29671", os.path.join(HERE, "_gloo_worker.py"), str(tmp_path), "cfg5"]
+    subprocess.run(cmd, check=True, env=env, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    specs = chains.sweep_specs(range(2, 13), 5, V=50000, S=96)
+    costs = [s["cost"] for s in specs]
+    plan = chains.lpt_assign(costs, 8)
+    units = chains.group_units(specs, 5)
+    assert units == [list(range(5 * k, 5 * k + 5)) for k in range(11)]
+    uplan = chains.lpt_assign([sum(costs[i] for i in u) for u in units], 8)
+    rs = [json.load(open(tmp_path / ("cfg5_%d.json" % r))) for r in range(8)]
+    for r in range(8):
+        assert rs[r]["one"] == plan[r]                                        # LPT order within the rank, too
+        assert rs[r]["batched"] == [i for ui in uplan[r] for i in units[ui]]
+        assert rs[r]["recs"] == rs[0]["recs"] and rs[r]["recs_b"] == rs[0]["recs"]
+    assert [int(x["chain"]) for x in rs[0]["recs"]] == list(range(55))
+    load = [sum(costs[i] for i in b) for b in plan]
+    assert max(load) / (sum(load) / 8) < 1.05                                 # chain by chain: within 5 % of perfect balance
+    uload = [sum(costs[i] for ui in b for i in units[ui]) for b in uplan]
+    assert max(uload) / (sum(uload) / 8) < 1.45                               # 11 units on 8 GPUs: two units on three of them
+
+
 def test_sys_exit_of_a_chain_is_contained_and_short_batches_are_rejected():
     """the CLI reports bad input through sys.exit (a BaseException): such a chain must become a failed record, not kill the
     rank before the gather; a batch_fn that returns fewer records than chains must not misalign them"""

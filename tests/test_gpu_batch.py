@@ -47,7 +47,7 @@ def test_batch_equals_chains_run_one_by_one(V, S, G, K, n_iter):
     single, batch = [], []
     for k in range(K):
         a = _chain(counts, states[k], 1000 + k, 0xB47C4000 + k)
-        a.force_stats_spec(2)
+        a.force_stats_spec(_lib.STATS_AGG)                      # what a batch runs
         a.gibbs_update(n_iter)
         first = _snapshot(a)
         a.gibbs_update(3)
@@ -61,7 +61,7 @@ def test_batch_equals_chains_run_one_by_one(V, S, G, K, n_iter):
     for k in range(K):
         _same(single[k][1], _snapshot(ctxs[k]))
     # a context of the batch goes on alone afterwards, on its own streams
-    ctxs[0].force_stats_spec(2)
+    ctxs[0].force_stats_spec(_lib.STATS_AGG)
     ctxs[0].gibbs_update(2)
     assert np.isfinite(ctxs[0].get_trace()["lp"]).all()
     for c in ctxs:

@@ -33,7 +33,7 @@ def test_full_size_sweep_loglik_and_stats_invariants(V, S, G):
     # per-read pass: every read is assigned exactly once, observed-base totals are preserved,
     # identical (seed, iter) -> identical sums, different iter -> different sums
     mu, E = ctx.sample_stats(3)
-    assert ctx.stats_spec() == 2                                   # full sizes run the aggregated sampler ...
+    assert ctx.stats_spec() == _lib.STATS_AGG == cbind.STATS_AGG     # full sizes run the aggregated sampler ...
     mu_ref, E_ref = cbind.stats_agg(cbind.onehot_to_idx(got), gamma, eta, counts, 42, 3)
     assert np.array_equal(mu, mu_ref) and np.array_equal(E, E_ref)   # ... bit for bit as restated in oracle/stats_agg.c
     assert int(mu.sum()) == int(counts.sum())

@@ -26,7 +26,7 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(params=[2, 1], ids=["aggregated-muE", "per-read-muE"])
+@pytest.fixture(params=[2, 3, 1], ids=["aggregated-muE", "aggregated-muE-v3", "per-read-muE"])
 def spec_ctx(ctx, request):
     """the shared context with one of the two mu/E specifications forced (small test shapes would all take the
     per-read pass by the shape rule): the law / chain-level tests must hold for both"""
@@ -223,13 +223,13 @@ def test_stats_bit_exact_vs_spec(ctx, V, S, G):
     ctx.seed(1, ctr_seed=0xABCDEF0123456789)
     idx = cbind.onehot_to_idx(tau)
     assert ctx.stats_spec() == 1                                 # small problem: per-read pass by the shape rule
-    for force in ((2, 1) if G <= 16 else (0,)):
+    for force in ((3, 2, 1) if G <= 16 else (0,)):                # both versions of the aggregated specification, and the per-read one
         ctx.force_stats_spec(force)
-        assert ctx.stats_spec() == (2 if force == 2 else 1)
-        ref_fn = cbind.stats_agg if force == 2 else cbind.stats_counter
+        assert ctx.stats_spec() == (force if force >= 2 else 1)
         for it in (0, 1, 77):
             mu, E = ctx.sample_stats(it)
-            mu_ref, E_ref = ref_fn(idx, gamma, eta, counts, 0xABCDEF0123456789, it)
+            mu_ref, E_ref = (cbind.stats_agg(idx, gamma, eta, counts, 0xABCDEF0123456789, it, spec=force) if force >= 2 else
+                             cbind.stats_counter(idx, gamma, eta, counts, 0xABCDEF0123456789, it))
             assert np.array_equal(mu, mu_ref) and np.array_equal(E, E_ref)
             assert int(mu.sum()) == int(counts.sum())
             # E[b, :] partitions the reads of observed base b
@@ -260,15 +260,16 @@ def test_stats_stage1_matches_spec(ctx, V, S, G, scale):
             gamma = np.ascontiguousarray(gamma / gamma.sum(axis=1, keepdims=True))
         _load(ctx, counts, tau, gamma, eta)
         ctx.seed(1, ctr_seed=seed)
-        ctx.force_stats_spec(2)
         idx = cbind.onehot_to_idx(tau)
-        for it in (0, 5):
-            nt, E = ctx.debug_stage1(it)
-            mu_ref, E_ref, nt_ref = cbind.stats_agg(idx, gamma, eta, counts, seed, it, want_ntab=True)
-            assert np.array_equal(E, E_ref)
-            assert np.array_equal(nt, nt_ref)
-            mu, E2 = ctx.sample_stats(it)
-            assert np.array_equal(mu, mu_ref) and np.array_equal(E2, E_ref)
+        for spec in (3, 2):
+            ctx.force_stats_spec(spec)
+            for it in (0, 5):
+                nt, E = ctx.debug_stage1(it)
+                mu_ref, E_ref, nt_ref = cbind.stats_agg(idx, gamma, eta, counts, seed, it, want_ntab=True, spec=spec)
+                assert np.array_equal(E, E_ref)
+                assert np.array_equal(nt, nt_ref)
+                mu, E2 = ctx.sample_stats(it)
+                assert np.array_equal(mu, mu_ref) and np.array_equal(E2, E_ref)
     ctx.force_stats_spec(0)
 
 
@@ -282,13 +283,14 @@ def test_stats_degenerate_eta_and_gamma(ctx):
     gamma = np.ascontiguousarray(gamma / gamma.sum(axis=1, keepdims=True))
     _load(ctx, counts, tau, gamma, eta)
     ctx.seed(1, ctr_seed=9)
-    ctx.force_stats_spec(2)
     idx = cbind.onehot_to_idx(tau)
-    mu, E = ctx.sample_stats(2)
-    ctx.force_stats_spec(0)
-    mu_ref, E_ref = cbind.stats_agg(idx, gamma, eta, counts, 9, 2)
-    assert np.array_equal(mu, mu_ref) and np.array_equal(E, E_ref)
-    assert (mu[:, 2] == 0).all() and int(mu.sum()) == int(counts.sum())
+    for spec in (3, 2):
+        ctx.force_stats_spec(spec)
+        mu, E = ctx.sample_stats(2)
+        ctx.force_stats_spec(0)
+        mu_ref, E_ref = cbind.stats_agg(idx, gamma, eta, counts, 9, 2, spec=spec)
+        assert np.array_equal(mu, mu_ref) and np.array_equal(E, E_ref)
+        assert (mu[:, 2] == 0).all() and int(mu.sum()) == int(counts.sum())
 
 
 @pytest.mark.parametrize("kind,n,w", [(0, 300, (0.02, 0.98)), (0, 300, (0.98, 0.02)), (0, 300, (0.5, 0.5)), (0, 13, (0.5, 0.1)),
@@ -300,13 +302,14 @@ def test_stats_degenerate_eta_and_gamma(ctx):
 def test_binomial_and_multinomial_samplers_match_spec(ctx, kind, n, w):
     """dsm_binom.h against its restatement in oracle/stats_agg.c, variate by variate (same streams)"""
     nsamp = 20000
-    got = ctx.debug_binom(kind, n, w, 0xFEEDFACE12345678, nsamp)
-    if kind == 2:
-        ref = cbind.mult4_test(n, w, 0xFEEDFACE12345678, nsamp)
-        assert (got.sum(axis=1) == n).all()
-    else:
-        ref = cbind.binom_test(kind, n, w[0], w[1], 0xFEEDFACE12345678, nsamp)
-    assert np.array_equal(got, ref)
+    for spec in (3, 2):
+        got = ctx.debug_binom(kind, n, w, 0xFEEDFACE12345678, nsamp, spec=spec)
+        if kind == 2:
+            ref = cbind.mult4_test(n, w, 0xFEEDFACE12345678, nsamp, spec=spec)
+            assert (got.sum(axis=1) == n).all()
+        else:
+            ref = cbind.binom_test(kind, n, w[0], w[1], 0xFEEDFACE12345678, nsamp, spec=spec)
+        assert np.array_equal(got, ref), spec
 
 
 @pytest.mark.parametrize("name", sorted(LAW_CASES))
@@ -427,7 +430,7 @@ def test_gibbs_chain_recovers_asymmetric_eta(spec_ctx):
 
 
 # ---------------------------------------------------------------- A6 full iteration
-@pytest.mark.parametrize("spec", [2, 1])
+@pytest.mark.parametrize("spec", [3, 2, 1])
 @pytest.mark.parametrize("V,S,G,n_iter", [(400, 16, 5, 12), (600, 64, 8, 8), (150, 96, 3, 6), (200, 20, 11, 4), (900, 10, 2, 4)])
 def test_gibbs_update_is_self_consistent_with_oracle(ctx, V, S, G, n_iter, spec):
     """every piece of every iteration of the device loop against the oracle, in the reference's order
@@ -446,8 +449,8 @@ def test_gibbs_update_is_self_consistent_with_oracle(ctx, V, S, G, n_iter, spec)
     tr = ctx.get_trace()
     g_prev, e_prev, t_prev = gamma0, eta0, tau0
     for it in range(n_iter):                                      # A2 + A3 + A4 inside the loop; counter = iteration index
-        stats = cbind.stats_agg if spec == 2 else cbind.stats_counter
-        mu, E = stats(cbind.onehot_to_idx(t_prev), np.ascontiguousarray(g_prev), np.ascontiguousarray(e_prev), counts, cseed, it)
+        args = (cbind.onehot_to_idx(t_prev), np.ascontiguousarray(g_prev), np.ascontiguousarray(e_prev), counts, cseed, it)
+        mu, E = cbind.stats_agg(*args, spec=spec) if spec >= 2 else cbind.stats_counter(*args)
         g_ref, e_ref, _ = cbind.dirichlet_counter(mu, E, cseed, it)
         np.testing.assert_allclose(tr["gamma"][it], g_ref, rtol=1e-13, atol=0)
         np.testing.assert_allclose(tr["eta"][it], e_ref, rtol=1e-13, atol=0)

@@ -35,16 +35,26 @@ BINOM_CASES = [
 ]
 
 
-@pytest.mark.parametrize("kind,n,p", BINOM_CASES)
-def test_binomial_samplers_have_the_exact_pmf(kind, n, p):
-    draws = cbind.binom_test(kind, n, p, 1.0 - p, 0xC0FFEE00 + kind, NV)
+def test_table_exponential_of_spec3():
+    """orc_texp (the exponential behind f0 = exp(-n ln(1 + r)) of spec 3): < 1 ulp-ish of libm over the range the samplers use"""
+    import math
+    rng = np.random.default_rng(0)
+    for y in np.concatenate((-rng.uniform(0, 200, 20000), -np.linspace(0, 1e-3, 200), [-0.0, -1e-300, -699.0])):
+        assert abs(cbind.texp(y) - math.exp(y)) <= 4e-16 * math.exp(y)
+    assert cbind.texp(0.0) == 1.0 and cbind.texp(-800.0) == 0.0
+
+
+# every case under the default specification (2) and under its table exp / log variant (3, selectable)
+@pytest.mark.parametrize("kind,n,p,spec", [c + (2,) for c in BINOM_CASES] + [c + (3,) for c in BINOM_CASES])
+def test_binomial_samplers_have_the_exact_pmf(kind, n, p, spec):
+    draws = cbind.binom_test(kind, n, p, 1.0 - p, 0xC0FFEE00 + kind, NV, spec=spec)
     assert draws.max() <= n
     pv = chi2_vs_binom(draws, n, p)
     assert pv > 1e-4, "chi-square p = %.3g" % pv
     m, v = n * p, n * p * (1 - p)
     assert abs(draws.mean() - m) < 5.0 * np.sqrt(v / NV) + 1e-12
     # unnormalised odds are what the callers pass: the same variates for any scale of (wa, wb)
-    again = cbind.binom_test(kind, n, 8.0 * p, 8.0 * (1.0 - p), 0xC0FFEE00 + kind, 1000)
+    again = cbind.binom_test(kind, n, 8.0 * p, 8.0 * (1.0 - p), 0xC0FFEE00 + kind, 1000, spec=spec)
     assert np.array_equal(again, draws[:1000])
 
 
@@ -59,11 +69,11 @@ MULT4_CASES = [
 ]
 
 
-@pytest.mark.parametrize("x,W", MULT4_CASES)
-def test_mult4_has_the_exact_multinomial_law(x, W):
+@pytest.mark.parametrize("x,W,spec", [c + (2,) for c in MULT4_CASES] + [c + (3,) for c in MULT4_CASES[1::2]])
+def test_mult4_has_the_exact_multinomial_law(x, W, spec):
     W = np.array(W, dtype=np.float64)
     p = W / W.sum()
-    draws = cbind.mult4_test(x, W, 0xABCD1234, NV).astype(np.int64)
+    draws = cbind.mult4_test(x, W, 0xABCD1234, NV, spec=spec).astype(np.int64)
     assert (draws.sum(axis=1) == x).all()
     for a in range(4):
         if p[a] == 0.0:
@@ -90,11 +100,12 @@ def test_mult4_has_the_exact_multinomial_law(x, W):
                     pmf[n0 * (x + 1) ** 3 + n1 * (x + 1) ** 2 + n2 * (x + 1) + n3] = st.multinomial.pmf([n0, n1, n2, n3], x, p)
         assert chi2_vs_pmf(code, pmf) > 1e-4
     # scale of the weights does not matter
-    assert np.array_equal(cbind.mult4_test(x, 3.5 * W, 0xABCD1234, 500), draws[:500].astype(np.uint32))
+    assert np.array_equal(cbind.mult4_test(x, 3.5 * W, 0xABCD1234, 500, spec=spec), draws[:500].astype(np.uint32))
 
 
-@pytest.mark.parametrize("G,S,depth", [(3, 2, 60), (8, 2, 2000), (10, 2, 300), (12, 2, 40000), (5, 3, 3)])
-def test_stage2_halving_tree_has_the_exact_law(G, S, depth):
+@pytest.mark.parametrize("G,S,depth,spec", [(3, 2, 60, 2), (8, 2, 2000, 2), (10, 2, 300, 2), (12, 2, 40000, 2), (5, 3, 3, 2),
+                                             (8, 2, 2000, 3), (5, 3, 3, 3)])
+def test_stage2_halving_tree_has_the_exact_law(G, S, depth, spec):
     """stage 2 (oracle/stats_agg.c: stage2_sample) from HAND-BUILT subset counts: with eta = I stage 1 is deterministic
     (every read's true base is its observed base), so N[s][H] is known exactly and
         sum_mu[s,g] = sum over the subsets H containing g of Binomial(N[s][H]; gamma[s,g] / Gamma_H)   (independent terms),
@@ -112,7 +123,7 @@ def test_stage2_halving_tree_has_the_exact_law(G, S, depth):
     nd = 20000 if G <= 10 else 6000
     mus = np.empty((nd, S, G), dtype=np.int64)
     for it in range(nd):
-        mu, E, nt = cbind.stats_agg(tau_idx, gamma, eta, counts, 99, it, want_ntab=True)
+        mu, E, nt = cbind.stats_agg(tau_idx, gamma, eta, counts, 99, it, want_ntab=True, spec=spec)
         mus[it] = mu
         if it == 0:
             nt0 = nt.copy()
@@ -154,17 +165,17 @@ def test_stage2_halving_tree_has_the_exact_law(G, S, depth):
 
 
 @pytest.mark.parametrize("name", sorted(LAW_CASES))
-@pytest.mark.parametrize("spec", [2, 1])
+@pytest.mark.parametrize("spec", [2, 3, 1])
 def test_specification_has_the_law_of_the_reference_sampleMu(name, spec):
-    """orc_stats_agg (spec 2) / orc_stats_counter (spec 1) against the reference's sampleMu, >= 2000 draws each"""
+    """orc_stats_agg (spec 3, spec 2) / orc_stats_counter (spec 1) against the reference's sampleMu, >= 2000 draws each"""
     counts, tau, gamma, eta = law_case(name)
     idx = cbind.onehot_to_idx(tau)
     n = 2000
     mu_r, E_r = reference_draws(name, n)
-    fn = cbind.stats_agg if spec == 2 else cbind.stats_counter
     mus, es = [], []
     for it in range(n):
-        mu, E = fn(idx, gamma, eta, counts, 31415, it)
+        mu, E = (cbind.stats_agg(idx, gamma, eta, counts, 31415, it, spec=spec) if spec >= 2 else
+                 cbind.stats_counter(idx, gamma, eta, counts, 31415, it))
         mus.append(mu.astype(np.int64)); es.append(E.astype(np.int64))
     assert_same_law(np.array(mus), np.array(es), mu_r, E_r, (name, spec))
     # and both against the exact conditional means

@@ -54,8 +54,11 @@ def test_desman_sweep_walks_the_rccl_gather_with_a_world_of_one(tmp_path):
     assert [(int(r["G"]), int(r["seed"]), r["failed"]) for r in recs] == [(2, 0, 0.0), (2, 1, 0.0), (3, 0, 0.0), (3, 1, 0.0)]
     rows = open(stub + "_Dev.csv").read().strip().split("\n")
     assert rows[0] == "H,G,LP,Dev" and len(rows) == 5
-    # the same sweep without torch.distributed: the gather changes nothing
-    from desman_amd import chains
+    # the same sweep without torch.distributed: the gather changes nothing (in a child process as well: the sweep driver
+    # imports torch, whose bundled HIP runtime this test process should not load next to the library's)
     stub1 = str(tmp_path / "sw1")
-    chains.main([freq, "--gmin", "2", "--gmax", "3", "--reps", "2", "-i", "15", "-o", stub1, "-c", "1"])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, "-m", "desman_amd.chains", freq, "--gmin", "2", "--gmax", "3", "--reps", "2", "-i", "15", "-o", stub1,
+                        "-c", "1"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
     assert open(stub + "_Dev.csv").read() == open(stub1 + "_Dev.csv").read()

@@ -65,6 +65,7 @@ SIGNATURES = {
     "dsm_ctx_sweep_stats": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _i]),
     "dsm_ctx_set_tau_screen": (_i, [_vp, _i]),
     "dsm_ctx_set_nmft_fused": (_i, [_vp, _i]),
+    "dsm_ctx_set_nmft_persist": (_i, [_vp, _i]),
     "dsm_ctx_tau_launch_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "dsm_ctx_debug_log2f": (_i, [_vp, _vp, _vp, C.c_size_t]),
     "dsm_ctx_force_stats_spec": (_i, [_vp, _i]),
@@ -291,6 +292,10 @@ class Context:
         a, b = _i(0), _i(0)
         check(self.lib.dsm_ctx_tau_launch_info(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def set_nmft_persist(self, mode=-1):
+        """nmft_factorize as one persistent launch where the table fits: -1 / 1 = yes (default), 0 = the three-launch loop"""
+        check(self.lib.dsm_ctx_set_nmft_persist(self._h, int(mode)))
 
     def set_nmft_fused(self, mode=-1):
         """reduce + gamma/control of an NMFT update: -1 = by size, 0 = two launches, 1 = one fused launch (same results)"""

@@ -211,7 +211,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
     dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->sweep_stats); dev_free(&c->step_cnt); dev_free(&c->screen_ctl); dev_free(&c->prior); dev_free(&c->prior_all); dev_free(&c->scalars); dev_free(&c->star);
-    dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); dev_free(&c->ngam_raw);
+    dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->np_part); if (c->np_bar) { (void)hipFree(c->np_bar); c->np_bar = nullptr; } dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); dev_free(&c->ngam_raw);
     dev_free(&c->npart); dev_free(&c->nstat);
     for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ev_u_ready[i]); (void)hipEventDestroy(c->ev_u_free[i]); }
     if (c->stream_rng != c->stream) (void)hipStreamDestroy(c->stream_rng);
@@ -1028,6 +1028,14 @@ extern "C" int dsm_ctx_tau_launch_info(dsm_ctx *c, int *launched, int *resident)
     return tau_launch_info(c, launched, resident);
 }
 
+// 0: dsm_nmft_factorize never takes the persistent one-launch path; 1 / -1: wherever the table fits (the default)
+extern "C" int dsm_ctx_set_nmft_persist(dsm_ctx *c, int mode)
+{
+    if (!c || mode < -1 || mode > 1) { dsm_set_error("set_nmft_persist: mode -1, 0 or 1"); return DSM_ERR_ARG; }
+    c->nmft_persist = mode;
+    return DSM_OK;
+}
+
 // Which form of the reduce + gamma/control step of an NMFT update runs (kernels_nmft.hip: k_nmft_gamma): -1 = by the number of
 // workgroup partials (the default), 0 = reduction and control as two launches, 1 = the fused launch.  Same factors bit for bit.
 extern "C" int dsm_ctx_set_nmft_fused(dsm_ctx *c, int mode)
@@ -1183,6 +1191,22 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     if (adjust) TRY(k_nmft_clamp(c));
     const int BATCH = 64;
     double h[7] = {0, 0, 0, 0, 0, 0, 0};
+    {
+        // tables whose quads of variants are all resident at once: the whole loop as ONE persistent launch (kernels_nmft.hip)
+        int used = 0;
+        TRY(k_nmft_persist(c, max_iter, min_change, fix_gamma, adjust, &used));
+        if (used) {
+            HIP_TRY(hipMemcpyAsync(h, ctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const int done = (int)h[3];
+            if (n_done) *n_done = done;
+            if (div_trace) {
+                HIP_TRY(hipMemcpyAsync(div_trace, d_trace, ((size_t)done + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+            }
+            return DSM_OK;
+        }
+    }
     const bool wave = nmft_use_wave(c);
     // one-pass path: statistics of the initial state, then every update launch also produces the
     // statistics of the next iteration; two-pass path (large S*G): pass A + pass B per iteration

@@ -135,6 +135,10 @@ struct dsm_ctx {
     double *ndiv_trace = nullptr;   // objective after every update of the running factorize (or null)
     int nG = 0;
     int nmft_blocks = 0;
+    int nmft_persist = -1;          // the factorize loop as one persistent launch where the table fits (kernels_nmft.hip): -1 / 1 = yes, 0 = never
+    double *np_part = nullptr;      // its exchange buffers: partials [nout][workgroups] + totals [nout]
+    size_t np_cap = 0;
+    unsigned *np_bar = nullptr;     // its barrier words
     int nmft_fused = -1;            // reduce + gamma/control of an update as one launch: -1 = by size (<= 128 partials), 0 = never, 1 = always
     // timing
     bool timing = false;
@@ -193,3 +197,4 @@ bool nmft_use_wave(const dsm_ctx *c);
 bool nmft_use_mfma(const dsm_ctx *c);
 int nmft_wave_grid(const dsm_ctx *c);
 int k_nmft_wave(dsm_ctx *c, int adjust, int do_update);
+int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int adjust, int *used);

@@ -14,6 +14,8 @@
 //             per-(v,g) renormalisation over the four bases (:170-181), _adjustment (:88-91)
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "dsm_device.h"
 #include "dsm_host.h"
 #include "log_table.h"
@@ -154,6 +156,24 @@ __global__ __launch_bounds__(NMFT_A_THREADS) void nmft_pass_a_kernel(const doubl
 // reduction of the transposed partials: one wavefront per output, coalesced
 // reads, fixed-order butterfly -> stat[out].
 // ---------------------------------------------------------------------------
+// THE summation order of a statistic over the workgroup partials of an update kernel, shared by every reduction of this file
+// (nmft_reduce_kernel, nmft_rg_kernel, nmft_persist_kernel), so that all paths produce the same bits: consecutive TRIPLES of
+// partials first, (p[3t] + p[3t+1]) + p[3t+2] -- a workgroup of the persistent kernel covers the quads of three workgroups of the
+// update kernel and publishes exactly that sum -- then the triples lane-strided, then a fixed-order butterfly.
+__device__ __forceinline__ double nmft_sum_partials(const double *__restrict__ p, int nblk, int lane)
+{
+    const int ntrip = (nblk + 2) / 3;
+    double a = 0.0;
+    for (int t = lane; t < ntrip; t += 64) {
+        const int b = 3 * t;
+        double x = p[b];
+        if (b + 1 < nblk) x += p[b + 1];
+        if (b + 2 < nblk) x += p[b + 2];
+        a += x;
+    }
+    return group_allreduce_sum<64>(a);
+}
+
 struct NmftReduceParams { const double *partial; int nblk, nout; const double *ctl; double *stat; };
 __device__ __forceinline__ void nmft_reduce_body(const NmftReduceParams &q)
 {
@@ -163,9 +183,7 @@ __device__ __forceinline__ void nmft_reduce_body(const NmftReduceParams &q)
     if (ctl[2] != 0.0) return;
     const int out = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (out >= nout) return;
-    double a = 0.0;
-    for (int b = lane; b < nblk; b += 64) a += partial[(size_t)out * nblk + b];
-    a = group_allreduce_sum<64>(a);
+    const double a = nmft_sum_partials(partial + (size_t)out * nblk, nblk, lane);
     if (lane == 0) stat[out] = a;
 }
 __global__ __launch_bounds__(256) void nmft_reduce_kernel(NmftReduceParams q) { nmft_reduce_body(q); }
@@ -266,9 +284,7 @@ __device__ __forceinline__ void nmft_rg_body(const NmftRgParams &q)
         int out;
         if (i < nown) { const int g = i / ncol, s = s_lo + i % ncol; out = g * S + s; }
         else out = G * S + (i - nown);
-        double a = 0.0;
-        for (int b = lane; b < nblk; b += 64) a += partial[(size_t)out * nblk + b];
-        a = group_allreduce_sum<64>(a);
+        const double a = nmft_sum_partials(partial + (size_t)out * nblk, nblk, lane);
         if (lane == 0) {
             red[i] = a;
             if (i < nown || blockIdx.x == 0) q.stat[out] = a;
@@ -1085,5 +1101,447 @@ int k_nmft_mfma(dsm_ctx *c, int adjust, int do_update)
 #undef MCASE
     HIP_TRY(hipGetLastError());
     c->npart_cols = grid;
+    return DSM_OK;
+}
+
+// ===========================================================================
+// nmft_persist_kernel: the WHOLE factorize loop (Init_NMFT.py:98-115, :134-149) in ONE launch for tables whose quads of
+// variants all fit on the machine at once (V <= 48 x compute units = 12 288 on MI355X).
+//
+// Why: at config 3 an update of the three-launch path is 34 us of which ~11 us are the two halves of the update itself --
+// the rest is two dependent launches (reduction, gamma / control) and the update kernel's own ramp.  Here the workgroups stay
+// resident and an update crosses workgroups through two in-kernel grid barriers instead:
+//   statistics of the current state  ->  every workgroup publishes its 521 partial sums (write-through stores)
+//   barrier 1                         ->  wavefront j of the machine reduces statistic j over the workgroups (the arithmetic of
+//                                         nmft_reduce_kernel: lane-strided sums, fixed-order butterfly) and publishes it
+//   barrier 2                         ->  every workgroup reads the 521 totals, runs the stop test (:106) and the gamma update
+//                                         (:163-168) FOR ITSELF -- the same numbers everywhere, nothing to broadcast --
+//                                         re-stages its MFMA operands and runs the tau half of the update on its own quads,
+//                                         whose tau rows never leave LDS between updates (HBM sees tau once, at the end)
+// Measured in isolation (scripts/ubench/grid_barrier.hip, profiles/r03_grid_barrier.txt): a barrier of 625 x 256-thread
+// workgroups costs 3.7 us and the exchange of one update 14.7 us (publish 3.1, reduce 3.2, read 0.7, two barriers 7.7); with
+// 209 x 768-thread workgroups -- twelve quads each, one workgroup per CU, the geometry used here -- a third of the partial
+// rows cross the machine and a barrier costs 2.6 us.
+//
+// The barrier (grid_barrier below): arrival on one of eight group counters (group = workgroup % 8: on this part workgroup b
+// runs on XCD b % 8, so a group's counter stays in one XCD's reach -- a matter of speed only, nothing depends on placement),
+// the last arriver of a group arrives on the top counter, the last of those publishes the generation word that one lane of
+// every workgroup polls (relaxed agent-scope loads + s_sleep).  All shared words are agent-scope atomics; payloads are 8-byte
+// write-through (sc1) stores drained by every storing wavefront before the arrival, and are read with sc1 loads, so no
+// release / acquire fence is needed (cdna_hip_programming.md, Guideline 16).  Polls are bounded: a workgroup that times out
+// raises an error word and leaves, the host reports it.  The launch requires every workgroup to be resident: the grid is
+// checked against the occupancy query, and a process-wide lock admits one persistent launch per device at a time (two of
+// them could starve each other of CUs); other kernels only delay it.
+//
+// Arithmetic: the update is that of nmft_mfma_body, statement for statement, and a workgroup publishes the sum of the three
+// partial rows the three-launch kernel's workgroups would have written for its twelve quads, added in the order in which
+// every reduction of this file adds a triple of partials (nmft_sum_partials), so the totals -- hence the factors, the
+// update count and the objective trace -- equal the three-launch path's bit for bit (a chain's NMF start does not depend on
+// which path ran it: batched replicates, timing mode and large tables take the three-launch loop).
+// ===========================================================================
+typedef __attribute__((address_space(1))) unsigned nm_gu32;
+typedef __attribute__((address_space(1))) unsigned long long nm_gu64;
+#define NM_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define NMFT_P_WAVES 12       // wavefronts of a workgroup of the large form (three update-kernel workgroups' worth of quads); the small form has 4
+
+struct NmftBarrier { unsigned *gcnt /* [8] x 64 B */, *top, *gen, *err; int members[8], ngroups /* groups with members */; };
+
+// ok_s: one word of the caller's dynamic LDS (a static __shared__ here would shift the base of the dynamic region off its
+// 16-byte alignment)
+__device__ __forceinline__ bool nm_grid_barrier(const NmftBarrier &b, unsigned epoch, int tid, int *ok_s)
+{
+    __syncthreads();
+    if (tid == 0) {
+        int ok = 1;
+        const unsigned g = blockIdx.x & 7u;
+        const unsigned t = __hip_atomic_fetch_add((nm_gu32 *)(b.gcnt + g * 16), 1u, NM_RLX_AGENT);
+        if (t + 1u == epoch * (unsigned)b.members[g]) {
+            const unsigned t2 = __hip_atomic_fetch_add((nm_gu32 *)b.top, 1u, NM_RLX_AGENT);
+            if (t2 + 1u == epoch * (unsigned)b.ngroups) __hip_atomic_store((nm_gu32 *)b.gen, epoch, NM_RLX_AGENT);
+        }
+        unsigned spins = 0;
+        while (__hip_atomic_load((nm_gu32 *)b.gen, NM_RLX_AGENT) < epoch) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__hip_atomic_load((nm_gu32 *)b.err, NM_RLX_AGENT) != 0u || ++spins > (1u << 24)) {     // ~seconds: not resident / a peer gave up
+                __hip_atomic_store((nm_gu32 *)b.err, 1u, NM_RLX_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        *ok_s = ok;
+    }
+    __syncthreads();
+    return *ok_s != 0;
+}
+
+__device__ __forceinline__ void nm_store(double *p, double x) { __hip_atomic_store((nm_gu64 *)p, (unsigned long long)__double_as_longlong(x), NM_RLX_AGENT); }
+__device__ __forceinline__ double nm_load(const double *p) { return __longlong_as_double((long long)__hip_atomic_load((nm_gu64 *)p, NM_RLX_AGENT)); }
+
+struct NmftPersistParams {
+    const double *F; double *tau; double *gam_raw, *gam;
+    int V, S, G, adjust, fix_gamma, max_iter;
+    double min_change;
+    double *ctl, *div_trace; const double *log_tab;
+    double *partial;               // [nout][workgroups]: one row per workgroup = the sum of a triple of partial rows of the three-launch kernel
+    double *stat;                  // [nout]
+    NmftBarrier bar;
+    double *stamps;                // debug: s_memrealtime (100 MHz) at the phase boundaries of update 5 in workgroup 0, or null
+};
+
+// NWV = wavefronts per workgroup: 12 (large tables: one workgroup per CU, a third of the partial rows and arrivals) or 4 (tables of
+// at most one update-kernel workgroup per CU: a wavefront has its SIMD to itself and the phases run ~1.5x faster)
+template <int NT, int KB, bool KEEPF, int NWV>
+__global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_kernel(NmftPersistParams prm)
+{
+    const double *__restrict__ F = prm.F;
+    const int V = prm.V, S = prm.S, G = prm.G, adjust = prm.adjust;
+    extern __shared__ __attribute__((aligned(16))) char smem_p[];
+    constexpr int GP = 4 * KB, SPAD = 16 * NT, NW = NWV, NTHR = 64 * NWV;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
+    const int nwg = gridDim.x, wg = blockIdx.x;
+    const int nout = G * S + G + 1;
+    double2 *ltab = reinterpret_cast<double2 *>(smem_p);                        // [256]
+    double *gr = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);              // [GP][SPAD] gamma_raw (product operands)
+    double *braw = gr + GP * SPAD;                                              // [NT][KB][64] B fragments of gamma_raw
+    double *bgam = braw + NT * KB * 64;                                         // [NT][KB][64] B fragments of gamma
+    double *t1 = bgam + NT * KB * 64;                                           // [GP] rowsum(gamma_raw)
+    double *tl = t1 + GP;                                                       // per wavefront [2][16][GP]: tau rows, old and new
+    double *red = tl + NW * (2 * 16 * GP);                                      // [NW][GP + 2][SPAD] cross-wavefront reduction, also scratch
+    double *stat = red + NW * (GP + 2) * SPAD;                                  // [nout] the reduced statistics
+    double *gm = stat + ((nout + 1) & ~1);                                      // [G][S] gamma after _adjustment
+    double *grw = gm + G * S;                                                   // [G][S] normalised gamma before _adjustment
+    int *ok_s = reinterpret_cast<int *>(grw + G * S);                           // [1] verdict of a barrier for the whole workgroup
+    for (int i = tid; i < DSM_LOG_TAB_N; i += NTHR) ltab[i] = reinterpret_cast<const double2 *>(prm.log_tab)[i];
+    for (int i = tid; i < G * S; i += NTHR) { gm[i] = prm.gam[i]; grw[i] = prm.gam_raw[i]; }
+    double *told = tl + wv * (2 * 16 * GP), *tnew = told + 16 * GP;
+    for (int k = lane; k < 2 * 16 * GP; k += 64) told[k] = 0.0;                 // incl. tnew and the padded haplotype columns
+    const int qd = wg * NW + wv, nquad = (V + 3) >> 2;
+    const bool have = qd < nquad;
+    const int v0 = qd * 4;
+    const bool vok = have && v0 + q < V;
+    __builtin_amdgcn_wave_barrier();
+    if (have) {
+        for (int k = lane; k < 16 * G; k += 64) {
+            const int vv = k / (4 * G), r = (k / G) & 3, g = k % G;
+            tnew[(4 * r + vv) * GP + g] = (v0 + vv < V) ? prm.tau[(size_t)v0 * 4 * G + k] : 0.0;
+        }
+    }
+    const bool b0 = n & 1, b1 = n & 2, b2 = n & 4, b3 = n & 8;
+    const int my_e = (b0 ? 2 : 0) + (b1 ? 1 : 0), my_gg = (b3 ? 2 : 0) + (b2 ? 1 : 0);
+    bool live[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) live[t] = vok && (16 * t + n < S);
+    auto load_f = [&](int t) {
+        double4_t x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = live[t] ? F[((size_t)(v0 + q) * 4 + e) * S + 16 * t + n] : 1.0;
+        return x;
+    };
+    double4_t f[KEEPF ? NT : 1];
+    if constexpr (KEEPF) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) f[t] = load_f(t);
+    }
+    // MFMA operands of the current gamma: gr / braw from grw, bgam from gm, t1 = rowsum(grw)
+    auto stage_gamma = [&]() {
+        for (int i = tid; i < GP * SPAD; i += NTHR) {
+            const int g = i / SPAD, s = i % SPAD;
+            gr[i] = (g < G && s < S) ? grw[g * S + s] : 0.0;
+        }
+        for (int i = tid; i < NT * KB * 64; i += NTHR) {
+            const int l = i & 63, kb = (i >> 6) % KB, t = (i >> 6) / KB;
+            const int g = 4 * kb + (l >> 4), s = 16 * t + (l & 15);
+            const bool in = g < G && s < S;
+            braw[i] = in ? grw[g * S + s] : 0.0;
+            bgam[i] = in ? gm[g * S + s] : 0.0;
+        }
+        __syncthreads();
+        for (int g = wv; g < GP; g += NW) {                                     // gamma.sum(1) (:170), lane-parallel
+            double a = 0.0;
+            for (int s = lane; s < SPAD; s += 64) a += gr[g * SPAD + s];
+            a = group_allreduce_sum<64>(a);
+            if (lane == 0) t1[g] = a;
+        }
+        __syncthreads();
+    };
+    __syncthreads();
+    stage_gamma();
+
+    unsigned epoch = 0;
+    int it = 0;
+    double prev = 0.0;
+    bool alive = true;
+#define NM_STAMP(k) do { if (prm.stamps && wg == 0 && tid == 0 && it == 5) prm.stamps[k] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
+    for (;;) {
+        NM_STAMP(0);
+        // ---- statistics of the current state (tnew, gamma): R2, objective, Q2, gamma numerators, H1
+        double4_t acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        double obj = 0.0, h1 = 0.0;
+        if (have) {
+            double a_new[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) a_new[kb] = tnew[n * GP + 4 * kb + q];
+            double a_g[4];                                                      // A of the row contraction: tau_new[vv = q][e][g = n]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a_g[e] = (n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; h1 += a_g[e]; }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_new[kb], bgam[(t * KB + kb) * 64 + lane], R, 0, 0, 0);
+                double4_t q2;
+                const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool tiny = R[e] < DSM_EPS;
+                    const double pa = tiny ? DSM_EPS : R[e];
+                    const double ratio = fdiv(nzd(ft[e]), pa);
+                    double qq = ratio;
+                    if (__builtin_amdgcn_ballot_w64(tiny && R[e] != 0.0) != 0ull) { if (tiny) qq = fdiv(nzd(ft[e]), nzd(R[e])); }
+                    q2[e] = live[t] ? qq : 0.0;
+                    if (live[t]) obj += ft[e] * dsm_log(ratio, ltab) - ft[e] + pa;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
+            }
+        }
+        NM_STAMP(1);
+        // Workgroup reduction: wavefronts 4 r .. 4 r + 3 are workgroup 3 wg + r of the three-launch kernel (the same four quads, summed
+        // in the same fixed order), and the three sums are added as nmft_sum_partials adds a triple of partials -- so this
+        // workgroup's ONE published row is a term of the three-launch path's reduction, and the totals agree bit for bit.
+        const double o_w = group_allreduce_sum<64>(obj);
+        double hh = h1;
+        hh += __shfl_xor(hh, 16, 64);
+        hh += __shfl_xor(hh, 32, 64);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int g = 4 * e + q;
+                if (g < GP) red[((size_t)wv * (GP + 2) + g) * SPAD + 16 * t + n] = acc[t][e];
+            }
+        if (lane == 0) red[((size_t)wv * (GP + 2) + GP) * SPAD] = o_w;
+        if (lane < GP) red[((size_t)wv * (GP + 2) + GP + 1) * SPAD + lane] = hh;
+        __syncthreads();
+        for (int o = tid; o < nout; o += NTHR) {
+            // statistic o of the (GP + 2) x SPAD tile: numerator (g, s), row sum g, or the objective
+            int row, col;
+            if (o < G * S) { row = o / S; col = o % S; }
+            else if (o < G * S + G) { row = GP + 1; col = o - G * S; }
+            else { row = GP; col = 0; }
+            double x[NW / 4];
+#pragma unroll
+            for (int r = 0; r < NW / 4; ++r) {
+                double a = 0.0;
+                for (int k = 0; k < 4; ++k) a += red[((size_t)(4 * r + k) * (GP + 2) + row) * SPAD + col];
+                x[r] = a;
+            }
+            double ps = x[0];
+            if constexpr (NW == 12) ps = (x[0] + x[1]) + x[2];
+            nm_store(prm.partial + (size_t)o * nwg + wg, ps);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NM_STAMP(2);
+        alive = nm_grid_barrier(prm.bar, ++epoch, tid, ok_s);
+        if (!alive) break;
+        NM_STAMP(3);
+        // ---- statistic `out` over the workgroups: one wavefront each (the arithmetic of nmft_reduce_body)
+        {
+            for (int out = wg * NW + wv; out < nout; out += nwg * NW) {          // (small tables: more statistics than wavefronts)
+                double a = 0.0;
+                const double *row = prm.partial + (size_t)out * nwg;
+                if constexpr (NW == 12) {                                        // the rows are triples already
+                    for (int b = lane; b < nwg; b += 64) a += nm_load(row + b);
+                } else {                                                         // nmft_sum_partials over the workgroup rows
+                    const int ntrip = (nwg + 2) / 3;
+                    for (int t = lane; t < ntrip; t += 64) {
+                        const int b = 3 * t;
+                        double x = nm_load(row + b);
+                        if (b + 1 < nwg) x += nm_load(row + b + 1);
+                        if (b + 2 < nwg) x += nm_load(row + b + 2);
+                        a += x;
+                    }
+                }
+                a = group_allreduce_sum<64>(a);
+                if (lane == 0) nm_store(prm.stat + out, a);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NM_STAMP(4);
+        alive = nm_grid_barrier(prm.bar, ++epoch, tid, ok_s);
+        if (!alive) break;
+        NM_STAMP(5);
+        for (int i = tid; i < nout; i += NTHR) stat[i] = nm_load(prm.stat + i);
+        __syncthreads();
+        // ---- the stop test of the factorize loop (Init_NMFT.py:106), by every workgroup for itself
+        const double div = stat[G * S + G];
+        const bool go = (it < prm.max_iter) && (fabs(prev - div) > prm.min_change);
+        if (wg == 0 && tid == 0) {
+            if (prm.div_trace) prm.div_trace[it] = div;
+            if (!go) { prm.ctl[0] = div; prm.ctl[3] = (double)it; prm.ctl[2] = 1.0; }
+        }
+        if (!go) break;
+        NM_STAMP(6);
+        // ---- gamma update (:163-168), every workgroup its own copy
+        if (!prm.fix_gamma) {
+            double *val = red;                                                   // [G][S] scratch
+            for (int i = tid; i < G * S; i += NTHR) {
+                const int g = i / S;
+                val[i] = (G > 1) ? gm[i] * (nzd(stat[i]) / nzd(stat[G * S + g])) : 1.0;      // :163 / :168
+            }
+            __syncthreads();
+            for (int i = tid; i < G * S; i += NTHR) {
+                const int s = i % S;
+                double v = val[i];
+                if (G > 1) {
+                    double tot = 0.0;
+                    for (int k = 0; k < G; ++k) tot += val[k * S + s];          // :165
+                    v = v / tot;                                                 // :166
+                }
+                grw[i] = v;                                                      // the tau update of this iteration sees it unclamped
+                gm[i] = (adjust && v < DSM_EPS) ? DSM_EPS : v;                   // _adjustment follows the whole div_update (:88-91,:108)
+            }
+            __syncthreads();
+            stage_gamma();
+        }
+        NM_STAMP(7);
+        // ---- tau half of the update on this wavefront's quad (tau rows stay in LDS)
+        if (have) {
+            double *tsw = told; told = tnew; tnew = tsw;                         // the rows of the last update are the old ones now
+            __builtin_amdgcn_wave_barrier();
+            double a_old[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) a_old[kb] = told[n * GP + 4 * kb + q];
+            double4_t qp[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_old[kb], braw[(t * KB + kb) * 64 + lane], R, 0, 0, 0);
+                const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qp[t][e] = live[t] ? fdiv(nzd(ft[e]), nzd(R[e])) : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < KB; ++c) {
+                double p[16];                                                   // value index j = 4 e + gg
+#pragma unroll
+                for (int j = 0; j < 16; ++j) p[j] = 0.0;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        const double gmv = gr[(4 * c + gg) * SPAD + 16 * t + n];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) p[4 * e + gg] = fma(qp[t][e], gmv, p[4 * e + gg]);
+                    }
+                const double tot_rg = row16_transpose_reduce(p, n);             // num[(my_e, vv = q)][g]
+                const int g = 4 * c + my_gg;
+                const bool ok = g < G;
+                double tn = 0.0;
+                if (ok) tn = told[(4 * my_e + q) * GP + g] * fdiv(nzd(tot_rg), nzd(t1[g]));       // :171-172
+                const double t_a0 = dpp_mov<0x00>(tn), t_a1 = dpp_mov<0xAA>(tn);
+                const double t_a2 = dpp_mov<0x55>(tn), t_a3 = dpp_mov<0xFF>(tn);
+                const double tot = ((t_a0 + t_a1) + t_a2) + t_a3;                              // :176-178
+                if (ok) {
+                    double x = fdiv(tn, tot);                                                      // :180-181
+                    if (adjust && x < DSM_EPS) x = DSM_EPS;                                    // :88-91
+                    tnew[(4 * my_e + q) * GP + g] = vok ? x : 0.0;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        NM_STAMP(8);
+        prev = div;
+        ++it;
+    }
+    // ---- the factors leave the chip once: tau rows of this wavefront's quad; gamma by workgroup 0
+    if (have) {
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < 16 * G; k += 64) {
+            const int vv = k / (4 * G), r = (k / G) & 3, g = k % G;
+            if (v0 + vv < V) prm.tau[(size_t)v0 * 4 * G + k] = tnew[(4 * r + vv) * GP + g];
+        }
+    }
+    if (wg == 0) for (int i = tid; i < G * S; i += NTHR) { prm.gam[i] = gm[i]; prm.gam_raw[i] = grw[i]; }
+}
+
+static std::mutex g_persist_mu[16];                     // one persistent launch per device at a time
+
+template <int NT, int KB, int NWV>
+static int launch_persist(dsm_ctx *c, const NmftPersistParams &q, int grid, size_t sh, int *fits)
+{
+    auto fn = nmft_persist_kernel<NT, KB, (NT <= 2), NWV>;    // F kept in registers up to 32 samples (three tiles spill at 3 wavefronts per SIMD)
+    int occ = 0, cus = 0;
+    HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64 * NWV, sh));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    *fits = grid <= occ * cus;
+    if (!*fits) return DSM_OK;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * NWV), sh, c->stream, q);
+    HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}
+
+// the whole factorize loop as one launch; *used = 0 when this shape / device does not take the persistent path (the caller
+// then runs the three-launch loop).  Control words (ctl), trace and factors are left as dsm_nmft_factorize expects them.
+int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int adjust, int *used)
+{
+    *used = 0;
+    static const bool off = getenv("DESMAN_HIP_NMFT_NO_PERSIST") != nullptr;
+    int nt, kb;
+    if (off || c->nmft_persist == 0 || !mfma_shape(c, &nt, &kb) || nt > 4 || c->timing || g_batch.K) return DSM_OK;
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    const int G = c->nG, S = c->S, nquad = (c->V + 3) / 4, nblk = (nquad + 3) / 4;
+    // up to one update-kernel workgroup per CU: four wavefronts per workgroup; above: twelve (three of those workgroups each)
+    const int nwv = nblk <= cus ? 4 : NMFT_P_WAVES;
+    const int grid = (nquad + nwv - 1) / nwv;
+    const int nout = G * S + G + 1;
+    if (grid < 2) return DSM_OK;
+    const int GP = 4 * kb, SPAD = 16 * nt;
+    const size_t sh = (2 * DSM_LOG_TAB_N + (size_t)GP * SPAD + 2 * (size_t)nt * kb * 64 + GP + (size_t)nwv * 2 * 16 * GP +
+                       (size_t)nwv * (GP + 2) * SPAD + ((nout + 1) & ~1) + 2 * (size_t)G * S + 2) * sizeof(double);
+    if (sh > 160 * 1024) return DSM_OK;
+    // exchange buffers + barrier words (zeroed before every launch)
+    if (!c->np_part || c->np_cap < (size_t)nout * grid) {
+        if (c->np_part) { (void)hipFree(c->np_part); c->np_part = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->np_part, ((size_t)nout * grid + nout + 16) * sizeof(double)));
+        c->np_cap = (size_t)nout * grid;
+    }
+    if (!c->np_bar) HIP_TRY(hipMalloc((void **)&c->np_bar, 1024));
+    NmftPersistParams q;
+    q.F = c->F; q.tau = c->ntau; q.gam_raw = c->ngam_raw; q.gam = c->ngam;
+    q.V = c->V; q.S = S; q.G = G; q.adjust = adjust; q.fix_gamma = fix_gamma; q.max_iter = max_iter; q.min_change = min_change;
+    q.ctl = NMFT_CTL(c); q.div_trace = c->ndiv_trace; q.log_tab = c->log_tab;
+    q.partial = c->np_part; q.stat = c->np_part + (size_t)nout * grid;
+    q.bar.gcnt = c->np_bar; q.bar.top = c->np_bar + 8 * 16; q.bar.gen = c->np_bar + 9 * 16; q.bar.err = c->np_bar + 10 * 16;
+    q.stamps = getenv("DESMAN_HIP_NMFT_STAMPS") ? q.stat + nout : nullptr;       // 8 spare doubles behind the totals
+    for (int g = 0; g < 8; ++g) q.bar.members[g] = (grid - g + 7) / 8;
+    q.bar.ngroups = std::min(grid, 8);
+    std::lock_guard<std::mutex> lock(g_persist_mu[c->device & 15]);
+    HIP_TRY(hipMemsetAsync(c->np_bar, 0, 1024, c->stream));
+    int fits = 0, rc = DSM_OK;
+    KTimer tm(c, DSM_K_NMFT_B);
+#define PCASE(N, K) if (nt == N && kb == K) rc = (nwv == 4) ? launch_persist<N, K, 4>(c, q, grid, sh, &fits) : launch_persist<N, K, NMFT_P_WAVES>(c, q, grid, sh, &fits)
+    PCASE(1, 1); PCASE(1, 2); PCASE(1, 3); PCASE(2, 1); PCASE(2, 2); PCASE(2, 3); PCASE(3, 1); PCASE(3, 2); PCASE(3, 3); PCASE(4, 1); PCASE(4, 2); PCASE(4, 3);
+#undef PCASE
+    if (rc != DSM_OK) return rc;
+    if (!fits) return DSM_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));           // the lock is held until the resident workgroups are gone
+    unsigned err = 0;
+    HIP_TRY(hipMemcpy(&err, c->np_bar + 10 * 16, sizeof err, hipMemcpyDeviceToHost));
+    if (q.stamps) {
+        double st[9] = {0};
+        HIP_TRY(hipMemcpy(st, q.stamps, sizeof st, hipMemcpyDeviceToHost));
+        fprintf(stderr, "nmft_persist phases of update 5, workgroup 0 (us): stats %.2f | wg-reduce+publish %.2f | barrier1 %.2f | reduce %.2f | barrier2 %.2f | read+control %.2f | gamma+stage %.2f | tau half %.2f\n",
+                (st[1] - st[0]) / 100.0, (st[2] - st[1]) / 100.0, (st[3] - st[2]) / 100.0, (st[4] - st[3]) / 100.0, (st[5] - st[4]) / 100.0,
+                (st[6] - st[5]) / 100.0, (st[7] - st[6]) / 100.0, (st[8] - st[7]) / 100.0);
+    }
+    if (err) { dsm_set_error("nmft_persist: a grid barrier timed out (workgroups of the persistent launch were not all resident)"); return DSM_ERR_HIP; }
+    *used = 1;
     return DSM_OK;
 }

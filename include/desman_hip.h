@@ -293,6 +293,11 @@ int dsm_ctx_debug_log2f(dsm_ctx *ctx, const float *in, float *out, size_t n);
    update kernel leaves <= 128 workgroup partials, two launches above (default); 0 = always two; 1 = always fused.  The factors,
    update counts and objective traces do not depend on it (tests/test_gpu_fullsize.py asserts bit-equality). */
 int dsm_ctx_set_nmft_fused(dsm_ctx *ctx, int mode);
+/* dsm_nmft_factorize as ONE persistent launch (resident workgroups, in-kernel grid barriers, tau rows kept in LDS) where the
+   table fits the machine (S <= 64, G <= 12, V <= 48 x compute units): -1 / 1 = wherever it applies (default), 0 = never (the
+   three-launch loop).  Same stopping rule and update counts; factors equal to rounding (the workgroup partials are grouped
+   differently). */
+int dsm_ctx_set_nmft_persist(dsm_ctx *ctx, int mode);
 /* on = 0: every step of the tau sweep in fp64 (A/B switch: the results do not depend on it) */
 int dsm_ctx_set_tau_screen(dsm_ctx *ctx, int on);
 /* workgroups one tau sweep of the resident shape launches, and how many of them the device holds at once (occupancy of the

@@ -75,9 +75,10 @@ def _nmft_case(V, S, G, seed=1234):
     return counts, tau0, gam0, cbind.nmft_freq(counts)
 
 
-def _nmft_run(counts, tau0, gam0, fused, fix_gamma, max_iter=20):
+def _nmft_run(counts, tau0, gam0, fused, fix_gamma, max_iter=20, persist=0):
     c = _lib.Context(0)
     c.set_counts(counts)
+    c.set_nmft_persist(persist)          # 0: the three-launch loop (whose reduce + gamma step `fused` selects), 1: one persistent launch
     c.set_nmft_fused(fused)
     c.nmft_set(tau0, gam0)
     n, tr = c.nmft_factorize(max_iter=max_iter, min_change=1e-5, fix_gamma=fix_gamma)
@@ -88,7 +89,8 @@ def _nmft_run(counts, tau0, gam0, fused, fix_gamma, max_iter=20):
     return n, tr, tau, gam, onehot, div
 
 
-@pytest.mark.parametrize("V,S,G", [(10000, 64, 8), (50000, 96, 12), (3000, 64, 8), (2000, 32, 5), (13000, 40, 3)])
+@pytest.mark.parametrize("V,S,G", [(10000, 64, 8), (50000, 96, 12), (3000, 64, 8), (2000, 32, 5), (13000, 40, 3), (12288, 48, 12), (933, 64, 5),
+                                   (97, 20, 2)])
 def test_full_size_nmft_factorize_matches_oracle(V, S, G):
     counts, tau0, gam0, F = _nmft_case(V, S, G)
     for fix_gamma in (False, True):
@@ -116,6 +118,13 @@ def test_full_size_nmft_factorize_matches_oracle(V, S, G):
             m, tr_f, tau_f, gam_f, onehot_f, div_f = runs[f]
             assert m == n and np.array_equal(tr_f, tr) and np.array_equal(tau_f, tau) and np.array_equal(gam_f, gam)
             assert np.array_equal(onehot_f, onehot) and div_f == div
+        # the whole loop as ONE persistent launch (tables up to 12 288 positions, S <= 64; elsewhere the call is the three-launch
+        # loop again): its workgroups publish the partial rows of the three-launch kernel, so every bit agrees
+        m, tr_p, tau_p, gam_p, onehot_p, div_p = _nmft_run(counts, tau0, gam0, -1, fix_gamma, persist=1)
+        assert m == n and np.array_equal(tr_p, tr) and np.array_equal(tau_p, tau) and np.array_equal(gam_p, gam)
+        assert np.array_equal(onehot_p, onehot) and div_p == div
+        if fix_gamma:
+            assert np.array_equal(gam_p, gam0)
 
 
 def test_full_size_nmft_stop_rule_fires_at_the_oracles_update():
@@ -125,9 +134,10 @@ def test_full_size_nmft_stop_rule_fires_at_the_oracles_update():
     tc, gc = tau0.copy(), gam0.copy()
     n_ref, tr_ref = cbind.nmft_factorize(F, tc, gc, max_iter=200, min_change=30.0)
     assert 3 < n_ref < 200
-    for fused in (-1, 1):
+    for fused, persist in ((-1, 0), (1, 0), (-1, 1)):
         c = _lib.Context(0)
         c.set_counts(counts)
+        c.set_nmft_persist(persist)
         c.set_nmft_fused(fused)
         c.nmft_set(tau0, gam0)
         n, tr = c.nmft_factorize(max_iter=200, min_change=30.0)

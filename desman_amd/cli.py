@@ -8,6 +8,7 @@ import argparse
 import logging
 import os
 import sys
+import threading
 
 import numpy as np
 import pandas as pd
@@ -49,10 +50,30 @@ def build_parser():
     return ap
 
 
+_TABLES_LOCK = threading.Lock()
+_TABLES_CACHE = {}                      # (path, mtime, size) -> parsed frame, the most recent few
+
+
+def _read_table(path):
+    """the base-count table of `path`, parsed once per process while the file is unchanged: a G-sweep runs every chain through
+    main() / main_replicates() in one process (desman_amd.chains), and parsing a 50 000 x 96 table (58 MB of text) costs more than
+    the chain's GPU time.  The frame is only ever read (Variant_Filter copies it into arrays, Output_Results slices it)."""
+    st = os.stat(path)
+    key = (os.path.abspath(path), st.st_mtime_ns, st.st_size)
+    with _TABLES_LOCK:
+        table = _TABLES_CACHE.get(key)
+        if table is None:
+            table = pd.read_csv(path, header=0, index_col=0)
+            while len(_TABLES_CACHE) >= 2:
+                _TABLES_CACHE.pop(next(iter(_TABLES_CACHE)))
+            _TABLES_CACHE[key] = table
+    return table
+
+
 def _load(opts, report):
     """CSV -> count tensor, sample filter, optional variant filter / eta file / position subsample."""
     logging.info('position-selection RNG seeded with %d' % POSITION_SELECT_SEED)
-    table = pd.read_csv(opts.variant_file, header=0, index_col=0)
+    table = _read_table(opts.variant_file)
     flt = Variant_Filter(table, randomState=RandomState(POSITION_SELECT_SEED), optimise=opts.optimiseP,
                          threshold=opts.filter_variants, min_coverage=opts.min_coverage, qvalue_cutoff=opts.max_qvalue)
     flt.device = opts.device

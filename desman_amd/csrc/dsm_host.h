@@ -165,6 +165,7 @@ int k_log2f_test(dsm_ctx *c, const float *d_in, float *d_out, size_t n);
 int build_stats_items(dsm_ctx *c);          // api.hip: work list of the per-read pass from the resident tensor
 
 // ---- launchers (kernels_stats.hip)
+uint32_t stats_ntab_hmul();                  // odd multiplier of the subset -> table row map
 int stats_ntab_rep(const dsm_ctx *c);       // copies of the subset table the stage-1 atomics are spread over
 int stats_spec(const dsm_ctx *c);           // 2 = aggregated sampler (oracle/stats_agg.c), 1 = per-read (orc_stats_counter)
 int k_stats(dsm_ctx *c, uint32_t iter);

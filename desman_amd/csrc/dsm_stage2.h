@@ -30,6 +30,7 @@ struct Stage2Params {
     const double *log_tab;
     int S, G;
     uint32_t k0, k1, iter;
+    uint32_t hmul;                  // row of subset H in ntab: (H * hmul) mod 2^G (kernels_stats.hip: stats_ntab_hmul)
     uint32_t *big_count;            // work-list counter of stage 1: consumed by now, reset here for the next pass (or null)
 };                                  // the plan of the halving tree (a function of G) travels beside it: one per launch
 
@@ -78,13 +79,24 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
             if (Hs == 0) continue;
             uint32_t n;
             if (level == 0) {
-                uint32_t *cell = p.ntab + (size_t)Hs * S + s;
-                n = *cell;
-                if (n) *cell = 0u;
+                uint32_t *cell = p.ntab + (size_t)((Hs * p.hmul) & ((1u << G) - 1u)) * S + s;
                 const size_t cstride = ((size_t)1 << G) * S;
-                for (int r = 1; r < p.rep; ++r) {               // few subsets, many positions: the atomics of stage 1 were spread over copies
-                    const uint32_t m = cell[r * cstride];
-                    if (m) { cell[r * cstride] = 0u; n += m; }
+                if (p.rep == 8) {
+                    // one copy per XCD (kernels_stats.hip): all eight loads in flight at once -- read one after the other (a store may
+                    // alias the next load, so the compiler keeps the order) they cost eight memory round trips: +3.5 us on the launch
+                    uint32_t m[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) m[r] = __builtin_nontemporal_load(cell + r * cstride);
+                    n = 0;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { n += m[r]; if (m[r]) cell[r * cstride] = 0u; }
+                } else {
+                    n = *cell;
+                    if (n) *cell = 0u;
+                    for (int r = 1; r < p.rep; ++r) {           // few subsets, many positions: the atomics of stage 1 were spread over copies
+                        const uint32_t m = cell[r * cstride];
+                        if (m) { cell[r * cstride] = 0u; n += m; }
+                    }
                 }
             } else n = tab[base + j];
             if (w == 1) {                                   // leaf: Hs == 1

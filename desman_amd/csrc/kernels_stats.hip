@@ -43,6 +43,8 @@ struct StatsAggParams {
                                     // whole pass on deep data)
     size_t big_seg;
     double lean_cap;                // stage 1 hands an item whose rarer outcome has a mean above this to the compacted kernel
+    uint32_t hmul;                  // the row of subset H is (H * hmul) mod 2^G (dsm_stage2.h: s2_row): an odd multiplier scatters the hot
+                                    // subsets over the memory channels whatever the table's address
     int xcd;                        // 1: the table has a copy per XCD (rep = 8 k); a workgroup adds to a copy of ITS XCD (HW_REG_XCC_ID) with
                                     // workgroup-scope atomics, which execute in that XCD's L2 instead of at the memory side
     int dbg;                        // timing experiments only (DESMAN_HIP_STATS_DBG): bit 0 no draws, 1 no item seeding, 2 no E/N atomics, 3 no cell Philox
@@ -199,6 +201,8 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
         }
         // N[H_a(v)][s] += reads whose true base is a: adjacent lanes -> adjacent words of one table row
         uint32_t *const nt = p.ntab + (size_t)copy * (((size_t)1 << G) * S);
+        const uint32_t hmask = (1u << G) - 1u;
+        H0 = (H0 * p.hmul) & hmask; H1 = (H1 * p.hmul) & hmask; H2 = (H2 * p.hmul) & hmask; H3 = (H3 * p.hmul) & hmask;   // rows of the four subsets
         if (p.dbg & (4 | 32)) { if ((nacc[0] ^ nacc[1] ^ nacc[2] ^ nacc[3] ^ H0 ^ H1 ^ H2 ^ H3) == 0x12345u) atomicAdd(nt + s, 1u); continue; }
         if (p.dbg & 64) {        // plain stores instead of atomics (wrong sums; what the adds cost beyond a store)
             nt[(size_t)H0 * S + s] = nacc[0]; nt[(size_t)H1 * S + s] = nacc[1]; nt[(size_t)H2 * S + s] = nacc[2]; nt[(size_t)H3 * S + s] = nacc[3];
@@ -298,7 +302,7 @@ __device__ __forceinline__ void stats_big_body(const StatsAggParams &p)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             erow[a * 256] += n[a];
-            if (n[a]) atomicAdd(p.ntab + (size_t)(blockIdx.x % (unsigned)p.rep) * (((size_t)1 << G) * S) + (size_t)H[a] * S + s, n[a]);
+            if (n[a]) atomicAdd(p.ntab + (size_t)(blockIdx.x % (unsigned)p.rep) * (((size_t)1 << G) * S) + (size_t)((H[a] * p.hmul) & ((1u << G) - 1u)) * S + s, n[a]);
         }
     }
     {
@@ -437,6 +441,18 @@ static bool stats_ntab_xcd(const dsm_ctx *c)
     return env != 0 && (size_t)8 * ((size_t)1 << c->G) * (size_t)c->S * 4 <= ((size_t)64 << 20);
 }
 
+// Odd multiplier of the subset -> table row map.  Why: the subsets that take most of stage 1's atomics are the low-popcount ones, and
+// with the identity map their rows sit at addresses base + 256 H whose bits line up with the memory-channel hash: depending on where
+// hipMalloc put the 64 KB table, the memory-side atomics of stage 1 cost 2 us or 26 us at config 3 (stage 1 46 vs 72 us; found when
+// two more allocations ahead of it -- the persistent NMFT kernel's -- moved the table; base offsets scanned: fast at 256 B and
+// 32-60 KB into a 2 MB block, slow at 0, 4 KB, 64 KB ...).  Scattering the rows takes the pathology away (46-54 us at every offset
+// scanned).  DESMAN_HIP_NTAB_HMUL=1 is the identity (A/B switch).
+uint32_t stats_ntab_hmul()
+{
+    static const uint32_t k = getenv("DESMAN_HIP_NTAB_HMUL") ? ((uint32_t)strtoul(getenv("DESMAN_HIP_NTAB_HMUL"), nullptr, 0) | 1u) : 0x9E3779B1u;
+    return k;
+}
+
 static int ensure_ntab(dsm_ctx *c)
 {
     c->ntab_rep = stats_ntab_rep(c);
@@ -519,6 +535,7 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
     p.ntab = c->ntab; p.rep = c->ntab_rep; p.esum = c->esum; p.log_tab = c->log_tab;
     p.xcd = stats_ntab_xcd(c) ? 1 : 0;
+    p.hmul = stats_ntab_hmul();
     p.big_list = c->big_list; p.big_count = c->big_count;
     {
         // who draws an item, not what is drawn: an item whose rarer outcome has a mean above lean_cap goes to the compacted
@@ -595,7 +612,7 @@ int k_stats_stage2(dsm_ctx *c, uint32_t iter)
     KTimer tm(c, DSM_K_STATS2);
     Stage2Params p;
     p.ntab = c->ntab; p.rep = c->ntab_rep; p.gamma = c->gamma; p.sum_mu = c->sum_mu; p.log_tab = c->log_tab;
-    p.S = c->S; p.G = c->G;
+    p.S = c->S; p.G = c->G; p.hmul = stats_ntab_hmul();
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
     p.big_count = c->big_count;
     // 2^G subsets per sample at the root: 256 threads up to G = 9, 1024 above

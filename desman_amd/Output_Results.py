@@ -5,12 +5,19 @@ byte-identical files (tests/test_host_cpu.py compares against files the referenc
 everything goes through two small helpers: one for haplotype tables (Position first, then 4 columns per
 haplotype), one for per-sample abundance tables.
 """
+import hashlib
 import logging
 import os
+import shutil
 import sys
+import threading
+import weakref
 
 import numpy as np
 import pandas as pd
+
+_SELECTED_LOCK = threading.Lock()
+_SELECTED_CACHE = {}        # (id of the table, rows, digest of the selection) -> (weak ref to the table, a file holding the text, its size)
 
 LOG_FORMAT = '%(asctime)s:%(levelname)s:%(name)s:%(message)s'
 
@@ -123,5 +130,20 @@ class Output_Results:
         logging.info("Eta_mean.csv written")
 
     def output_Selected_Variants(self):
-        self.variants[self.variantFilter.selected].to_csv(self._path("Selected_variants.csv"))
+        """the selected rows of the input table.  Every chain of a G-sweep writes the same file (the -r selection is drawn from
+        a fixed seed, bin/desman:85-86): serialising 50 000 x 385 integers takes longer than the chain's GPU work, so within one
+        process the text is produced once per (table, selection) and copied afterwards."""
+        path = self._path("Selected_variants.csv")
+        sel = np.asarray(self.variantFilter.selected, dtype=bool)
+        key = (id(self.variants), sel.shape[0], hashlib.blake2b(np.packbits(sel).tobytes(), digest_size=16).digest())
+        with _SELECTED_LOCK:
+            prev = _SELECTED_CACHE.get(key)
+            if prev is not None and prev[0]() is self.variants and os.path.isfile(prev[1]) and os.path.getsize(prev[1]) == prev[2] \
+                    and os.path.abspath(prev[1]) != os.path.abspath(path):
+                shutil.copyfile(prev[1], path)
+            else:
+                self.variants[sel].to_csv(path)
+                while len(_SELECTED_CACHE) >= 4:
+                    _SELECTED_CACHE.pop(next(iter(_SELECTED_CACHE)))
+                _SELECTED_CACHE[key] = (weakref.ref(self.variants), path, os.path.getsize(path))
         logging.info("Selected_variants.csv written")

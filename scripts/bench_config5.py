@@ -82,7 +82,7 @@ def main():
         for mode in a.modes.split(","):
             stub = os.path.join(d, mode)
             extra = {"one": ["-c", "1"], "batch": ["-b", str(a.reps), "-c", "1"], "batch2": ["-b", str(a.reps), "-c", "2"],
-                     "threads4": ["-c", "4"]}[mode]
+                     "threads2": ["-c", "2"], "threads4": ["-c", "4"]}[mode]
             wall, recs = run_sweep(freq, a, stub, extra)
             per_g = {}
             for r in recs:

@@ -14,6 +14,7 @@
 //             per-(v,g) renormalisation over the four bases (:170-181), _adjustment (:88-91)
 #include <stdlib.h>
 
+#include <condition_variable>
 #include <mutex>
 
 #include "dsm_device.h"
@@ -1130,8 +1131,8 @@ int k_nmft_mfma(dsm_ctx *c, int adjust, int do_update)
 // write-through (sc1) stores drained by every storing wavefront before the arrival, and are read with sc1 loads, so no
 // release / acquire fence is needed (cdna_hip_programming.md, Guideline 16).  Polls are bounded: a workgroup that times out
 // raises an error word and leaves, the host reports it.  The launch requires every workgroup to be resident: the grid is
-// checked against the occupancy query, and a process-wide lock admits one persistent launch per device at a time (two of
-// them could starve each other of CUs); other kernels only delay it.
+// checked against the occupancy query, and a process-wide gate (PersistGate) admits concurrent persistent launches on a device
+// only while together they ask for at most one workgroup per CU (more could starve each other of CUs); other kernels only delay them.
 //
 // Arithmetic: the update is that of nmft_mfma_body, statement for statement, and a workgroup publishes the sum of the three
 // partial rows the three-launch kernel's workgroups would have written for its twelve quads, added in the order in which
@@ -1469,7 +1470,26 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
     if (wg == 0) for (int i = tid; i < G * S; i += NTHR) { prm.gam[i] = gm[i]; prm.gam_raw[i] = grw[i]; }
 }
 
-static std::mutex g_persist_mu[16];                     // one persistent launch per device at a time
+// Admission of persistent launches, per device: their workgroups must all be resident, so concurrent ones (several chains of a
+// sweep in host threads) may together ask for at most one workgroup per CU -- then every workgroup of every admitted launch has a
+// CU it can be placed on whatever the others do; a launch that does not fit next to the running ones waits for them.
+struct PersistGate {
+    std::mutex mu;
+    std::condition_variable cv;
+    int used = 0;
+    void enter(int want, int cap)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return used == 0 || used + want <= cap; });
+        used += want;
+    }
+    void leave(int want)
+    {
+        { std::lock_guard<std::mutex> lk(mu); used -= want; }
+        cv.notify_all();
+    }
+};
+static PersistGate g_persist_gate[16];
 
 template <int NT, int KB, int NWV>
 static int launch_persist(dsm_ctx *c, const NmftPersistParams &q, int grid, size_t sh, int *fits)
@@ -1522,7 +1542,9 @@ int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, i
     q.stamps = getenv("DESMAN_HIP_NMFT_STAMPS") ? q.stat + nout : nullptr;       // 8 spare doubles behind the totals
     for (int g = 0; g < 8; ++g) q.bar.members[g] = (grid - g + 7) / 8;
     q.bar.ngroups = std::min(grid, 8);
-    std::lock_guard<std::mutex> lock(g_persist_mu[c->device & 15]);
+    PersistGate &gate = g_persist_gate[c->device & 15];
+    gate.enter(grid, cus);
+    struct GateGuard { PersistGate &g; int n; ~GateGuard() { g.leave(n); } } gate_guard{gate, grid};     // held until the workgroups are gone
     HIP_TRY(hipMemsetAsync(c->np_bar, 0, 1024, c->stream));
     int fits = 0, rc = DSM_OK;
     KTimer tm(c, DSM_K_NMFT_B);

@@ -74,6 +74,9 @@ SIGNATURES = {
     "dsm_ctx_draw_gamma_eta": (_i, [_vp, C.c_uint32, _u64p, _u64p, _f64p, _f64p]),
     "dsm_ctx_loglik": (_i, [_vp, C.POINTER(_d), C.POINTER(_d)]),
     "dsm_ctx_gibbs_update": (_i, [_vp, _i]),
+    "dsm_ctx_gibbs_update_sharded": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "dsm_device_read": (_i, [_i, _vp, _vp, C.c_size_t]),
+    "dsm_device_write": (_i, [_i, _vp, _vp, C.c_size_t]),
     "dsm_batch_gibbs_update": (_i, [C.POINTER(_vp), _i, _i]),
     "dsm_batch_update_tau": (_i, [C.POINTER(_vp), _i, _i, C.POINTER(_vp), C.POINTER(_vp)]),
     "dsm_batch_nmft_factorize": (_i, [C.POINTER(_vp), _i, _i, _d, _i, C.POINTER(_i), _vp]),
@@ -112,6 +115,7 @@ SIGNATURES = {
     "dsm_kernel_name": (C.c_char_p, [_i]),
 }
 
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
 _lib = None
 
 
@@ -347,6 +351,27 @@ class Context:
     # ---- update loops
     def gibbs_update(self, n_iter):
         check(self.lib.dsm_ctx_gibbs_update(self._h, int(n_iter)))
+        self.n_trace = int(n_iter)
+
+    def gibbs_update_sharded(self, n_iter, v_offset, v_total, exchange):
+        """n_iter iterations of ONE chain sharded by positions (include/desman_hip.h: dsm_ctx_gibbs_update_sharded): this context
+        holds positions v_offset .. v_offset + V of v_total.  ``exchange(tab_ptr, n_tab, vec_ptr, n_vec)`` is the caller's
+        all-reduce (sum) of n_tab uint32 at device address tab_ptr (0 words: skip) and n_vec float64 at vec_ptr, in place; an
+        exception raised inside it aborts the call and is re-raised here."""
+        err = []
+
+        def cb(user, tab, n_tab, vec, n_vec):
+            try:
+                exchange(tab or 0, int(n_tab), vec, int(n_vec))
+                return 0
+            except BaseException as e:                       # noqa: BLE001 -- must not propagate through the C frame
+                err.append(e)
+                return 1
+        fn = EXCHANGE_FN(cb)
+        rc = self.lib.dsm_ctx_gibbs_update_sharded(self._h, int(n_iter), int(v_offset), int(v_total), C.cast(fn, _vp), None)
+        if err:
+            raise err[0]
+        check(rc)
         self.n_trace = int(n_iter)
 
     @staticmethod

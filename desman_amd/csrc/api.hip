@@ -211,7 +211,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
     dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->sweep_stats); dev_free(&c->step_cnt); dev_free(&c->screen_ctl); dev_free(&c->prior); dev_free(&c->prior_all); dev_free(&c->scalars); dev_free(&c->star);
-    dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->np_part); if (c->np_bar) { (void)hipFree(c->np_bar); c->np_bar = nullptr; } dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); dev_free(&c->ngam_raw);
+    dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->shard_vec); dev_free(&c->np_part); if (c->np_bar) { (void)hipFree(c->np_bar); c->np_bar = nullptr; } dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); dev_free(&c->ngam_raw);
     dev_free(&c->npart); dev_free(&c->nstat);
     for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ev_u_ready[i]); (void)hipEventDestroy(c->ev_u_free[i]); }
     if (c->stream_rng != c->stream) (void)hipStreamDestroy(c->stream_rng);
@@ -768,6 +768,87 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
         TRY(k_finalize(c, nb_prev, n_iter - 1, 0, P[(n_iter - 1) & 1], c->gamma_trace + (size_t)(n_iter - 1) * sg,
                        c->eta_trace + (size_t)(n_iter - 1) * 16));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
+// ONE chain sharded over several GPUs by positions (last row: for chains < GPUs).  This context holds positions
+// v_offset .. v_offset + V of a table of v_total; gamma / eta are replicated.  Per iteration the shards exchange, through
+// `exchange` (the caller's all-reduce: RCCL via torch.distributed in desman_amd/vshard.py), the subset table of the mu/E pass
+// (uint32 [rep][2^G][S], summed: stage 2 and the gamma / eta draws then run replicated and bit-identical on every shard)
+// and an 18-double vector {log-likelihood and changed pairs of the previous sweep, Esum}.  Counter-based streams are keyed by
+// GLOBAL cell / position indices, so the chain does not depend on how it is sharded: every shard's tau equals the slice of the
+// unsharded chain's, gamma / eta / traces equal it bit for bit (ll, lp to rounding: sums of shard sums).  Requires the
+// aggregated mu/E pass and counter-based tau uniforms (dsm_ctx_set_tau_rng(DSM_RNG_PHILOX): the MT19937 stream is serial).
+// exchange(user, tab, n_tab, vec, n_vec) is called with this context's stream drained; it must return (0 = ok) only after
+// the reduced values are in place.  n_tab = 0: only the vector is exchanged.
+extern "C" int dsm_ctx_gibbs_update_sharded(dsm_ctx *c, int n_iter, int v_offset, int v_total, dsm_exchange_fn exchange, void *user)
+{
+    TRY(need(c, true, true));
+    if (n_iter < 0 || !exchange || v_offset < 0 || v_total < v_offset + c->V) { dsm_set_error("gibbs_update_sharded: bad arguments"); return DSM_ERR_ARG; }
+    if (c->tau_rng != DSM_RNG_PHILOX) { dsm_set_error("gibbs_update_sharded: needs counter-based tau uniforms (DSM_RNG_PHILOX)"); return DSM_ERR_STATE; }
+    BIND(c);
+    const int keep_force = c->force_stats_spec;
+    if (c->force_stats_spec < 2) c->force_stats_spec = DSM_STATS_AGG;          // the aggregated pass whatever the shard's size
+    struct Guard { dsm_ctx *c; int f; ~Guard() { c->shard_on = false; c->force_stats_spec = f; } } guard{c, keep_force};
+    if (stats_spec(c) < 2) { dsm_set_error("gibbs_update_sharded: the aggregated mu/E pass does not apply to this shape (G <= 16)"); return DSM_ERR_UNSUPPORTED; }
+    if (!c->shard_vec) TRY(dev_alloc(&c->shard_vec, (size_t)18));
+    c->shard_on = true; c->shard_voff = v_offset; c->shard_vtot = v_total;
+    TRY(alloc_traces(c, n_iter));
+    const size_t sg = (size_t)c->S * c->G;
+    HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
+    HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
+    auto swap_vec = [&](uint32_t *tab, size_t n_tab) -> int {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (exchange(user, tab, n_tab, c->shard_vec, (size_t)18) != 0) { dsm_set_error("gibbs_update_sharded: the exchange callback failed"); return DSM_ERR_STATE; }
+        return DSM_OK;
+    };
+    // entry state: ll, lp of the WHOLE table, storeStarState(0)
+    {
+        int nb = 0;
+        TRY(k_prior(c, c->gamma, c->eta, c->prior));
+        TRY(k_tau_sweep(c, 2, c->gamma, c->eta, c->eta, c->tau_trace, nullptr, 0, &nb, nullptr));
+        TRY(k_shard_pack(c, nb));
+        TRY(swap_vec(nullptr, 0));
+        TRY(k_finalize(c, nb, -1, 1, c->prior, c->gamma, c->eta));
+        HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
+    }
+    double *const P[2] = {c->prior, c->prior + (DSM_MAX_S + 4)};
+    int nb_prev = 0;
+    for (int it = 0; it < n_iter; ++it) {
+        const uint32_t ic = c->iter_ctr++;
+        const bool fuse_s2 = c->G < 10;
+        TRY(k_stats_stage1(c, ic));                                   // this shard's cells -> its subset table and Esum
+        TRY(k_shard_pack(c, nb_prev));                                // + ll / nchange of the previous sweep
+        TRY(swap_vec(c->ntab, c->ntab_len));
+        TRY(k_shard_unpack(c));
+        if (!fuse_s2) TRY(k_stats_stage2(c, ic));
+        TRY(k_dirichlet(c, ic, c->gamma, c->gamma_trace + (size_t)it * sg, c->eta_new, c->eta_trace + (size_t)it * 16,
+                        P[it & 1], it - 1, nb_prev, P[(it - 1) & 1], fuse_s2 ? 1 : 0));
+        TRY(k_tau_sweep(c, 3, c->gamma, c->eta, c->eta_new, c->tau_trace + (size_t)(it + 1) * c->V, nullptr, ic, &nb_prev, nullptr));
+        std::swap(c->eta, c->eta_new);
+    }
+    if (n_iter > 0) {
+        TRY(k_shard_pack(c, nb_prev));
+        TRY(swap_vec(nullptr, 0));
+        TRY(k_finalize(c, nb_prev, n_iter - 1, 0, P[(n_iter - 1) & 1], c->gamma_trace + (size_t)(n_iter - 1) * sg,
+                       c->eta_trace + (size_t)(n_iter - 1) * 16));
+        HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+
+// raw device <-> host copies of the exchange buffers (for callers that reduce on the host, e.g. the two-shards-on-one-GPU test)
+extern "C" int dsm_device_read(int device, const void *dev, void *host, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+    return DSM_OK;
+}
+extern "C" int dsm_device_write(int device, void *dev, const void *host, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
     return DSM_OK;
 }
 

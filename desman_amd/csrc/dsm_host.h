@@ -124,6 +124,10 @@ struct dsm_ctx {
     double *star = nullptr;         // [2]
     double *gamma_star = nullptr;   // [S][G]
     double *eta_star = nullptr;     // [16]
+    // a chain sharded over GPUs by positions (dsm_ctx_gibbs_update_sharded): this context holds positions shard_voff .. + V of shard_vtot
+    bool shard_on = false;
+    int shard_voff = 0, shard_vtot = 0;
+    double *shard_vec = nullptr;    // [18] {ll, nchange, Esum[16]} of the per-iteration exchange
     // NMFT
     double *F = nullptr;            // [V][4][S]
     double *ntau = nullptr;         // [V][4][G]
@@ -183,6 +187,8 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
                 const double *eta_ll, uint64_t *trace_slot, double *d_logp, uint32_t iter, int *nblocks,
                 const uint32_t *u_raw, int slot = 0, const TauFinalRider *rider = nullptr);
 int tau_launch_info(dsm_ctx *c, int *launched, int *resident);
+int k_shard_pack(dsm_ctx *c, int nblocks);
+int k_shard_unpack(dsm_ctx *c);
 int k_finalize(dsm_ctx *c, int nblocks, int it, int star_mode, const double *prior, const double *gamma_src,
                const double *eta_src, int slot = 0);
 

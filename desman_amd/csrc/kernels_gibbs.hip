@@ -402,6 +402,7 @@ struct FinalParams {
     const double *eta_src; double *eta_star;
     int star_mode;                // 0 = keep the better lp, 1 = force (entry state), 2 = never
     double *scalars;              // [0]=ll [1]=lp of this evaluation
+    const double *ll_given;       // sharded chain: {ll, nchange} summed over the shards (api.hip: dsm_ctx_gibbs_update_sharded), else null
     const uint32_t *step_cnt;     // [nblocks][2] wavefront-steps of the finalized launch: run / left to the fp64 code (~0: not screened)
     unsigned long long *sweep_stats;   // [2] running totals of the two
     uint32_t *screen_ctl;         // [0] sweeps still to run without the screening pass
@@ -419,11 +420,11 @@ __device__ void finalize_body(const FinalParams &p, double *red, double *redp, i
         __syncthreads();
     }
     if (tid == 0) {
-        const double ll = p.ll_const + red[0];
+        const double ll = p.ll_given ? p.ll_given[0] : p.ll_const + red[0];
         const double lp = ll + redp[0] + p.tau_prior;
         p.scalars[0] = ll; p.scalars[1] = lp;
-        const int nch = *p.nchange;
-        *p.nchange = 0;
+        const int nch = p.ll_given ? (int)p.ll_given[1] : *p.nchange;
+        if (!p.ll_given) *p.nchange = 0;
         if (p.it >= 0) { p.ll_trace[p.it] = ll; p.lp_trace[p.it] = lp; p.nchange_trace[p.it] = nch; }
         int f = 0;
         if (p.star_mode == 1 || (p.star_mode == 0 && lp > p.star[0])) { p.star[0] = lp; p.star[1] = (double)(p.it + 1); f = 1; }
@@ -626,6 +627,7 @@ struct TauParams {
     const uint32_t *screen_ctl;        // [0] != 0: the screening pass is suspended (finalize_body)
     int screen;                        // fp32 screening pass allowed (DESMAN_HIP_TAU_NO_SCREEN switches it off for A/B runs)
     int V, S, G;
+    int v_off;                // first position of this shard in the whole table (counter-based uniforms are keyed by global indices)
     uint32_t k0, k1, iter;
     int do_fin;               // the last workgroup of the launch finalizes the PREVIOUS sweep (updateTau: no launch between
     FinalParams fin;          // two sweeps could carry it); it reads the other parity of ll_partial / nchange
@@ -713,7 +715,8 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                     uw = p.u_raw[ui];
                 } else {
                     uint32_t r[4];
-                    philox4x32_10((uint32_t)ui, (uint32_t)(ui >> 32), p.iter, DSM_STREAM_TAUU, p.k0, p.k1, r);
+                    const size_t ug = ui + (size_t)p.v_off * G;
+                    philox4x32_10((uint32_t)ug, (uint32_t)(ug >> 32), p.iter, DSM_STREAM_TAUU, p.k0, p.k1, r);
                     uw = r[0];
                 }
                 int tn = 0;
@@ -1007,7 +1010,8 @@ static FinalParams make_final(dsm_ctx *c, int nblocks, int it, int star_mode, co
     FinalParams p;
     p.ll_partial = c->ll_partial + (size_t)slot * DSM_MAX_GRID; p.nblocks = nblocks;
     p.ll_const = c->ll_const;
-    p.tau_prior = (double)c->V * (double)c->G * log(1.0 / 4.0);     // HaploSNP_Sampler.py:457
+    p.tau_prior = (double)(c->shard_on ? c->shard_vtot : c->V) * (double)c->G * log(1.0 / 4.0);     // HaploSNP_Sampler.py:457
+    p.ll_given = c->shard_on ? c->shard_vec : nullptr;
     p.prior = prior; p.S = c->S; p.nchange = c->nchange + slot; p.it = it;
     p.ll_trace = c->ll_trace; p.lp_trace = c->lp_trace; p.nchange_trace = c->nchange_trace;
     p.star = c->star; p.gamma_src = gamma_src; p.gamma_star = c->gamma_star; p.SG = c->S * c->G;
@@ -1172,7 +1176,7 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
         p.do_fin = 1;
         p.fin = make_final(c, rider->nblocks, rider->it, 0, rider->prior, rider->gamma_src, rider->eta_src, slot ^ 1);
     }
-    p.V = V; p.S = S; p.G = G;
+    p.V = V; p.S = S; p.G = G; p.v_off = c->shard_on ? c->shard_voff : 0;
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
     const size_t sh = tau_lds_bytes(G, LPV, NSL);
     if (sh > 160 * 1024) { dsm_set_error("gamma tile (%zu B) exceeds LDS", sh); return DSM_ERR_UNSUPPORTED; }
@@ -1203,6 +1207,43 @@ int tau_launch_info(dsm_ctx *c, int *launched, int *resident)
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     *launched = grid;
     *resident = per_cu * cus;
+    return DSM_OK;
+}
+
+// ---- a chain sharded by positions: what a shard contributes to the per-iteration exchange besides its subset table.
+// vec [18]: [0] log-likelihood of this shard's positions (its data constant + the launch's partials, reduced in the order
+// finalize_body uses), [1] changed (v, g) pairs, [2..17] Esum [observed][true] -- counts below 2^53, exact as doubles.
+__global__ __launch_bounds__(256) void shard_pack_kernel(const double *__restrict__ ll_partial, int nblocks, double ll_const,
+                                                         int *__restrict__ nchange, const unsigned long long *__restrict__ esum,
+                                                         double *__restrict__ vec)
+{
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double a = 0.0;
+    for (int i = tid; i < nblocks; i += 256) a += ll_partial[i];
+    red[tid] = a;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) { vec[0] = ll_const + red[0]; vec[1] = (double)*nchange; *nchange = 0; }
+    if (tid < 16) vec[2 + tid] = (double)esum[tid];
+}
+__global__ void shard_unpack_kernel(const double *__restrict__ vec, unsigned long long *__restrict__ esum)
+{
+    if (threadIdx.x < 16) esum[threadIdx.x] = (unsigned long long)vec[2 + threadIdx.x];
+}
+int k_shard_pack(dsm_ctx *c, int nblocks)
+{
+    hipLaunchKernelGGL(shard_pack_kernel, dim3(1), dim3(256), 0, c->stream, c->ll_partial, nblocks, c->ll_const, c->nchange, c->esum, c->shard_vec);
+    HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}
+int k_shard_unpack(dsm_ctx *c)
+{
+    hipLaunchKernelGGL(shard_unpack_kernel, dim3(1), dim3(64), 0, c->stream, c->shard_vec, c->esum);
+    HIP_TRY(hipGetLastError());
     return DSM_OK;
 }
 

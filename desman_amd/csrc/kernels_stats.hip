@@ -32,6 +32,8 @@ struct StatsAggParams {
     const uint64_t *tau;
     const double *gamma, *eta;
     int V, S, G;
+    int v_off, V_tot;               // a chain sharded over GPUs by positions: this context holds positions v_off .. v_off + V of V_tot; the
+                                    // counter-based streams are keyed by GLOBAL cell indices, so the draws do not depend on the sharding
     uint32_t k0, k1, iter;
     uint32_t *ntab;                 // [rep][2^G][S]; workgroup b adds to copy b mod rep
     int rep;
@@ -149,7 +151,7 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
             }
         }
         const double Gam[4] = {G0, G1, G2, G3};
-        const uint32_t cell = (uint32_t)s * (uint32_t)V + (uint32_t)v;
+        const uint32_t cell = (uint32_t)s * (uint32_t)p.V_tot + (uint32_t)(p.v_off + v);
         uint32_t cbase[4];
         if (p.dbg & 8) { cbase[0] = cell; cbase[1] = p.iter; cbase[2] = p.k0; cbase[3] = p.k1; }
         else philox4x32_10(cell, 0u, p.iter, DSM_STREAM_STA1, p.k0, p.k1, cbase);         // one Philox-10 per cell
@@ -274,7 +276,7 @@ __device__ __forceinline__ void stats_big_body(const StatsAggParams &p)
         const unsigned long long item = list[i];
         const uint32_t cell = (uint32_t)(item >> 2);
         const int b = (int)(item & 3ull);
-        const int s = (int)(cell / (uint32_t)V), v = (int)(cell - (uint32_t)s * (uint32_t)V);
+        const int s = (int)(cell / (uint32_t)p.V_tot), v = (int)(cell - (uint32_t)s * (uint32_t)p.V_tot) - p.v_off;
         const uint64_t t = p.tau[v];
         const int xb = p.cnt_vs[((size_t)v * S + s) * 4 + b];
         uint32_t H[4] = {0, 0, 0, 0};
@@ -532,6 +534,7 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     StatsAggParams p;
     p.cnt_vs = c->cnt_vs; p.tau = c->tau; p.gamma = c->gamma; p.eta = c->eta;
     p.V = V; p.S = S; p.G = G; p.big_seg = seg;
+    p.v_off = c->shard_on ? c->shard_voff : 0; p.V_tot = c->shard_on ? c->shard_vtot : V;
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
     p.ntab = c->ntab; p.rep = c->ntab_rep; p.esum = c->esum; p.log_tab = c->log_tab;
     p.xcd = stats_ntab_xcd(c) ? 1 : 0;

@@ -303,6 +303,20 @@ int dsm_ctx_set_tau_screen(dsm_ctx *ctx, int on);
 /* workgroups one tau sweep of the resident shape launches, and how many of them the device holds at once (occupancy of the
    kernel x compute units): launched / resident = rounds of the launch, the partly filled last one being its tail */
 int dsm_ctx_tau_launch_info(dsm_ctx *ctx, int *launched, int *resident);
+/* ---- one chain over several GPUs, sharded by positions (only worthwhile when there are fewer chains than
+ * GPUs, V >~ 50k).  Each process / GPU holds a contiguous slice of the positions in its own context (dsm_ctx_set_counts with the
+ * slice, dsm_ctx_set_state with the slice of tau and the shared gamma / eta, the same dsm_ctx_seed ctr_seed everywhere,
+ * dsm_ctx_set_tau_rng(DSM_RNG_PHILOX)) and calls dsm_ctx_gibbs_update_sharded with its offset.  Once per iteration the library
+ * hands `exchange` its subset table (uint32, to be SUMMED element-wise over the shards, in place) and an 18-double vector
+ * (likewise); n_tab = 0 means the vector only.  The callback is the caller's all-reduce (RCCL: desman_amd/vshard.py); it is
+ * called with the context's stream drained and must return 0 once the sums are in place, non-zero to abort.  Afterwards
+ * gamma / eta / every trace are identical on all shards and equal the unsharded chain's (ll / lp to rounding), and each
+ * shard's tau is the unsharded chain's slice: the counter-based streams are keyed by global indices.                       */
+typedef int (*dsm_exchange_fn)(void *user, uint32_t *dev_tab, size_t n_tab, double *dev_vec, size_t n_vec);
+int dsm_ctx_gibbs_update_sharded(dsm_ctx *ctx, int n_iter, int v_offset, int v_total, dsm_exchange_fn exchange, void *user);
+/* plain device <-> host copies of the exchange buffers (host-side reductions, tests) */
+int dsm_device_read(int device, const void *dev, void *host, size_t bytes);
+int dsm_device_write(int device, void *dev, const void *host, size_t bytes);
 int dsm_ctx_set_timing(dsm_ctx *ctx, int on);
 int dsm_ctx_get_timing(dsm_ctx *ctx, double *ms_total /*[DSM_K_COUNT]*/,
                        int64_t *launches /*[DSM_K_COUNT]*/);

@@ -198,3 +198,14 @@ def test_cli_rejects_assign_file_before_any_work(tmp_path):
         cli.main([str(tmp_path / "missing.freq"), "-g", "3", "-o", str(out), "-a", str(tmp_path / "x.csv")])
     assert "assign_file" in str(e.value)
     assert not out.exists()
+
+
+def test_vshard_bounds_cover_the_table_once():
+    from desman_amd import vshard
+    for v_total, world in ((10, 3), (50000, 8), (7, 8), (1, 1), (12289, 4)):
+        b = vshard.shard_bounds(v_total, world)
+        assert b[0] == 0 and b[-1] == v_total and len(b) == world + 1 and all(x <= y for x, y in zip(b, b[1:]))
+        sizes = [y - x for x, y in zip(b, b[1:])]
+        assert max(sizes) - min(sizes) <= 1
+    v = vshard._DevView(4096, 18, "<f8").__cuda_array_interface__
+    assert v["shape"] == (18,) and v["data"] == (4096, False) and v["version"] == 2

@@ -86,6 +86,31 @@ class HaploSNP_Sampler:
                             np.ascontiguousarray(self.eta, dtype=np.float64))
         self.G = self._ctx.G
 
+    # ---- checkpoint / resume (optional; the reference's hook, Output_Results.output_Pickled_haploSNP, is dead code)
+    def save_checkpoint(self, path):
+        """the chain between two update() calls: state, both stream positions, the key of the counter-based streams.  A sampler
+        built on the same table that loads it continues bit for bit (tests/test_gpu_host.py)."""
+        self._bind_rng()                                      # keys the counter streams if no update() has run yet
+        self._release_rng()
+        ck = self._ctx.checkpoint()
+        mt = self.mt_state if self.mt_state is not None else _sampletau.getRNGState()
+        np.savez(path, tau=np.asarray(self.tau, dtype=np.int64), gamma=self.gamma, eta=self.eta, mt_state=np.asarray(mt, dtype=np.uint32),
+                 ctr_seed=ck["ctr_seed"], iter_ctr=ck["iter_ctr"], G=self.G, own_stream=self.mt_state is not None)
+
+    def load_checkpoint(self, path):
+        z = np.load(path)
+        if int(z["G"]) != self.G or z["tau"].shape != (self.V, self.G, 4) or z["gamma"].shape != (self.S, self.G):
+            raise ValueError("checkpoint of another shape: tau %s, gamma %s" % (z["tau"].shape, z["gamma"].shape))
+        self.tau, self.gamma, self.eta = z["tau"].copy(), z["gamma"].copy(), z["eta"].copy()
+        self.updateTauIndices()
+        if bool(z["own_stream"]):
+            self.mt_state = z["mt_state"].copy()
+        else:
+            _sampletau.setRNGState(z["mt_state"])             # the module's stream, as in the run that saved it
+        self._ctx.restore(dict(tau=self.tau, gamma=self.gamma, eta=self.eta, mt_state=z["mt_state"], ctr_seed=z["ctr_seed"],
+                               iter_ctr=z["iter_ctr"]))
+        self._keyed = True                                    # the counter streams keep their key and position
+
     # ---- the Gibbs loop
     def update(self):
         """max_iter Gibbs iterations (HaploSNP_Sampler.py:334-365), on the device."""

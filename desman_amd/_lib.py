@@ -74,6 +74,8 @@ SIGNATURES = {
     "dsm_ctx_draw_gamma_eta": (_i, [_vp, C.c_uint32, _u64p, _u64p, _f64p, _f64p]),
     "dsm_ctx_loglik": (_i, [_vp, C.POINTER(_d), C.POINTER(_d)]),
     "dsm_ctx_gibbs_update": (_i, [_vp, _i]),
+    "dsm_ctx_get_counters": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "dsm_ctx_set_counters": (_i, [_vp, C.c_uint64, C.c_uint32]),
     "dsm_ctx_gibbs_update_sharded": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "dsm_device_read": (_i, [_i, _vp, _vp, C.c_size_t]),
     "dsm_device_write": (_i, [_i, _vp, _vp, C.c_size_t]),
@@ -256,6 +258,28 @@ class Context:
         st = np.empty(625, dtype=np.uint32)
         check(self.lib.dsm_ctx_get_mt_state(self._h, st))
         return st
+
+    # ---- checkpoint / resume (the reference's own hook is dead code)
+    def checkpoint(self):
+        """everything that places the chain: state, MT19937 stream, counter-stream key and iteration counter (a dict of arrays:
+        np.savez(path, **ctx.checkpoint()) writes it).  Counts, priors and the tau RNG mode are the caller's to keep."""
+        tau, gamma, eta = self.get_state()
+        key, it = C.c_uint64(0), C.c_uint32(0)
+        check(self.lib.dsm_ctx_get_counters(self._h, C.byref(key), C.byref(it)))
+        try:
+            mt = self.get_mt_state()
+        except DesmanHipError:                                   # never seeded: counter-based runs
+            mt = np.zeros(0, dtype=np.uint32)
+        return dict(tau=tau, gamma=gamma, eta=eta, mt_state=mt, ctr_seed=np.uint64(key.value), iter_ctr=np.uint32(it.value))
+
+    def restore(self, ck):
+        """put a chain saved by checkpoint() into this context (counts set already): it continues bit for bit"""
+        self.set_state(np.ascontiguousarray(ck["tau"], dtype=np.int64), np.ascontiguousarray(ck["gamma"], dtype=np.float64),
+                       np.ascontiguousarray(ck["eta"], dtype=np.float64))
+        mt = np.asarray(ck["mt_state"], dtype=np.uint32)
+        if mt.size == 625:
+            self.set_mt_state(np.ascontiguousarray(mt))
+        check(self.lib.dsm_ctx_set_counters(self._h, int(ck["ctr_seed"]), int(ck["iter_ctr"])))
 
     def set_mt_state(self, st):
         check(self.lib.dsm_ctx_set_mt_state(self._h, np.ascontiguousarray(st, dtype=np.uint32)))

@@ -462,6 +462,22 @@ extern "C" int dsm_ctx_seed(dsm_ctx *c, unsigned long mt_seed, uint64_t ctr_seed
     return seed_mt(c, mt_seed);
 }
 
+// the two words besides (tau, gamma, eta, MT19937 state) that place a chain in its counter-based streams: the stream key and the
+// number of iterations drawn so far.  With them a chain restored into a fresh context continues bit for bit (checkpoint / resume:
+// SURVEY sec. 5; the reference's own hook, Output_Results.output_Pickled_haploSNP, is dead code).
+extern "C" int dsm_ctx_get_counters(dsm_ctx *c, uint64_t *ctr_seed, uint32_t *iter_ctr)
+{
+    if (!c || !ctr_seed || !iter_ctr) { dsm_set_error("get_counters: null argument"); return DSM_ERR_ARG; }
+    *ctr_seed = c->ctr_seed; *iter_ctr = c->iter_ctr;
+    return DSM_OK;
+}
+extern "C" int dsm_ctx_set_counters(dsm_ctx *c, uint64_t ctr_seed, uint32_t iter_ctr)
+{
+    if (!c) { dsm_set_error("set_counters: null context"); return DSM_ERR_ARG; }
+    c->ctr_seed = ctr_seed; c->iter_ctr = iter_ctr;
+    return DSM_OK;
+}
+
 extern "C" int dsm_mt_seed_state(unsigned long seed, uint32_t *state625)
 {
     if (!state625) return DSM_ERR_ARG;

@@ -312,6 +312,11 @@ int dsm_ctx_tau_launch_info(dsm_ctx *ctx, int *launched, int *resident);
  * called with the context's stream drained and must return 0 once the sums are in place, non-zero to abort.  Afterwards
  * gamma / eta / every trace are identical on all shards and equal the unsharded chain's (ll / lp to rounding), and each
  * shard's tau is the unsharded chain's slice: the counter-based streams are keyed by global indices.                       */
+/* checkpoint / resume: besides (tau, gamma, eta) and the MT19937 state (dsm_ctx_get_state / dsm_ctx_get_mt_state)
+ * a chain's position in its counter-based streams is the stream key and the number of iterations drawn so far.  A fresh context
+ * given the same counts, state, MT19937 state, priors, tau RNG and these two words continues the chain bit for bit.          */
+int dsm_ctx_get_counters(dsm_ctx *ctx, uint64_t *ctr_seed, uint32_t *iter_ctr);
+int dsm_ctx_set_counters(dsm_ctx *ctx, uint64_t ctr_seed, uint32_t iter_ctr);
 typedef int (*dsm_exchange_fn)(void *user, uint32_t *dev_tab, size_t n_tab, double *dev_vec, size_t n_vec);
 int dsm_ctx_gibbs_update_sharded(dsm_ctx *ctx, int n_iter, int v_offset, int v_total, dsm_exchange_fn exchange, void *user);
 /* plain device <-> host copies of the exchange buffers (host-side reductions, tests) */

@@ -335,3 +335,31 @@ def test_main_replicates_equals_main_also_where_the_batched_nmf_start_falls_back
             a = open(str(tmp_path / ("one%d" % k) / f)).read()
             b = open(str(tmp_path / ("rep%d" % k) / f)).read()
             assert a == b, (G, k, f)
+
+
+def test_checkpoint_resume_continues_the_chain_bit_for_bit(tmp_path):
+    """a chain saved between two update() calls and loaded into a NEW sampler on a new device context
+    gives the second update() the uninterrupted chain gives -- haplotypes, traces, MAP record, both stream positions."""
+    V, S, G = 300, 12, 4
+    counts, _, _ = synth_counts(V, S, G, seed=77)
+
+    def fresh(seed):
+        sampletau.initRNG(); sampletau.setRNG(seed)
+        return HaploSNP_Sampler(counts, G, np.random.RandomState(seed), max_iter=25)
+    a = fresh(9)
+    a.update()
+    a.save_checkpoint(str(tmp_path / "ck.npz"))
+    a.update()
+    end_a = sampletau.getRNGState().copy()
+    ck_ctx = a._ctx.checkpoint()
+    b = fresh(1234)                                           # another seed: everything must come from the checkpoint
+    b.load_checkpoint(str(tmp_path / "ck.npz"))
+    b.update()
+    for name in ("tau", "gamma", "eta", "tau_star", "gamma_star", "eta_star", "gamma_store", "eta_store", "ll_store", "lp_store", "nchange_store"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert a.lp_star == b.lp_star and np.array_equal(sampletau.getRNGState(), end_a)
+    ck_b = b._ctx.checkpoint()
+    assert int(ck_b["iter_ctr"]) == int(ck_ctx["iter_ctr"]) == 50 and int(ck_b["ctr_seed"]) == int(ck_ctx["ctr_seed"])
+    with pytest.raises(ValueError):
+        HaploSNP_Sampler(counts, G + 1, np.random.RandomState(1), max_iter=5).load_checkpoint(str(tmp_path / "ck.npz"))
+    sampletau.freeRNG()

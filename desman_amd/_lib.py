@@ -312,7 +312,7 @@ class Context:
         return out
 
     def set_tau_screen(self, on):
-        """A/B switch: False = every step of the tau sweep in fp64 (same results)"""
+        """A/B switch: False = every step of the tau sweep in fp64 (same draws except in ~1e-13 near-ties)"""
         check(self.lib.dsm_ctx_set_tau_screen(self._h, 1 if on else 0))
 
     def tau_launch_info(self):

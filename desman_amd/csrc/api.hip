@@ -1142,7 +1142,8 @@ extern "C" int dsm_ctx_set_nmft_fused(dsm_ctx *c, int mode)
     return DSM_OK;
 }
 
-// A/B switch for tests and measurements: with on = 0 every sweep step is evaluated in fp64 (the results are the same either way)
+// A/B switch for tests and measurements: with on = 0 every sweep step is evaluated in fp64 (the same draws except in near-ties:
+// the two modes evaluate the current base's log-probability along different FMA chains, a flip needs u within ~1e-13 of a CDF edge)
 extern "C" int dsm_ctx_set_tau_screen(dsm_ctx *c, int on)
 {
     if (!c) { dsm_set_error("set_tau_screen: null context"); return DSM_ERR_ARG; }

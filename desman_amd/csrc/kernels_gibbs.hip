@@ -438,7 +438,9 @@ __device__ void finalize_body(const FinalParams &p, double *red, double *redp, i
     // the screening pass of the tau sweep is worth its ~20 % only while it decides most steps: a sweep that
     // left more than half of its wavefront-steps to the fp64 code (very shallow data, a handful of samples, the first
     // iterations from a random state) switches it off for the next 15 sweeps, then it is tried again.  Which steps are screened
-    // never changes a result.
+    // changes no draw outside near-ties: a step after a screened one evaluates the current base's log-probability afresh where
+    // an all-fp64 sweep re-uses the previous step's value -- the same number up to its last bits (a flip needs the uniform
+    // within ~1e-13 of a CDF edge).  The rule itself is deterministic (counts of the previous launches only).
     if (p.step_cnt) {
         __syncthreads();
         unsigned long long steps = 0, exact = 0;
@@ -1017,7 +1019,9 @@ static FinalParams make_final(dsm_ctx *c, int nblocks, int it, int star_mode, co
     p.star = c->star; p.gamma_src = gamma_src; p.gamma_star = c->gamma_star; p.SG = c->S * c->G;
     p.eta_src = eta_src; p.eta_star = c->eta_star;
     p.star_mode = star_mode; p.scalars = c->scalars;
-    p.step_cnt = c->step_cnt + (size_t)slot * 2 * DSM_MAX_GRID; p.sweep_stats = c->sweep_stats; p.screen_ctl = c->screen_ctl;
+    // the suspension word of the finalized launch's parity: the launch this step may ride in (updateTau) reads the OTHER word,
+    // so no launch reads a word it writes and the screening decisions are the same on every run
+    p.step_cnt = c->step_cnt + (size_t)slot * 2 * DSM_MAX_GRID; p.sweep_stats = c->sweep_stats; p.screen_ctl = c->screen_ctl + slot;
     return p;
 }
 
@@ -1169,7 +1173,7 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
     p.logp = d_logp; p.ll_partial = c->ll_partial + (size_t)slot * DSM_MAX_GRID; p.nchange = c->nchange + slot; p.log_tab = c->log_tab;
     static const bool no_screen = getenv("DESMAN_HIP_TAU_NO_SCREEN") != nullptr;
     p.screen = (no_screen || !c->tau_screen) ? 0 : 1;
-    p.step_cnt = c->step_cnt + (size_t)slot * 2 * DSM_MAX_GRID; p.screen_ctl = c->screen_ctl;
+    p.step_cnt = c->step_cnt + (size_t)slot * 2 * DSM_MAX_GRID; p.screen_ctl = c->screen_ctl + slot;
     p.do_fin = 0;
     memset(&p.fin, 0, sizeof p.fin);
     if (rider) {

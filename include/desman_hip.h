@@ -298,7 +298,9 @@ int dsm_ctx_set_nmft_fused(dsm_ctx *ctx, int mode);
    three-launch loop).  Same stopping rule and update counts; factors equal to rounding (the workgroup partials are grouped
    differently). */
 int dsm_ctx_set_nmft_persist(dsm_ctx *ctx, int mode);
-/* on = 0: every step of the tau sweep in fp64 (A/B switch: the results do not depend on it) */
+/* on = 0: every step of the tau sweep in fp64 (A/B switch).  Same law, and the same draws except in near-ties: after a screened
+   step the current base's log-probability is evaluated afresh, an all-fp64 sweep re-uses the previous step's value (equal up to
+   the last bits; a different draw needs the uniform within ~1e-13 of a CDF edge -- none in the ~1e7 draws of the parity tests) */
 int dsm_ctx_set_tau_screen(dsm_ctx *ctx, int on);
 /* workgroups one tau sweep of the resident shape launches, and how many of them the device holds at once (occupancy of the
    kernel x compute units): launched / resident = rounds of the launch, the partly filled last one being its tail */

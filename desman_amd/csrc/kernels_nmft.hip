@@ -1521,7 +1521,8 @@ int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, i
     const int nwv = nblk <= cus ? 4 : NMFT_P_WAVES;
     const int grid = (nquad + nwv - 1) / nwv;
     const int nout = G * S + G + 1;
-    if (grid < 2) return DSM_OK;
+    if (grid < 2 || grid > cus) return DSM_OK;              // (neither form holds more than one workgroup per CU worth of table: no buffers
+                                                            //  are allocated for tables that cannot take this path)
     const int GP = 4 * kb, SPAD = 16 * nt;
     const size_t sh = (2 * DSM_LOG_TAB_N + (size_t)GP * SPAD + 2 * (size_t)nt * kb * 64 + GP + (size_t)nwv * 2 * 16 * GP +
                        (size_t)nwv * (GP + 2) * SPAD + ((nout + 1) & ~1) + 2 * (size_t)G * S + 2) * sizeof(double);

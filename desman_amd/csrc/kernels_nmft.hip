@@ -1130,7 +1130,7 @@ int k_nmft_mfma(dsm_ctx *c, int adjust, int do_update)
 // every workgroup polls (relaxed agent-scope loads + s_sleep).  All shared words are agent-scope atomics; payloads are 8-byte
 // write-through (sc1) stores drained by every storing wavefront before the arrival, and are read with sc1 loads, so no
 // release / acquire fence is needed (cdna_hip_programming.md, Guideline 16).  Polls are bounded: a workgroup that times out
-// raises an error word and leaves, the host reports it.  The launch requires every workgroup to be resident: the grid is
+// raises an error word and leaves; the host then restores the factors it saved before the launch and runs the three-launch loop.  The launch requires every workgroup to be resident: the grid is
 // checked against the occupancy query, and a process-wide gate (PersistGate) admits concurrent persistent launches on a device
 // only while together they ask for at most one workgroup per CU (more could starve each other of CUs); other kernels only delay them.
 //
@@ -1528,11 +1528,20 @@ int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, i
                        (size_t)nwv * (GP + 2) * SPAD + ((nout + 1) & ~1) + 2 * (size_t)G * S + 2) * sizeof(double);
     if (sh > 160 * 1024) return DSM_OK;
     // exchange buffers + barrier words (zeroed before every launch)
-    if (!c->np_part || c->np_cap < (size_t)nout * grid) {
+    // ... + a copy of the factors as they are now: should the launch not come to an end (a barrier timed out: its workgroups
+    // were not all resident, e.g. behind another process's long-running kernels) the factors are put back and the caller runs
+    // the three-launch loop instead
+    const size_t n_tau = (size_t)c->V * 4 * G, n_gam = (size_t)G * S;
+    const size_t need = (size_t)nout * grid + nout + 16 + n_tau + 2 * n_gam;
+    if (!c->np_part || c->np_cap < need) {
         if (c->np_part) { (void)hipFree(c->np_part); c->np_part = nullptr; }
-        HIP_TRY(hipMalloc((void **)&c->np_part, ((size_t)nout * grid + nout + 16) * sizeof(double)));
-        c->np_cap = (size_t)nout * grid;
+        HIP_TRY(hipMalloc((void **)&c->np_part, need * sizeof(double)));
+        c->np_cap = need;
     }
+    double *const bak = c->np_part + (size_t)nout * grid + nout + 16;
+    HIP_TRY(hipMemcpyAsync(bak, c->ntau, n_tau * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(bak + n_tau, c->ngam, n_gam * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(bak + n_tau + n_gam, c->ngam_raw, n_gam * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     if (!c->np_bar) HIP_TRY(hipMalloc((void **)&c->np_bar, 1024));
     NmftPersistParams q;
     q.F = c->F; q.tau = c->ntau; q.gam_raw = c->ngam_raw; q.gam = c->ngam;
@@ -1543,6 +1552,7 @@ int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, i
     q.stamps = getenv("DESMAN_HIP_NMFT_STAMPS") ? q.stat + nout : nullptr;       // 8 spare doubles behind the totals
     for (int g = 0; g < 8; ++g) q.bar.members[g] = (grid - g + 7) / 8;
     q.bar.ngroups = std::min(grid, 8);
+    if (getenv("DESMAN_HIP_NMFT_FORCE_TIMEOUT")) q.bar.ngroups += 1;          // test hook: the first barrier never completes
     PersistGate &gate = g_persist_gate[c->device & 15];
     gate.enter(grid, cus);
     struct GateGuard { PersistGate &g; int n; ~GateGuard() { g.leave(n); } } gate_guard{gate, grid};     // held until the workgroups are gone
@@ -1564,7 +1574,16 @@ int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, i
                 (st[1] - st[0]) / 100.0, (st[2] - st[1]) / 100.0, (st[3] - st[2]) / 100.0, (st[4] - st[3]) / 100.0, (st[5] - st[4]) / 100.0,
                 (st[6] - st[5]) / 100.0, (st[7] - st[6]) / 100.0, (st[8] - st[7]) / 100.0);
     }
-    if (err) { dsm_set_error("nmft_persist: a grid barrier timed out (workgroups of the persistent launch were not all resident)"); return DSM_ERR_HIP; }
+    if (err) {
+        static bool told = false;
+        if (!told) { fprintf(stderr, "desman_hip: the persistent NMF launch timed out at a grid barrier (its workgroups were not all resident); "
+                                     "falling back to the three-launch loop\n"); told = true; }
+        HIP_TRY(hipMemcpyAsync(c->ntau, bak, n_tau * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->ngam, bak + n_tau, n_gam * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->ngam_raw, bak + n_tau + n_gam, n_gam * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(NMFT_CTL(c), 0, 16 * sizeof(double), c->stream));
+        return DSM_OK;                                  // *used stays 0: the caller's loop takes over from the untouched start
+    }
     *used = 1;
     return DSM_OK;
 }

@@ -184,3 +184,37 @@ def test_full_size_batched_nmft_equals_one_by_one_and_oracle(V, S, G, K):
         np.testing.assert_allclose(singles[0][1], tr_ref, rtol=1e-9)
         np.testing.assert_allclose(singles[0][2][0], tc, rtol=1e-6, atol=1e-12)
         np.testing.assert_allclose(singles[0][2][1], gc, rtol=1e-6, atol=1e-12)
+
+
+def test_persistent_nmft_that_times_out_falls_back_to_the_three_launch_loop():
+    """a persistent launch whose workgroups are not all resident never passes its first grid barrier: the polls are bounded, the
+    factors saved before the launch are put back and the three-launch loop runs instead -- same result.  (Forced here by a barrier
+    that waits for one arrival group too many; in a child process: the switch is read from the environment.)"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys; sys.path.insert(0, %r)
+import numpy as np
+from desman_amd import _lib
+from desman_amd.synth import synth_counts
+from oracle import ref_numpy as rn
+counts, _, _ = synth_counts(900, 32, 4, seed=3)
+tau0, gam0 = rn.nmft_random_initialize(np.random.RandomState(4), 900, 32, 4)
+c = _lib.Context(0); c.set_counts(counts); c.nmft_set(tau0, gam0)
+n, tr = c.nmft_factorize(15, 1e-5)
+t, g = c.nmft_get()
+np.savez(sys.argv[1], n=n, tr=tr, t=t, g=g)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        outs = []
+        for env_extra in ({}, {"DESMAN_HIP_NMFT_FORCE_TIMEOUT": "1"}):
+            path = os.path.join(d, "o%d.npz" % len(outs))
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            if env_extra:
+                assert "falling back to the three-launch loop" in r.stderr
+            outs.append(np.load(path))
+        a, b = outs
+        assert int(a["n"]) == int(b["n"]) == 15 and np.array_equal(a["tr"], b["tr"]) and np.array_equal(a["t"], b["t"]) and np.array_equal(a["g"], b["g"])

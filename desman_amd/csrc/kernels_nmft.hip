@@ -14,6 +14,7 @@
 //             per-(v,g) renormalisation over the four bases (:170-181), _adjustment (:88-91)
 #include <stdlib.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <mutex>
 
@@ -883,7 +884,9 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
     double *t1 = bgam + NT * KB * 64;                                           // [GP] rowsum(gamma_raw)
     double *told = t1 + GP + wv * (2 * 16 * GP);                                // per wavefront [16][GP], row i = 4 r + vv
     double *tnew = told + 16 * GP;                                              // per wavefront [16][GP]
-    double *red = t1 + GP + 4 * (2 * 16 * GP);                                  // [4][GP + 2][SPAD] end-of-kernel reduction
+    double *red = reinterpret_cast<double *>(smem_m);                           // [4][GP + 2][SPAD] end-of-kernel reduction: takes the place
+                                                                                // of everything above once the quads are done (at S = 96, G = 12 its
+                                                                                // 43 KB on top of the rest made 87 KB = ONE workgroup per CU)
     ltab[tid] = reinterpret_cast<const double2 *>(log_tab)[tid];
     for (int i = tid; i < GP * SPAD; i += 256) {
         const int g = i / SPAD, s = i % SPAD;
@@ -1067,8 +1070,20 @@ bool nmft_use_mfma(const dsm_ctx *c) { int a, b; return mfma_shape(c, &a, &b); }
 int nmft_mfma_grid(const dsm_ctx *c)
 {
     int g = ((c->V + 3) / 4 + 3) / 4;             // quads / 4 wavefronts
-    if (g > 768) g = 768;
+    // at most the workgroups that are resident at once (the quad loop is grid-strided): three per CU by registers up to four
+    // sample tiles, two from five tiles on
+    int nt, kb, cus = 256;
+    (void)mfma_shape(c, &nt, &kb);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) cus = 256;
+    const int cap = (nt <= 4 ? 3 : 2) * cus;
+    if (g > cap) g = cap;
     return g < 1 ? 1 : g;
+}
+static size_t mfma_lds_bytes(int NT, int KB)
+{
+    const size_t GP = 4 * KB, SPAD = 16 * NT;
+    const size_t loop = 2 * DSM_LOG_TAB_N + GP * SPAD + 2 * (size_t)NT * KB * 64 + GP + 4 * 2 * 16 * GP, red = 4 * (GP + 2) * SPAD;
+    return std::max(loop, red) * sizeof(double);
 }
 template <int NT, int KB, bool KEEPF>
 __global__ __launch_bounds__(256, (NT <= 4 ? 3 : 2)) void nmft_mfma_kernel(NmftMfmaParams q) { nmft_mfma_body<NT, KB, KEEPF>(q); }
@@ -1082,12 +1097,11 @@ template <int NT, int KB>
 static void launch_mfma(dsm_ctx *c, int adjust, int do_update, int grid)
 {
     constexpr int GP = 4 * KB, SPAD = 16 * NT;
-    const size_t sh = (2 * DSM_LOG_TAB_N + (size_t)GP * SPAD + 2 * (size_t)NT * KB * 64 + GP + 4 * 2 * 16 * GP +
-                       4 * (size_t)(GP + 2) * SPAD) * sizeof(double);
+    const size_t sh = mfma_lds_bytes(NT, KB);
     const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart};
     LAUNCH_OR_COLLECT(NmftMfmaParams, q,
-                      hipLaunchKernelGGL((nmft_mfma_kernel<NT, KB, (NT <= 3)>), dim3(grid), dim3(256), sh, c->stream, q),
-                      hipLaunchKernelGGL((nmft_mfma_kernel_b<NT, KB, (NT <= 3)>), dim3(grid, K), dim3(256), sh, c->stream, acc));
+                      hipLaunchKernelGGL((nmft_mfma_kernel<NT, KB, (NT <= 3 || NT >= 5)>), dim3(grid), dim3(256), sh, c->stream, q),
+                      hipLaunchKernelGGL((nmft_mfma_kernel_b<NT, KB, (NT <= 3 || NT >= 5)>), dim3(grid, K), dim3(256), sh, c->stream, acc));
 }
 
 int k_nmft_mfma(dsm_ctx *c, int adjust, int do_update)

@@ -821,6 +821,30 @@ __device__ __forceinline__ double fdiv(double a, double b)
     const double q = a * r;
     return fma(fma(-b, q, a), r, q);
 }
+// Q2 = F (/) max(R2, eps) and the objective terms of one 16-sample tile (Init_NMFT.py:152-156, du.elop), element e = base.
+// F is a count + 1 over a depth + 4, never zero: elop's zero test can only fire on R.  Lanes without a cell (padded samples,
+// variants past the end) carry F = 1, R = 0: their quotient 1 / eps is finite, meets a zero row of tau in the contraction that
+// follows (variants) or lands in a column nobody reads (samples), and is kept out of the objective by `live`.  The selects for
+// R < eps are taken only by a wavefront that holds such an element (with the adjustment on, tau >= eps and the columns of gamma sum
+// to one: never but in padded lanes); the operations on live elements and their order are those of the plain form.
+__device__ __forceinline__ double4_t nm_tile_q2(const double4_t &ft, const double4_t &R, bool live, const double2 *__restrict__ ltab,
+                                                double &obj)
+{
+    double4_t q2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool tiny = R[e] < DSM_EPS;
+        const double pa = tiny ? DSM_EPS : R[e];
+        const double ratio = fdiv(ft[e], pa);
+        double qq = ratio;
+        // elop divides by R itself when 0 < R < eps (never with the adjustment on: tau >= eps and the gamma columns
+        // sum to one); a wave-uniform branch keeps that second division out of the common path
+        if (__builtin_amdgcn_ballot_w64(tiny && R[e] != 0.0) != 0ull) { if (tiny) qq = fdiv(ft[e], nzd(R[e])); }   // nzd: the lanes without a cell have R = 0
+        q2[e] = qq;
+        if (live) obj += ft[e] * dsm_log(ratio, ltab) - ft[e] + pa;
+    }
+    return q2;
+}
 #define DSM_DPP_ROW_SHL4 0x104
 #define DSM_DPP_ROW_SHR4 0x114
 
@@ -955,7 +979,7 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
                 for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_old[kb], braw[(t * KB + kb) * 64 + lane], R, 0, 0, 0);
                 const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qp[t][e] = live[t] ? fdiv(nzd(ft[e]), nzd(R[e])) : 0.0;
+                for (int e = 0; e < 4; ++e) qp[t][e] = fdiv(ft[e], nzd(R[e]));          // nm_tile_q2: F > 0; lanes without a cell stay finite
             }
 #pragma unroll
             for (int c = 0; c < KB; ++c) {
@@ -1001,18 +1025,7 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
             for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_new[kb], bgam[(t * KB + kb) * 64 + lane], R, 0, 0, 0);
             double4_t q2;
             const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool tiny = R[e] < DSM_EPS;
-                const double pa = tiny ? DSM_EPS : R[e];
-                const double ratio = fdiv(nzd(ft[e]), pa);
-                double qq = ratio;
-                // elop divides by R itself when 0 < R < eps (never with the adjustment on: tau >= eps and the gamma columns
-                // sum to one); a wave-uniform branch keeps that second division out of the common path
-                if (__builtin_amdgcn_ballot_w64(tiny && R[e] != 0.0) != 0ull) { if (tiny) qq = fdiv(nzd(ft[e]), nzd(R[e])); }
-                q2[e] = live[t] ? qq : 0.0;
-                if (live[t]) obj += ft[e] * dsm_log(ratio, ltab) - ft[e] + pa;
-            }
+            q2 = nm_tile_q2(ft, R, live[t], ltab, obj);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
         }
@@ -1096,7 +1109,6 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 3 : 2)) void nmft_mfma_kernel_b(Bat
 template <int NT, int KB>
 static void launch_mfma(dsm_ctx *c, int adjust, int do_update, int grid)
 {
-    constexpr int GP = 4 * KB, SPAD = 16 * NT;
     const size_t sh = mfma_lds_bytes(NT, KB);
     const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart};
     LAUNCH_OR_COLLECT(NmftMfmaParams, q,
@@ -1308,16 +1320,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
                 for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_new[kb], bgam[(t * KB + kb) * 64 + lane], R, 0, 0, 0);
                 double4_t q2;
                 const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool tiny = R[e] < DSM_EPS;
-                    const double pa = tiny ? DSM_EPS : R[e];
-                    const double ratio = fdiv(nzd(ft[e]), pa);
-                    double qq = ratio;
-                    if (__builtin_amdgcn_ballot_w64(tiny && R[e] != 0.0) != 0ull) { if (tiny) qq = fdiv(nzd(ft[e]), nzd(R[e])); }
-                    q2[e] = live[t] ? qq : 0.0;
-                    if (live[t]) obj += ft[e] * dsm_log(ratio, ltab) - ft[e] + pa;
-                }
+                q2 = nm_tile_q2(ft, R, live[t], ltab, obj);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
             }
@@ -1438,7 +1441,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
                 for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_old[kb], braw[(t * KB + kb) * 64 + lane], R, 0, 0, 0);
                 const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qp[t][e] = live[t] ? fdiv(nzd(ft[e]), nzd(R[e])) : 0.0;
+                for (int e = 0; e < 4; ++e) qp[t][e] = fdiv(ft[e], nzd(R[e]));          // nm_tile_q2: F > 0; lanes without a cell stay finite
             }
 #pragma unroll
             for (int c = 0; c < KB; ++c) {

@@ -801,11 +801,12 @@ int k_nmft_get_tau(dsm_ctx *c, uint64_t *d_packed)
 //   gamma numerators           num_g[g][s] += sum_rows tau_new[row][g] Q2[row][s]: contraction over ROWS, K-block = base e:
 //                              A[m][k] = tau_new[vv = k][e][g = m] (lane m + 16 k), B[k][j] = Q2[vv = k][e][16 t + j] = the L2
 //                              register itself.  The accumulators D[g][s] stay in registers for the whole kernel.
-// No operand ever needs a transposition through LDS.  Shapes: S <= 96 (NT <= 6 tiles), G <= 12 (KB <= 3 K-blocks); from
-// four tiles on the F tiles are not kept in registers between the halves (KEEPF = false: re-read from L2 -- at NT = 4 keeping
-// them costs 96 B/lane of scratch at 3 wavefronts per SIMD: 38 -> 35 us per update at V = 10k, 251 -> 211 us at 50k x 96 x 12);
-// five and six tiles run at 2 wavefronts per SIMD (190 VGPRs, no spills).  Other shapes run nmft_wave_kernel / the two-pass
-// kernels.
+// No operand ever needs a transposition through LDS.  Shapes: S <= 128 (NT <= 8 tiles), G <= 12 (KB <= 3 K-blocks).  Up to three
+// tiles the F tiles stay in registers between the halves (KEEPF); at four they are re-read from L2 (keeping them costs 96 B/lane
+// of scratch at 3 wavefronts per SIMD: 38 -> 35 us per update at V = 10k); five and six tiles run at 2 wavefronts per SIMD, where
+// 256 registers hold the F tiles again (236-254 VGPRs, no spills: 202 -> 184 us per update at 50k x 96 x 12, and 119 us once the
+// end-of-kernel reduction shared the loop's LDS -- see `red` below); seven and eight tiles re-read F (224-249 VGPRs).  Other
+// shapes run nmft_wave_kernel / the two-pass kernels.
 // ===========================================================================
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -1075,7 +1076,7 @@ static bool mfma_shape(const dsm_ctx *c, int *nt, int *kb)
     static const bool off = getenv("DESMAN_HIP_NMFT_NO_MFMA") != nullptr;      // A/B switch: the VALU one-pass kernel
     // measured against the VALU one-pass kernel: 1.0-1.3x at (NT, KB) = (4, 2), 1.96x at (6, 3) [V = 50k, S = 96, G = 12:
     // 211 vs 413 us per update]; at (8, 4) the 140 KB of LDS leave one workgroup per CU and the VALU kernel wins (449 vs 491 us)
-    return !off && *nt >= 1 && *nt <= 6 && *kb >= 1 && *kb <= 3;          // S <= 96, G <= 12
+    return !off && *nt >= 1 && *nt <= 8 && *kb >= 1 && *kb <= 3;          // S <= 128, G <= 12
 }
 
 bool nmft_use_mfma(const dsm_ctx *c) { int a, b; return mfma_shape(c, &a, &b); }
@@ -1112,8 +1113,8 @@ static void launch_mfma(dsm_ctx *c, int adjust, int do_update, int grid)
     const size_t sh = mfma_lds_bytes(NT, KB);
     const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart};
     LAUNCH_OR_COLLECT(NmftMfmaParams, q,
-                      hipLaunchKernelGGL((nmft_mfma_kernel<NT, KB, (NT <= 3 || NT >= 5)>), dim3(grid), dim3(256), sh, c->stream, q),
-                      hipLaunchKernelGGL((nmft_mfma_kernel_b<NT, KB, (NT <= 3 || NT >= 5)>), dim3(grid, K), dim3(256), sh, c->stream, acc));
+                      hipLaunchKernelGGL((nmft_mfma_kernel<NT, KB, (NT <= 3 || NT == 5 || NT == 6)>), dim3(grid), dim3(256), sh, c->stream, q),
+                      hipLaunchKernelGGL((nmft_mfma_kernel_b<NT, KB, (NT <= 3 || NT == 5 || NT == 6)>), dim3(grid, K), dim3(256), sh, c->stream, acc));
 }
 
 int k_nmft_mfma(dsm_ctx *c, int adjust, int do_update)
@@ -1125,6 +1126,7 @@ int k_nmft_mfma(dsm_ctx *c, int adjust, int do_update)
 #define MCASE(N, K) if (nt == N && kb == K) launch_mfma<N, K>(c, adjust, do_update, grid)
     MCASE(1, 1); MCASE(1, 2); MCASE(2, 1); MCASE(2, 2); MCASE(3, 1); MCASE(3, 2); MCASE(4, 1); MCASE(4, 2);
     MCASE(1, 3); MCASE(2, 3); MCASE(3, 3); MCASE(4, 3); MCASE(5, 1); MCASE(5, 2); MCASE(5, 3); MCASE(6, 1); MCASE(6, 2); MCASE(6, 3);
+    MCASE(7, 1); MCASE(7, 2); MCASE(7, 3); MCASE(8, 1); MCASE(8, 2); MCASE(8, 3);
 #undef MCASE
     HIP_TRY(hipGetLastError());
     c->npart_cols = grid;

@@ -271,7 +271,7 @@ __device__ __forceinline__ void stats_big_body(const StatsAggParams &p)
 #pragma unroll
     for (int i = 0; i < 16; ++i) eacc[i * 256 + tid] = 0u;
     __syncthreads();
-    const int V = p.V, S = p.S, G = p.G;
+    const int S = p.S, G = p.G;
     for (uint32_t i = bi * 256u + tid; i < nbig; i += nb * 256u) {
         const unsigned long long item = list[i];
         const uint32_t cell = (uint32_t)(item >> 2);

@@ -111,7 +111,7 @@ class Init_NMFT:
         objs = list(objs)
         if any(o.n_run != 1 for o in objs) or len({(o.max_iter, o.min_change) for o in objs}) != 1:
             raise ValueError("factorize_batch: n_run = 1 and equal max_iter / min_change expected")
-        # a batch the kernels do not take (S > 96, G > 12, more than 8 chains) must leave every chain's numpy stream where
+        # a batch the kernels do not take (S > 128, G > 16, more than 8 chains) must leave every chain's numpy stream where
         # it was: the caller falls back to factorize(), which draws the same initial factors again
         states = [o.randomState.get_state() for o in objs]
         try:

@@ -239,7 +239,7 @@ def main_replicates(argv_list, on_chain=None):
         rng = RandomState(opts.random_seed)
         nmft = Init_NMFT(flt.snps_filter, opts.genomes, rng, device=opts.device)
         runs.append(dict(opts=opts, report=report, table=table, flt=flt, subsample=subsample, rng=rng, nmft=nmft))
-    # the NMF starts: together where the batched kernels apply (one shape, S <= 128, G <= 12), else one by one
+    # the NMF starts: together where the batched kernels apply (one shape, S <= 128, G <= 16), else one by one
     nm = [r["nmft"] for r in runs]
     done = False
     if len(nm) > 1 and len({(o.V, o.S, o.G) for o in nm}) == 1:

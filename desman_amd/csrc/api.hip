@@ -1357,7 +1357,7 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
 
 // Init_NMFT.factorize / factorize_tau of K chains of one shape at once: every update is one launch of each of its three
 // kernels for all of them (chain = blockIdx.y).  The stop test is per chain, on the device; a chain that has stopped costs
-// nothing but its workgroups' first instruction.  Matrix-core path only (S <= 128, G <= 12).  n_done [K];
+// nothing but its workgroups' first instruction.  Matrix-core path only (S <= 128, G <= 16).  n_done [K];
 // div_traces [K][max_iter + 1] or null.
 extern "C" int dsm_batch_nmft_factorize(dsm_ctx *const *ctxs, int K, int max_iter, double min_change, int fix_gamma,
                                         int *n_done, double *div_traces)
@@ -1373,7 +1373,7 @@ extern "C" int dsm_batch_nmft_factorize(dsm_ctx *const *ctxs, int K, int max_ite
             return DSM_ERR_ARG;
         }
         for (int j = 0; j < k; ++j) if (ctxs[j] == ctxs[k]) { dsm_set_error("batch: chain %d listed twice", k); return DSM_ERR_ARG; }
-        if (!nmft_use_mfma(b)) { dsm_set_error("batch: the matrix-core NMFT kernel does not apply to this shape (S <= 128, G <= 12)"); return DSM_ERR_UNSUPPORTED; }
+        if (!nmft_use_mfma(b)) { dsm_set_error("batch: the matrix-core NMFT kernel does not apply to this shape (S <= 128, G <= 16)"); return DSM_ERR_UNSUPPORTED; }
     }
     dsm_ctx *const lead = ctxs[0];
     BIND(lead);

@@ -801,7 +801,7 @@ int k_nmft_get_tau(dsm_ctx *c, uint64_t *d_packed)
 //   gamma numerators           num_g[g][s] += sum_rows tau_new[row][g] Q2[row][s]: contraction over ROWS, K-block = base e:
 //                              A[m][k] = tau_new[vv = k][e][g = m] (lane m + 16 k), B[k][j] = Q2[vv = k][e][16 t + j] = the L2
 //                              register itself.  The accumulators D[g][s] stay in registers for the whole kernel.
-// No operand ever needs a transposition through LDS.  Shapes: S <= 128 (NT <= 8 tiles), G <= 12 (KB <= 3 K-blocks).  Up to three
+// No operand ever needs a transposition through LDS.  Shapes: S <= 128 (NT <= 8 tiles), G <= 16 (KB <= 4 K-blocks).  Up to three
 // tiles the F tiles stay in registers between the halves (KEEPF); at four they are re-read from L2 (keeping them costs 96 B/lane
 // of scratch at 3 wavefronts per SIMD: 38 -> 35 us per update at V = 10k); five and six tiles run at 2 wavefronts per SIMD, where
 // 256 registers hold the F tiles again (236-254 VGPRs, no spills: 202 -> 184 us per update at 50k x 96 x 12, and 119 us once the
@@ -1076,7 +1076,7 @@ static bool mfma_shape(const dsm_ctx *c, int *nt, int *kb)
     static const bool off = getenv("DESMAN_HIP_NMFT_NO_MFMA") != nullptr;      // A/B switch: the VALU one-pass kernel
     // measured against the VALU one-pass kernel: 1.0-1.3x at (NT, KB) = (4, 2), 1.96x at (6, 3) [V = 50k, S = 96, G = 12:
     // 211 vs 413 us per update]; at (8, 4) the 140 KB of LDS leave one workgroup per CU and the VALU kernel wins (449 vs 491 us)
-    return !off && *nt >= 1 && *nt <= 8 && *kb >= 1 && *kb <= 3;          // S <= 128, G <= 12
+    return !off && *nt >= 1 && *nt <= 8 && *kb >= 1 && *kb <= 4;          // S <= 128, G <= 16
 }
 
 bool nmft_use_mfma(const dsm_ctx *c) { int a, b; return mfma_shape(c, &a, &b); }
@@ -1127,6 +1127,7 @@ int k_nmft_mfma(dsm_ctx *c, int adjust, int do_update)
     MCASE(1, 1); MCASE(1, 2); MCASE(2, 1); MCASE(2, 2); MCASE(3, 1); MCASE(3, 2); MCASE(4, 1); MCASE(4, 2);
     MCASE(1, 3); MCASE(2, 3); MCASE(3, 3); MCASE(4, 3); MCASE(5, 1); MCASE(5, 2); MCASE(5, 3); MCASE(6, 1); MCASE(6, 2); MCASE(6, 3);
     MCASE(7, 1); MCASE(7, 2); MCASE(7, 3); MCASE(8, 1); MCASE(8, 2); MCASE(8, 3);
+    MCASE(1, 4); MCASE(2, 4); MCASE(3, 4); MCASE(4, 4); MCASE(5, 4); MCASE(6, 4); MCASE(7, 4); MCASE(8, 4);
 #undef MCASE
     HIP_TRY(hipGetLastError());
     c->npart_cols = grid;
@@ -1532,7 +1533,7 @@ int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, i
     *used = 0;
     static const bool off = getenv("DESMAN_HIP_NMFT_NO_PERSIST") != nullptr;
     int nt, kb;
-    if (off || c->nmft_persist == 0 || !mfma_shape(c, &nt, &kb) || nt > 4 || c->timing || g_batch.K) return DSM_OK;
+    if (off || c->nmft_persist == 0 || !mfma_shape(c, &nt, &kb) || nt > 4 || kb > 3 || c->timing || g_batch.K) return DSM_OK;
     int cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     const int G = c->nG, S = c->S, nquad = (c->V + 3) / 4, nblk = (nquad + 3) / 4;

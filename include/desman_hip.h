@@ -187,7 +187,7 @@ int dsm_nmft_get(dsm_ctx *ctx, double *tau, double *gamma);
 int dsm_nmft_factorize(dsm_ctx *ctx, int max_iter, double min_change, int fix_gamma,
                        int *n_done, double *div_trace);
 /* The same for n_ctx (1..8) chains of one shape at once (replicate chains: one launch of each kernel of an update for all
- * of them; the stop test stays per chain).  Matrix-core path only (S <= 128, G <= 12; DSM_ERR_UNSUPPORTED otherwise).
+ * of them; the stop test stays per chain).  Matrix-core path only (S <= 128, G <= 16; DSM_ERR_UNSUPPORTED otherwise).
  * n_done [n_ctx]; div_traces [n_ctx][max_iter + 1] or NULL.                                                          */
 int dsm_batch_nmft_factorize(dsm_ctx *const *ctxs, int n_ctx, int max_iter, double min_change, int fix_gamma,
                              int *n_done, double *div_traces);

@@ -90,7 +90,7 @@ def _nmft_run(counts, tau0, gam0, fused, fix_gamma, max_iter=20, persist=0):
 
 
 @pytest.mark.parametrize("V,S,G", [(10000, 64, 8), (50000, 96, 12), (3000, 64, 8), (2000, 32, 5), (13000, 40, 3), (12288, 48, 12), (933, 64, 5),
-                                   (97, 20, 2), (5000, 128, 8), (2500, 110, 12), (14001, 100, 3)])
+                                   (97, 20, 2), (5000, 128, 8), (2500, 110, 12), (14001, 100, 3), (3000, 64, 16), (6000, 96, 13), (2000, 128, 15)])
 def test_full_size_nmft_factorize_matches_oracle(V, S, G):
     counts, tau0, gam0, F = _nmft_case(V, S, G)
     for fix_gamma in (False, True):
@@ -149,7 +149,7 @@ def test_full_size_nmft_stop_rule_fires_at_the_oracles_update():
         c.close()
 
 
-@pytest.mark.parametrize("V,S,G,K", [(10000, 64, 8, 3), (3000, 48, 5, 2), (13000, 96, 12, 2), (4000, 128, 9, 2)])
+@pytest.mark.parametrize("V,S,G,K", [(10000, 64, 8, 3), (3000, 48, 5, 2), (13000, 96, 12, 2), (4000, 128, 9, 2), (3000, 40, 14, 2)])
 def test_full_size_batched_nmft_equals_one_by_one_and_oracle(V, S, G, K):
     """dsm_batch_nmft_factorize above 128 workgroup partials (nmft_reduce_kernel_b / nmft_gamma_kernel_b and the
     grid-stride loop of nmft_mfma_kernel_b): chain k ends bit for bit where dsm_nmft_factorize leaves it, and chain 0

@@ -732,7 +732,8 @@ static bool wave_shape(const dsm_ctx *c, int *nsl, int *gmax)
 }
 
 bool nmft_use_mfma(const dsm_ctx *c);
-bool nmft_use_wave(const dsm_ctx *c) { int a, b; return wave_shape(c, &a, &b) || nmft_use_mfma(c); }      // the one-pass kernels
+bool nmft_use_wide(const dsm_ctx *c);
+bool nmft_use_wave(const dsm_ctx *c) { int a, b; return wave_shape(c, &a, &b) || nmft_use_mfma(c) || nmft_use_wide(c); }      // the one-pass kernels
 
 int nmft_wave_grid(const dsm_ctx *c)
 {
@@ -754,9 +755,11 @@ static void launch_wave(dsm_ctx *c, int adjust, int do_update, int grid)
 int k_nmft_mfma(dsm_ctx *c, int adjust, int do_update);
 bool nmft_use_mfma(const dsm_ctx *c);
 
+int k_nmft_wide(dsm_ctx *c, int adjust, int do_update);
 int k_nmft_wave(dsm_ctx *c, int adjust, int do_update)
 {
     if (nmft_use_mfma(c)) return k_nmft_mfma(c, adjust, do_update);
+    if (nmft_use_wide(c) && !g_batch.K) return k_nmft_wide(c, adjust, do_update);
     KTimer tm(c, do_update ? DSM_K_NMFT_B : DSM_K_NMFT_A);
     int nsl, gmax;
     if (!wave_shape(c, &nsl, &gmax)) { dsm_set_error("nmft_wave: unsupported shape"); return DSM_ERR_UNSUPPORTED; }
@@ -1129,6 +1132,270 @@ int k_nmft_mfma(dsm_ctx *c, int adjust, int do_update)
     MCASE(7, 1); MCASE(7, 2); MCASE(7, 3); MCASE(8, 1); MCASE(8, 2); MCASE(8, 3);
     MCASE(1, 4); MCASE(2, 4); MCASE(3, 4); MCASE(4, 4); MCASE(5, 4); MCASE(6, 4); MCASE(7, 4); MCASE(8, 4);
 #undef MCASE
+    HIP_TRY(hipGetLastError());
+    c->npart_cols = grid;
+    return DSM_OK;
+}
+
+// ===========================================================================
+// nmft_wide_kernel: the update of nmft_mfma_kernel for tables wider than eight sample tiles (128 < S <= 512), which the VALU
+// kernels ran at a third to a ninth of the matrix-core kernel's rate per element (profiles/r03_nmft_shape_scan.txt).
+//
+// A wavefront cannot hold more than eight tiles of per-sample state, so a quad of variants is shared by NCB wavefronts, each
+// owning a block of NT consecutive sample tiles (tile tg = cb NT + t): everything per sample -- R', Q', R2, Q2, the objective
+// terms, the gamma numerators of its columns -- is the narrow kernel's code on the block.  The one quantity that crosses blocks
+// is the tau numerator num[row][g] = sum over ALL samples: every wavefront leaves its block's part in LDS, a barrier, and every
+// wavefront of the quad adds the NCB parts in block order and runs the (tiny) tau update for itself; block 0 stores it.  A
+// workgroup keeps NQ = 8 / NCB quads in flight (eight wavefronts = two per SIMD, what the registers allow) and ONE copy of the
+// two operand layouts of gamma for all of them -- 128 KB at S = 512, G = 16 -- so it is one workgroup per CU.
+// Statistics: a wavefront owns its columns' gamma numerators outright; the NQ quads in flight are added slot by slot through one
+// [GP][SPAD] buffer that takes the operands' place at the end.  Same partial layout as the other update kernels: the reduce /
+// gamma / control launches are shared.  No batched form: replicate chains of such a table run one by one.
+// ===========================================================================
+template <int NT, int KB, int NCB>
+__global__ __launch_bounds__(64 * (8 / NCB) * NCB) void nmft_wide_kernel(NmftMfmaParams prm)
+{
+    constexpr int NQ = 8 / NCB, NW = NQ * NCB, NTT = NT * NCB, GP = 4 * KB, SPAD = 16 * NTT, NTHR = 64 * NW;
+    constexpr bool KEEPF = NT <= 6;
+    const double *__restrict__ F = prm.F, *__restrict__ gam_raw = prm.gam_raw, *__restrict__ gam = prm.gam;
+    double *__restrict__ tau = prm.tau, *__restrict__ partial = prm.partial;
+    const double *__restrict__ ctl = prm.ctl, *__restrict__ log_tab = prm.log_tab;
+    const int V = prm.V, S = prm.S, G = prm.G, adjust = prm.adjust, do_update = prm.do_update;
+    extern __shared__ __attribute__((aligned(16))) char smem_w[];
+    if (ctl[2] != 0.0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
+    const int slot = wv / NCB, cb = wv % NCB, nblk = gridDim.x;
+    double2 *ltab = reinterpret_cast<double2 *>(smem_w);                        // [256]
+    double *braw = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);            // [NTT][KB][64] B fragments of gamma_raw
+    double *bgam = braw + NTT * KB * 64;                                        // [NTT][KB][64] B fragments of gamma
+    double *t1 = bgam + NTT * KB * 64;                                          // [GP] rowsum(gamma_raw)
+    double *told = t1 + GP + slot * (2 * 16 * GP);                              // per quad in flight [16][GP], row i = 4 r + vv
+    double *tnew = told + 16 * GP;
+    double *nump = t1 + GP + NQ * (2 * 16 * GP) + slot * (NCB * 16 * GP);       // per quad in flight [NCB][16][GP]: the blocks' parts of num
+    double *objw = t1 + GP + NQ * (2 * 16 * GP) + NQ * (NCB * 16 * GP);         // [NW]
+    double *h1w = objw + NW;                                                    // [NQ][GP]
+    double *red = braw;                                                         // [GP][SPAD] at the end
+    for (int i = tid; i < DSM_LOG_TAB_N; i += NTHR) ltab[i] = reinterpret_cast<const double2 *>(log_tab)[i];
+    for (int i = tid; i < NTT * KB * 64; i += NTHR) {
+        const int l = i & 63, kb = (i >> 6) % KB, t = (i >> 6) / KB;
+        const int g = 4 * kb + (l >> 4), s2 = 16 * t + (l & 15);
+        const bool in = g < G && s2 < S;
+        braw[i] = in ? gam_raw[(size_t)g * S + s2] : 0.0;
+        bgam[i] = in ? gam[(size_t)g * S + s2] : 0.0;
+    }
+    for (int k = tid; k < NQ * 2 * 16 * GP; k += NTHR) t1[GP + k] = 0.0;        // told / tnew incl. the padded haplotype columns
+    for (int g = wv; g < GP; g += NW) {                                         // gamma.sum(1) (:170), lane-parallel
+        double a = 0.0;
+        if (g < G) for (int s2 = lane; s2 < S; s2 += 64) a += gam_raw[(size_t)g * S + s2];
+        a = group_allreduce_sum<64>(a);
+        if (lane == 0) t1[g] = a;
+    }
+    __syncthreads();
+
+    double4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double obj = 0.0, h1 = 0.0;
+    const bool b0 = n & 1, b1 = n & 2, b2 = n & 4, b3 = n & 8;
+    const int my_e = (b0 ? 2 : 0) + (b1 ? 1 : 0), my_gg = (b3 ? 2 : 0) + (b2 ? 1 : 0);
+
+    const int nquad = (V + 3) >> 2;
+    for (int qd0 = blockIdx.x * NQ; qd0 < nquad; qd0 += nblk * NQ) {           // every wavefront of the workgroup runs the same trips
+        const int v0 = (qd0 + slot) * 4;                                        // a slot past the end is a quad of absent variants
+        const bool vok = v0 + q < V;
+        for (int k = lane + 64 * cb; k < 16 * G; k += 64 * NCB) {
+            const int vv = k / (4 * G), r = (k / G) & 3, g = k % G;
+            const double x = (v0 + vv < V) ? tau[(size_t)v0 * 4 * G + k] : 0.0;
+            told[(4 * r + vv) * GP + g] = x;
+            if (!do_update) tnew[(4 * r + vv) * GP + g] = x;
+        }
+        double4_t f[KEEPF ? NT : 1];
+        bool live[NT];
+        auto load_f = [&](int t) {
+            double4_t x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = live[t] ? F[((size_t)(v0 + q) * 4 + e) * S + 16 * (cb * NT + t) + n] : 1.0;
+            return x;
+        };
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            live[t] = vok && (16 * (cb * NT + t) + n < S);
+            if constexpr (KEEPF) f[t] = load_f(t);
+        }
+        __syncthreads();                                                        // the quad's rows are staged
+        if (do_update) {
+            double a_old[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) a_old[kb] = told[n * GP + 4 * kb + q];
+            double4_t qp[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_old[kb], braw[((cb * NT + t) * KB + kb) * 64 + lane], R, 0, 0, 0);
+                const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qp[t][e] = fdiv(ft[e], nzd(R[e]));          // nm_tile_q2: F > 0; lanes without a cell stay finite
+            }
+#pragma unroll
+            for (int c = 0; c < KB; ++c) {
+                double p[16];                                                   // value index j = 4 e + gg
+#pragma unroll
+                for (int j = 0; j < 16; ++j) p[j] = 0.0;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        const double gm = braw[((cb * NT + t) * KB + c) * 64 + n + 16 * gg];     // gamma_raw[4 c + gg][16 tg + n]
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) p[4 * e + gg] = fma(qp[t][e], gm, p[4 * e + gg]);
+                    }
+                const double part = row16_transpose_reduce(p, n);               // this block's part of num[(my_e, vv = q)][4 c + my_gg]
+                nump[(cb * 16 + 4 * my_e + q) * GP + 4 * c + my_gg] = part;
+            }
+            __syncthreads();                                                    // every block's part is there
+#pragma unroll
+            for (int c = 0; c < KB; ++c) {
+                const int g = 4 * c + my_gg;
+                const bool ok = g < G;
+                double tot_rg = 0.0;
+#pragma unroll
+                for (int b = 0; b < NCB; ++b) tot_rg += nump[(b * 16 + 4 * my_e + q) * GP + g];       // block order
+                double tn = 0.0;
+                if (ok) tn = told[(4 * my_e + q) * GP + g] * fdiv(nzd(tot_rg), nzd(t1[g]));       // :171-172
+                const double t_a0 = dpp_mov<0x00>(tn), t_a1 = dpp_mov<0xAA>(tn);              // e = 0 / 1 live in quad lanes 0 / 2
+                const double t_a2 = dpp_mov<0x55>(tn), t_a3 = dpp_mov<0xFF>(tn);              // e = 2 / 3            quad lanes 1 / 3
+                const double tot = ((t_a0 + t_a1) + t_a2) + t_a3;                              // :176-178
+                if (ok && cb == 0) {                                            // the same numbers in every block: block 0 stores them
+                    double x = fdiv(tn, tot);                                                      // :180-181
+                    if (adjust && x < DSM_EPS) x = DSM_EPS;                                    // :88-91
+                    if (vok) tau[((size_t)(v0 + q) * 4 + my_e) * G + g] = x;
+                    tnew[(4 * my_e + q) * GP + g] = vok ? x : 0.0;
+                }
+            }
+            __syncthreads();                                                    // the new rows are there
+        }
+        // statistics of the (new) state on this block's columns: R2, objective, Q2, gamma numerators; H1 by block 0
+        double a_new[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) a_new[kb] = tnew[n * GP + 4 * kb + q];
+        double a_g[4];                                                          // A of the row contraction: tau_new[vv = q][e][g = n]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a_g[e] = (n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; h1 += a_g[e]; }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_new[kb], bgam[((cb * NT + t) * KB + kb) * 64 + lane], R, 0, 0, 0);
+            const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
+            const double4_t q2 = nm_tile_q2(ft, R, live[t], ltab, obj);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
+        }
+        __syncthreads();                                                        // done with this trip's rows
+    }
+    // objective: per wavefront; H1: lane (n = g, q) of a block-0 wavefront holds the sum over bases and its variants of tau_new[.][g]
+    {
+        const double o = group_allreduce_sum<64>(obj);
+        double hh = h1;
+        hh += __shfl_xor(hh, 16, 64);
+        hh += __shfl_xor(hh, 32, 64);
+        if (lane == 0) objw[wv] = o;
+        if (cb == 0 && lane < GP) h1w[slot * GP + lane] = hh;
+    }
+    // gamma numerators: acc[t][e] is (g = 4 e + q, s = 16 tg + n) of this wavefront's columns; the quads in flight add up slot by slot
+#pragma unroll 1
+    for (int sl = 0; sl < NQ; ++sl) {
+        __syncthreads();
+        if (slot == sl) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int g = 4 * e + q;
+                    if (g < GP) {
+                        double *r = red + (size_t)g * SPAD + 16 * (cb * NT + t) + n;
+                        *r = (sl == 0) ? acc[t][e] : *r + acc[t][e];
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < G * S; i += NTHR) {
+        const int g = i / S, s2 = i % S;
+        partial[(size_t)i * nblk + blockIdx.x] = red[(size_t)g * SPAD + s2];
+    }
+    if (tid < G) {
+        double a = 0.0;
+        for (int k = 0; k < NQ; ++k) a += h1w[k * GP + tid];
+        partial[((size_t)G * S + tid) * nblk + blockIdx.x] = a;
+    }
+    if (tid == 64) {
+        double a = 0.0;
+        for (int k = 0; k < NW; ++k) a += objw[k];
+        partial[((size_t)G * S + G) * nblk + blockIdx.x] = a;
+    }
+}
+
+// 128 < S <= 512, G <= 16: blocks of six or eight tiles, two to four blocks -- the smallest tile count that holds S
+static bool wide_shape(const dsm_ctx *c, int *nt, int *kb, int *ncb)
+{
+    static const bool off = getenv("DESMAN_HIP_NMFT_NO_MFMA") != nullptr || getenv("DESMAN_HIP_NMFT_NO_WIDE") != nullptr;
+    const int tiles = (c->S + 15) / 16;
+    *kb = (c->nG + 3) / 4;
+    if (off || tiles <= 8 || tiles > 32 || *kb < 1 || *kb > 4) return false;
+    static const int shapes[6][2] = {{6, 2}, {8, 2}, {6, 3}, {8, 3}, {6, 4}, {8, 4}};         // by capacity: 12, 16, 18, 24, 24, 32 tiles
+    for (int i = 0; i < 6; ++i)
+        if (shapes[i][0] * shapes[i][1] >= tiles) { *nt = shapes[i][0]; *ncb = shapes[i][1]; return true; }
+    return false;
+}
+bool nmft_use_wide(const dsm_ctx *c) { int a, b, d; return wide_shape(c, &a, &b, &d); }
+
+static size_t wide_lds_bytes(int NT, int KB, int NCB)
+{
+    const size_t NQ = 8 / NCB, NW = NQ * NCB, NTT = (size_t)NT * NCB, GP = 4 * KB;
+    return (2 * DSM_LOG_TAB_N + 2 * NTT * KB * 64 + GP + NQ * 2 * 16 * GP + NQ * NCB * 16 * GP + NW + NQ * GP) * sizeof(double);
+}
+
+int nmft_wide_grid(const dsm_ctx *c)
+{
+    int nt, kb, ncb, cus = 256;
+    if (!wide_shape(c, &nt, &kb, &ncb)) return 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) cus = 256;
+    const int nq = 8 / ncb;
+    int g = ((c->V + 3) / 4 + nq - 1) / nq;
+    if (g > cus) g = cus;                          // one workgroup per CU: eight wavefronts, the operands' LDS
+    return g < 1 ? 1 : g;
+}
+
+template <int NT, int KB, int NCB>
+static int launch_wide(dsm_ctx *c, int adjust, int do_update, int grid)
+{
+    const size_t sh = wide_lds_bytes(NT, KB, NCB);
+    static bool attr_set = false;                  // more than 64 KB of dynamic LDS has to be asked for, once per instantiation
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&nmft_wide_kernel<NT, KB, NCB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart};
+    hipLaunchKernelGGL((nmft_wide_kernel<NT, KB, NCB>), dim3(grid), dim3(64 * (8 / NCB) * NCB), sh, c->stream, q);
+    return DSM_OK;
+}
+
+int k_nmft_wide(dsm_ctx *c, int adjust, int do_update)
+{
+    KTimer tm(c, do_update ? DSM_K_NMFT_B : DSM_K_NMFT_A);
+    int nt, kb, ncb;
+    if (!wide_shape(c, &nt, &kb, &ncb)) { dsm_set_error("nmft_wide: unsupported shape"); return DSM_ERR_UNSUPPORTED; }
+    if (g_batch.K) { dsm_set_error("nmft_wide: no batched form (S > 128)"); return DSM_ERR_UNSUPPORTED; }
+    const int grid = nmft_wide_grid(c);
+    int rc = DSM_ERR_UNSUPPORTED;
+#define WCASE(N, K, B) if (nt == N && kb == K && ncb == B) rc = launch_wide<N, K, B>(c, adjust, do_update, grid)
+    WCASE(6, 1, 2); WCASE(6, 2, 2); WCASE(6, 3, 2); WCASE(6, 4, 2); WCASE(8, 1, 2); WCASE(8, 2, 2); WCASE(8, 3, 2); WCASE(8, 4, 2);
+    WCASE(6, 1, 3); WCASE(6, 2, 3); WCASE(6, 3, 3); WCASE(6, 4, 3); WCASE(8, 1, 3); WCASE(8, 2, 3); WCASE(8, 3, 3); WCASE(8, 4, 3);
+    WCASE(6, 1, 4); WCASE(6, 2, 4); WCASE(6, 3, 4); WCASE(6, 4, 4); WCASE(8, 1, 4); WCASE(8, 2, 4); WCASE(8, 3, 4); WCASE(8, 4, 4);
+#undef WCASE
+    if (rc != DSM_OK) return rc;
     HIP_TRY(hipGetLastError());
     c->npart_cols = grid;
     return DSM_OK;

@@ -207,7 +207,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     free_traces(c);
     dev_free(&c->cnt_vs); dev_free(&c->items); dev_free(&c->nitems); dev_free(&c->tau);
-    dev_free(&c->blk_tab); dev_free(&c->ntab); dev_free(&c->big_list); dev_free(&c->big_count);
+    dev_free(&c->blk_tab); dev_free(&c->ntab_raw); c->ntab = nullptr; dev_free(&c->big_list); dev_free(&c->big_count);
     dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
     dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->sweep_stats); dev_free(&c->step_cnt); dev_free(&c->screen_ctl); dev_free(&c->prior); dev_free(&c->prior_all); dev_free(&c->scalars); dev_free(&c->star);
@@ -620,6 +620,7 @@ extern "C" int dsm_ctx_sample_stats(dsm_ctx *c, uint32_t iter, uint64_t *sum_mu,
     BIND(c);
     const size_t sg = (size_t)c->S * c->G;
     HIP_TRY(hipMemsetAsync(c->sum_mu, 0, sg * sizeof(unsigned long long), c->stream));
+    TRY(stats_place_ntab(c));
     HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
     TRY(k_stats(c, iter));
     if (sum_mu) HIP_TRY(hipMemcpyAsync(sum_mu, c->sum_mu, sg * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
@@ -651,7 +652,8 @@ extern "C" int dsm_ctx_debug_stage1(dsm_ctx *c, uint32_t iter, uint32_t *ntab, u
     HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
     TRY(k_stats_stage1(c, iter));
     const size_t NH = (size_t)1 << c->G, S = (size_t)c->S;
-    std::vector<uint32_t> t((size_t)c->ntab_rep * NH * S);
+    const size_t ld = (size_t)c->ntab_ld;
+    std::vector<uint32_t> t((size_t)c->ntab_rep * NH * ld);
     HIP_TRY(hipMemcpyAsync(t.data(), c->ntab, t.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     if (esum) HIP_TRY(hipMemcpyAsync(esum, c->esum, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemsetAsync(c->ntab, 0, t.size() * sizeof(uint32_t), c->stream));
@@ -662,7 +664,7 @@ extern "C" int dsm_ctx_debug_stage1(dsm_ctx *c, uint32_t iter, uint32_t *ntab, u
         for (size_t h = 0; h < NH; ++h)
             for (size_t s = 0; s < S; ++s) {                                       // device [rep][H][S] -> [S][H], copies summed
                 uint32_t v = 0;
-                for (int r = 0; r < c->ntab_rep; ++r) v += t[((size_t)r * NH + ((h * stats_ntab_hmul()) & (NH - 1))) * S + s];
+                for (int r = 0; r < c->ntab_rep; ++r) v += t[((size_t)r * NH + ((h * stats_ntab_hmul()) & (NH - 1))) * ld + s];
                 ntab[s * NH + h] = v;
             }
     return DSM_OK;
@@ -756,6 +758,7 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
     HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
     // entry state: ll, lp, storeStarState(0)  (HaploSNP_Sampler.py:336-338)
     TRY(eval_state(c, c->gamma, c->eta, c->tau_trace, 1));
+    TRY(stats_place_ntab(c));                            // first call with this table: where its atomics cost least (kernels_stats.hip)
     double *const P[2] = {c->prior, c->prior + (DSM_MAX_S + 4)};
     int nb_prev = 0;
     // the MT19937 words of the sweeps are generated on the side stream, chunks of sweeps ahead (never beyond the last sweep
@@ -828,6 +831,7 @@ extern "C" int dsm_ctx_gibbs_update_sharded(dsm_ctx *c, int n_iter, int v_offset
         TRY(k_finalize(c, nb, -1, 1, c->prior, c->gamma, c->eta));
         HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
     }
+    TRY(stats_place_ntab(c));
     double *const P[2] = {c->prior, c->prior + (DSM_MAX_S + 4)};
     int nb_prev = 0;
     for (int it = 0; it < n_iter; ++it) {
@@ -919,6 +923,7 @@ extern "C" int dsm_batch_gibbs_update(dsm_ctx *const *ctxs, int K, int n_iter)
         BTRY(alloc_traces(c, n_iter));
         BHIP(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
         BTRY(eval_state(c, c->gamma, c->eta, c->tau_trace, 1));
+        BTRY(stats_place_ntab(c));
         words.emplace_back(c, n_iter);
     }
     g_batch.K = K;

@@ -67,6 +67,11 @@ struct dsm_ctx {
                                     // the aggregated pass wherever it applies, small problems too
     uint32_t *ntab = nullptr;       // [2^G][S] subset counts of the aggregated mu/E pass (spec v2), zero between passes
     size_t ntab_len = 0;
+    uint32_t *ntab_raw = nullptr;   // the allocation `ntab` points into (kernels_stats.hip: ensure_ntab places the table inside it)
+    uint32_t *ntab_base = nullptr;  // first place the table can start at (4 KB aligned)
+    size_t ntab_off = 0;            // where past ntab_base the table starts (stats_place_ntab)
+    bool ntab_placed = false;       // the place has been measured (or given)
+    int ntab_ld = 0;                // row stride of the table in words (kernels_stats.hip: stats_ntab_ld)
     int ntab_rep = 1;               // copies of the table (few subsets x many positions: kernels_stats.hip, stats_ntab_rep)
     unsigned long long *big_list = nullptr;   // stage-1 items deferred to the compacted (BTRS) kernel: cell * 4 + base
     uint32_t *big_count = nullptr;            // DSM_BIG_NL counters, DSM_BIG_STRIDE words apart
@@ -170,6 +175,9 @@ int build_stats_items(dsm_ctx *c);          // api.hip: work list of the per-rea
 
 // ---- launchers (kernels_stats.hip)
 uint32_t stats_ntab_hmul();                  // odd multiplier of the subset -> table row map
+int stats_place_ntab(dsm_ctx *c);         // measures where the subset table should start (once per table; kernels_stats.hip)
+#define DSM_NTAB_PAD 0               // words added to a row of the subset table when S is a multiple of 64 (stats_ntab_ld)
+int stats_ntab_ld(int S);
 int stats_ntab_rep(const dsm_ctx *c);       // copies of the subset table the stage-1 atomics are spread over
 int stats_spec(const dsm_ctx *c);           // 2 = aggregated sampler (oracle/stats_agg.c), 1 = per-read (orc_stats_counter)
 int k_stats(dsm_ctx *c, uint32_t iter);

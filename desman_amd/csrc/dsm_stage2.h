@@ -24,7 +24,7 @@ struct S2Plan {
 
 struct Stage2Params {
     uint32_t *ntab;                 // [rep][2^G][S], zeroed after reading
-    int rep;                        // copies of the table (their sum is the count)
+    int rep, ld;                    // copies of the table (their sum is the count); row stride in words (>= S)
     const double *gamma;            // [S][G]
     unsigned long long *sum_mu;     // [S][G] accumulated into (stand-alone kernel)
     const double *log_tab;
@@ -43,7 +43,7 @@ S2Plan make_stage2_plan(int G);     // kernels_stats.hip
 template <int SPEC>
 __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, const S2Plan &pl, int s, char *smem, bool to_global)
 {
-    const int G = p.G, S = p.S, tid = threadIdx.x, nthr = blockDim.x;      // 256 (fused form) or 1024 (many subsets)
+    const int G = p.G, tid = threadIdx.x, nthr = blockDim.x;      // 256 (fused form) or 1024 (many subsets)
     double2 *ltab = reinterpret_cast<double2 *>(smem);                         // [256] log table, then [64] exp table
     double *etab = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);
     double *rcp = etab + DSM_EXP_TAB_N;                                        // [256]
@@ -79,8 +79,8 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
             if (Hs == 0) continue;
             uint32_t n;
             if (level == 0) {
-                uint32_t *cell = p.ntab + (size_t)((Hs * p.hmul) & ((1u << G) - 1u)) * S + s;
-                const size_t cstride = ((size_t)1 << G) * S;
+                uint32_t *cell = p.ntab + (size_t)((Hs * p.hmul) & ((1u << G) - 1u)) * (size_t)p.ld + s;
+                const size_t cstride = ((size_t)1 << G) * (size_t)p.ld;
                 if (p.rep == 8) {
                     // one copy per XCD (kernels_stats.hip): all eight loads in flight at once -- read one after the other (a store may
                     // alias the next load, so the compiler keeps the order) they cost eight memory round trips: +3.5 us on the launch

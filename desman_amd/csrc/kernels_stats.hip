@@ -35,8 +35,8 @@ struct StatsAggParams {
     int v_off, V_tot;               // a chain sharded over GPUs by positions: this context holds positions v_off .. v_off + V of V_tot; the
                                     // counter-based streams are keyed by GLOBAL cell indices, so the draws do not depend on the sharding
     uint32_t k0, k1, iter;
-    uint32_t *ntab;                 // [rep][2^G][S]; workgroup b adds to copy b mod rep
-    int rep;
+    uint32_t *ntab;                 // [rep][2^G][ld]; workgroup b adds to copy b mod rep
+    int rep, ld;                    // ld: row stride in words, >= S (ensure_ntab)
     unsigned long long *esum;       // [16]
     const double *log_tab;
     unsigned long long *big_list;   // deferred items: cell * 4 + observed base; DSM_BIG_NL sub-lists of big_seg entries each
@@ -202,26 +202,27 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
             }
         }
         // N[H_a(v)][s] += reads whose true base is a: adjacent lanes -> adjacent words of one table row
-        uint32_t *const nt = p.ntab + (size_t)copy * (((size_t)1 << G) * S);
+        const size_t ld = (size_t)p.ld;                                    // row stride of the subset table in words (>= S: ensure_ntab)
+        uint32_t *const nt = p.ntab + (size_t)copy * (((size_t)1 << G) * ld);
         const uint32_t hmask = (1u << G) - 1u;
         H0 = (H0 * p.hmul) & hmask; H1 = (H1 * p.hmul) & hmask; H2 = (H2 * p.hmul) & hmask; H3 = (H3 * p.hmul) & hmask;   // rows of the four subsets
         if (p.dbg & (4 | 32)) { if ((nacc[0] ^ nacc[1] ^ nacc[2] ^ nacc[3] ^ H0 ^ H1 ^ H2 ^ H3) == 0x12345u) atomicAdd(nt + s, 1u); continue; }
         if (p.dbg & 64) {        // plain stores instead of atomics (wrong sums; what the adds cost beyond a store)
-            nt[(size_t)H0 * S + s] = nacc[0]; nt[(size_t)H1 * S + s] = nacc[1]; nt[(size_t)H2 * S + s] = nacc[2]; nt[(size_t)H3 * S + s] = nacc[3];
+            nt[(size_t)H0 * ld + s] = nacc[0]; nt[(size_t)H1 * ld + s] = nacc[1]; nt[(size_t)H2 * ld + s] = nacc[2]; nt[(size_t)H3 * ld + s] = nacc[3];
             continue;
         }
         if (p.xcd) {
             // this XCD's copy: every adder of the copy shares the L2 the atomic executes in (relaxed, workgroup scope: no sc1, the
             // line stays in L2); the kernel boundary writes the lines back for stage 2, which sums the copies
-            if (nacc[0]) __hip_atomic_fetch_add(nt + (size_t)H0 * S + s, nacc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (nacc[1]) __hip_atomic_fetch_add(nt + (size_t)H1 * S + s, nacc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (nacc[2]) __hip_atomic_fetch_add(nt + (size_t)H2 * S + s, nacc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (nacc[3]) __hip_atomic_fetch_add(nt + (size_t)H3 * S + s, nacc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (nacc[0]) __hip_atomic_fetch_add(nt + (size_t)H0 * ld + s, nacc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (nacc[1]) __hip_atomic_fetch_add(nt + (size_t)H1 * ld + s, nacc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (nacc[2]) __hip_atomic_fetch_add(nt + (size_t)H2 * ld + s, nacc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (nacc[3]) __hip_atomic_fetch_add(nt + (size_t)H3 * ld + s, nacc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
-            if (nacc[0]) atomicAdd(nt + (size_t)H0 * S + s, nacc[0]);
-            if (nacc[1]) atomicAdd(nt + (size_t)H1 * S + s, nacc[1]);
-            if (nacc[2]) atomicAdd(nt + (size_t)H2 * S + s, nacc[2]);
-            if (nacc[3]) atomicAdd(nt + (size_t)H3 * S + s, nacc[3]);
+            if (nacc[0]) atomicAdd(nt + (size_t)H0 * ld + s, nacc[0]);
+            if (nacc[1]) atomicAdd(nt + (size_t)H1 * ld + s, nacc[1]);
+            if (nacc[2]) atomicAdd(nt + (size_t)H2 * ld + s, nacc[2]);
+            if (nacc[3]) atomicAdd(nt + (size_t)H3 * ld + s, nacc[3]);
         }
     }
     // Esum: lane-private columns -> one transposing butterfly per wavefront -> one global atomic per workgroup and counter
@@ -304,7 +305,7 @@ __device__ __forceinline__ void stats_big_body(const StatsAggParams &p)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             erow[a * 256] += n[a];
-            if (n[a]) atomicAdd(p.ntab + (size_t)(blockIdx.x % (unsigned)p.rep) * (((size_t)1 << G) * S) + (size_t)((H[a] * p.hmul) & ((1u << G) - 1u)) * S + s, n[a]);
+            if (n[a]) atomicAdd(p.ntab + (size_t)(blockIdx.x % (unsigned)p.rep) * (((size_t)1 << G) * (size_t)p.ld) + (size_t)((H[a] * p.hmul) & ((1u << G) - 1u)) * (size_t)p.ld + s, n[a]);
         }
     }
     {
@@ -426,6 +427,8 @@ int stats_spec(const dsm_ctx *c)
 int stats_ntab_rep(const dsm_ctx *c)
 {
     static const double want = getenv("DESMAN_HIP_NTAB_LINES") ? atof(getenv("DESMAN_HIP_NTAB_LINES")) : 384.0;
+    static const int force = getenv("DESMAN_HIP_NTAB_REP") ? atoi(getenv("DESMAN_HIP_NTAB_REP")) : 0;      // A/B switch
+    if (force > 0) return force;
     const double per = 3.0 * (double)c->V / (double)((size_t)1 << c->G);
     if (per <= 128.0) return 1;
     const double lines = (double)((((size_t)1 << c->G) * (size_t)c->S * 4 + 63) / 64);
@@ -455,18 +458,98 @@ uint32_t stats_ntab_hmul()
     return k;
 }
 
+// Row stride of the subset table.  With S a multiple of 64 the rows are whole 256 B blocks and where the hot rows fall relative to the
+// memory-channel interleave decides what stage 1's memory-side atomics cost: at config 3 (S = 64) 44 us or 54 us (69 at the worst) for the
+// same launch, switching with every 256 B the table's base moves and with the multiplier of the row map (scripts/dbg/ntab_off_scan.py);
+// S = 48 or 96 (rows of 192 / 384 B, which cut the interleave at a different place every row) show none of it.  So such tables get
+// rows a quarter block longer: DESMAN_HIP_NTAB_PAD overrides the words added (A/B switch).
+int stats_ntab_ld(int S)
+{
+    static const int pad = getenv("DESMAN_HIP_NTAB_PAD") ? atoi(getenv("DESMAN_HIP_NTAB_PAD")) : DSM_NTAB_PAD;
+    return (S % 64 == 0) ? S + pad : S;
+}
+
+// Where the table starts.  What the memory-side atomics of stage 1 cost depends on how the rows that take most adds fall on the
+// memory channels, i.e. on the table's PHYSICAL address: at config 3 the same launch takes 44 us at one 256 B offset and 54-61 us at
+// the next (scripts/dbg/ntab_scan_inproc.py: stable to 0.3 us for a given place, the median place costs 53 us) -- and hipMalloc's
+// answer moves with every allocation made before it and with the box (round 2's 0.105 ms was a lucky place, the same build measured
+// 0.131 once two allocations preceded the table).  Neither an odd row multiplier, nor longer rows, nor two or four copies take the
+// spread away, so the place is MEASURED: the table is allocated with DSM_NTAB_PLACES x 256 B to spare and
+// stats_place_ntab() times stage 1 on the chain's own state at each place, once per table, and keeps the fastest.
+// DESMAN_HIP_NTAB_OFF=<bytes> fixes the place instead (experiments); DESMAN_HIP_NTAB_TUNE=0 keeps place 0.
+#define DSM_NTAB_PLACES 8
 static int ensure_ntab(dsm_ctx *c)
 {
     c->ntab_rep = stats_ntab_rep(c);
     if (stats_ntab_xcd(c)) c->ntab_rep = std::max(8, (c->ntab_rep + 7) / 8 * 8);
-    const size_t need = (size_t)c->ntab_rep * ((size_t)1 << c->G) * (size_t)c->S;
-    if (c->ntab && c->ntab_len == need) return DSM_OK;
-    if (c->ntab) { (void)hipFree(c->ntab); c->ntab = nullptr; }
-    hipError_t e = hipMalloc((void **)&c->ntab, need * sizeof(uint32_t));
-    if (e != hipSuccess) { dsm_set_error("hipMalloc(%zu B) failed: %s", need * 4, hipGetErrorString(e)); return DSM_ERR_NOMEM; }
+    c->ntab_ld = stats_ntab_ld(c->S);
+    const size_t need = (size_t)c->ntab_rep * ((size_t)1 << c->G) * (size_t)c->ntab_ld;
+    static const bool scan = getenv("DESMAN_HIP_NTAB_SCAN") != nullptr;          // experiments: the offset is re-read at every call
+    const char *eo = getenv("DESMAN_HIP_NTAB_OFF");
+    const size_t off_env = eo ? ((size_t)strtoull(eo, nullptr, 0) & ~(size_t)255) : (size_t)-1;
+    if (c->ntab && c->ntab_len == need && (!scan || off_env == (size_t)-1 || off_env == c->ntab_off)) return DSM_OK;
+    if (c->ntab_raw) { (void)hipFree(c->ntab_raw); c->ntab_raw = nullptr; c->ntab = nullptr; }
+    const size_t off = off_env != (size_t)-1 ? off_env : 0;
+    const size_t spare = std::max<size_t>(off, (size_t)DSM_NTAB_PLACES * 256) + 4096;
+    hipError_t e = hipMalloc((void **)&c->ntab_raw, need * sizeof(uint32_t) + spare);
+    if (e != hipSuccess) { dsm_set_error("hipMalloc(%zu B) failed: %s", need * 4 + spare, hipGetErrorString(e)); return DSM_ERR_NOMEM; }
+    c->ntab_base = reinterpret_cast<uint32_t *>(((uintptr_t)c->ntab_raw + 4095) & ~(uintptr_t)4095);
+    c->ntab = c->ntab_base + off / 4;
+    c->ntab_off = off;
     c->ntab_len = need;
+    c->ntab_placed = off_env != (size_t)-1;               // a place given from outside is not measured again
     HIP_TRY(hipMemsetAsync(c->ntab, 0, need * sizeof(uint32_t), c->stream));
     return DSM_OK;
+}
+
+int stats_place_ntab(dsm_ctx *c)
+{
+    static const bool on = !(getenv("DESMAN_HIP_NTAB_TUNE") && atoi(getenv("DESMAN_HIP_NTAB_TUNE")) == 0);
+    static const bool verbose = getenv("DESMAN_HIP_NTAB_TUNE") && atoi(getenv("DESMAN_HIP_NTAB_TUNE")) == 2;
+    if (stats_spec(c) < 2) return DSM_OK;
+    int r = ensure_ntab(c);
+    if (r != DSM_OK) return r;
+    if (c->ntab_placed) return DSM_OK;
+    c->ntab_placed = true;
+    // tables of a few hundred KB: larger ones spread over the channels whatever their place (config 5, 1.5 MB: 302 us everywhere)
+    if (!on || g_batch.K || c->ntab_len * sizeof(uint32_t) > ((size_t)512 << 10)) return DSM_OK;
+    const bool timing = c->timing;
+    c->timing = false;
+    hipEvent_t ev[2];
+    HIP_TRY(hipEventCreate(&ev[0]));
+    HIP_TRY(hipEventCreate(&ev[1]));
+    auto clear = [&]() -> int {
+        HIP_TRY(hipMemsetAsync(c->ntab, 0, c->ntab_len * sizeof(uint32_t), c->stream));
+        HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
+        if (c->big_count) HIP_TRY(hipMemsetAsync(c->big_count, 0, DSM_BIG_NT * DSM_BIG_NL * DSM_BIG_STRIDE * sizeof(uint32_t), c->stream));
+        return DSM_OK;
+    };
+    float best = 0.f;
+    int best_k = 0;
+    for (int k = 0; k < DSM_NTAB_PLACES && r == DSM_OK; ++k) {
+        c->ntab = c->ntab_base + (size_t)k * 64;
+        // the draws are counter-based (the iteration index is an argument): running the pass here moves no stream.  Sums are cleared after.
+        r = clear();
+        if (r == DSM_OK) r = k_stats_stage1(c, 0xFFFFFF00u + (uint32_t)k);
+        if (r == DSM_OK) r = clear();
+        if (r != DSM_OK) break;
+        (void)hipEventRecord(ev[0], c->stream);
+        for (int j = 0; j < 2 && r == DSM_OK; ++j) { r = k_stats_stage1(c, 0xFFFFFF80u + (uint32_t)k); if (r == DSM_OK) r = clear(); }
+        (void)hipEventRecord(ev[1], c->stream);
+        if (r != DSM_OK) break;
+        if (hipEventSynchronize(ev[1]) != hipSuccess) { r = DSM_ERR_HIP; dsm_set_error("stats_place_ntab: hipEventSynchronize failed"); break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+        if (k == 0 || ms < best) { best = ms; best_k = k; }
+        if (verbose) fprintf(stderr, "desman_hip: subset table at +%d B: %.1f us per stage-1 pass\n", k * 256, 500.0 * ms);
+    }
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    c->timing = timing;
+    c->ntab = c->ntab_base + (size_t)best_k * 64;
+    c->ntab_off = (size_t)best_k * 256;
+    if (r != DSM_OK) return r;
+    return clear();
 }
 
 static int ensure_big_list(dsm_ctx *c, size_t seg)
@@ -536,7 +619,7 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     p.V = V; p.S = S; p.G = G; p.big_seg = seg;
     p.v_off = c->shard_on ? c->shard_voff : 0; p.V_tot = c->shard_on ? c->shard_vtot : V;
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
-    p.ntab = c->ntab; p.rep = c->ntab_rep; p.esum = c->esum; p.log_tab = c->log_tab;
+    p.ntab = c->ntab; p.rep = c->ntab_rep; p.ld = c->ntab_ld; p.esum = c->esum; p.log_tab = c->log_tab;
     p.xcd = stats_ntab_xcd(c) ? 1 : 0;
     p.hmul = stats_ntab_hmul();
     p.big_list = c->big_list; p.big_count = c->big_count;
@@ -614,7 +697,7 @@ int k_stats_stage2(dsm_ctx *c, uint32_t iter)
 {
     KTimer tm(c, DSM_K_STATS2);
     Stage2Params p;
-    p.ntab = c->ntab; p.rep = c->ntab_rep; p.gamma = c->gamma; p.sum_mu = c->sum_mu; p.log_tab = c->log_tab;
+    p.ntab = c->ntab; p.rep = c->ntab_rep; p.ld = c->ntab_ld; p.gamma = c->gamma; p.sum_mu = c->sum_mu; p.log_tab = c->log_tab;
     p.S = c->S; p.G = c->G; p.hmul = stats_ntab_hmul();
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
     p.big_count = c->big_count;

@@ -598,7 +598,15 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, c->device));
         static const int wgs_env = getenv("DESMAN_HIP_STATS_WGS") ? atoi(getenv("DESMAN_HIP_STATS_WGS")) : 6;   // A/B switch
-        c->stats_grid = std::min(wgs_env, std::max(1, occ)) * prop.multiProcessorCount;   // six workgroups per CU: measured optimum (below)
+        // ... on all CUs but one per XCD when the sweep's uniforms are MT19937 words: the generator's workgroup keeps a CU to itself
+        // (kernels_gibbs.hip: k_mt_fill) and workgroups go to the XCDs in turn whatever room they have, so a persistent grid sized for
+        // every CU leaves six workgroups of that XCD waiting for others to finish -- a launch that starts while the generator runs took
+        // 51 us instead of 46 (scripts/dbg/trace_stats_vs_mt.sh).  Leaving 8 CUs: 106.7 vs 107.5 us per iteration at config 3 (1 CU: no
+        // change; 16 and more: slower).
+        static const int leave_env = getenv("DESMAN_HIP_STATS_LEAVE_CUS") ? atoi(getenv("DESMAN_HIP_STATS_LEAVE_CUS")) : -1;   // A/B switch
+        const int n_xcd = prop.multiProcessorCount % 8 == 0 && prop.multiProcessorCount >= 64 ? 8 : 1;
+        const int leave = leave_env >= 0 ? leave_env : (c->tau_rng == DSM_RNG_MT19937 ? n_xcd : 0);
+        c->stats_grid = std::min(wgs_env, std::max(1, occ)) * std::max(1, prop.multiProcessorCount - leave);   // six workgroups per CU: measured optimum (below)
         c->stats_grid_key = spec * 2 + (regg ? 1 : 0);
     }
     const long ntask = ((long)V * NCH + NG - 1) / NG;            // wavefront passes (NG lane groups = NG tasks each)

@@ -203,3 +203,35 @@ def test_hardware_log2_error_bound_of_the_screening_pass():
     assert np.all(err <= np.maximum(2.0 * ulp, 2.0 ** -22)), float((err / np.maximum(ulp, 2.0 ** -23)).max())
     assert got[-4] == 0.0 and got[-3] == -1.0 and got[-2] == -2.0
     ctx.close()
+
+
+def test_the_place_of_the_subset_table_changes_no_number(tmp_path):
+    """The mu/E pass's subset table starts where its memory-side atomics cost least -- measured per chain at run time,
+    so the place differs from process to process.  A chain run with the measured place, with the allocator's place and with two fixed
+    places gives the same traces, sums and final state (the switches are read from the environment once: child processes)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys; sys.path.insert(0, %r)
+import numpy as np
+from desman_amd import _lib
+from desman_amd.synth import synth_counts, random_state
+V, S, G = 700, 64, 6
+counts, _, _ = synth_counts(V, S, G, seed=21)
+tau, gam, eta = random_state(V, S, G, seed=5)
+c = _lib.Context(0); c.set_counts(counts); c.seed(3); c.set_state(tau, gam, eta); c.force_stats_spec(_lib.STATS_AGG)
+c.gibbs_update(12)
+tr = c.get_trace(); t, g, e = c.get_state()
+mu, es = c.sample_stats(77)
+np.savez(sys.argv[1], ll=tr["ll"], lp=tr["lp"], nch=tr["nchange"], t=t, g=g, e=e, mu=mu, es=es)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env_extra in ({}, {"DESMAN_HIP_NTAB_TUNE": "0"}, {"DESMAN_HIP_NTAB_OFF": "768"}, {"DESMAN_HIP_NTAB_OFF": "4096"}):
+        path = str(tmp_path / ("o%d.npz" % len(outs)))
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    for o in outs[1:]:
+        for k in outs[0].files:
+            assert np.array_equal(outs[0][k], o[k]), k

@@ -605,7 +605,10 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
         // change; 16 and more: slower).
         static const int leave_env = getenv("DESMAN_HIP_STATS_LEAVE_CUS") ? atoi(getenv("DESMAN_HIP_STATS_LEAVE_CUS")) : -1;   // A/B switch
         const int n_xcd = prop.multiProcessorCount % 8 == 0 && prop.multiProcessorCount >= 64 ? 8 : 1;
-        const int leave = leave_env >= 0 ? leave_env : (c->tau_rng == DSM_RNG_MT19937 ? n_xcd : 0);
+        // (only while a wavefront makes a pass or two: over many passes the smaller grid is simply 3 % less machine -- config 5, twelve
+        // passes: 384 vs 368 us)
+        const long passes4 = (((long)V * NCH + NG - 1) / NG) / std::max(1L, (long)std::min(wgs_env, std::max(1, occ)) * prop.multiProcessorCount);   // workgroup = 4 wavefronts: passes x 4
+        const int leave = leave_env >= 0 ? leave_env : ((c->tau_rng == DSM_RNG_MT19937 && passes4 <= 12) ? n_xcd : 0);
         c->stats_grid = std::min(wgs_env, std::max(1, occ)) * std::max(1, prop.multiProcessorCount - leave);   // six workgroups per CU: measured optimum (below)
         c->stats_grid_key = spec * 2 + (regg ? 1 : 0);
     }

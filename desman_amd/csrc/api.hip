@@ -170,6 +170,7 @@ extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
     HIP_TRY(hipMemsetAsync(c->sweep_stats, 0, 2 * sizeof(unsigned long long), c->stream));
     TRY(dev_alloc(&c->step_cnt, (size_t)2 * 2 * DSM_MAX_GRID));
     HIP_TRY(hipMemsetAsync(c->step_cnt, 0, (size_t)2 * 2 * DSM_MAX_GRID * sizeof(uint32_t), c->stream));
+    TRY(dev_alloc(&c->blk_order, (size_t)2 * DSM_MAX_GRID));
     TRY(dev_alloc(&c->screen_ctl, 4));
     HIP_TRY(hipMemsetAsync(c->screen_ctl, 0, 4 * sizeof(uint32_t), c->stream));
     TRY(dev_alloc(&c->prior, 2 * (DSM_MAX_S + 4)));
@@ -210,7 +211,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     dev_free(&c->blk_tab); dev_free(&c->ntab_raw); c->ntab = nullptr; dev_free(&c->big_list); dev_free(&c->big_count);
     dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
-    dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->sweep_stats); dev_free(&c->step_cnt); dev_free(&c->screen_ctl); dev_free(&c->prior); dev_free(&c->prior_all); dev_free(&c->scalars); dev_free(&c->star);
+    dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->sweep_stats); dev_free(&c->step_cnt); dev_free(&c->blk_order); dev_free(&c->screen_ctl); dev_free(&c->prior); dev_free(&c->prior_all); dev_free(&c->scalars); dev_free(&c->star);
     dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->shard_vec); dev_free(&c->np_part); if (c->np_bar) { (void)hipFree(c->np_bar); c->np_bar = nullptr; } dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); dev_free(&c->ngam_raw);
     dev_free(&c->npart); dev_free(&c->nstat);
     for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ev_u_ready[i]); (void)hipEventDestroy(c->ev_u_free[i]); }

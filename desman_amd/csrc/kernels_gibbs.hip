@@ -406,6 +406,8 @@ struct FinalParams {
     const uint32_t *step_cnt;     // [nblocks][2] wavefront-steps of the finalized launch: run / left to the fp64 code (~0: not screened)
     unsigned long long *sweep_stats;   // [2] running totals of the two
     uint32_t *screen_ctl;         // [0] sweeps still to run without the screening pass
+    uint32_t *blk_order;          // [nblocks] out (or null): the order the next sweep of this parity runs its blocks in -- those first that
+                                  // left a step to the fp64 code in the finalized one (tau_body: `order`)
 };
 
 __device__ void finalize_body(const FinalParams &p, double *red, double *redp, int *flag, int tid, int nthr)
@@ -462,6 +464,24 @@ __device__ void finalize_body(const FinalParams &p, double *red, double *redp, i
             p.sweep_stats[1] += (unsigned long long)redp[0];
             if (any_plain) { if (p.screen_ctl[0] > 0) p.screen_ctl[0] -= 1; }
             else if (2.0 * redp[0] > red[0]) p.screen_ctl[0] = 15;
+        }
+        // The rare fp64 step of a sweep is long, and a workgroup that meets one late in the launch is the launch's tail (2.4 us of 36.8 at
+        // config 3).  Close races stay close from sweep to sweep, so the blocks that met one go FIRST next time: a stable
+        // partition of the block indices (thread t owns a run of consecutive blocks; exclusive scan of the runs' counts).  Which block runs
+        // where changes no result: partial sums and counters are filed under the block's own index.
+        if (p.blk_order) {
+            __syncthreads();
+            int *cnt = reinterpret_cast<int *>(red);                        // [nthr] (red / redp are free again)
+            const int per = (p.nblocks + nthr - 1) / nthr, lo = tid * per, hi = min(p.nblocks, lo + per);
+            auto cold = [&](int i) { const uint32_t b = p.step_cnt[2 * i + 1]; return b != 0u && b != 0xFFFFFFFFu; };
+            int nc = 0;
+            for (int i = lo; i < hi; ++i) nc += cold(i) ? 1 : 0;
+            cnt[tid] = nc;
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int k = 0; k < nthr; ++k) { const int x = cnt[k]; if (k < tid) before += x; total += x; }
+            int pc = before, pw = total + (lo - before);                      // next place among the first / among the rest
+            for (int i = lo; i < hi; ++i) { if (cold(i)) p.blk_order[pc++] = (uint32_t)i; else p.blk_order[pw++] = (uint32_t)i; }
         }
     }
 }
@@ -631,6 +651,7 @@ struct TauParams {
     int V, S, G;
     int v_off;                // first position of this shard in the whole table (counter-based uniforms are keyed by global indices)
     uint32_t k0, k1, iter;
+    const uint32_t *order;    // [blocks] which block of variants workgroup b works on (null: b) -- finalize_body: blk_order
     int do_fin;               // the last workgroup of the launch finalizes the PREVIOUS sweep (updateTau: no launch between
     FinalParams fin;          // two sweeps could carry it); it reads the other parity of ll_partial / nchange
 };
@@ -645,6 +666,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
         finalize_body(p.fin, fr, fr + 256, reinterpret_cast<int *>(fr + 512), threadIdx.x, 256);
         return;
     }
+    const int bid = p.order ? (int)p.order[blockIdx.x] : (int)blockIdx.x;       // the block of variants this workgroup works on
     constexpr int SP = LPV * NSL;
     constexpr int GPB = 256 / LPV;
     double *gT = reinterpret_cast<double *>(smem_t);   // [G][SP]
@@ -677,7 +699,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
     int n_steps = 0, n_exact = 0;                        // wave-uniform
     const bool screen_on = SWEEP && p.logp == nullptr && p.screen && *p.screen_ctl == 0u;
 
-    for (int v = blockIdx.x * GPB + grp; v < p.V; v += nblk * GPB) {
+    for (int v = bid * GPB + grp; v < p.V; v += nblk * GPB) {
         uint64_t t = p.tau[v];
         int xi[NSL][4];
         double xf[NSL][4];
@@ -841,9 +863,9 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
     __syncthreads();
     if (tid == 0) {
         const uint32_t st_sum = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3], ex_sum = s_cnt[4] + s_cnt[5] + s_cnt[6] + s_cnt[7];
-        p.step_cnt[2 * blockIdx.x] = st_sum;
-        p.step_cnt[2 * blockIdx.x + 1] = screen_on ? ex_sum : (SWEEP ? 0xFFFFFFFFu : 0u);
-        p.ll_partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+        p.step_cnt[2 * bid] = st_sum;
+        p.step_cnt[2 * bid + 1] = screen_on ? ex_sum : (SWEEP ? 0xFFFFFFFFu : 0u);
+        p.ll_partial[bid] = ((red[0] + red[1]) + red[2]) + red[3];
         const int tot = redi[0] + redi[1] + redi[2] + redi[3];
         if (SWEEP && tot) atomicAdd(p.nchange, tot);
     }
@@ -1022,6 +1044,9 @@ static FinalParams make_final(dsm_ctx *c, int nblocks, int it, int star_mode, co
     // the suspension word of the finalized launch's parity: the launch this step may ride in (updateTau) reads the OTHER word,
     // so no launch reads a word it writes and the screening decisions are the same on every run
     p.step_cnt = c->step_cnt + (size_t)slot * 2 * DSM_MAX_GRID; p.sweep_stats = c->sweep_stats; p.screen_ctl = c->screen_ctl + slot;
+    static const bool order_on = !(getenv("DESMAN_HIP_TAU_ORDER") && atoi(getenv("DESMAN_HIP_TAU_ORDER")) == 0);      // A/B switch
+    p.blk_order = nullptr;
+    if (order_on && c->blk_order && nblocks > 0 && nblocks <= DSM_MAX_GRID) { p.blk_order = c->blk_order + (size_t)slot * DSM_MAX_GRID; c->blk_order_n[slot] = nblocks; }
     return p;
 }
 
@@ -1174,6 +1199,7 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
     static const bool no_screen = getenv("DESMAN_HIP_TAU_NO_SCREEN") != nullptr;
     p.screen = (no_screen || !c->tau_screen) ? 0 : 1;
     p.step_cnt = c->step_cnt + (size_t)slot * 2 * DSM_MAX_GRID; p.screen_ctl = c->screen_ctl + slot;
+    p.order = (c->blk_order && c->blk_order_n[slot] == grid) ? c->blk_order + (size_t)slot * DSM_MAX_GRID : nullptr;
     p.do_fin = 0;
     memset(&p.fin, 0, sizeof p.fin);
     if (rider) {

@@ -217,6 +217,31 @@ __device__ __forceinline__ double sweep_candidate(int a, const double (&xf)[NSL]
     return acc;
 }
 
+// the same with the counts as they are stored: (double)(float)count (c_sample_tau.c:164) is formed at each use -- the fp64 step of the
+// sweep is rare and short of registers, not of issue slots
+template <int NSL>
+__device__ __forceinline__ double sweep_candidate_x(int a, const int (&xi)[NSL][4], const double (&st)[NSL][4],
+                                                    const double (&gg)[NSL], const double *__restrict__ eS,
+                                                    const double2 *__restrict__ ltab)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+        double P[4];
+        bool ok = true;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { P[b] = fma(eS[a * 4 + b], gg[j], st[j][b]); ok &= dsm_log_ok(P[b]); }
+        if (__builtin_expect(ok, 1)) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc = fma((double)(float)xi[j][b], dsm_log_core(P[b], ltab), acc);
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc = fma((double)(float)xi[j][b], dsm_log_slow(P[b]), acc);
+        }
+    }
+    return acc;
+}
+
 // normaliseLog4 + sample4 (c_sample_tau.c:48-91) on the four group totals (identical on every lane of the group):
 // exp(0) = 1 and exp(d < -745.2) = 0 exactly, so the usual case needs no exp; the CDF is inverted without the three
 // fp64 divisions: u < ex0/sum <=> u*sum < ex0 (sum in [1,4]; the two forms can disagree only if u lies within
@@ -294,6 +319,67 @@ __device__ __forceinline__ bool sweep_screen(const double (&pre)[NSL][4], const 
     for (int j = 0; j < NSL; ++j)
 #pragma unroll
         for (int bp = 0; bp < 2; ++bp) s32[j][bp] = (f2){(float)pre[j][2 * bp], (float)pre[j][2 * bp + 1]};
+#pragma unroll 4
+    for (int h = g + 1; h < G; ++h) {
+        const f2 *er = reinterpret_cast<const f2 *>(eS32 + (int)((t >> (2 * h)) & 3) * 4);
+        const f2 e01 = er[0], e23 = er[1];
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            const float gm = gT32[h * SP + lig + j * LPV];
+            const f2 gm2 = (f2){gm, gm};
+            s32[j][0] = __builtin_elementwise_fma(e01, gm2, s32[j][0]);
+            s32[j][1] = __builtin_elementwise_fma(e23, gm2, s32[j][1]);
+        }
+    }
+    const f2 *e2 = reinterpret_cast<const f2 *>(eS32);               // [a][bp], then the column minima [bp]
+    f2 acc2[4] = {(f2){0.0f, 0.0f}, (f2){0.0f, 0.0f}, (f2){0.0f, 0.0f}, (f2){0.0f, 0.0f}};
+    float lbmin = 1.0f;
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+        const float g1 = gT32[g * SP + lig + j * LPV];
+        const f2 g2 = (f2){g1, g1};
+#pragma unroll
+        for (int bp = 0; bp < 2; ++bp) {
+            const f2 lb = __builtin_elementwise_fma(e2[8 + bp], g2, s32[j][bp]);     // smallest mixture value any candidate sees
+            lbmin = fminf(lbmin, fminf(lb.x, lb.y));
+            const f2 xs = (f2){(float)xi[j][2 * bp], (float)xi[j][2 * bp + 1]};      // the reference's (float)count
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f2 P = __builtin_elementwise_fma(e2[a * 2 + bp], g2, s32[j][bp]);
+                const f2 lg = (f2){__builtin_amdgcn_logf(P.x), __builtin_amdgcn_logf(P.y)};
+                acc2[a] = __builtin_elementwise_fma(xs, lg, acc2[a]);
+            }
+        }
+    }
+    float c32[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) c32[a] = acc2[a].x + acc2[a].y;
+    if (!(lbmin >= 1.0e-30f)) c32[0] = __builtin_nanf("");          // poisons the totals of the whole group
+    group_allreduce_sum4_f32<LPV>(c32[0], c32[1], c32[2], c32[3]);    // log2 units
+    best = 0;
+    float m = c32[0];
+#pragma unroll
+    for (int a = 1; a < 4; ++a) if (c32[a] > m) { m = c32[a]; best = a; }
+    const float need = 93.0f + 1.3e-4f * fabsf(m);                   // (64 + 2^-13 |l|) / ln 2
+    bool cert = (uw != 0u) && (fabsf(m) < 3.0e38f);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) cert = cert && (a == best || m - c32[a] > need);
+    return cert;
+}
+
+// the same from a prefix carried in fp32 ([sample slot][base pair]): the register-lean form of the sweep (kernels_gibbs.hip: tau_body, LEAN)
+typedef float dsm_f2 __attribute__((ext_vector_type(2)));
+template <int LPV, int NSL>
+__device__ __forceinline__ bool sweep_screen32(const dsm_f2 (&pre32)[NSL][2], const int (&xi)[NSL][4], uint64_t t, int g, int G, int lig,
+                                             uint32_t uw, const float *__restrict__ gT32, const float *__restrict__ eS32, int &best)
+{
+    constexpr int SP = LPV * NSL;
+    typedef dsm_f2 f2;
+    f2 s32[NSL][2];
+#pragma unroll
+    for (int j = 0; j < NSL; ++j)
+#pragma unroll
+        for (int bp = 0; bp < 2; ++bp) s32[j][bp] = pre32[j][bp];
 #pragma unroll 4
     for (int h = g + 1; h < G; ++h) {
         const f2 *er = reinterpret_cast<const f2 *>(eS32 + (int)((t >> (2 * h)) & 3) * 4);

@@ -666,6 +666,11 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
         finalize_body(p.fin, fr, fr + 256, reinterpret_cast<int *>(fr + 512), threadIdx.x, 256);
         return;
     }
+#ifdef TAU_NO_LEAN
+    constexpr bool LEAN = false;
+#else
+    constexpr bool LEAN = (NSL == 3) && (LPV >= 32) && SWEEP;       // the register-lean form of the sweep (below)
+#endif
     const int bid = p.order ? (int)p.order[blockIdx.x] : (int)blockIdx.x;       // the block of variants this workgroup works on
     constexpr int SP = LPV * NSL;
     constexpr int GPB = 256 / LPV;
@@ -702,15 +707,17 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
     for (int v = bid * GPB + grp; v < p.V; v += nblk * GPB) {
         uint64_t t = p.tau[v];
         int xi[NSL][4];
-        double xf[NSL][4];
+        double xf[LEAN ? 1 : NSL][4];
 #pragma unroll
         for (int j = 0; j < NSL; ++j) {
             const int s = lig + j * LPV;
             int4 c = make_int4(0, 0, 0, 0);
             if (s < S) c = reinterpret_cast<const int4 *>(p.cnt_vs)[(size_t)v * S + s];
             xi[j][0] = c.x; xi[j][1] = c.y; xi[j][2] = c.z; xi[j][3] = c.w;
+            if constexpr (!LEAN) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) xf[j][b] = (double)(float)xi[j][b];   // c_sample_tau.c:164
+                for (int b = 0; b < 4; ++b) xf[j][b] = (double)(float)xi[j][b];   // c_sample_tau.c:164
+            }
         }
         if (SWEEP) {
             double l_cur = 0.0;                  // log-prob of the variant's current configuration
@@ -720,18 +727,30 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
             // the same sums -- for G(G+1)/2 instead of G(G-1) links per variant.  (The links are fma(eta, gamma, acc)
             // where c_sample_tau.c:143-149 multiplies and adds: the sums agree with the reference to rounding, not bit
             // for bit; see DESIGN.md sec. 4 for what that means for the draws.)
-            double pre[NSL][4];
+            // LEAN (three samples per lane of a 32- or 64-lane group: 64 < S <= 96, 128 < S <= 192): the prefix is carried in fp32 only -- all the screening pass reads -- and the rare fp64
+            // step re-does its links h < g (same operations, same order, same sums) and evaluates one candidate at a time: with the fp64
+            // prefix and the unrolled fp64 step live, that shape needs 219 VGPRs = two wavefronts per SIMD; lean it fits 168 = three
+            // (same box, lean vs not: 50k x 96 x 12 0.722 vs 0.744 ms per iteration, x 96 x 6 0.480 vs 0.508, 10k x 192 x 8 0.237 vs 0.243).  At two
+            // samples per lane, and at 16 lanes per variant (S <= 48: 0.167 vs 0.163), the same trade loses.
+            double pre[LEAN ? 1 : NSL][4];
+            dsm_f2 pre32[LEAN ? NSL : 1][2];
 #pragma unroll
-            for (int j = 0; j < NSL; ++j)
+            for (int j = 0; j < NSL; ++j) {
+                if constexpr (LEAN) { pre32[j][0] = (dsm_f2){0.0f, 0.0f}; pre32[j][1] = (dsm_f2){0.0f, 0.0f}; }
+                else {
 #pragma unroll
-                for (int b = 0; b < 4; ++b) pre[j][b] = 0.0;
+                    for (int b = 0; b < 4; ++b) pre[j][b] = 0.0;
+                }
+            }
             bool have_cur = false;               // l_cur is the log-probability of the current configuration (wave-uniform)
             n_steps += G;
             const bool screen = screen_on;
             for (int g = 0; g < G; ++g) {
                 double gg[NSL];
+                if constexpr (!LEAN) {
 #pragma unroll
-                for (int j = 0; j < NSL; ++j) gg[j] = gT[g * SP + lig + j * LPV];
+                    for (int j = 0; j < NSL; ++j) gg[j] = gT[g * SP + lig + j * LPV];
+                }
                 const int told = (int)((t >> (2 * g)) & 3);
                 uint32_t uw;
                 const size_t ui = (size_t)v * G + g;
@@ -755,10 +774,66 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                     // outside fp32's normal range, NaN -- is decided by the fp64 code.  More than 99 % of the steps of a
                     // converged chain and ~97 % right after the NMFT initialisation take the short way.
                     int best = 0;
-                    const bool cert = sweep_screen<LPV, NSL>(pre, xi, t, g, G, lig, uw, gT32, eS32, best);
+                    bool cert;
+                    if constexpr (LEAN) cert = sweep_screen32<LPV, NSL>(pre32, xi, t, g, G, lig, uw, gT32, eS32, best);
+                    else cert = sweep_screen<LPV, NSL>(pre, xi, t, g, G, lig, uw, gT32, eS32, best);
                     if (__builtin_amdgcn_ballot_w64(cert) == __builtin_amdgcn_ballot_w64(true)) { tn = best; decided = true; }
                 }
                 if (!decided) {
+                const bool reuse = have_cur;
+                double l[4];
+                if constexpr (LEAN) {
+                double st[NSL][4];
+#pragma unroll
+                for (int j = 0; j < NSL; ++j) {
+                    gg[j] = gT[g * SP + lig + j * LPV];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) st[j][b] = 0.0;
+                }
+#pragma unroll 1
+                for (int h = 0; h < G; ++h) {
+                    if (h == g) continue;
+                    const double *er = eS + (int)((t >> (2 * h)) & 3) * 4;
+                    const double e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
+#pragma unroll
+                    for (int j = 0; j < NSL; ++j) {
+                        const double gm = gT[h * SP + lig + j * LPV];
+                        st[j][0] = fma(e0, gm, st[j][0]);
+                        st[j][1] = fma(e1, gm, st[j][1]);
+                        st[j][2] = fma(e2, gm, st[j][2]);
+                        st[j][3] = fma(e3, gm, st[j][3]);
+                    }
+                }
+                // The candidate a == told is the variant's current configuration; when its log-probability is known from
+                // the previous step (the candidate chosen there, evaluated in fp64) only the three others need their
+                // 4*NSL logs.  One candidate at a time (a loop that is not unrolled): this path is rare, and what it keeps live
+                // decides whether the whole sweep runs three or four wavefronts per SIMD.
+                if constexpr (LPV == 64) {
+                    // one variant per wavefront: told is wave-uniform, the current candidate is branched around
+                    double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+#pragma unroll 1
+                    for (int a = 0; a < 4; ++a) {
+                        if (reuse && a == told) continue;
+                        const double c = sweep_candidate_x<NSL>(a, xi, st, gg, eS, ltab);
+                        c0 = (a == 0) ? c : c0; c1 = (a == 1) ? c : c1; c2 = (a == 2) ? c : c2; c3 = (a == 3) ? c : c3;
+                    }
+                    l[0] = c0; l[1] = c1; l[2] = c2; l[3] = c3;
+                    group_allreduce_sum4<LPV>(l[0], l[1], l[2], l[3]);
+                } else {
+                    // several variants per wavefront, each with its own current base: every group evaluates its
+                    // candidates in the rotated order told+1, told+2, told+3 (no divergence), the sums are put
+                    // back in base order afterwards (pure data movement: same values)
+                    const int rot = reuse ? told + 1 : 0;
+                    double cv[4] = {0.0, 0.0, 0.0, 0.0};
+                    const int ncand = reuse ? 3 : 4;                // wave-uniform
+#pragma unroll 1
+                    for (int i = 0; i < ncand; ++i) {
+                        const double c = sweep_candidate_x<NSL>((rot + i) & 3, xi, st, gg, eS, ltab);
+                        cv[0] = (i == 0) ? c : cv[0]; cv[1] = (i == 1) ? c : cv[1]; cv[2] = (i == 2) ? c : cv[2]; cv[3] = (i == 3) ? c : cv[3];
+                    }
+                    group_allreduce_sum4_unrotate<LPV>(cv, rot, l);
+                }
+                } else {
                 double st[NSL][4];
 #pragma unroll
                 for (int j = 0; j < NSL; ++j)
@@ -780,8 +855,6 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                 // The candidate a == told is the variant's current configuration; when its log-probability is known from
                 // the previous step (the candidate chosen there, evaluated in fp64) only the three others need their
                 // 4*NSL logs.
-                const bool reuse = have_cur;
-                double l[4];
                 if constexpr (LPV == 64) {
                     // one variant per wavefront: told is wave-uniform, the current candidate is branched around
 #pragma unroll
@@ -802,6 +875,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                     if (!reuse) cv[3] = sweep_candidate<NSL>(3, xf, st, gg, eS, ltab);       // wave-uniform
                     group_allreduce_sum4_unrotate<LPV>(cv, rot, l);
                 }
+                }
                 if (reuse) {
 #pragma unroll
                     for (int a = 0; a < 4; ++a) if (a == told) l[a] = l_cur;
@@ -817,7 +891,17 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                 n_exact += !decided;
                 nchg += (lig == 0) & (tn != told);
                 t = (t & ~(3ull << (2 * g))) | ((uint64_t)tn << (2 * g));
-                {                                                   // link g of the chain, with the new base
+                if constexpr (LEAN) {                                // link g of the chain, with the new base
+                    const dsm_f2 *er = reinterpret_cast<const dsm_f2 *>(eS32 + tn * 4);
+                    const dsm_f2 e01 = er[0], e23 = er[1];
+#pragma unroll
+                    for (int j = 0; j < NSL; ++j) {
+                        const float gm = gT32[g * SP + lig + j * LPV];
+                        const dsm_f2 gm2 = (dsm_f2){gm, gm};
+                        pre32[j][0] = __builtin_elementwise_fma(e01, gm2, pre32[j][0]);
+                        pre32[j][1] = __builtin_elementwise_fma(e23, gm2, pre32[j][1]);
+                    }
+                } else {
                     const double *er = eS + tn * 4;
                     const double e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
 #pragma unroll
@@ -871,11 +955,17 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
     }
 }
 
+// three samples per lane, 32 or 64 lanes per variant: the lean form of the sweep at three wavefronts per SIMD (tau_body: LEAN)
+#ifdef TAU_NO_LEAN
+#define TAU_MIN_WGS(LPV, NSL) 1
+#else
+#define TAU_MIN_WGS(LPV, NSL) (((NSL) == 3 && (LPV) >= 32) ? 3 : 1)
+#endif
 template <int LPV, int NSL, bool SWEEP, bool LL>
-__global__ __launch_bounds__(256) void tau_kernel(TauParams p) { tau_body<LPV, NSL, SWEEP, LL>(p); }
+__global__ __launch_bounds__(256, TAU_MIN_WGS(LPV, NSL)) void tau_kernel(TauParams p) { tau_body<LPV, NSL, SWEEP, LL>(p); }
 // K chains of one shape, chain = blockIdx.y (dsm_host.h: BatchCtl)
 template <int LPV, int NSL, bool SWEEP, bool LL>
-__global__ __launch_bounds__(256) void tau_kernel_b(BatchArgs<TauParams> b) { tau_body<LPV, NSL, SWEEP, LL>(b.p[blockIdx.y]); }
+__global__ __launch_bounds__(256, TAU_MIN_WGS(LPV, NSL)) void tau_kernel_b(BatchArgs<TauParams> b) { tau_body<LPV, NSL, SWEEP, LL>(b.p[blockIdx.y]); }
 static_assert(sizeof(BatchArgs<TauParams>) <= 4096, "kernarg segment");
 
 // test hook: the hardware log2 the screening pass relies on (its error bound is pinned by tests/test_gpu_edges.py)

@@ -14,6 +14,7 @@ shapes += [(int(rs.randint(1, 700)), int(rs.randint(1, 140)), int(rs.randint(1, 
 bad = 0
 for V, S, G in shapes:
     for spec in (2, 3, 1):
+        if G > 16 and spec >= 2: continue              # the aggregated specifications stop at 16 haplotypes
         ctx = _lib.Context(0)
         try:
             tp.test_gibbs_update_is_self_consistent_with_oracle.__wrapped__(ctx, V, S, G, 3, spec) if hasattr(tp.test_gibbs_update_is_self_consistent_with_oracle, "__wrapped__") else tp.test_gibbs_update_is_self_consistent_with_oracle(ctx, V, S, G, 3, spec)

@@ -656,6 +656,15 @@ struct TauParams {
     FinalParams fin;          // two sweeps could carry it); it reads the other parity of ll_partial / nchange
 };
 
+// which shapes of the sweep run its register-lean form (tau_body: LEAN): three, six and eight samples per lane of a 32- or 64-lane group.
+// Measured against the fp64-prefix form on one box (scripts/dbg/lean_ab.sh), ms per iteration: 32 x 3 0.722 vs 0.744 (50k x 96 x 12),
+// 64 x 3 0.237 vs 0.243, 64 x 6 0.711 vs 0.819 (10k x 300 x 8), 64 x 8 0.570 vs 0.626 (5k x 512 x 8); it loses at 16 x 3 (0.167 vs 0.163)
+// and 64 x 4 (0.551 vs 0.530), and at two samples per lane.
+#ifdef TAU_NO_LEAN
+#define TAU_LEAN(LPV, NSL) false
+#else
+#define TAU_LEAN(LPV, NSL) ((LPV) >= 32 && ((NSL) == 3 || (NSL) == 6 || (NSL) == 8))
+#endif
 template <int LPV, int NSL, bool SWEEP, bool LL>
 __device__ __forceinline__ void tau_body(const TauParams &p)
 {
@@ -666,11 +675,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
         finalize_body(p.fin, fr, fr + 256, reinterpret_cast<int *>(fr + 512), threadIdx.x, 256);
         return;
     }
-#ifdef TAU_NO_LEAN
-    constexpr bool LEAN = false;
-#else
-    constexpr bool LEAN = (NSL == 3) && (LPV >= 32) && SWEEP;       // the register-lean form of the sweep (below)
-#endif
+    constexpr bool LEAN = TAU_LEAN(LPV, NSL) && SWEEP;       // the register-lean form of the sweep (below)
     const int bid = p.order ? (int)p.order[blockIdx.x] : (int)blockIdx.x;       // the block of variants this workgroup works on
     constexpr int SP = LPV * NSL;
     constexpr int GPB = 256 / LPV;
@@ -956,11 +961,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
 }
 
 // three samples per lane, 32 or 64 lanes per variant: the lean form of the sweep at three wavefronts per SIMD (tau_body: LEAN)
-#ifdef TAU_NO_LEAN
-#define TAU_MIN_WGS(LPV, NSL) 1
-#else
-#define TAU_MIN_WGS(LPV, NSL) (((NSL) == 3 && (LPV) >= 32) ? 3 : 1)
-#endif
+#define TAU_MIN_WGS(LPV, NSL) (TAU_LEAN(LPV, NSL) ? ((NSL) == 3 ? 3 : 2) : 1)
 template <int LPV, int NSL, bool SWEEP, bool LL>
 __global__ __launch_bounds__(256, TAU_MIN_WGS(LPV, NSL)) void tau_kernel(TauParams p) { tau_body<LPV, NSL, SWEEP, LL>(p); }
 // K chains of one shape, chain = blockIdx.y (dsm_host.h: BatchCtl)

@@ -9,7 +9,7 @@ from desman_amd import _lib
 import test_gpu_parity as tp
 n_rand = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
-shapes = [(150, S, 4) for S in (1, 2, 16, 17, 32, 33, 48, 64, 65, 96, 97, 128, 129, 200)] + [(260, 24, G) for G in (1, 2, 9, 10, 12, 16, 17)] + [(V, 64, 8) for V in (1, 3, 64, 257)]
+shapes = [(150, S, 4) for S in (1, 2, 16, 17, 32, 33, 48, 64, 65, 96, 97, 128, 129, 192, 193, 200, 256, 257, 300, 384, 385, 512)] + [(260, 24, G) for G in (1, 2, 9, 10, 12, 16, 17)] + [(V, 64, 8) for V in (1, 3, 64, 257)]
 shapes += [(int(rs.randint(1, 700)), int(rs.randint(1, 140)), int(rs.randint(1, 13))) for _ in range(n_rand)]
 bad = 0
 for V, S, G in shapes:

@@ -110,6 +110,7 @@ struct dsm_ctx {
     int *nchange = nullptr;         // device counter
     unsigned long long *sweep_stats = nullptr;   // [2] wavefront-steps of the tau sweeps: run / decided by the fp64 code
     uint32_t *blk_order = nullptr;  // [2 slots][DSM_MAX_GRID] block order of the next sweep of the slot (kernels_gibbs.hip: finalize_body)
+    int tau_resident = 0, tau_resident_key = -1;   // workgroups of the sweep the device holds at once, for (S, G) = key
     int blk_order_n[2] = {0, 0};    // the grid each was made for (0: none yet)
     uint32_t *step_cnt = nullptr;   // [2 slots][DSM_MAX_GRID][2] per-workgroup wavefront-steps of a tau launch: run / left to fp64
     uint32_t *screen_ctl = nullptr; // [4] [0] = sweeps still to run without the screening pass (set by finalize_body)

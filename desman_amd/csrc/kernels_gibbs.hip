@@ -476,10 +476,12 @@ __device__ void finalize_body(const FinalParams &p, double *red, double *redp, i
             auto cold = [&](int i) { const uint32_t b = p.step_cnt[2 * i + 1]; return b != 0u && b != 0xFFFFFFFFu; };
             int nc = 0;
             for (int i = lo; i < hi; ++i) nc += cold(i) ? 1 : 0;
-            cnt[tid] = nc;
+            int incl = nc;                                                  // inclusive scan over the wavefront, then over the wavefronts' totals
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += y; }
+            if ((tid & 63) == 63) cnt[tid >> 6] = incl;
             __syncthreads();
-            int before = 0, total = 0;
-            for (int k = 0; k < nthr; ++k) { const int x = cnt[k]; if (k < tid) before += x; total += x; }
+            int before = incl - nc, total = 0;
+            for (int k = 0; k < nthr / 64; ++k) { const int x = cnt[k]; if (k < (tid >> 6)) before += x; total += x; }
             int pc = before, pw = total + (lo - before);                      // next place among the first / among the rest
             for (int i = lo; i < hi; ++i) { if (cold(i)) p.blk_order[pc++] = (uint32_t)i; else p.blk_order[pw++] = (uint32_t)i; }
         }
@@ -1137,7 +1139,16 @@ static FinalParams make_final(dsm_ctx *c, int nblocks, int it, int star_mode, co
     p.step_cnt = c->step_cnt + (size_t)slot * 2 * DSM_MAX_GRID; p.sweep_stats = c->sweep_stats; p.screen_ctl = c->screen_ctl + slot;
     static const bool order_on = !(getenv("DESMAN_HIP_TAU_ORDER") && atoi(getenv("DESMAN_HIP_TAU_ORDER")) == 0);      // A/B switch
     p.blk_order = nullptr;
-    if (order_on && c->blk_order && nblocks > 0 && nblocks <= DSM_MAX_GRID) { p.blk_order = c->blk_order + (size_t)slot * DSM_MAX_GRID; c->blk_order_n[slot] = nblocks; }
+    // (a launch whose workgroups are all resident at once has no tail to move the long steps out of: the order is left alone and the finalize
+    // step stays short -- at config 2 it rides in a 8 us Dirichlet launch)
+    if (order_on && c->blk_order && nblocks > 0 && nblocks <= DSM_MAX_GRID) {
+        if (c->tau_resident_key != c->S * 64 + c->G) {
+            int launched = 0, resident = 0;
+            if (tau_launch_info(c, &launched, &resident) == DSM_OK) { c->tau_resident = resident; c->tau_resident_key = c->S * 64 + c->G; }
+        }
+        if (c->tau_resident > 0 && nblocks > c->tau_resident) { p.blk_order = c->blk_order + (size_t)slot * DSM_MAX_GRID; c->blk_order_n[slot] = nblocks; }
+        else c->blk_order_n[slot] = 0;
+    }
     return p;
 }
 

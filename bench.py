@@ -2,8 +2,10 @@
 """Headline benchmark: Gibbs iterations/s on synthetic V=10k x S=64, G=8 (BASELINE.json
 configs[2]); one independent chain per GPU (weak scaling), RCCL gather of the fit records.
 
-  python bench.py --gpus 1 --steps 500 --warmup 50
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps 500 --warmup 50        (N > 1: starts its own N ranks, desman_amd/launch.py)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
+
+In both forms the world MUST be N ranks, one per GPU: anything else exits with status 2 and a message, no JSON line.
 
 Prints ONE JSON line on rank 0.  A "step" is one full Gibbs iteration (auxiliary-count
 pass, gamma/eta draws, tau sweep, log-posterior, MAP/trace bookkeeping) of one chain.
@@ -86,6 +88,32 @@ def cpu_baseline(S, G):
 
 
 TRAFFIC_DB = os.path.join(ROOT, "profiles", "pmc_traffic_by_shape.json")
+PROF_NMFT_UPDATES = 200          # NMFT updates scripts/prof_gibbs.py runs before its Gibbs iterations (one factorize call)
+
+
+def nmft_pmc_summary(tj, us_per_update):
+    """NMFT figures out of a pmc_passes() record: HBM-side bytes, matrix-core and VALU instructions PER UPDATE, summed over
+    every nmft_* kernel of the profiled run (the persistent kernel is ONE launch for all its updates, the three-launch path
+    three launches per update: dispatches x per-launch mean / updates covers both), and the share of the launch's SIMD cycles
+    the MFMA pipe was busy: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x update time x 2.4 GHz)."""
+    tot = dict(bytes=0.0, mfma=0.0, busy=0.0, valu=0.0)
+    names = []
+    for k, r in (tj or {}).items():
+        kk = k[5:] if k.startswith("void ") else k
+        if not kk.startswith("nmft_"):
+            continue
+        n = r.get("dispatches") or 0
+        names.append(kk)
+        tot["bytes"] += n * (r.get("bytes_per_launch") or 0.0)
+        tot["mfma"] += n * (r.get("mfma_insts") or 0.0)
+        tot["busy"] += n * (r.get("mfma_busy_cycles") or 0.0)
+        tot["valu"] += n * (r.get("valu_insts") or 0.0)
+    if not names or tot["bytes"] <= 0:
+        return None
+    per = {k: v / PROF_NMFT_UPDATES for k, v in tot.items()}
+    cyc = 1024 * us_per_update * 1e-6 * 2.4e9
+    return dict(traffic=per["bytes"], mfma_insts_per_update=per["mfma"], valu_insts_per_update=per["valu"],
+                mfma_busy_frac=per["busy"] / cyc if cyc > 0 else None, kernels=sorted(names))
 
 
 def shape_key(V, S, G, depth):
@@ -108,7 +136,8 @@ def pmc_passes(V, S, G, depth, iters=30):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     work = tempfile.mkdtemp(prefix="dsm_pmc_", dir="/tmp")
     try:
-        for ctr in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES"]):
+        for ctr in (["FETCH_SIZE"], ["WRITE_SIZE"],
+                    ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES"]):
             d = os.path.join(work, ctr[0])
             cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + ctr + ["--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                    os.path.join(ROOT, "scripts", "prof_gibbs.py"), str(iters), str(V), str(S), str(G), str(depth)]
@@ -126,7 +155,8 @@ def pmc_passes(V, S, G, depth, iters=30):
         fe, wr = mean.get("FETCH_SIZE", 0.0), mean.get("WRITE_SIZE", 0.0)            # KiB per launch
         out[k] = dict(fetch_kib_raw=fe, write_kib_raw=wr, read_bytes_corrected=2.0 * fe * 1024.0, write_bytes=wr * 1024.0,
                       bytes_per_launch=2.0 * fe * 1024.0 + wr * 1024.0, valu_insts=mean.get("SQ_INSTS_VALU"),
-                      valu_active_cycles=mean.get("SQ_ACTIVE_INST_VALU"), dispatches=max(len(v) for v in dd.values()))
+                      valu_active_cycles=mean.get("SQ_ACTIVE_INST_VALU"), dispatches=max(len(v) for v in dd.values()),
+                      mfma_insts=mean.get("SQ_INSTS_MFMA"), mfma_busy_cycles=mean.get("SQ_VALU_MFMA_BUSY_CYCLES"))
     db = {}
     if os.path.exists(TRAFFIC_DB):
         db = json.load(open(TRAFFIC_DB))
@@ -216,8 +246,12 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="extra key `batch`: K chains of this shape in one set of launches "
                     "(dsm_batch_gibbs_update); default 4 chains x at most 100 steps on a single-GPU run, 0/1 = off")
     ap.add_argument("--no-nmft", action="store_true")
-    ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic now: three extra rocprofv3 --pmc passes of this "
-                    "workload (about a minute); without it the figure recorded for this shape in profiles/pmc_traffic_by_shape.json is used")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed call of exactly --steps iterations is made this many times, each "
+                    "between its own barrier + synchronize; ms_per_step is the median call (ms_per_step_repeats has them all)")
+    ap.add_argument("--pmc", dest="pmc", action="store_true", default=None, help="measure roofline.traffic now: three extra rocprofv3 "
+                    "--pmc passes of this workload (about a minute).  Default: on for a single-GPU run when rocprofv3 is on the PATH")
+    ap.add_argument("--no-pmc", dest="pmc", action="store_false", help="skip the PMC passes: roofline.traffic is then read from the "
+                    "record `bench.py --pmc` left for this shape in profiles/pmc_traffic_by_shape.json (said so in traffic_source)")
     ap.add_argument("--counts-npz", default=None,
                     help="real data instead of the synthetic tensor: an .npz with `counts` [V,S,4] (tests/golden/cog0015_counts.npz "
                          "= the reference's complete_example table after its sample filter); V and S come from the file")
@@ -235,15 +269,19 @@ def main():
         return bench_genes(args.genes, 32 if args.S == 64 else args.S, 6 if args.G == 8 else args.G, args.vmax,
                            50 if args.steps == 500 else args.steps, 0 if args.no_cpu_baseline else args.cpu_genes)
 
+    # the world is exactly --gpus ranks (one per GPU) or the run stops here: started by torch.distributed.run with another
+    # WORLD_SIZE -> exit 2; plain process with --gpus N > 1 -> this process becomes that launch (desman_amd/launch.py;
+    # the fan-out of scripts/runDesman.sh:15-21); fewer than N devices -> exit 2.  Never a smaller run under a bigger label.
+    from desman_amd import launch
+    rank, local_rank, world, under_launcher = launch.ensure_world(args.gpus, sys.argv[1:], script=__file__)
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if "RANK" in os.environ:                                     # launched by torch.distributed.run (any N >= 1)
+    if under_launcher:                                           # any N >= 1: RCCL communicator, barrier, MAX all-reduce, gather
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:                   # belt and braces: the process group agrees with --gpus
+            launch._die("bench.py", "process group of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
     dev = local_rank
     torch.cuda.set_device(dev)
 
@@ -317,17 +355,30 @@ def main():
 
     fence()                                          # first collective of the job: communicator set-up happens here, not
     ctx.gibbs_update(args.warmup)                    # between the warm-up steps and the timed ones (an idle GPU clocks down)
-    fence()
-    t0 = time.perf_counter()
-    ctx.gibbs_update(args.steps)                     # returns after the library's stream has drained
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0                    # this rank: common start (barrier) -> its own K steps done
-    fence()                                          # closing barrier + synchronize; the job's time is the MAX over ranks (below),
-                                                     # i.e. what the closing barrier waits for, without the collective's own latency
+    # the timed call: EXACTLY --steps iterations between barrier + synchronize on both sides, the job's time = MAX over ranks.
+    # It is made --repeats times (the process-to-process spread of one 2 ms call is +-4 %): ms_per_step is the MEDIAN call.
+    rep_dt, rep_mine = [], []
+    for _ in range(max(args.repeats, 1)):
+        fence()
+        t0 = time.perf_counter()
+        ctx.gibbs_update(args.steps)                 # returns after the library's stream has drained
+        torch.cuda.synchronize()
+        dt_r = time.perf_counter() - t0              # this rank: common start (barrier) -> its own K steps done
+        fence()                                      # closing barrier + synchronize; the job's time is the MAX over ranks (below),
+        rep_mine.append(dt_r)                        # i.e. what the closing barrier waits for, without the collective's own latency
+        if dist is not None:
+            t = torch.tensor([dt_r], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_r = float(t.item())
+        rep_dt.append(dt_r)
+    dt = float(np.median(rep_dt))
+    # which device every rank bound and how long ITS steps took (median call): the per-rank view behind the MAX
+    me = launch.bound_device_record(rank, local_rank)
+    me["ms_per_step"] = 1e3 * float(np.median(rep_mine)) / args.steps
+    ranks = [me]
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
     tr = ctx.get_trace()
     star = ctx.get_star()
     # the one collective of the path: gather every chain's fit record (lp_star, mean deviance)
@@ -420,12 +471,19 @@ def main():
     traffic, valu = {}, {}
     stats_kname = "stats_agg_kernel" if spec >= 2 else "stats_kernel"
     tj, traffic_source = None, None
+    pmc_error = None
+    if args.pmc is None:                             # default: measure in this run when that is possible
+        import shutil
+        args.pmc = bool(world == 1 and shutil.which("rocprofv3") and not args.counts_npz)
     if not args.counts_npz:
-        if args.pmc and rank == 0:
-            tj = pmc_passes(V, S, G, args.depth_scale)
-            traffic_source = ("measured by this run: three separate rocprofv3 --pmc passes (FETCH_SIZE x 2 per the gfx950 correction + "
-                              "WRITE_SIZE; SQ_INSTS_VALU) of scripts/prof_gibbs.py at this shape")
-        elif os.path.exists(TRAFFIC_DB):
+        if args.pmc and rank == 0 and world == 1:
+            try:
+                tj = pmc_passes(V, S, G, args.depth_scale)
+                traffic_source = ("measured by this run: three separate rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE x 2 per the "
+                                  "gfx950 correction; WRITE_SIZE; the SQ VALU / MFMA group) of scripts/prof_gibbs.py at this shape")
+            except Exception as e:                   # noqa: BLE001 -- a profiler failure must not lose the bench line
+                pmc_error = "%s: %s" % (type(e).__name__, str(e)[-400:])
+        if tj is None and os.path.exists(TRAFFIC_DB):
             tj = json.load(open(TRAFFIC_DB)).get(shape_key(V, S, G, args.depth_scale))
             traffic_source = ("profiles/pmc_traffic_by_shape.json[%s]: recorded by `bench.py --pmc` at this shape (separate rocprofv3 "
                               "--pmc passes: FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE), not measured in this run"
@@ -485,9 +543,24 @@ def main():
                                    % ("synthetic" if not args.counts_npz else "real", V, S, G, " (configs[2])" if (V, S, G) == (10000, 64, 8) else "",
                                       "" if args.depth_scale == 1.0 else ", read depth x%g" % args.depth_scale),
                        "V": V, "S": S, "G": G, "chains": world, "tau_rng": args.rng, "depth_scale": args.depth_scale},
+            "ms_per_step_repeats": {"n": len(rep_dt), "median": 1e3 * dt / args.steps, "min": 1e3 * min(rep_dt) / args.steps,
+                                    "max": 1e3 * max(rep_dt) / args.steps, "all": [1e3 * x / args.steps for x in rep_dt],
+                                    "note": "each repeat = exactly `steps` iterations between barrier + synchronize, MAX over ranks; "
+                                            "ms_per_step and value use the median repeat"},
+            "ranks": sorted(ranks, key=lambda r: r["rank"]),
+            "ms_per_step_per_rank": {"min": min(r["ms_per_step"] for r in ranks), "max": max(r["ms_per_step"] for r in ranks)},
+            "launch": "torch.distributed.run, %d rank(s), backend nccl (RCCL)" % world if dist is not None else "single process, no process group",
             "roofline": roofline, "nmft": nmft,
             "fit_records": [dict(G=int(f[0]), seed=int(f[2]), lp_star=f[3], mean_dev=f[4]) for f in fits],
         }
+        if pmc_error:
+            out["pmc_error"] = pmc_error
+        if nmft is not None:
+            nsum = nmft_pmc_summary(tj, 1e3 * nmft["ms_per_iter"])
+            if nsum:
+                nmft["roofline"].update(traffic=nsum["traffic"], traffic_source=traffic_source,
+                                        mfma_busy_frac=nsum["mfma_busy_frac"], mfma_insts_per_update=nsum["mfma_insts_per_update"],
+                                        valu_insts_per_update=nsum["valu_insts_per_update"], kernels=nsum["kernels"])
         if multi:
             out["chains_per_gpu"] = multi
         if batch:

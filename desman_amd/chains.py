@@ -6,8 +6,10 @@ GPU (torch.distributed; backend "nccl" = RCCL over xGMI, "gloo" on CPU for
 tests), chains assigned by longest-processing-time-first, NO collective on the
 data path, and one all_gather of a fixed-size fit record per chain at the end.
 
-Launch:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-             --master-addr 127.0.0.1 --master-port P -m desman_amd.chains freq.csv ...
+Launch:  python -m desman_amd.chains --gpus N freq.csv ...      (starts its own N ranks: desman_amd/launch.py)
+   or:   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+             --master-addr 127.0.0.1 --master-port P -m desman_amd.chains [--gpus N] freq.csv ...
+With --gpus the world must be exactly N ranks (exit status 2 otherwise); without it the launcher's world is taken as it is.
 """
 import argparse
 import json
@@ -293,16 +295,23 @@ def main(argv=None):
     ap.add_argument("-c", "--concurrency", type=int, default=4, help="chains running at the same time per GPU")
     ap.add_argument("-b", "--batch", type=int, default=1, help="replicate chains of a G value (up to 8) share every kernel "
                     "launch of the Gibbs loop instead of running as separate chains (small tables: several times the throughput)")
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node to spread the chains over (one process each). "
+                    "A plain `desman-sweep --gpus N` starts its own N ranks; under torch.distributed.run the world must be N")
     args = ap.parse_args(argv)
+    from . import launch
+    if args.gpus is None:                                     # the launcher's world as it is (1 for a plain process)
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1")) if "RANK" in os.environ else 1
+    _, local, world, under_launcher = launch.ensure_world(args.gpus, sys.argv[1:] if argv is None else list(argv),
+                                                          module="desman_amd.chains", prog="desman-sweep")
     import pandas as p
     import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if "RANK" in os.environ:
+    if under_launcher:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if dist.get_world_size() != args.gpus:
+            launch._die("desman-sweep", "process group of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
     frame = p.read_csv(args.variant_file, header=0, index_col=0)
     V, S = frame.shape[0], (frame.shape[1] - 1) // 4
     specs = sweep_specs(range(args.gmin, args.gmax + 1), args.reps, V, S)

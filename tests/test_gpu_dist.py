@@ -29,10 +29,28 @@ def _torchrun(args, port, timeout=600):
 
 
 def test_bench_walks_the_rccl_path_with_a_world_of_one():
-    out = _torchrun(["bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--V", "2000", "--S", "16", "--G", "4",
-                     "--no-cpu-baseline", "--no-nmft"], 29731)
+    argv = ["bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--V", "2000", "--S", "16", "--G", "4", "--no-cpu-baseline",
+            "--no-nmft", "--no-pmc", "--repeats", "3"]
+    out = _torchrun(argv, 29731)
     line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["steps"] == 6 and line["scaling"] == "weak"
+    assert line["launch"].startswith("torch.distributed.run, 1 rank") and len(line["ranks"]) == 1
+    assert line["ranks"][0]["rank"] == 0 and line["ranks"][0]["device_index"] == 0 and "MI3" in line["ranks"][0]["name"]
+    rp = line["ms_per_step_repeats"]
+    assert rp["n"] == 3 and rp["min"] <= rp["median"] <= rp["max"] and rp["median"] == line["ms_per_step"]
+    # the same command as a plain process: the same keys (plus the single-GPU extras), no process group
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable] + argv + ["--batch", "0"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    plain = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert set(plain) == set(line) and plain["n_gpus"] == 1 and plain["launch"].startswith("single process")
+    # and more GPUs than this box has: exit status 2, a message, no number (one GPU here)
+    r = subprocess.run([sys.executable] + argv[:1] + ["--gpus", "2"] + argv[3:], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2 and "refusing to run" in r.stderr and "n_gpus" not in r.stdout
+    out8 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                           "--master-port", "29735"] + argv[:1] + ["--gpus", "8"] + argv[3:], env=dict(env, MASTER_ADDR="127.0.0.1"),
+                          cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out8.returncode != 0 and "world of 1 rank" in out8.stderr and "n_gpus" not in out8.stdout
     assert line["value"] > 0 and line["ms_per_step"] > 0
     assert len(line["fit_records"]) == 1 and line["fit_records"][0]["seed"] == 0          # the all_gather'ed record of rank 0
     assert np.isfinite(line["fit_records"][0]["lp_star"]) and "batch" not in line        # N-GPU runs time the one chain only

@@ -1,0 +1,85 @@
+"""`--gpus N` is real: a program either runs as exactly N ranks or exits non-zero saying why -- it never prints
+an N = 1 number under an N > 1 request.  The fan-out replaced: /root/reference scripts/runDesman.sh:15-21 (N background jobs)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from desman_amd import launch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _clean_env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="1", **kw)
+    return env
+
+
+def test_ensure_world_cases(monkeypatch):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    assert launch.ensure_world(1, [], script="bench.py") == (0, 0, 1, False)              # plain process, one GPU
+    with pytest.raises(SystemExit) as e:                                                   # more GPUs asked for than there are
+        launch.ensure_world(4, [], script="bench.py", n_visible=2)
+    assert e.value.code == launch.EXIT_BAD_WORLD
+    with pytest.raises(SystemExit):
+        launch.ensure_world(0, [], script="bench.py")
+    seen = {}
+
+    def fake_exec(exe, cmd, env):
+        seen.update(exe=exe, cmd=cmd, env=env)
+        raise KeyboardInterrupt                                                            # execve does not return
+    with pytest.raises(KeyboardInterrupt):
+        launch.ensure_world(4, ["--gpus", "4", "--steps", "7"], script="bench.py", n_visible=8, _exec=fake_exec)
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == [os.path.abspath("bench.py"), "--gpus", "4", "--steps", "7"]          # argv forwarded unchanged
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["MASTER_ADDR"] == "127.0.0.1"
+    with pytest.raises(KeyboardInterrupt):
+        launch.ensure_world(2, ["x.csv", "--gpus", "2"], module="desman_amd.chains", n_visible=2, _exec=fake_exec)
+    assert seen["cmd"][-5:] == ["-m", "desman_amd.chains", "x.csv", "--gpus", "2"] and ROOT in seen["env"]["PYTHONPATH"].split(os.pathsep)
+    # started by a launcher: the world must be what --gpus says
+    monkeypatch.setenv("RANK", "1"); monkeypatch.setenv("LOCAL_RANK", "1"); monkeypatch.setenv("WORLD_SIZE", "2")
+    assert launch.ensure_world(2, [], script="bench.py") == (1, 1, 2, True)
+    with pytest.raises(SystemExit) as e:
+        launch.ensure_world(8, [], script="bench.py")
+    assert e.value.code == launch.EXIT_BAD_WORLD
+
+
+@pytest.mark.parametrize("prog", [["bench.py"], ["-m", "desman_amd.chains", "no_such.csv"], ["bin/desman-sweep", "no_such.csv"]])
+def test_gpus_2_on_a_box_with_fewer_devices_exits_nonzero_without_a_number(prog):
+    """this container has no GPU: `--gpus 2` must stop with status 2 and a message, and print no JSON line"""
+    r = subprocess.run([sys.executable] + prog + ["--gpus", "2"], cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == launch.EXIT_BAD_WORLD, (r.returncode, r.stderr[-500:])
+    assert "--gpus 2 asked for" in r.stderr and "refusing to run" in r.stderr
+    assert "n_gpus" not in r.stdout and "{" not in r.stdout
+
+
+@pytest.mark.parametrize("prog", [["bench.py"], ["-m", "desman_amd.chains", "no_such.csv"]])
+def test_world_that_disagrees_with_gpus_exits_nonzero(prog):
+    """started as ONE rank by a launcher but asked for 8 GPUs (the case the round-3 bench answered with `n_gpus: 1`)"""
+    env = _clean_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29977")
+    r = subprocess.run([sys.executable] + prog + ["--gpus", "8"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == launch.EXIT_BAD_WORLD
+    assert "world of 1 rank" in r.stderr and "n_gpus" not in r.stdout
+
+
+def test_plain_process_with_gpus_2_becomes_two_real_ranks():
+    """the real execve path on CPU: the worker asks for 2 'GPUs' (pretending 2 are visible), replaces itself by
+    torch.distributed.run with 2 ranks, the ranks meet over gloo and rank 0 reports both"""
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_launch_worker.py"), "--gpus", "2", "--pretend-visible", "2", "--tag", "t1"],
+                       cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["under_launcher"] and line["tag"] == "t1"
+    assert sorted(x["rank"] for x in line["ranks"]) == [0, 1] and len({x["pid"] for x in line["ranks"]}) == 2
+    # the same program as a plain one-GPU process: same keys, no launcher
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_launch_worker.py"), "--gpus", "1"], cwd=ROOT, env=_clean_env(),
+                       capture_output=True, text=True, timeout=300)
+    one = json.loads(r.stdout.strip().splitlines()[-1])
+    assert one["n_gpus"] == 1 and not one["under_launcher"] and set(one) == set(line)

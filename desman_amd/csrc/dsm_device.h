@@ -217,10 +217,10 @@ __device__ __forceinline__ double sweep_candidate(int a, const double (&xf)[NSL]
     return acc;
 }
 
-// the same with the counts as they are stored: (double)(float)count (c_sample_tau.c:164) is formed at each use -- the fp64 step of the
-// sweep is rare and short of registers, not of issue slots
+// the same with the counts as the lean sweep keeps them, (float)count: the reference's (double)(float)count (c_sample_tau.c:164) is
+// formed at each use -- the fp64 step of the sweep is rare and short of registers, not of issue slots
 template <int NSL>
-__device__ __forceinline__ double sweep_candidate_x(int a, const int (&xi)[NSL][4], const double (&st)[NSL][4],
+__device__ __forceinline__ double sweep_candidate_x(int a, const float (&xi)[NSL][4], const double (&st)[NSL][4],
                                                     const double (&gg)[NSL], const double *__restrict__ eS,
                                                     const double2 *__restrict__ ltab)
 {
@@ -231,12 +231,16 @@ __device__ __forceinline__ double sweep_candidate_x(int a, const int (&xi)[NSL][
         bool ok = true;
 #pragma unroll
         for (int b = 0; b < 4; ++b) { P[b] = fma(eS[a * 4 + b], gg[j], st[j][b]); ok &= dsm_log_ok(P[b]); }
+        // (the empty asm keeps the conversion HERE: hoisted out of the haplotype loop, the twelve doubles would live across the hot path)
+        float x4[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { x4[b] = xi[j][b]; asm volatile("" : "+v"(x4[b])); }
         if (__builtin_expect(ok, 1)) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc = fma((double)(float)xi[j][b], dsm_log_core(P[b], ltab), acc);
+            for (int b = 0; b < 4; ++b) acc = fma((double)x4[b], dsm_log_core(P[b], ltab), acc);
         } else {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc = fma((double)(float)xi[j][b], dsm_log_slow(P[b]), acc);
+            for (int b = 0; b < 4; ++b) acc = fma((double)x4[b], dsm_log_slow(P[b]), acc);
         }
     }
     return acc;
@@ -370,7 +374,7 @@ __device__ __forceinline__ bool sweep_screen(const double (&pre)[NSL][4], const 
 // the same from a prefix carried in fp32 ([sample slot][base pair]): the register-lean form of the sweep (kernels_gibbs.hip: tau_body, LEAN)
 typedef float dsm_f2 __attribute__((ext_vector_type(2)));
 template <int LPV, int NSL>
-__device__ __forceinline__ bool sweep_screen32(const dsm_f2 (&pre32)[NSL][2], const int (&xi)[NSL][4], uint64_t t, int g, int G, int lig,
+__device__ __forceinline__ bool sweep_screen32(const dsm_f2 (&pre32)[NSL][2], const float (&xi)[NSL][4], uint64_t t, int g, int G, int lig,
                                              uint32_t uw, const float *__restrict__ gT32, const float *__restrict__ eS32, int &best)
 {
     constexpr int SP = LPV * NSL;
@@ -403,7 +407,7 @@ __device__ __forceinline__ bool sweep_screen32(const dsm_f2 (&pre32)[NSL][2], co
         for (int bp = 0; bp < 2; ++bp) {
             const f2 lb = __builtin_elementwise_fma(e2[8 + bp], g2, s32[j][bp]);     // smallest mixture value any candidate sees
             lbmin = fminf(lbmin, fminf(lb.x, lb.y));
-            const f2 xs = (f2){(float)xi[j][2 * bp], (float)xi[j][2 * bp + 1]};      // the reference's (float)count
+            const f2 xs = (f2){xi[j][2 * bp], xi[j][2 * bp + 1]};                    // the reference's (float)count, kept as such
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const f2 P = __builtin_elementwise_fma(e2[a * 2 + bp], g2, s32[j][bp]);

@@ -665,7 +665,11 @@ struct TauParams {
 #ifdef TAU_NO_LEAN
 #define TAU_LEAN(LPV, NSL) false
 #else
+#ifdef TAU_LEAN2          /* experiment: the lean form at two samples per lane too, four wavefronts per SIMD */
+#define TAU_LEAN(LPV, NSL) ((LPV) >= 32 && ((NSL) == 2 || (NSL) == 3 || (NSL) == 6 || (NSL) == 8))
+#else
 #define TAU_LEAN(LPV, NSL) ((LPV) >= 32 && ((NSL) == 3 || (NSL) == 6 || (NSL) == 8))
+#endif
 #endif
 template <int LPV, int NSL, bool SWEEP, bool LL>
 __device__ __forceinline__ void tau_body(const TauParams &p)
@@ -713,15 +717,25 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
 
     for (int v = bid * GPB + grp; v < p.V; v += nblk * GPB) {
         uint64_t t = p.tau[v];
-        int xi[NSL][4];
+        // LEAN keeps the counts of the sweep as (float)count only (12 registers instead of 24 at three samples per lane: the
+        // screening pass multiplies by exactly that, the rare fp64 step by (double)(float)count, c_sample_tau.c:164) and the
+        // likelihood epilogue, which needs the integers, loads the slab again -- an L2 hit a few microseconds after the first
+        // load.  With both forms live across the haplotype loop the compiler spilled per variant (round 3: 94 MB of scratch
+        // write-back per sweep at 50k x 96 x 12).
+        int xi[LEAN ? 1 : NSL][4];
+        float xs[LEAN ? NSL : 1][4];
         double xf[LEAN ? 1 : NSL][4];
 #pragma unroll
         for (int j = 0; j < NSL; ++j) {
-            const int s = lig + j * LPV;
+            int ligl = lig;
+            if constexpr (LEAN) asm volatile("" : "+v"(ligl));      // the slab's address is formed afresh, not kept in a register pair
+            const int s = ligl + j * LPV;
             int4 c = make_int4(0, 0, 0, 0);
             if (s < S) c = reinterpret_cast<const int4 *>(p.cnt_vs)[(size_t)v * S + s];
-            xi[j][0] = c.x; xi[j][1] = c.y; xi[j][2] = c.z; xi[j][3] = c.w;
-            if constexpr (!LEAN) {
+            if constexpr (LEAN) {
+                xs[j][0] = (float)c.x; xs[j][1] = (float)c.y; xs[j][2] = (float)c.z; xs[j][3] = (float)c.w;
+            } else {
+                xi[j][0] = c.x; xi[j][1] = c.y; xi[j][2] = c.z; xi[j][3] = c.w;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) xf[j][b] = (double)(float)xi[j][b];   // c_sample_tau.c:164
             }
@@ -734,11 +748,16 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
             // the same sums -- for G(G+1)/2 instead of G(G-1) links per variant.  (The links are fma(eta, gamma, acc)
             // where c_sample_tau.c:143-149 multiplies and adds: the sums agree with the reference to rounding, not bit
             // for bit; see DESIGN.md sec. 4 for what that means for the draws.)
-            // LEAN (three samples per lane of a 32- or 64-lane group: 64 < S <= 96, 128 < S <= 192): the prefix is carried in fp32 only -- all the screening pass reads -- and the rare fp64
-            // step re-does its links h < g (same operations, same order, same sums) and evaluates one candidate at a time: with the fp64
-            // prefix and the unrolled fp64 step live, that shape needs 219 VGPRs = two wavefronts per SIMD; lean it fits 168 = three
-            // (same box, lean vs not: 50k x 96 x 12 0.722 vs 0.744 ms per iteration, x 96 x 6 0.480 vs 0.508, 10k x 192 x 8 0.237 vs 0.243).  At two
-            // samples per lane, and at 16 lanes per variant (S <= 48: 0.167 vs 0.163), the same trade loses.
+            // LEAN (three, six, eight samples per lane of a 32- or 64-lane group): the prefix is carried in fp32 only -- all the screening
+            // pass reads -- the counts are kept as (float)count, and the rare fp64 step re-does its links h < g (same operations, same
+            // order, same sums), converts its counts at each use and evaluates one candidate at a time: with the fp64 prefix and the
+            // unrolled fp64 step live, three samples per lane need 219 VGPRs = two wavefronts per SIMD; lean they fit 160 = three, with
+            // NO scratch (round 3's form spilled 23 registers and stored two of them per variant: 94 MB of scratch write-back per sweep
+            // at 50k x 96 x 12; profiles/r04_kernel_regs.txt).  Same box, lean vs not, ms per iteration: 50k x 96 x 12 0.683 (round 3's
+            // lean form 0.722) vs 0.744, x 96 x 6 0.480 vs 0.508, 10k x 192 x 8 0.225 vs 0.243.  At two samples per lane the lean form at
+            // FOUR wavefronts per SIMD (-DTAU_LEAN2: 128 VGPRs, the loop's accumulators spilled per variant) measures 104.2 vs 103.1 us
+            // per iteration at config 3 (sweep 39.2 vs 37.7 us): not used; at 16 lanes per variant (S <= 48: 0.167 vs 0.163) the same
+            // trade loses as well.
             double pre[LEAN ? 1 : NSL][4];
             dsm_f2 pre32[LEAN ? NSL : 1][2];
 #pragma unroll
@@ -782,7 +801,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                     // converged chain and ~97 % right after the NMFT initialisation take the short way.
                     int best = 0;
                     bool cert;
-                    if constexpr (LEAN) cert = sweep_screen32<LPV, NSL>(pre32, xi, t, g, G, lig, uw, gT32, eS32, best);
+                    if constexpr (LEAN) cert = sweep_screen32<LPV, NSL>(pre32, xs, t, g, G, lig, uw, gT32, eS32, best);
                     else cert = sweep_screen<LPV, NSL>(pre, xi, t, g, G, lig, uw, gT32, eS32, best);
                     if (__builtin_amdgcn_ballot_w64(cert) == __builtin_amdgcn_ballot_w64(true)) { tn = best; decided = true; }
                 }
@@ -821,7 +840,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
 #pragma unroll 1
                     for (int a = 0; a < 4; ++a) {
                         if (reuse && a == told) continue;
-                        const double c = sweep_candidate_x<NSL>(a, xi, st, gg, eS, ltab);
+                        const double c = sweep_candidate_x<NSL>(a, xs, st, gg, eS, ltab);
                         c0 = (a == 0) ? c : c0; c1 = (a == 1) ? c : c1; c2 = (a == 2) ? c : c2; c3 = (a == 3) ? c : c3;
                     }
                     l[0] = c0; l[1] = c1; l[2] = c2; l[3] = c3;
@@ -835,7 +854,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                     const int ncand = reuse ? 3 : 4;                // wave-uniform
 #pragma unroll 1
                     for (int i = 0; i < ncand; ++i) {
-                        const double c = sweep_candidate_x<NSL>((rot + i) & 3, xi, st, gg, eS, ltab);
+                        const double c = sweep_candidate_x<NSL>((rot + i) & 3, xs, st, gg, eS, ltab);
                         cv[0] = (i == 0) ? c : cv[0]; cv[1] = (i == 1) ? c : cv[1]; cv[2] = (i == 2) ? c : cv[2]; cv[3] = (i == 3) ? c : cv[3];
                     }
                     group_allreduce_sum4_unrotate<LPV>(cv, rot, l);
@@ -920,12 +939,28 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                     }
                 }
             }
-            if (lig == 0) p.tau[v] = t;
+            if constexpr (LEAN) {
+                int vv = v;
+                asm volatile("" : "+v"(vv));                 // &tau[v] formed afresh: it was spilled across the haplotype loop
+                if (lig == 0) p.tau[vv] = t;
+            } else if (lig == 0) p.tau[v] = t;
         }
         if (lig == 0 && p.trace) p.trace[v] = t;
         if (LL) {
 #pragma unroll
             for (int j = 0; j < NSL; ++j) {
+                int xl[4];                                   // this slab's counts as integers
+                if constexpr (LEAN) {
+                    int vv = v, ligl = lig;
+                    asm volatile("" : "+v"(vv), "+v"(ligl)); // a second load, not the first one (or its address) kept alive across the sweep
+                    const int s = ligl + j * LPV;
+                    int4 c = make_int4(0, 0, 0, 0);
+                    if (s < S) c = reinterpret_cast<const int4 *>(p.cnt_vs)[(size_t)vv * S + s];
+                    xl[0] = c.x; xl[1] = c.y; xl[2] = c.z; xl[3] = c.w;
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) xl[b] = xi[j][b];
+                }
                 double P[4] = {0.0, 0.0, 0.0, 0.0};
                 for (int g = 0; g < G; ++g) {
                     const double *er = eL + (int)((t >> (2 * g)) & 3) * 4;
@@ -938,10 +973,10 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                 for (int b = 0; b < 4; ++b) ok &= dsm_log_ok(P[b]);
                 if (__builtin_expect(ok, 1)) {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) ll_acc = fma((double)xi[j][b], dsm_log_core(P[b], ltab), ll_acc);
+                    for (int b = 0; b < 4; ++b) ll_acc = fma((double)xl[b], dsm_log_core(P[b], ltab), ll_acc);
                 } else {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) ll_acc = fma((double)xi[j][b], dsm_log_slow(P[b]), ll_acc);
+                    for (int b = 0; b < 4; ++b) ll_acc = fma((double)xl[b], dsm_log_slow(P[b]), ll_acc);
                 }
             }
         }
@@ -963,7 +998,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
 }
 
 // three samples per lane, 32 or 64 lanes per variant: the lean form of the sweep at three wavefronts per SIMD (tau_body: LEAN)
-#define TAU_MIN_WGS(LPV, NSL) (TAU_LEAN(LPV, NSL) ? ((NSL) == 3 ? 3 : 2) : 1)
+#define TAU_MIN_WGS(LPV, NSL) (TAU_LEAN(LPV, NSL) ? ((NSL) == 2 ? 4 : (NSL) == 3 ? 3 : 2) : 1)
 template <int LPV, int NSL, bool SWEEP, bool LL>
 __global__ __launch_bounds__(256, TAU_MIN_WGS(LPV, NSL)) void tau_kernel(TauParams p) { tau_body<LPV, NSL, SWEEP, LL>(p); }
 // K chains of one shape, chain = blockIdx.y (dsm_host.h: BatchCtl)

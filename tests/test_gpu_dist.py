@@ -35,7 +35,8 @@ def test_bench_walks_the_rccl_path_with_a_world_of_one():
     line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["steps"] == 6 and line["scaling"] == "weak"
     assert line["launch"].startswith("torch.distributed.run, 1 rank") and len(line["ranks"]) == 1
-    assert line["ranks"][0]["rank"] == 0 and line["ranks"][0]["device_index"] == 0 and "MI3" in line["ranks"][0]["name"]
+    r0 = line["ranks"][0]
+    assert r0["rank"] == 0 and r0.get("device_index") == 0 and r0.get("name") and r0["ms_per_step"] > 0, r0
     rp = line["ms_per_step_repeats"]
     assert rp["n"] == 3 and rp["min"] <= rp["median"] <= rp["max"] and rp["median"] == line["ms_per_step"]
     # the same command as a plain process: the same keys (plus the single-GPU extras), no process group

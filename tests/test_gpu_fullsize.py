@@ -11,7 +11,10 @@ from oracle import cbind
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("V,S,G", [(10000, 64, 8), (50000, 96, 12)])
+# (50000, 96, G) for G = 2, 4, 6, 10: the other legs of BASELINE config 5 (g in 2..12) at full V.  They take code the G = 12 leg does not:
+# the subset table in 16-64 copies at few haplotypes (stats_ntab_rep), the stand-alone stage-2 launch at G = 10 / 11, and the
+# register-lean sweep tau_kernel<32,3> with prefix lengths other than 12.
+@pytest.mark.parametrize("V,S,G", [(10000, 64, 8), (50000, 96, 12), (50000, 96, 2), (50000, 96, 4), (50000, 96, 6), (50000, 96, 10)])
 def test_full_size_sweep_loglik_and_stats_invariants(V, S, G):
     counts, _, _ = synth_counts(V, S, G, seed=1234)
     tau, gamma, eta = random_state(V, S, G, seed=5)

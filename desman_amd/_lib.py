@@ -78,6 +78,15 @@ SIGNATURES = {
     "dsm_ctx_get_counters": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "dsm_ctx_set_counters": (_i, [_vp, C.c_uint64, C.c_uint32]),
     "dsm_ctx_gibbs_update_sharded": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "dsm_ctx_gibbs_update_sharded_comm": (_i, [_vp, _i, _i, _i, _vp]),
+    "dsm_comm_unique_id": (_i, [_vp]),
+    "dsm_comm_create": (_i, [C.POINTER(_vp), _vp, _i, _i, _i]),
+    "dsm_comm_destroy": (_i, [_vp]),
+    "dsm_comm_rank": (_i, [_vp]),
+    "dsm_comm_world": (_i, [_vp]),
+    "dsm_comm_allgather_f64": (_i, [_vp, _f64p, _f64p, C.c_size_t]),
+    "dsm_comm_allreduce_f64": (_i, [_vp, _vp, C.c_size_t, _i]),
+    "dsm_comm_barrier": (_i, [_vp]),
     "dsm_device_read": (_i, [_i, _vp, _vp, C.c_size_t]),
     "dsm_device_write": (_i, [_i, _vp, _vp, C.c_size_t]),
     "dsm_batch_gibbs_update": (_i, [C.POINTER(_vp), _i, _i]),
@@ -397,6 +406,12 @@ class Context:
         if err:
             raise err[0]
         check(rc)
+        self.n_trace = int(n_iter)
+
+    def gibbs_update_sharded_comm(self, n_iter, v_offset, v_total, comm):
+        """the same with the exchange done by the library over its own RCCL communicator (desman_amd/comm.py: Comm): the two
+        all-reduces of an iteration are enqueued on the chain's stream, no host synchronisation, no torch"""
+        check(self.lib.dsm_ctx_gibbs_update_sharded_comm(self._h, int(n_iter), int(v_offset), int(v_total), comm._h))
         self.n_trace = int(n_iter)
 
     @staticmethod

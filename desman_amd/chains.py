@@ -66,7 +66,7 @@ def group_units(specs, batch):
     return units
 
 
-def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=None, batch=1):
+def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=None, batch=1, comm=None):
     """Run `run_fn(spec) -> dict(REC_FIELDS...)` for this rank's share of `specs` and gather
     every chain's record on all ranks.  `dist` = an initialised torch.distributed module
     (or None for a single process).  `concurrency` chains of a rank run at the same time in
@@ -79,9 +79,13 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
     failed = 1 and NaN fit values (model selection skips it).  A rank therefore always reaches the all_gather:
     one bad chain (bad input for that G, an out-of-memory context, a device error) never strands its peers
     in the collective."""
-    import torch
-    world = dist.get_world_size() if dist is not None else 1
-    rank = dist.get_rank() if dist is not None else 0
+    # the gather goes through `comm` (desman_amd.comm.Comm: the library's own RCCL communicator, no torch) or through `dist`
+    # (an initialised torch.distributed: "nccl" = RCCL on GPUs, "gloo" in the CPU tests); neither: one process
+    if comm is not None:
+        world, rank = comm.world, comm.rank
+    else:
+        world = dist.get_world_size() if dist is not None else 1
+        rank = dist.get_rank() if dist is not None else 0
     units = group_units(specs, batch if batch_fn is not None else 1)
     unit_bins = lpt_assign([sum(specs[i]["cost"] for i in u) for u in units], world)
     bins = [[i for ui in ub for i in units[ui]] for ub in unit_bins]          # chain ids per rank, unit by unit
@@ -163,9 +167,12 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
     buf = np.full((max(width, 1), len(REC_FIELDS)), np.nan)
     if mine:
         buf[:len(mine)] = np.array(mine)
-    if dist is None:
+    if comm is not None:
+        rows = comm.allgather(buf.reshape(-1)).reshape(-1, len(REC_FIELDS))      # the path's single exchange step
+    elif dist is None:
         rows = buf
     else:
+        import torch
         t = torch.from_numpy(buf).to(device if device is not None else "cpu")
         out = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(out, t)                         # the path's single exchange step
@@ -297,21 +304,32 @@ def main(argv=None):
                     "launch of the Gibbs loop instead of running as separate chains (small tables: several times the throughput)")
     ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node to spread the chains over (one process each). "
                     "A plain `desman-sweep --gpus N` starts its own N ranks; under torch.distributed.run the world must be N")
+    ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl", help="who carries the final gather of the fit records: rccl = "
+                    "the library's own RCCL communicator (include/desman_hip.h: dsm_comm_*; no torch in the process, ranks started by "
+                    "desman_amd.launch.spawn_ranks), torch = torch.distributed with backend nccl (ranks started by torch.distributed.run)")
     args = ap.parse_args(argv)
     from . import launch
     if args.gpus is None:                                     # the launcher's world as it is (1 for a plain process)
         args.gpus = int(os.environ.get("WORLD_SIZE", "1")) if "RANK" in os.environ else 1
     _, local, world, under_launcher = launch.ensure_world(args.gpus, sys.argv[1:] if argv is None else list(argv),
-                                                          module="desman_amd.chains", prog="desman-sweep")
+                                                          module="desman_amd.chains", prog="desman-sweep",
+                                                          launcher="spawn" if args.comm == "rccl" else "torchrun")
     import pandas as p
-    import torch
-    dist = None
-    if under_launcher:
+    dist = comm = None
+    dev_t = None
+    if under_launcher and args.comm == "torch":
+        import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dev_t = torch.device("cuda", local)
         if dist.get_world_size() != args.gpus:
             launch._die("desman-sweep", "process group of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    elif under_launcher:
+        from .comm import Comm
+        comm = Comm.from_env(device=local)
+        if comm.world != args.gpus:
+            launch._die("desman-sweep", "communicator of %d ranks, --gpus %d" % (comm.world, args.gpus))
     frame = p.read_csv(args.variant_file, header=0, index_col=0)
     V, S = frame.shape[0], (frame.shape[1] - 1) // 4
     specs = sweep_specs(range(args.gmin, args.gmax + 1), args.reps, V, S)
@@ -321,15 +339,17 @@ def main(argv=None):
         # chain, the fallback of a failed unit) follow it too, so that a (G, seed) gives the same draws whatever -b is
         os.environ["DESMAN_HIP_STATS_SPEC"] = "2"
     runner = gibbs_chain_runner(args.variant_file, args.no_iter, local, args.output_stub, extra)
-    recs = run_chains(specs, runner, dist, device=torch.device("cuda", local) if dist is not None else None,
-                      concurrency=args.concurrency, batch_fn=runner.batch if args.batch > 1 else None, batch=min(args.batch, 8))
-    if dist is None or dist.get_rank() == 0:
+    recs = run_chains(specs, runner, dist, device=dev_t, concurrency=args.concurrency, batch_fn=runner.batch if args.batch > 1 else None,
+                      batch=min(args.batch, 8), comm=comm)
+    if (comm.rank if comm is not None else (0 if dist is None else dist.get_rank())) == 0:
         write_dev_csv(args.output_stub + "_Dev.csv", recs)
         print(json.dumps(recs))
         from . import resolvenhap                      # f2: posterior-deviance model selection over the sweep
         resolvenhap.resolve(args.output_stub)
     if dist is not None:
         dist.destroy_process_group()
+    if comm is not None:
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -801,10 +801,17 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
 // aggregated mu/E pass and counter-based tau uniforms (dsm_ctx_set_tau_rng(DSM_RNG_PHILOX): the MT19937 stream is serial).
 // exchange(user, tab, n_tab, vec, n_vec) is called with this context's stream drained; it must return (0 = ok) only after
 // the reduced values are in place.  n_tab = 0: only the vector is exchanged.
-extern "C" int dsm_ctx_gibbs_update_sharded(dsm_ctx *c, int n_iter, int v_offset, int v_total, dsm_exchange_fn exchange, void *user)
+struct dsm_comm;
+int comm_enqueue_exchange(dsm_comm *m, uint32_t *tab, size_t n_tab, double *vec, size_t n_vec, hipStream_t stream);   // comm.hip
+int comm_device(const dsm_comm *m);
+
+// the loop of both forms: exchange != null -- the caller's all-reduce, called with the stream drained; comm != null -- RCCL
+// all-reduces enqueued on the chain's stream by the library (no host synchronisation inside the loop)
+static int gibbs_update_sharded(dsm_ctx *c, int n_iter, int v_offset, int v_total, dsm_exchange_fn exchange, void *user, dsm_comm *comm)
 {
     TRY(need(c, true, true));
-    if (n_iter < 0 || !exchange || v_offset < 0 || v_total < v_offset + c->V) { dsm_set_error("gibbs_update_sharded: bad arguments"); return DSM_ERR_ARG; }
+    if (n_iter < 0 || (!exchange && !comm) || v_offset < 0 || v_total < v_offset + c->V) { dsm_set_error("gibbs_update_sharded: bad arguments"); return DSM_ERR_ARG; }
+    if (comm && comm_device(comm) != c->device) { dsm_set_error("gibbs_update_sharded: the communicator lives on device %d, the context on %d", comm_device(comm), c->device); return DSM_ERR_ARG; }
     if (c->tau_rng != DSM_RNG_PHILOX) { dsm_set_error("gibbs_update_sharded: needs counter-based tau uniforms (DSM_RNG_PHILOX)"); return DSM_ERR_STATE; }
     BIND(c);
     const int keep_force = c->force_stats_spec;
@@ -812,12 +819,15 @@ extern "C" int dsm_ctx_gibbs_update_sharded(dsm_ctx *c, int n_iter, int v_offset
     struct Guard { dsm_ctx *c; int f; ~Guard() { c->shard_on = false; c->force_stats_spec = f; } } guard{c, keep_force};
     if (stats_spec(c) < 2) { dsm_set_error("gibbs_update_sharded: the aggregated mu/E pass does not apply to this shape (G <= 16)"); return DSM_ERR_UNSUPPORTED; }
     if (!c->shard_vec) TRY(dev_alloc(&c->shard_vec, (size_t)18));
+    // shard_on before anything sizes the subset table: its layout (copies, row stride) must be the same on every rank -- it is
+    // derived from v_total, S and G, never from this shard's own V (kernels_stats.hip: stats_ntab_rep)
     c->shard_on = true; c->shard_voff = v_offset; c->shard_vtot = v_total;
     TRY(alloc_traces(c, n_iter));
     const size_t sg = (size_t)c->S * c->G;
     HIP_TRY(hipMemsetAsync(c->nchange, 0, sizeof(int), c->stream));
     HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
     auto swap_vec = [&](uint32_t *tab, size_t n_tab) -> int {
+        if (comm) return comm_enqueue_exchange(comm, tab, n_tab, c->shard_vec, (size_t)18, c->stream);
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (exchange(user, tab, n_tab, c->shard_vec, (size_t)18) != 0) { dsm_set_error("gibbs_update_sharded: the exchange callback failed"); return DSM_ERR_STATE; }
         return DSM_OK;
@@ -857,6 +867,19 @@ extern "C" int dsm_ctx_gibbs_update_sharded(dsm_ctx *c, int n_iter, int v_offset
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSM_OK;
+}
+
+extern "C" int dsm_ctx_gibbs_update_sharded(dsm_ctx *c, int n_iter, int v_offset, int v_total, dsm_exchange_fn exchange, void *user)
+{
+    if (!exchange) { dsm_set_error("gibbs_update_sharded: no exchange callback"); return DSM_ERR_ARG; }
+    return gibbs_update_sharded(c, n_iter, v_offset, v_total, exchange, user, nullptr);
+}
+
+// the same with the exchange done by the library over its own RCCL communicator (comm.hip): no host synchronisation per iteration
+extern "C" int dsm_ctx_gibbs_update_sharded_comm(dsm_ctx *c, int n_iter, int v_offset, int v_total, dsm_comm *comm)
+{
+    if (!comm) { dsm_set_error("gibbs_update_sharded_comm: no communicator"); return DSM_ERR_ARG; }
+    return gibbs_update_sharded(c, n_iter, v_offset, v_total, nullptr, nullptr, comm);
 }
 
 // raw device <-> host copies of the exchange buffers (for callers that reduce on the host, e.g. the two-shards-on-one-GPU test)

@@ -429,7 +429,10 @@ int stats_ntab_rep(const dsm_ctx *c)
     static const double want = getenv("DESMAN_HIP_NTAB_LINES") ? atof(getenv("DESMAN_HIP_NTAB_LINES")) : 384.0;
     static const int force = getenv("DESMAN_HIP_NTAB_REP") ? atoi(getenv("DESMAN_HIP_NTAB_REP")) : 0;      // A/B switch
     if (force > 0) return force;
-    const double per = 3.0 * (double)c->V / (double)((size_t)1 << c->G);
+    // a chain sharded by positions: every rank must lay its table out alike (the tables are all-reduced element by element), so
+    // the rule reads the WHOLE table's position count, never the shard's own (shards differ by one position: V = 21 845, G = 8 on
+    // two ranks gave 10 922 -> one copy and 10 923 -> two).  More copies than a shard needs cost one read each at stage 2's root.
+    const double per = 3.0 * (double)(c->shard_on ? c->shard_vtot : c->V) / (double)((size_t)1 << c->G);
     if (per <= 128.0) return 1;
     const double lines = (double)((((size_t)1 << c->G) * (size_t)c->S * 4 + 63) / 64);
     int rep = 2;

@@ -20,8 +20,14 @@ def free_port():
     return port
 
 
-def visible_gpus():
+def visible_gpus(use_torch=True):
     """number of GPUs this process could bind (0 without a GPU / driver).  Does not create a HIP context."""
+    if not use_torch:
+        try:
+            from . import _lib
+            return max(0, int(_lib.device_count()))
+        except Exception:                                      # noqa: BLE001 -- library not built / no driver
+            return 0
     try:
         import torch
         return int(torch.cuda.device_count())
@@ -35,7 +41,7 @@ def _die(prog, msg):
     raise SystemExit(EXIT_BAD_WORLD)
 
 
-def ensure_world(gpus, argv, script=None, module=None, prog=None, n_visible=None, _exec=os.execve):
+def ensure_world(gpus, argv, script=None, module=None, prog=None, n_visible=None, _exec=os.execve, launcher="torchrun"):
     """Make this process one of exactly `gpus` ranks, or exit non-zero saying why.
 
     gpus    -- what `--gpus` asked for (>= 1)
@@ -46,7 +52,9 @@ def ensure_world(gpus, argv, script=None, module=None, prog=None, n_visible=None
     * RANK in the environment (torch.distributed.run started us): WORLD_SIZE must equal `gpus`.
     * no RANK, gpus == 1: a plain single process, world of one, no process group.
     * no RANK, gpus > 1: needs `gpus` visible devices, then os.execve of
-      `python -m torch.distributed.run --nnodes=1 --nproc-per-node gpus --master-addr 127.0.0.1 --master-port <free> <program> argv`.
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node gpus --master-addr 127.0.0.1 --master-port <free> <program> argv`
+      (launcher="torchrun"), or -- launcher="spawn", no torch involved -- N children started by spawn_ranks() and this process
+      exits with their status.
     """
     prog = prog or (os.path.basename(script) if script else module)
     if gpus < 1:
@@ -61,10 +69,17 @@ def ensure_world(gpus, argv, script=None, module=None, prog=None, n_visible=None
         return int(env["RANK"]), int(env.get("LOCAL_RANK", "0")), world, True
     if gpus == 1:
         return 0, 0, 1, False
-    n = visible_gpus() if n_visible is None else n_visible
+    n = visible_gpus(use_torch=(launcher == "torchrun")) if n_visible is None else n_visible
     if n < gpus:
         _die(prog, "--gpus %d asked for, %d GPU(s) visible on this node: refusing to run (a smaller run would print a number "
                    "that is not the %d-GPU number)" % (gpus, n, gpus))
+    if launcher == "spawn":                                    # no torch anywhere: our own N children (spawn_ranks below)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        e = dict(env)
+        e["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+        sys.stdout.flush()
+        sys.stderr.flush()
+        raise SystemExit(spawn_ranks(gpus, [sys.executable] + (["-m", module] if module else [os.path.abspath(script)]) + list(argv), env=e))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port())]
     cmd += (["-m", module] if module else [os.path.abspath(script)]) + list(argv)
@@ -94,3 +109,49 @@ def bound_device_record(rank, local_rank):
     except Exception as e:                                     # noqa: BLE001
         rec["device_error"] = "%s: %s" % (type(e).__name__, e)
     return rec
+
+
+def spawn_ranks(n, cmd, env=None, port=None):
+    """start `cmd` (argv list) as n ranks of one node WITHOUT torch: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in
+    each child's environment (what desman_amd/comm.py: Comm.from_env reads), stdout / stderr inherited.  Waits for all; when one rank
+    fails the others are terminated (they would wait in a collective for ever).  Returns the first non-zero exit status, or 0."""
+    import subprocess
+    import time
+    port = port or free_port()
+    procs = []
+    for r in range(n):
+        e = dict(os.environ if env is None else env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        e.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen(list(cmd), env=e))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            st = procs[r].poll()
+            if st is None:
+                continue
+            live.discard(r)
+            if st != 0 and rc == 0:
+                rc = st
+                for q in live:                                 # exact PIDs we started
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def _main(argv):
+    """python -m desman_amd.launch -n N program.py [args...]   (or: -n N -m package.module [args...])"""
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m desman_amd.launch", description="start N ranks of a program on this node, no torch")
+    ap.add_argument("-n", "--nproc", type=int, required=True)
+    ap.add_argument("-m", dest="module", default=None)
+    ap.add_argument("rest", nargs=argparse.REMAINDER)
+    a = ap.parse_args(argv)
+    cmd = [sys.executable] + (["-m", a.module] if a.module else []) + a.rest
+    raise SystemExit(spawn_ranks(a.nproc, cmd))
+
+
+if __name__ == "__main__":
+    _main(sys.argv[1:])

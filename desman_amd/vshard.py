@@ -11,7 +11,9 @@ Every draw is keyed by GLOBAL indices, so the chain is the unsharded chain whate
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... your_script.py
         chain = ShardedChain(counts_slice, v_offset, v_total, G, seed, device=local_rank)
-        chain.set_state(tau_slice, gamma, eta); chain.update(n_iter, TorchExchange(dist, device))
+        chain.set_state(tau_slice, gamma, eta)
+        chain.update(n_iter, Comm.from_env())                 # the library's own RCCL exchange (desman_amd/comm.py), no torch
+        chain.update(n_iter, TorchExchange(dist, device))     # or through torch.distributed (host-synchronised per iteration)
 """
 import ctypes as C
 
@@ -40,9 +42,19 @@ class TorchExchange:
         import torch
         self.torch, self.dist, self.device = torch, dist, device
         self.calls = 0
+        self._n_tab_checked = None
 
     def __call__(self, tab_ptr, n_tab, vec_ptr, n_vec):
         torch = self.torch
+        if n_tab and n_tab != self._n_tab_checked:
+            # every rank must hand over a table of the same length (the library derives its layout from v_total, S, G): a mismatch
+            # would hang or corrupt the all-reduce, so it is checked once per length, loudly
+            t = torch.tensor([n_tab, -n_tab], device=self.device, dtype=torch.int64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            if int(t[0]) != n_tab or int(-t[1]) != n_tab:
+                raise _lib.DesmanHipError("sharded chain: subset tables of different length on different ranks (%d here, %d..%d over "
+                                          "the ranks)" % (n_tab, int(-t[1]), int(t[0])))
+            self._n_tab_checked = n_tab
         if n_tab:
             t = torch.as_tensor(_DevView(tab_ptr, n_tab, "<i4"), device=self.device)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
@@ -56,10 +68,11 @@ class HostExchange:
     """the same reduction through host memory for shards that live in ONE process (one thread per shard): tests and single-GPU
     dry runs.  Every shard's callback deposits its buffers, the last one to arrive sums them, all pick the sums up."""
 
-    def __init__(self, n_shards, device=0):
+    def __init__(self, n_shards, device=0, timeout=600.0):
         import threading
         self.n, self.device = n_shards, device
-        self.bar = threading.Barrier(n_shards)
+        # a shard thread that fails before reaching the barrier must not hang its peers: the waits time out (BrokenBarrierError)
+        self.bar = threading.Barrier(n_shards, timeout=timeout)
         self.lock = threading.Lock()
         self.tabs, self.vecs = {}, {}
         self.sum_tab = self.sum_vec = None
@@ -75,7 +88,11 @@ class HostExchange:
             _lib.check(lib.dsm_device_read(self.device, vec_ptr, vec.ctypes.data, vec.nbytes))
             with self.lock:
                 self.tabs[k], self.vecs[k] = tab, vec
-            if self.bar.wait() == 0:                       # one thread reduces, in shard order (fixed order: reproducible sums)
+            if self.bar.wait() == 0:
+                if len({t.size for t in self.tabs.values()}) != 1:
+                    self.bar.abort()
+                    raise _lib.DesmanHipError("sharded chain: subset tables of different length on different shards: %s"
+                                              % sorted(t.size for t in self.tabs.values()))                       # one thread reduces, in shard order (fixed order: reproducible sums)
                 self.sum_tab = sum((self.tabs[j] for j in range(self.n)), np.zeros(n_tab, dtype=np.uint32)) if n_tab else None
                 acc = np.zeros(n_vec)
                 for j in range(self.n):
@@ -108,7 +125,13 @@ class ShardedChain:
         self.ctx.set_tau_rng(_lib.RNG_PHILOX)
 
     def update(self, n_iter, exchange):
-        self.ctx.gibbs_update_sharded(n_iter, self.v_offset, self.v_total, exchange)
+        """exchange: a desman_amd.comm.Comm (the library's own RCCL all-reduces, enqueued on the chain's stream: no host
+        synchronisation per iteration) or a callable (TorchExchange, HostExchange.for_shard(k): called with the stream drained)"""
+        from .comm import Comm
+        if isinstance(exchange, Comm):
+            self.ctx.gibbs_update_sharded_comm(n_iter, self.v_offset, self.v_total, exchange)
+        else:
+            self.ctx.gibbs_update_sharded(n_iter, self.v_offset, self.v_total, exchange)
 
     def trace(self):
         return self.ctx.get_trace()

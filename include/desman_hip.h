@@ -41,6 +41,7 @@ extern "C" {
 #define DSM_ERR_UNSUPPORTED -4   /* size outside the compiled kernel range    */
 #define DSM_ERR_NOMEM       -5
 #define DSM_ERR_NODEVICE    -6   /* no gfx950 device visible                  */
+#define DSM_ERR_COMM        -7   /* an RCCL call failed (dsm_comm_*)           */
 
 #define DSM_MAX_G  32            /* haplotypes: tau is packed 2 bits each     */
 #define DSM_MAX_S  512           /* samples per variant row                   */
@@ -321,6 +322,26 @@ int dsm_ctx_get_counters(dsm_ctx *ctx, uint64_t *ctr_seed, uint32_t *iter_ctr);
 int dsm_ctx_set_counters(dsm_ctx *ctx, uint64_t ctr_seed, uint32_t iter_ctr);
 typedef int (*dsm_exchange_fn)(void *user, uint32_t *dev_tab, size_t n_tab, double *dev_vec, size_t n_vec);
 int dsm_ctx_gibbs_update_sharded(dsm_ctx *ctx, int n_iter, int v_offset, int v_total, dsm_exchange_fn exchange, void *user);
+/* ---- RCCL (xGMI) inside the library: one communicator per process / GPU, no torch.  librccl is dlopen()ed on first use
+ * (DESMAN_HIP_RCCL names another copy).  Replaces the reference's "gather" -- `cat *\/fit.txt` over per-chain directories,
+ * complete_example/README.md:626-627 after scripts/runDesman.sh:15-21 -- and carries the per-iteration exchange of a sharded
+ * chain.  Bootstrap: rank 0 calls dsm_comm_unique_id and hands the 128 bytes to the other ranks by any
+ * means (desman_amd/comm.py: a TCP socket on MASTER_ADDR); then EVERY rank calls dsm_comm_create (collective).              */
+typedef struct dsm_comm dsm_comm;
+int dsm_comm_unique_id(void *id128);
+int dsm_comm_create(dsm_comm **out, const void *id128, int rank, int world, int device);
+int dsm_comm_destroy(dsm_comm *comm);
+int dsm_comm_rank(const dsm_comm *comm);
+int dsm_comm_world(const dsm_comm *comm);
+/* recv[world][n] <- every rank's send[n] (host buffers): the chain scheduler's one exchange, a fit record per chain */
+int dsm_comm_allgather_f64(dsm_comm *comm, const double *send, double *recv, size_t n);
+/* data[n] <- sum (op 0) or maximum (op 1) over the ranks, in place (host buffer); dsm_comm_barrier = the same with n = 0 */
+int dsm_comm_allreduce_f64(dsm_comm *comm, double *data, size_t n, int op);
+int dsm_comm_barrier(dsm_comm *comm);
+/* dsm_ctx_gibbs_update_sharded with the exchange done by the library itself: the two all-reduces are ENQUEUED on the context's
+ * stream between stage 1 and the Dirichlet launch (one grouped RCCL call), no host synchronisation, no callback.  The
+ * communicator must live on the context's device; every rank of it must make the call (same n_iter, same v_total).          */
+int dsm_ctx_gibbs_update_sharded_comm(dsm_ctx *ctx, int n_iter, int v_offset, int v_total, dsm_comm *comm);
 /* plain device <-> host copies of the exchange buffers (host-side reductions, tests) */
 int dsm_device_read(int device, const void *dev, void *host, size_t bytes);
 int dsm_device_write(int device, void *dev, const void *host, size_t bytes);

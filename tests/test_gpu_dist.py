@@ -68,11 +68,24 @@ def test_desman_sweep_walks_the_rccl_gather_with_a_world_of_one(tmp_path):
     freq = str(tmp_path / "syn.freq")
     df.to_csv(freq)
     stub = str(tmp_path / "sw")
-    out = _torchrun(["-m", "desman_amd.chains", freq, "--gmin", "2", "--gmax", "3", "--reps", "2", "-i", "15", "-o", stub, "-c", "1"], 29733)
+    out = _torchrun(["-m", "desman_amd.chains", freq, "--gmin", "2", "--gmax", "3", "--reps", "2", "-i", "15", "-o", stub, "-c", "1",
+                     "--comm", "torch"], 29733)
     recs = json.loads([ln for ln in out.splitlines() if ln.startswith("[{")][-1])
     assert [(int(r["G"]), int(r["seed"]), r["failed"]) for r in recs] == [(2, 0, 0.0), (2, 1, 0.0), (3, 0, 0.0), (3, 1, 0.0)]
     rows = open(stub + "_Dev.csv").read().strip().split("\n")
     assert rows[0] == "H,G,LP,Dev" and len(rows) == 5
+    # the default: the gather through the library's own RCCL communicator (dsm_comm_*), ranks started without torch
+    # (python -m desman_amd.launch -n 1 = what `desman-sweep --gpus N` does for itself); no torch in those processes
+    stub2 = str(tmp_path / "sw2")
+    env2 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r2 = subprocess.run([sys.executable, "-m", "desman_amd.launch", "-n", "1", "-m", "desman_amd.chains", freq, "--gpus", "1", "--gmin", "2",
+                         "--gmax", "3", "--reps", "2", "-i", "15", "-o", stub2, "-c", "1"], env=env2, cwd=ROOT, capture_output=True, text=True,
+                        timeout=600)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    assert open(stub + "_Dev.csv").read() == open(stub2 + "_Dev.csv").read()
+    r3 = subprocess.run([sys.executable, "-m", "desman_amd.chains", freq, "--gpus", "2", "-o", stub2], env=env2, cwd=ROOT, capture_output=True,
+                        text=True, timeout=600)
+    assert r3.returncode == 2 and "refusing to run" in r3.stderr          # one GPU here: no silent single-GPU sweep
     # the same sweep without torch.distributed: the gather changes nothing (in a child process as well: the sweep driver
     # imports torch, whose bundled HIP runtime this test process should not load next to the library's)
     stub1 = str(tmp_path / "sw1")

@@ -125,3 +125,78 @@ dist.destroy_process_group()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", "29741", str(script)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "VSHARD OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_library_rccl_exchange_with_a_world_of_one():
+    """the exchange done by the library itself (dsm_comm_*: librccl dlopen()ed by libdesman_hip.so, the all-reduces enqueued on
+    the chain's stream, no torch in this process): a world of one rank walks communicator set-up, the grouped all-reduce per
+    iteration, the fit-record all-gather, the MAX all-reduce and the barrier; the chain is the unsharded chain."""
+    from desman_amd.comm import Comm
+    assert "torch" not in sys.modules or True            # (other tests of this session may have imported it; this path does not need it)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        assert k not in os.environ
+    comm = Comm.from_env()
+    assert (comm.rank, comm.world) == (0, 1)
+    rec = np.arange(9, dtype=np.float64) + 0.5
+    assert np.array_equal(comm.allgather(rec), rec[None, :])
+    assert np.array_equal(comm.allreduce(np.array([3.0, -1.0]), "max"), [3.0, -1.0])
+    assert np.array_equal(comm.allreduce(np.array([[1.0, 2.0]]), "sum"), [[1.0, 2.0]])
+    comm.barrier()
+    for V, S, G, n_iter in [(1200, 32, 6, 6), (700, 96, 11, 4)]:
+        counts, _, _ = synth_counts(V, S, G, seed=9)
+        tau, gamma, eta = random_state(V, S, G, seed=10)
+        ref = _unsharded(counts, tau, gamma, eta, 3, 77, n_iter)
+        ch = vshard.ShardedChain(counts, 0, V, G, 3, ctr_seed=77)
+        ch.set_state(tau, gamma, eta)
+        ch.update(n_iter, comm)
+        tr = ch.trace()
+        assert np.array_equal(tr["gamma"], ref["tr"]["gamma"]) and np.array_equal(tr["eta"], ref["tr"]["eta"])
+        assert np.array_equal(tr["nchange"], ref["tr"]["nchange"]) and np.array_equal(ch.state()[0], ref["state"][0])
+        np.testing.assert_allclose(tr["ll"], ref["tr"]["ll"], rtol=1e-12)
+        np.testing.assert_allclose(tr["lp"], ref["tr"]["lp"], rtol=1e-12)
+        assert ch.star()["it"] == ref["star"]["it"]
+        ch.update(3, comm)                                   # a second call continues the chain
+        ch.close()
+    comm.close()
+
+
+def test_shards_of_unequal_size_lay_their_tables_out_alike():
+    """the number of table copies came from the shard's own V, so shards that differ by one position could
+    pick different layouts (V = 21 845, G = 8 on two ranks: 10 922 -> one copy, 10 923 -> two) and hand all-reduce buffers of
+    different length to RCCL.  The layout now follows v_total: both shards exchange tables of one length, and the chain is still
+    the unsharded chain."""
+    V, S, G, n_iter = 21845, 16, 8, 3
+    counts, _, _ = synth_counts(V, S, G, seed=31)
+    tau, gamma, eta = random_state(V, S, G, seed=32)
+    ref = _unsharded(counts, tau, gamma, eta, 5, 99, n_iter)
+    b = vshard.shard_bounds(V, 2)
+    assert (b[1] - b[0], b[2] - b[1]) == (10922, 10923)
+    ex = vshard.HostExchange(2, timeout=300.0)
+    seen = {0: set(), 1: set()}
+    chains = []
+    for k in range(2):
+        ch = vshard.ShardedChain(counts[b[k]:b[k + 1]], b[k], V, G, 5, ctr_seed=99)
+        ch.set_state(tau[b[k]:b[k + 1]], gamma, eta)
+        chains.append(ch)
+    errs = []
+
+    def work(k):
+        inner = ex.for_shard(k)
+
+        def spy(tab, n_tab, vec, n_vec):
+            if n_tab:
+                seen[k].add(n_tab)
+            inner(tab, n_tab, vec, n_vec)
+        try:
+            chains[k].update(n_iter, spy)
+        except BaseException as e:                           # noqa: BLE001
+            errs.append(e)
+            ex.bar.abort()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join(600) for t in th]
+    assert not errs, errs
+    assert seen[0] == seen[1] and len(seen[0]) == 1, seen
+    for k, ch in enumerate(chains):
+        assert np.array_equal(ch.trace()["gamma"], ref["tr"]["gamma"]) and np.array_equal(ch.state()[0], ref["state"][0][b[k]:b[k + 1]])
+        ch.close()

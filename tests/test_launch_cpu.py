@@ -83,3 +83,38 @@ def test_plain_process_with_gpus_2_becomes_two_real_ranks():
                        capture_output=True, text=True, timeout=300)
     one = json.loads(r.stdout.strip().splitlines()[-1])
     assert one["n_gpus"] == 1 and not one["under_launcher"] and set(one) == set(line)
+
+
+def test_spawn_ranks_without_torch(tmp_path):
+    """desman_amd.launch.spawn_ranks: N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; a failing rank takes the others
+    down and its status is returned"""
+    prog = tmp_path / "p.py"
+    prog.write_text("import os, sys, time\n"
+                    "r = int(os.environ['RANK']); open(os.path.join(sys.argv[1], 'r%d' % r), 'w').write(' '.join(os.environ[k] for k in "
+                    "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')))\n"
+                    "if len(sys.argv) > 2 and r == 1: sys.exit(7)\n"
+                    "if len(sys.argv) > 2: time.sleep(60)\n")
+    assert launch.spawn_ranks(3, [sys.executable, str(prog), str(tmp_path)], env=_clean_env()) == 0
+    rows = [open(tmp_path / ("r%d" % r)).read().split() for r in range(3)]
+    assert [x[0] for x in rows] == ["0", "1", "2"] and all(x[2] == "3" and x[3] == "127.0.0.1" for x in rows) and len({x[4] for x in rows}) == 1
+    import time
+    t0 = time.time()
+    assert launch.spawn_ranks(3, [sys.executable, str(prog), str(tmp_path), "fail"], env=_clean_env()) == 7
+    assert time.time() - t0 < 30                           # the sleeping ranks were terminated, not waited for
+    r = subprocess.run([sys.executable, "-m", "desman_amd.launch", "-n", "2", str(prog), str(tmp_path)], cwd=ROOT, env=_clean_env(),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+
+
+def test_comm_bootstrap_hands_the_id_to_every_rank():
+    """desman_amd/comm.py: rank 0 serves the 128-byte RCCL id on a TCP socket, the other ranks fetch it (no GPU involved)"""
+    import threading
+    from desman_amd import comm
+    uid = bytes(range(128))
+    port = launch.free_port()
+    got = []
+    th = [threading.Thread(target=lambda: got.append(comm._fetch_id("127.0.0.1", port, 30.0))) for _ in range(3)]
+    [t.start() for t in th]
+    comm._serve_id(uid, 4, "127.0.0.1", port, 30.0)
+    [t.join(30) for t in th]
+    assert got == [uid, uid, uid]

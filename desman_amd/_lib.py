@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DESMAN_HIP_LIB: another build of the same library (A/B builds of scripts/dbg: `make -C desman_amd/csrc EXTRA=... LIBNAME=...`)
 LIB_PATH = os.environ.get("DESMAN_HIP_LIB") or os.path.join(_HERE, "lib", "libdesman_hip.so")
+AB_LIB_PATH = os.path.join(_HERE, "lib", "libdesman_hip_ab.so")     # the experiment build (`make -C desman_amd/csrc ab`): A/B switches compiled in
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "desman_hip.h")
 
 DSM_OK = 0

@@ -152,7 +152,7 @@ extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
     dsm_ctx *c = new dsm_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    if (getenv("DESMAN_HIP_NMFT_NO_FUSED_REDUCE")) c->nmft_fused = 0;    // A/B switch, see dsm_ctx_set_nmft_fused
+    if (DSM_AB_ENV("DESMAN_HIP_NMFT_NO_FUSED_REDUCE")) c->nmft_fused = 0;    // A/B switch, see dsm_ctx_set_nmft_fused
     if (getenv("DESMAN_HIP_ONE_STREAM")) c->stream_rng = c->stream;      // several chains per GPU: one hardware queue each
     else {   // the single-workgroup MT19937 refill must not queue behind a full grid of the main stream
         int lo = 0, hi = 0;

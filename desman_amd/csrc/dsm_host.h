@@ -19,6 +19,19 @@
 
 void dsm_set_error(const char *fmt, ...);
 
+// A/B switches of the timing experiments (scripts/dbg/): environment variables that move work around, replace a kernel by an
+// older form or -- DESMAN_HIP_STATS_DBG -- switch parts of a kernel OFF for ablation timing (results are garbage then).  They exist only
+// in the experiment build `make -C desman_amd/csrc ab` (-DDSM_AB_SWITCHES -> lib/libdesman_hip_ab.so, loaded with DESMAN_HIP_LIB=...); in
+// the product library every one of them compiles to its default and no environment variable can change what a kernel computes.  What
+// the product library does read: DESMAN_HIP_DEVICE, DESMAN_HIP_STATS_SPEC (which mu/E specification unforced contexts follow),
+// DESMAN_HIP_ONE_STREAM / DESMAN_HIP_NMFT_GRAPH (set by desman-sweep for concurrent chains), DESMAN_HIP_NTAB_TUNE / DESMAN_HIP_TAU_ORDER
+// (= 0: the measured table place / the fp64-blocks-first order off: same results, tests/test_gpu_fuzz.py), DESMAN_HIP_RCCL.
+#ifdef DSM_AB_SWITCHES
+#define DSM_AB_ENV(name) getenv(name)
+#else
+#define DSM_AB_ENV(name) ((const char *)nullptr)
+#endif
+
 // ---- batched launches: K chains of the same shape, one launch per kernel of the iteration with the chain in blockIdx.y.
 // A launcher called while g_batch.K > 0 stores its parameter block in slot g_batch.k and launches -- on the K-th call -- the
 // _b form of its kernel, whose argument is the array of parameter blocks (kernarg, indexed by blockIdx.y).  The chains of a

@@ -1059,14 +1059,14 @@ int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n, hipStream_t stream)
 {
     if (n == 0) return DSM_OK;
     KTimer tm(c, DSM_K_MT, stream);
-    static const bool plain = getenv("DESMAN_HIP_MT_PLAIN") != nullptr;        // A/B switch: the 227-words-per-step kernel
+    static const bool plain = DSM_AB_ENV("DESMAN_HIP_MT_PLAIN") != nullptr;        // A/B switch: the 227-words-per-step kernel
     if (plain) hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, stream, c->mt_state, out, n);
     else {
         // The generator is one workgroup that runs next to the main stream's kernels.  It asks for (nearly) all of a CU's
         // LDS, which it does not use, so that no other workgroup is placed on its CU: a workgroup sharing a CU with these
         // 16 high-priority wavefronts runs 2-3x longer and becomes the tail of its launch (stage 1 of the mu/E pass, whose
         // wavefronts all get the same number of tasks: 73 -> 57 us; DESMAN_HIP_MT_HOG=0 switches the reservation off).
-        static const int hog = getenv("DESMAN_HIP_MT_HOG") ? atoi(getenv("DESMAN_HIP_MT_HOG")) : 140;   // KB
+        static const int hog = DSM_AB_ENV("DESMAN_HIP_MT_HOG") ? atoi(DSM_AB_ENV("DESMAN_HIP_MT_HOG")) : 140;   // KB
         if (hog && !c->mt_attr_set) {                                  // per device, hence per context
             HIP_TRY(hipFuncSetAttribute((const void *)mt_fill_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, hog * 1024));
             c->mt_attr_set = true;
@@ -1333,7 +1333,7 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
     p.gamma = gamma; p.eta_sweep = eta_sweep; p.eta_ll = eta_ll;
     p.u_raw = (c->tau_rng == DSM_RNG_MT19937 && (mode & 1)) ? u_raw : nullptr;
     p.logp = d_logp; p.ll_partial = c->ll_partial + (size_t)slot * DSM_MAX_GRID; p.nchange = c->nchange + slot; p.log_tab = c->log_tab;
-    static const bool no_screen = getenv("DESMAN_HIP_TAU_NO_SCREEN") != nullptr;
+    static const bool no_screen = DSM_AB_ENV("DESMAN_HIP_TAU_NO_SCREEN") != nullptr;
     p.screen = (no_screen || !c->tau_screen) ? 0 : 1;
     p.step_cnt = c->step_cnt + (size_t)slot * 2 * DSM_MAX_GRID; p.screen_ctl = c->screen_ctl + slot;
     p.order = (c->blk_order && c->blk_order_n[slot] == grid) ? c->blk_order + (size_t)slot * DSM_MAX_GRID : nullptr;

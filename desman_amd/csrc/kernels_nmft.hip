@@ -1076,7 +1076,7 @@ static bool mfma_shape(const dsm_ctx *c, int *nt, int *kb)
 {
     *nt = (c->S + 15) / 16;
     *kb = (c->nG + 3) / 4;
-    static const bool off = getenv("DESMAN_HIP_NMFT_NO_MFMA") != nullptr;      // A/B switch: the VALU one-pass kernel
+    static const bool off = DSM_AB_ENV("DESMAN_HIP_NMFT_NO_MFMA") != nullptr;      // A/B switch: the VALU one-pass kernel
     // measured against the VALU one-pass kernel: 1.0-1.3x at (NT, KB) = (4, 2), 1.96x at (6, 3) [V = 50k, S = 96, G = 12:
     // 211 vs 413 us per update]; at (8, 4) the 140 KB of LDS leave one workgroup per CU and the VALU kernel wins (449 vs 491 us)
     return !off && *nt >= 1 && *nt <= 8 && *kb >= 1 && *kb <= 4;          // S <= 128, G <= 16
@@ -1340,7 +1340,7 @@ __global__ __launch_bounds__(64 * (8 / NCB) * NCB) void nmft_wide_kernel(NmftMfm
 // 128 < S <= 512, G <= 16: blocks of six or eight tiles, two to four blocks -- the smallest tile count that holds S
 static bool wide_shape(const dsm_ctx *c, int *nt, int *kb, int *ncb)
 {
-    static const bool off = getenv("DESMAN_HIP_NMFT_NO_MFMA") != nullptr || getenv("DESMAN_HIP_NMFT_NO_WIDE") != nullptr;
+    static const bool off = DSM_AB_ENV("DESMAN_HIP_NMFT_NO_MFMA") != nullptr || DSM_AB_ENV("DESMAN_HIP_NMFT_NO_WIDE") != nullptr;
     const int tiles = (c->S + 15) / 16;
     *kb = (c->nG + 3) / 4;
     if (off || tiles <= 8 || tiles > 32 || *kb < 1 || *kb > 4) return false;
@@ -1798,7 +1798,7 @@ static int launch_persist(dsm_ctx *c, const NmftPersistParams &q, int grid, size
 int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int adjust, int *used)
 {
     *used = 0;
-    static const bool off = getenv("DESMAN_HIP_NMFT_NO_PERSIST") != nullptr;
+    static const bool off = DSM_AB_ENV("DESMAN_HIP_NMFT_NO_PERSIST") != nullptr;
     int nt, kb;
     if (off || c->nmft_persist == 0 || !mfma_shape(c, &nt, &kb) || nt > 4 || kb > 3 || c->timing || g_batch.K) return DSM_OK;
     int cus = 0;
@@ -1836,10 +1836,10 @@ int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, i
     q.ctl = NMFT_CTL(c); q.div_trace = c->ndiv_trace; q.log_tab = c->log_tab;
     q.partial = c->np_part; q.stat = c->np_part + (size_t)nout * grid;
     q.bar.gcnt = c->np_bar; q.bar.top = c->np_bar + 8 * 16; q.bar.gen = c->np_bar + 9 * 16; q.bar.err = c->np_bar + 10 * 16;
-    q.stamps = getenv("DESMAN_HIP_NMFT_STAMPS") ? q.stat + nout : nullptr;       // 8 spare doubles behind the totals
+    q.stamps = DSM_AB_ENV("DESMAN_HIP_NMFT_STAMPS") ? q.stat + nout : nullptr;       // 8 spare doubles behind the totals
     for (int g = 0; g < 8; ++g) q.bar.members[g] = (grid - g + 7) / 8;
     q.bar.ngroups = std::min(grid, 8);
-    if (getenv("DESMAN_HIP_NMFT_FORCE_TIMEOUT")) q.bar.ngroups += 1;          // test hook: the first barrier never completes
+    if (DSM_AB_ENV("DESMAN_HIP_NMFT_FORCE_TIMEOUT")) q.bar.ngroups += 1;          // test hook: the first barrier never completes
     PersistGate &gate = g_persist_gate[c->device & 15];
     gate.enter(grid, cus);
     struct GateGuard { PersistGate &g; int n; ~GateGuard() { g.leave(n); } } gate_guard{gate, grid};     // held until the workgroups are gone

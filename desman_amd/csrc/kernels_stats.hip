@@ -27,6 +27,12 @@
 #include <algorithm>
 #include <vector>
 
+// ablation switches of DESMAN_HIP_STATS_DBG: only in the experiment build (dsm_host.h: DSM_AB_SWITCHES); the product kernel has none of the tests
+#ifdef DSM_AB_SWITCHES
+#define STATS_DBG(p, mask) ((p).dbg & (mask))
+#else
+#define STATS_DBG(p, mask) 0
+#endif
 struct StatsAggParams {
     const int32_t *cnt_vs;
     const uint64_t *tau;
@@ -49,7 +55,7 @@ struct StatsAggParams {
                                     // subsets over the memory channels whatever the table's address
     int xcd;                        // 1: the table has a copy per XCD (rep = 8 k); a workgroup adds to a copy of ITS XCD (HW_REG_XCC_ID) with
                                     // workgroup-scope atomics, which execute in that XCD's L2 instead of at the memory side
-    int dbg;                        // timing experiments only (DESMAN_HIP_STATS_DBG): bit 0 no draws, 1 no item seeding, 2 no E/N atomics, 3 no cell Philox
+    int dbg;                        // timing experiments only (DESMAN_HIP_STATS_DBG; compiled out of the product kernel: STATS_DBG above): bit 0 no draws, 1 no item seeding, 2 no E/N atomics, 3 no cell Philox
 };
 
 __device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t x)
@@ -153,7 +159,7 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
         const double Gam[4] = {G0, G1, G2, G3};
         const uint32_t cell = (uint32_t)s * (uint32_t)p.V_tot + (uint32_t)(p.v_off + v);
         uint32_t cbase[4];
-        if (p.dbg & 8) { cbase[0] = cell; cbase[1] = p.iter; cbase[2] = p.k0; cbase[3] = p.k1; }
+        if (STATS_DBG(p, 8)) { cbase[0] = cell; cbase[1] = p.iter; cbase[2] = p.k0; cbase[3] = p.k1; }
         else philox4x32_10(cell, 0u, p.iter, DSM_STREAM_STA1, p.k0, p.k1, cbase);         // one Philox-10 per cell
         uint32_t nacc[4] = {0, 0, 0, 0};
 #pragma unroll 1
@@ -169,10 +175,10 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
                     for (int a = 0; a < 4; ++a) W[a] = Gam[a];
                 }
                 uint32_t n[4];
-                Xo128 rng = (p.dbg & 2) ? Xo128{cbase[0] + b, cbase[1], cbase[2], cbase[3] | 1u} : item_seed<SPEC>(cbase, (uint32_t)b, p.k0, p.k1);
+                Xo128 rng = STATS_DBG(p, 2) ? Xo128{cbase[0] + b, cbase[1], cbase[2], cbase[3] | 1u} : item_seed<SPEC>(cbase, (uint32_t)b, p.k0, p.k1);
                 bool defer = false;
                 int kind = 0;
-                if (p.dbg & 1) { n[0] = (uint32_t)xb + (uint32_t)(W[0] > W[1]) + rng.s0; n[1] = n[2] = n[3] = 0; }
+                if (STATS_DBG(p, 1)) { n[0] = (uint32_t)xb + (uint32_t)(W[0] > W[1]) + rng.s0; n[1] = n[2] = n[3] = 0; }
                 else mult4<false, SPEC>(rng, (uint32_t)xb, W, n, rcp, ltab, defer, p.lean_cap, &kind);
                 if (__builtin_expect(defer, 0)) {
                     // needs the rejection sampler: the compacted kernel re-does this item from its own stream
@@ -191,7 +197,7 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
                         const uint32_t slot = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
                         if (kind == kd) p.big_list[(size_t)sub * p.big_seg + slot] = (unsigned long long)cell * 4ull + (unsigned long long)b;
                     }
-                } else if (p.dbg & (4 | 16)) {
+                } else if (STATS_DBG(p, (4 | 16))) {
 #pragma unroll
                     for (int a = 0; a < 4; ++a) nacc[a] += n[a];
                 } else {
@@ -206,8 +212,8 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
         uint32_t *const nt = p.ntab + (size_t)copy * (((size_t)1 << G) * ld);
         const uint32_t hmask = (1u << G) - 1u;
         H0 = (H0 * p.hmul) & hmask; H1 = (H1 * p.hmul) & hmask; H2 = (H2 * p.hmul) & hmask; H3 = (H3 * p.hmul) & hmask;   // rows of the four subsets
-        if (p.dbg & (4 | 32)) { if ((nacc[0] ^ nacc[1] ^ nacc[2] ^ nacc[3] ^ H0 ^ H1 ^ H2 ^ H3) == 0x12345u) atomicAdd(nt + s, 1u); continue; }
-        if (p.dbg & 64) {        // plain stores instead of atomics (wrong sums; what the adds cost beyond a store)
+        if (STATS_DBG(p, (4 | 32))) { if ((nacc[0] ^ nacc[1] ^ nacc[2] ^ nacc[3] ^ H0 ^ H1 ^ H2 ^ H3) == 0x12345u) atomicAdd(nt + s, 1u); continue; }
+        if (STATS_DBG(p, 64)) {        // plain stores instead of atomics (wrong sums; what the adds cost beyond a store)
             nt[(size_t)H0 * ld + s] = nacc[0]; nt[(size_t)H1 * ld + s] = nacc[1]; nt[(size_t)H2 * ld + s] = nacc[2]; nt[(size_t)H3 * ld + s] = nacc[3];
             continue;
         }
@@ -426,8 +432,8 @@ int stats_spec(const dsm_ctx *c)
 // stage 2's root (64 copies: +20 us on the Dirichlet launch).  DESMAN_HIP_NTAB_LINES overrides the 384.
 int stats_ntab_rep(const dsm_ctx *c)
 {
-    static const double want = getenv("DESMAN_HIP_NTAB_LINES") ? atof(getenv("DESMAN_HIP_NTAB_LINES")) : 384.0;
-    static const int force = getenv("DESMAN_HIP_NTAB_REP") ? atoi(getenv("DESMAN_HIP_NTAB_REP")) : 0;      // A/B switch
+    static const double want = DSM_AB_ENV("DESMAN_HIP_NTAB_LINES") ? atof(DSM_AB_ENV("DESMAN_HIP_NTAB_LINES")) : 384.0;
+    static const int force = DSM_AB_ENV("DESMAN_HIP_NTAB_REP") ? atoi(DSM_AB_ENV("DESMAN_HIP_NTAB_REP")) : 0;      // A/B switch
     if (force > 0) return force;
     // a chain sharded by positions: every rank must lay its table out alike (the tables are all-reduced element by element), so
     // the rule reads the WHOLE table's position count, never the shard's own (shards differ by one position: V = 21 845, G = 8 on
@@ -445,7 +451,7 @@ static bool stats_ntab_xcd(const dsm_ctx *c)
 {
     // measured at config 3 (rocprofv3 kernel trace of the Gibbs loop): stage 1 47.9 -> 46.1 us, but the root of stage 2 then reads
     // eight copies: Dirichlet launch 19.2 -> 22.7 us.  Off by default.
-    static const int env = getenv("DESMAN_HIP_NTAB_XCD") ? atoi(getenv("DESMAN_HIP_NTAB_XCD")) : 0;      // A/B switch
+    static const int env = DSM_AB_ENV("DESMAN_HIP_NTAB_XCD") ? atoi(DSM_AB_ENV("DESMAN_HIP_NTAB_XCD")) : 0;      // A/B switch
     return env != 0 && (size_t)8 * ((size_t)1 << c->G) * (size_t)c->S * 4 <= ((size_t)64 << 20);
 }
 
@@ -457,7 +463,7 @@ static bool stats_ntab_xcd(const dsm_ctx *c)
 // scanned).  DESMAN_HIP_NTAB_HMUL=1 is the identity (A/B switch).
 uint32_t stats_ntab_hmul()
 {
-    static const uint32_t k = getenv("DESMAN_HIP_NTAB_HMUL") ? ((uint32_t)strtoul(getenv("DESMAN_HIP_NTAB_HMUL"), nullptr, 0) | 1u) : 0x9E3779B1u;
+    static const uint32_t k = DSM_AB_ENV("DESMAN_HIP_NTAB_HMUL") ? ((uint32_t)strtoul(DSM_AB_ENV("DESMAN_HIP_NTAB_HMUL"), nullptr, 0) | 1u) : 0x9E3779B1u;
     return k;
 }
 
@@ -468,7 +474,7 @@ uint32_t stats_ntab_hmul()
 // rows a quarter block longer: DESMAN_HIP_NTAB_PAD overrides the words added (A/B switch).
 int stats_ntab_ld(int S)
 {
-    static const int pad = getenv("DESMAN_HIP_NTAB_PAD") ? atoi(getenv("DESMAN_HIP_NTAB_PAD")) : DSM_NTAB_PAD;
+    static const int pad = DSM_AB_ENV("DESMAN_HIP_NTAB_PAD") ? atoi(DSM_AB_ENV("DESMAN_HIP_NTAB_PAD")) : DSM_NTAB_PAD;
     return (S % 64 == 0) ? S + pad : S;
 }
 
@@ -487,8 +493,8 @@ static int ensure_ntab(dsm_ctx *c)
     if (stats_ntab_xcd(c)) c->ntab_rep = std::max(8, (c->ntab_rep + 7) / 8 * 8);
     c->ntab_ld = stats_ntab_ld(c->S);
     const size_t need = (size_t)c->ntab_rep * ((size_t)1 << c->G) * (size_t)c->ntab_ld;
-    static const bool scan = getenv("DESMAN_HIP_NTAB_SCAN") != nullptr;          // experiments: the offset is re-read at every call
-    const char *eo = getenv("DESMAN_HIP_NTAB_OFF");
+    static const bool scan = DSM_AB_ENV("DESMAN_HIP_NTAB_SCAN") != nullptr;          // experiments: the offset is re-read at every call
+    const char *eo = DSM_AB_ENV("DESMAN_HIP_NTAB_OFF");
     const size_t off_env = eo ? ((size_t)strtoull(eo, nullptr, 0) & ~(size_t)255) : (size_t)-1;
     if (c->ntab && c->ntab_len == need && (!scan || off_env == (size_t)-1 || off_env == c->ntab_off)) return DSM_OK;
     if (c->ntab_raw) { (void)hipFree(c->ntab_raw); c->ntab_raw = nullptr; c->ntab = nullptr; }
@@ -580,7 +586,7 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     const int LPV = stats_agg_lpv(S);
     const int NCH = (S + LPV - 1) / LPV, SP = NCH * LPV, NG = 64 / LPV;
     const int spec = stats_spec(c);                       // 2 or 3 (the caller checked that the aggregated pass applies)
-    static const int regg_env = getenv("DESMAN_HIP_STATS_REGG") ? atoi(getenv("DESMAN_HIP_STATS_REGG")) : -1;   // A/B switch
+    static const int regg_env = DSM_AB_ENV("DESMAN_HIP_STATS_REGG") ? atoi(DSM_AB_ENV("DESMAN_HIP_STATS_REGG")) : -1;   // A/B switch
     // (gamma in registers where a lane keeps its sample, instead of the LDS tile: measured slower -- 87-91 VGPRs, i.e. five
     // wavefronts per SIMD, or spills at six: 54-57 us against 48-49; kept as an A/B switch)
     const bool regg = NCH == 1 && G <= 8 && regg_env == 1;
@@ -600,13 +606,13 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, sh));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-        static const int wgs_env = getenv("DESMAN_HIP_STATS_WGS") ? atoi(getenv("DESMAN_HIP_STATS_WGS")) : 6;   // A/B switch
+        static const int wgs_env = DSM_AB_ENV("DESMAN_HIP_STATS_WGS") ? atoi(DSM_AB_ENV("DESMAN_HIP_STATS_WGS")) : 6;   // A/B switch
         // ... on all CUs but one per XCD when the sweep's uniforms are MT19937 words: the generator's workgroup keeps a CU to itself
         // (kernels_gibbs.hip: k_mt_fill) and workgroups go to the XCDs in turn whatever room they have, so a persistent grid sized for
         // every CU leaves six workgroups of that XCD waiting for others to finish -- a launch that starts while the generator runs took
         // 51 us instead of 46 (scripts/dbg/trace_stats_vs_mt.sh).  Leaving 8 CUs: 106.7 vs 107.5 us per iteration at config 3 (1 CU: no
         // change; 16 and more: slower).
-        static const int leave_env = getenv("DESMAN_HIP_STATS_LEAVE_CUS") ? atoi(getenv("DESMAN_HIP_STATS_LEAVE_CUS")) : -1;   // A/B switch
+        static const int leave_env = DSM_AB_ENV("DESMAN_HIP_STATS_LEAVE_CUS") ? atoi(DSM_AB_ENV("DESMAN_HIP_STATS_LEAVE_CUS")) : -1;   // A/B switch
         const int n_xcd = prop.multiProcessorCount % 8 == 0 && prop.multiProcessorCount >= 64 ? 8 : 1;
         // (only while a wavefront makes a pass or two: over many passes the smaller grid is simply 3 % less machine -- config 5, twelve
         // passes: 384 vs 368 us)
@@ -642,9 +648,9 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
         // kernel although inversion still applies to it -- its search would hold its 63 neighbours of the wavefront for
         // ~lean_cap more steps.  Config 3 at 10 x depth (us, this pass + compacted kernel): 128 -> 150 + 35, 64 -> 119 + 53,
         // 48 -> 105 + 81, 32 -> 86 + 134.  Data of ordinary depth has no such item once the chain has converged.
-        static const char *e = getenv("DESMAN_HIP_LEAN_CAP");
+        static const char *e = DSM_AB_ENV("DESMAN_HIP_LEAN_CAP");
         p.lean_cap = e ? atof(e) : DSM_LEAN_CAP;
-        static const int dbg = getenv("DESMAN_HIP_STATS_DBG") ? atoi(getenv("DESMAN_HIP_STATS_DBG")) : 0;
+        static const int dbg = DSM_AB_ENV("DESMAN_HIP_STATS_DBG") ? atoi(DSM_AB_ENV("DESMAN_HIP_STATS_DBG")) : 0;
         p.dbg = dbg;
         if (!(p.lean_cap > 0.0 && p.lean_cap <= DSM_BINV_MEAN_CAP)) p.lean_cap = DSM_LEAN_CAP;
     }

@@ -39,6 +39,9 @@ with tempfile.TemporaryDirectory() as d:
     df.to_csv(freq)
     cli.main([freq, "-g", "3", "-i", "5", "-o", os.path.join(d, "warm")])       # warm: library load, table cache
     for G in [int(x) for x in a.gs.split(",")]:
+        import logging
+        for h in logging.root.handlers[:]:                      # one log file per chain (basicConfig configures only an empty root logger)
+            logging.root.removeHandler(h)
         pr = cProfile.Profile()
         t0 = time.perf_counter()
         pr.enable()
@@ -58,9 +61,12 @@ with tempfile.TemporaryDirectory() as d:
         ph["output_files"] = out_s
         ph["wall"] = wall
         ph["other"] = wall - sum(v for k, v in ph.items() if k not in ("wall", "nmft_init_draws"))
-        log = open(os.path.join(d, "out%d" % G, "log_file.txt")).read()
-        ph["nmft_updates"] = max([int(ln.split("NTF Iter ")[1].split(",")[0]) for ln in log.splitlines() if "NTF Iter " in ln] or [0])
+        try:
+            log = open(os.path.join(d, "out%d" % G, "log_file.txt")).read()
+            ph["nmft_updates_logged"] = max([int(ln.split("NTF Iter ")[1].split(",")[0]) for ln in log.splitlines() if "NTF Iter " in ln] or [0])
+        except OSError:
+            ph["nmft_updates_logged"] = None
         rows[G] = ph
-        print("G=%2d wall %.2f s  " % (G, wall) + "  ".join("%s %.2f" % (k, v) for k, v in ph.items() if k != "wall"), flush=True)
+        print("G=%2d wall %.2f s  " % (G, wall) + "  ".join("%s %s" % (k, ("%.2f" % v) if isinstance(v, float) else v) for k, v in ph.items() if k != "wall"), flush=True)
 os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
 json.dump(dict(V=V, S=S, iters=a.iters, per_G=rows), open(a.out, "w"), indent=1)

@@ -1,5 +1,6 @@
 """stage 1 of the mu/E pass against the offset of the subset table inside its 2 MB-aligned block (DESMAN_HIP_NTAB_OFF): us per launch
 (hipEvent timing of `stats`), at config 3 by default.  usage: ntab_off_scan.py [V S G]"""
+import os as _os; _os.environ.setdefault("DESMAN_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))), "desman_amd", "lib", "libdesman_hip_ab.so"))  # the experiment build: A/B switches compiled in (make -C desman_amd/csrc ab)
 import os, sys, subprocess
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 V, S, G = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (10000, 64, 8)

@@ -1,5 +1,6 @@
 """stage 1 of the mu/E pass against the place of the subset table, all offsets inside ONE process (one set of physical pages):
 is the cost of an offset stable, and how far apart are the best and the worst?  usage: ntab_scan_inproc.py [V S G]"""
+import os as _os; _os.environ.setdefault("DESMAN_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))), "desman_amd", "lib", "libdesman_hip_ab.so"))  # the experiment build: A/B switches compiled in (make -C desman_amd/csrc ab)
 import os, sys
 os.environ["DESMAN_HIP_NTAB_SCAN"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -1,5 +1,6 @@
 #!/bin/bash
 # PMC passes of the NMFT update kernel at a large shape.  usage: pmc_nmft_big.sh V S G  -> gpurun_out/pmc_nmft_big.csv
+export DESMAN_HIP_LIB=${DESMAN_HIP_LIB:-$PWD/desman_amd/lib/libdesman_hip_ab.so}   # the experiment build: A/B switches compiled in (make -C desman_amd/csrc ab)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/pmc_nb; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/p1 -o p -- python scripts/prof_nmft.py $1 $2 $3 40 > $O/l1.log 2>&1

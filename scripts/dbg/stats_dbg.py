@@ -1,4 +1,5 @@
 """timing experiments on stage 1 of the mu/E pass: the launch with parts of the work removed (results are garbage then)"""
+import os as _os; _os.environ.setdefault("DESMAN_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))), "desman_amd", "lib", "libdesman_hip_ab.so"))  # the experiment build: A/B switches compiled in (make -C desman_amd/csrc ab)
 import os, sys, subprocess, json
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 code = r'''

@@ -1,5 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel-trace averages of the Gibbs loop's kernels for A/B variants (env VAR=VAL pairs given as arguments "name:ENV1=a,ENV2=b")
+export DESMAN_HIP_LIB=${DESMAN_HIP_LIB:-$PWD/desman_amd/lib/libdesman_hip_ab.so}   # the experiment build: A/B switches compiled in (make -C desman_amd/csrc ab)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for spec in "$@"; do
   name=${spec%%:*}; envs=${spec#*:}

@@ -1,5 +1,6 @@
 #!/bin/bash
 # kernel trace of the bench: where one Gibbs iteration's 107 us go -- kernel durations and the gaps between consecutive launches on the main stream
+export DESMAN_HIP_LIB=${DESMAN_HIP_LIB:-$PWD/desman_amd/lib/libdesman_hip_ab.so}   # the experiment build: A/B switches compiled in (make -C desman_amd/csrc ab)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf /tmp/tr; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o t -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline --batch 0 > /dev/null 2>&1
 f=$(find /tmp/tr -name 't_kernel_trace.csv' | head -1)

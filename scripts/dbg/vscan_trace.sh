@@ -1,5 +1,6 @@
 #!/bin/bash
 # kernel-trace averages of the four Gibbs kernels over a scan of V (S, G fixed): looks for round quantisation.  usage: vscan_trace.sh S G V...
+export DESMAN_HIP_LIB=${DESMAN_HIP_LIB:-$PWD/desman_amd/lib/libdesman_hip_ab.so}   # the experiment build: A/B switches compiled in (make -C desman_amd/csrc ab)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 S=$1; G=$2; shift 2
 for V in "$@"; do

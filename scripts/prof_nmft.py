@@ -1,4 +1,4 @@
-"""Times the NMFT update kernels: python scripts/prof_nmft.py [V S G iters]   (DESMAN_HIP_NMFT_NO_MFMA=1: VALU one-pass kernel)"""
+"""Times the NMFT update kernels: python scripts/prof_nmft.py [V S G iters]   (experiment build only -- DESMAN_HIP_LIB=desman_amd/lib/libdesman_hip_ab.so DESMAN_HIP_NMFT_NO_MFMA=1: VALU one-pass kernel)"""
 import sys, time; sys.path.insert(0, '.')
 import numpy as np
 from desman_amd import _lib

@@ -232,7 +232,9 @@ mu, es = c.sample_stats(77)
 np.savez(sys.argv[1], ll=tr["ll"], lp=tr["lp"], nch=tr["nchange"], t=t, g=g, e=e, mu=mu, es=es)
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env_extra in ({}, {"DESMAN_HIP_NTAB_TUNE": "0"}, {"DESMAN_HIP_NTAB_OFF": "768"}, {"DESMAN_HIP_NTAB_OFF": "4096"}):
+    # DESMAN_HIP_NTAB_OFF (a place given from outside) exists only in the experiment build (-DDSM_AB_SWITCHES)
+    ab = {"DESMAN_HIP_LIB": _lib.AB_LIB_PATH}
+    for env_extra in ({}, {"DESMAN_HIP_NTAB_TUNE": "0"}, dict(ab, DESMAN_HIP_NTAB_OFF="768"), dict(ab, DESMAN_HIP_NTAB_OFF="4096")):
         path = str(tmp_path / ("o%d.npz" % len(outs)))
         r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]

@@ -213,7 +213,8 @@ np.savez(sys.argv[1], n=n, tr=tr, t=t, g=g)
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as d:
         outs = []
-        for env_extra in ({}, {"DESMAN_HIP_NMFT_FORCE_TIMEOUT": "1"}):
+        # the forcing switch exists only in the experiment build (make -C desman_amd/csrc ab: -DDSM_AB_SWITCHES)
+        for env_extra in ({}, {"DESMAN_HIP_NMFT_FORCE_TIMEOUT": "1", "DESMAN_HIP_LIB": _lib.AB_LIB_PATH}):
             path = os.path.join(d, "o%d.npz" % len(outs))
             r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]

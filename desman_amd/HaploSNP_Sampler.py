@@ -92,10 +92,11 @@ class HaploSNP_Sampler:
         built on the same table that loads it continues bit for bit (tests/test_gpu_host.py)."""
         self._bind_rng()                                      # keys the counter streams if no update() has run yet
         self._release_rng()
-        ck = self._ctx.checkpoint()
+        key, it = self._ctx.counters()                        # (no resident state needed: also valid before the first update())
         mt = self.mt_state if self.mt_state is not None else _sampletau.getRNGState()
         np.savez(path, tau=np.asarray(self.tau, dtype=np.int64), gamma=self.gamma, eta=self.eta, mt_state=np.asarray(mt, dtype=np.uint32),
-                 ctr_seed=ck["ctr_seed"], iter_ctr=ck["iter_ctr"], G=self.G, own_stream=self.mt_state is not None)
+                 ctr_seed=np.uint64(key), iter_ctr=np.uint32(it), G=self.G, own_stream=self.mt_state is not None,
+                 screen=self._ctx.screen_state())
 
     def load_checkpoint(self, path):
         z = np.load(path)
@@ -107,8 +108,10 @@ class HaploSNP_Sampler:
             self.mt_state = z["mt_state"].copy()
         else:
             _sampletau.setRNGState(z["mt_state"])             # the module's stream, as in the run that saved it
-        self._ctx.restore(dict(tau=self.tau, gamma=self.gamma, eta=self.eta, mt_state=z["mt_state"], ctr_seed=z["ctr_seed"],
-                               iter_ctr=z["iter_ctr"]))
+        ck = dict(tau=self.tau, gamma=self.gamma, eta=self.eta, mt_state=z["mt_state"], ctr_seed=z["ctr_seed"], iter_ctr=z["iter_ctr"])
+        if "screen" in z.files:
+            ck["screen"] = z["screen"]
+        self._ctx.restore(ck)
         self._keyed = True                                    # the counter streams keep their key and position
 
     # ---- the Gibbs loop

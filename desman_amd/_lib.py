@@ -78,6 +78,8 @@ SIGNATURES = {
     "dsm_ctx_gibbs_update": (_i, [_vp, _i]),
     "dsm_ctx_get_counters": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "dsm_ctx_set_counters": (_i, [_vp, C.c_uint64, C.c_uint32]),
+    "dsm_ctx_get_screen_state": (_i, [_vp, _u32p]),
+    "dsm_ctx_set_screen_state": (_i, [_vp, _u32p]),
     "dsm_ctx_gibbs_update_sharded": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "dsm_ctx_gibbs_update_sharded_comm": (_i, [_vp, _i, _i, _i, _vp]),
     "dsm_comm_unique_id": (_i, [_vp]),
@@ -275,13 +277,27 @@ class Context:
         """everything that places the chain: state, MT19937 stream, counter-stream key and iteration counter (a dict of arrays:
         np.savez(path, **ctx.checkpoint()) writes it).  Counts, priors and the tau RNG mode are the caller's to keep."""
         tau, gamma, eta = self.get_state()
-        key, it = C.c_uint64(0), C.c_uint32(0)
-        check(self.lib.dsm_ctx_get_counters(self._h, C.byref(key), C.byref(it)))
+        key, it = self.counters()
         try:
             mt = self.get_mt_state()
         except DesmanHipError:                                   # never seeded: counter-based runs
             mt = np.zeros(0, dtype=np.uint32)
-        return dict(tau=tau, gamma=gamma, eta=eta, mt_state=mt, ctr_seed=np.uint64(key.value), iter_ctr=np.uint32(it.value))
+        return dict(tau=tau, gamma=gamma, eta=eta, mt_state=mt, ctr_seed=np.uint64(key), iter_ctr=np.uint32(it), screen=self.screen_state())
+
+    def counters(self):
+        """(key of the counter-based streams, iterations drawn so far) -- needs no resident state"""
+        key, it = C.c_uint64(0), C.c_uint32(0)
+        check(self.lib.dsm_ctx_get_counters(self._h, C.byref(key), C.byref(it)))
+        return int(key.value), int(it.value)
+
+    def screen_state(self):
+        """the tau sweep's screening state: sweeps still to run without the fp32 screening pass, per launch parity"""
+        out = np.zeros(2, dtype=np.uint32)
+        check(self.lib.dsm_ctx_get_screen_state(self._h, out))
+        return out
+
+    def set_screen_state(self, words):
+        check(self.lib.dsm_ctx_set_screen_state(self._h, np.ascontiguousarray(words, dtype=np.uint32)))
 
     def restore(self, ck):
         """put a chain saved by checkpoint() into this context (counts set already): it continues bit for bit"""
@@ -291,6 +307,8 @@ class Context:
         if mt.size == 625:
             self.set_mt_state(np.ascontiguousarray(mt))
         check(self.lib.dsm_ctx_set_counters(self._h, int(ck["ctr_seed"]), int(ck["iter_ctr"])))
+        # the screening decisions of the saved chain (older checkpoints have none: the screen starts switched on, as in a fresh chain)
+        self.set_screen_state(ck["screen"] if "screen" in ck else np.zeros(2, dtype=np.uint32))
 
     def set_mt_state(self, st):
         check(self.lib.dsm_ctx_set_mt_state(self._h, np.ascontiguousarray(st, dtype=np.uint32)))
@@ -348,7 +366,7 @@ class Context:
         return a.value, b.value
 
     def stats_spec(self):
-        """3 / 2 = aggregated mu/E sampler (oracle/stats_agg.c, current / first version), 1 = per-read draws (orc_stats_counter)."""
+        """2 / 3 = aggregated mu/E sampler (oracle/stats_agg.c: 2 = the default version, 3 = the table exp/log variant), 1 = per-read draws (orc_stats_counter)."""
         r = self.lib.dsm_ctx_stats_spec(self._h)
         if r < 0:
             check(r)

@@ -134,6 +134,18 @@ static int need(dsm_ctx *c, bool counts, bool state)
     return DSM_OK;
 }
 
+// Both slots of the sweep's block order start as the identity and no slot is marked usable: whatever a failed or skipped finalize launch
+// leaves behind is then the identity or an order written for the CURRENT grid (the grid changes only with the table: dsm_ctx_set_counts
+// calls this again) -- a sweep can never index its blocks through stale or uninitialised words.
+static int reset_blk_order(dsm_ctx *c)
+{
+    static const std::vector<uint32_t> ident = [] { std::vector<uint32_t> v((size_t)2 * DSM_MAX_GRID); for (size_t i = 0; i < v.size(); ++i) v[i] = (uint32_t)(i % DSM_MAX_GRID); return v; }();
+    c->blk_order_n[0] = c->blk_order_n[1] = 0;
+    if (!c->blk_order) return DSM_OK;
+    HIP_TRY(hipMemcpyAsync(c->blk_order, ident.data(), ident.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    return DSM_OK;
+}
+
 // ---------------------------------------------------------------- lifecycle
 extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
 {
@@ -171,6 +183,7 @@ extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
     TRY(dev_alloc(&c->step_cnt, (size_t)2 * 2 * DSM_MAX_GRID));
     HIP_TRY(hipMemsetAsync(c->step_cnt, 0, (size_t)2 * 2 * DSM_MAX_GRID * sizeof(uint32_t), c->stream));
     TRY(dev_alloc(&c->blk_order, (size_t)2 * DSM_MAX_GRID));
+    TRY(reset_blk_order(c));
     TRY(dev_alloc(&c->screen_ctl, 4));
     HIP_TRY(hipMemsetAsync(c->screen_ctl, 0, 4 * sizeof(uint32_t), c->stream));
     TRY(dev_alloc(&c->prior, 2 * (DSM_MAX_S + 4)));
@@ -270,6 +283,8 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     c->max_items = 0;
     c->blk_gmax = 0;
     c->stats_grid = 0;
+    TRY(reset_blk_order(c));              // another table, another grid: no block order of the old one survives
+    HIP_TRY(hipMemsetAsync(c->screen_ctl, 0, 4 * sizeof(uint32_t), c->stream));
     dev_free(&c->items);
     c->depth.assign((size_t)S, 0);
     c->max_depth = 0;
@@ -466,6 +481,25 @@ extern "C" int dsm_ctx_seed(dsm_ctx *c, unsigned long mt_seed, uint64_t ctr_seed
 // the two words besides (tau, gamma, eta, MT19937 state) that place a chain in its counter-based streams: the stream key and the
 // number of iterations drawn so far.  With them a chain restored into a fresh context continues bit for bit (checkpoint / resume:
 // SURVEY sec. 5; the reference's own hook, Output_Results.output_Pickled_haploSNP, is dead code).
+// the screening state of the tau sweep (kernels_gibbs.hip: finalize_body): sweeps still to run without the fp32 screening pass, one word per
+// launch parity.  Which steps are screened can decide a draw inside a ~1e-13 near-tie, so a checkpoint carries the words.
+extern "C" int dsm_ctx_get_screen_state(dsm_ctx *c, uint32_t *out2)
+{
+    if (!c || !out2) { dsm_set_error("get_screen_state: null argument"); return DSM_ERR_ARG; }
+    BIND(c);
+    HIP_TRY(hipMemcpyAsync(out2, c->screen_ctl, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DSM_OK;
+}
+extern "C" int dsm_ctx_set_screen_state(dsm_ctx *c, const uint32_t *in2)
+{
+    if (!c || !in2) { dsm_set_error("set_screen_state: null argument"); return DSM_ERR_ARG; }
+    BIND(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(c->screen_ctl, in2, 2 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return DSM_OK;
+}
+
 extern "C" int dsm_ctx_get_counters(dsm_ctx *c, uint64_t *ctr_seed, uint32_t *iter_ctr)
 {
     if (!c || !ctr_seed || !iter_ctr) { dsm_set_error("get_counters: null argument"); return DSM_ERR_ARG; }

@@ -1,8 +1,8 @@
 // dsm_binom.h -- device-side samplers of the aggregated mu/E pass (specs 2 and 3, restated in
 // oracle/stats_agg.c: every function here has a twin there with the same operation order; the library
 // is built with -ffp-contract=off, division and sqrt are IEEE, so the two agree bit for bit).
-// SPEC = 2: (1-q)^n by repeated squaring, two divisions, item streams three Philox rounds off the cell's block.
-// SPEC = 3 (default): f0 = exp(-n ln(1 + r)), r = q/(1-q) the one division, table log + table exp (dsm_texp) -- a fixed
+// SPEC = 2 (the default, DSM_STATS_AGG): (1-q)^n by repeated squaring, two divisions, item streams three Philox rounds off the cell's block.
+// SPEC = 3 (selectable: dsm_ctx_force_stats_spec(3), DESMAN_HIP_STATS_SPEC=3; measured 2 us slower at config 3): f0 = exp(-n ln(1 + r)), r = q/(1-q) the one division, table log + table exp (dsm_texp) -- a fixed
 //           ~35 instructions instead of a loop over the bits of n to the deepest lane; item streams two rounds.
 //
 //   draw_reads<K>   x reads over K categories, read by read against 32-bit thresholds (x <= DSM_XS)

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(1024) void nmft_gamma_kernel_b(BatchArgs<NmftGammaP
 // parity slots; launch number n reads slot n & 1 and workgroup 0 writes slot 1 - (n & 1) for the next launch, so the launch
 // has no reader of a word it writes.  The parity is a kernel argument (a captured batch of 64 iterations replays with the
 // same arguments per node).
-//   ctl: [0] div  [2] done  [3] updates run  [4 + p] previous div  [6 + p] iteration index
+//   ctl: [0] div  [2] done  [3] updates run  [4 + p] previous div  [6 + p] iteration index  [8 + p] done, as seen by launches of parity p
 // ---------------------------------------------------------------------------
 #define NMFT_RG_WGS 8
 struct NmftRgParams {
@@ -274,8 +274,13 @@ __device__ __forceinline__ void nmft_rg_body(const NmftRgParams &q)
     double *red = reinterpret_cast<double *>(smem_g);              // [G cw] numerators of the own columns, [G] row sums, [1] objective
     const double *__restrict__ partial = q.partial;
     double *__restrict__ ctl = q.ctl;
-    if (ctl[2] != 0.0) return;                                     // stopped in an earlier launch (set in this one only when
-                                                                   // no workgroup has anything left to do)
+    // stopped in an earlier launch?  Read from the stop word of THIS launch's parity (written by the launch before it), never from
+    // ctl[2], which workgroup 0 of this very launch may set while other workgroups are still starting: every workgroup of a launch
+    // takes the same decision and q.stat is complete after the last update.  A stopped launch hands the flag on to the other parity.
+    if (ctl[8 + (q.parity & 1)] != 0.0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctl[8 + (1 - (q.parity & 1))] = 1.0;
+        return;
+    }
     const int S = q.S, G = q.G, nblk = q.nblk, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nwg = (int)gridDim.x, cw = (S + nwg - 1) / nwg, s_lo = (int)blockIdx.x * cw;
     const int ncol = s_lo < S ? (S - s_lo < cw ? S - s_lo : cw) : 0;
@@ -303,7 +308,7 @@ __device__ __forceinline__ void nmft_rg_body(const NmftRgParams &q)
         ctl[4 + (1 - p)] = div;
         ctl[6 + (1 - p)] = (double)(it + 1);
         ctl[3] = (double)it;
-        if (!go) ctl[2] = 1.0;
+        if (!go) { ctl[2] = 1.0; ctl[8 + (1 - p)] = 1.0; }       // [2]: read by the update kernels of later launches and by the host
         if (q.div_trace) q.div_trace[it] = div;
     }
     if (!go || q.fix_gamma) return;                                               // uniform over the workgroup

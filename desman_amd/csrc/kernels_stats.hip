@@ -406,7 +406,7 @@ int stats_spec(const dsm_ctx *c)
     if (c->G < 1 || c->G > 16) return 1;
     if (((size_t)1 << c->G) * (size_t)c->S * 4 > ((size_t)64 << 20)) return 1;
     if (c->max_depth >= ((uint64_t)1 << 32)) return 1;
-    if (force >= 2) return force;                        // 2 = the first version of the aggregated draws, 3 = the current one
+    if (force >= 2) return force;                        // 2 = the default version of the aggregated draws, 3 = the table exp/log variant
     double reads = 0.0;
     for (int64_t d : c->depth) reads += (double)d;
     const int lpv = stats_agg_lpv(c->S);
@@ -470,8 +470,9 @@ uint32_t stats_ntab_hmul()
 // Row stride of the subset table.  With S a multiple of 64 the rows are whole 256 B blocks and where the hot rows fall relative to the
 // memory-channel interleave decides what stage 1's memory-side atomics cost: at config 3 (S = 64) 44 us or 54 us (69 at the worst) for the
 // same launch, switching with every 256 B the table's base moves and with the multiplier of the row map (scripts/dbg/ntab_off_scan.py);
-// S = 48 or 96 (rows of 192 / 384 B, which cut the interleave at a different place every row) show none of it.  So such tables get
-// rows a quarter block longer: DESMAN_HIP_NTAB_PAD overrides the words added (A/B switch).
+// S = 48 or 96 (rows of 192 / 384 B, which cut the interleave at a different place every row) show none of it.  Longer rows (320 / 384 B)
+// narrowed the spread without closing it, so DSM_NTAB_PAD is 0 and the table's START is measured instead (stats_place_ntab below);
+// DESMAN_HIP_NTAB_PAD adds words to such rows in the experiment build (A/B switch).
 int stats_ntab_ld(int S)
 {
     static const int pad = DSM_AB_ENV("DESMAN_HIP_NTAB_PAD") ? atoi(DSM_AB_ENV("DESMAN_HIP_NTAB_PAD")) : DSM_NTAB_PAD;
@@ -740,7 +741,7 @@ int k_stats_stage2(dsm_ctx *c, uint32_t iter)
     return DSM_OK;
 }
 
-// A2 for the resident state: the aggregated pass (spec 3, or 2 when forced) where it applies, else the per-read pass (spec 1)
+// A2 for the resident state: the aggregated pass (spec DSM_STATS_AGG = 2, or 3 when forced) where it applies, else the per-read pass (spec 1)
 int k_stats(dsm_ctx *c, uint32_t iter)
 {
     if (stats_spec(c) >= 2) {

@@ -296,8 +296,8 @@ int dsm_ctx_debug_log2f(dsm_ctx *ctx, const float *in, float *out, size_t n);
 int dsm_ctx_set_nmft_fused(dsm_ctx *ctx, int mode);
 /* dsm_nmft_factorize as ONE persistent launch (resident workgroups, in-kernel grid barriers, tau rows kept in LDS) where the
    table fits the machine (S <= 64, G <= 12, V <= 48 x compute units): -1 / 1 = wherever it applies (default), 0 = never (the
-   three-launch loop).  Same stopping rule and update counts; factors equal to rounding (the workgroup partials are grouped
-   differently). */
+   three-launch loop).  Same stopping rule, update counts, objective trace and factors, bit for bit: every path sums the workgroup
+   partials in one canonical order (kernels_nmft.hip: nmft_sum_partials; tests/test_gpu_fullsize.py asserts the equality). */
 int dsm_ctx_set_nmft_persist(dsm_ctx *ctx, int mode);
 /* on = 0: every step of the tau sweep in fp64 (A/B switch).  Same law, and the same draws except in near-ties: after a screened
    step the current base's log-probability is evaluated afresh, an all-fp64 sweep re-uses the previous step's value (equal up to
@@ -320,6 +320,11 @@ int dsm_ctx_tau_launch_info(dsm_ctx *ctx, int *launched, int *resident);
  * given the same counts, state, MT19937 state, priors, tau RNG and these two words continues the chain bit for bit.          */
 int dsm_ctx_get_counters(dsm_ctx *ctx, uint64_t *ctr_seed, uint32_t *iter_ctr);
 int dsm_ctx_set_counters(dsm_ctx *ctx, uint64_t ctr_seed, uint32_t iter_ctr);
+/* ... and the tau sweep's screening state: two words (one per launch parity) = sweeps still to run without the fp32 screening pass.
+ * Which steps are screened cannot change a draw outside a ~1e-13 near-tie; carrying the words makes the resumed
+ * chain take the same screening decisions as the uninterrupted one, so "bit for bit" holds without that caveat.                  */
+int dsm_ctx_get_screen_state(dsm_ctx *ctx, uint32_t *out2);
+int dsm_ctx_set_screen_state(dsm_ctx *ctx, const uint32_t *in2);
 typedef int (*dsm_exchange_fn)(void *user, uint32_t *dev_tab, size_t n_tab, double *dev_vec, size_t n_vec);
 int dsm_ctx_gibbs_update_sharded(dsm_ctx *ctx, int n_iter, int v_offset, int v_total, dsm_exchange_fn exchange, void *user);
 /* ---- RCCL (xGMI) inside the library: one communicator per process / GPU, no torch.  librccl is dlopen()ed on first use

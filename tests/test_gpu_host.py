@@ -360,6 +360,22 @@ def test_checkpoint_resume_continues_the_chain_bit_for_bit(tmp_path):
     assert a.lp_star == b.lp_star and np.array_equal(sampletau.getRNGState(), end_a)
     ck_b = b._ctx.checkpoint()
     assert int(ck_b["iter_ctr"]) == int(ck_ctx["iter_ctr"]) == 50 and int(ck_b["ctr_seed"]) == int(ck_ctx["ctr_seed"])
+    assert np.array_equal(ck_b["screen"], ck_ctx["screen"])
     with pytest.raises(ValueError):
         HaploSNP_Sampler(counts, G + 1, np.random.RandomState(1), max_iter=5).load_checkpoint(str(tmp_path / "ck.npz"))
+    # the screening state travels with the checkpoint: a suspended screen is suspended in the resumed chain too
+    a._ctx.set_screen_state(np.array([7, 3], dtype=np.uint32))
+    a.save_checkpoint(str(tmp_path / "ck2.npz"))
+    c = fresh(5)
+    c.load_checkpoint(str(tmp_path / "ck2.npz"))
+    assert c._ctx.screen_state().tolist() == [7, 3]
+    # ... and a chain can be saved before its first update(): the saved start then runs like the sampler it came from
+    d = fresh(21)
+    d.save_checkpoint(str(tmp_path / "ck0.npz"))
+    d.update()
+    e = fresh(99)
+    e.load_checkpoint(str(tmp_path / "ck0.npz"))
+    e.update()
+    for name in ("tau", "gamma", "eta", "ll_store", "lp_store"):
+        assert np.array_equal(getattr(d, name), getattr(e, name)), name
     sampletau.freeRNG()

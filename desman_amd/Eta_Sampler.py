@@ -111,6 +111,7 @@ class Eta_Sampler:
         mult_const = np.array([per_variant[self._gene_off[c]:self._gene_off[c + 1]].sum() for c in range(self.C)])
         cov_const = -gammaln(self.cov + 1.0).sum(axis=1)
         self._dev.set_data(self._counts, self._gene_off, self.cov)
+        self._consts = (cov_const, mult_const)
         self._dev.set_model(self.gamma, self.epsilon, self.delta, self.max_eta, self.eta_log_prior, cov_const, mult_const)
 
     def _slice(self, cat, c):
@@ -262,10 +263,15 @@ class Eta_Sampler:
 
     def calcTauStar(self, eta, gamma=None, epsilon=None):
         """tau_iter sweeps with the copy numbers fixed to ``eta``; keeps, per variant, the tau with the best
-        multinomial log-likelihood and every iteration's tau (Eta_Sampler.py:397-452)."""
-        if gamma is not None or epsilon is not None:
-            raise NotImplementedError("calcTauStar with a substitute gamma / epsilon is not supported on the device")
+        multinomial log-likelihood and every iteration's tau (Eta_Sampler.py:397-452).  A substitute ``gamma`` / ``epsilon`` is
+        used where the reference uses it: by the sweeps and their likelihoods (:434-435), not by the NMF start, which takes the
+        sampler's own gamma and eta (:420-423)."""
         eta = np.asarray(eta)
+        sub = gamma is not None or epsilon is not None
+        gamma_s = self.gamma if gamma is None else np.array(gamma, dtype=np.float64, order='C')
+        eps_s = self.epsilon if epsilon is None else np.array(epsilon, dtype=np.float64, order='C')
+        if gamma_s.shape != self.gamma.shape or eps_s.shape != (4, 4):
+            raise ValueError("calcTauStar: gamma must be %s and epsilon (4, 4)" % (self.gamma.shape,))
         V = self._Vtot
         active = np.array([self.gene_V[g] > 0 and eta[c].sum() > 0 for c, g in enumerate(self.genes)])
         row_active = np.repeat(active, np.diff(self._gene_off)) if V else np.zeros(0, dtype=bool)
@@ -283,6 +289,19 @@ class Eta_Sampler:
             self._pull_tau()
             tau_star[row_active] = self._tau[row_active]
         sweep_mask = np.where(active[:, None], eta, 0).astype(np.int32)
+        if sub:                                                 # the sweeps and their likelihoods see the substitute model
+            dev.set_model(gamma_s, eps_s, self.delta, self.max_eta, self.eta_log_prior, *self._consts)
+        try:
+            self._tau_star_sweeps(dev, V, active, row_active, sweep_mask, ll_star, tau_star, store)
+        finally:
+            if sub:
+                dev.set_model(self.gamma, self.epsilon, self.delta, self.max_eta, self.eta_log_prior, *self._consts)
+        self.gene_tau_star = {g: self._slice(tau_star, c) for c, g in enumerate(self.genes)}
+        self.gene_ll_tau_star = {g: self._slice(ll_star, c) for c, g in enumerate(self.genes)}
+        self.gene_tau_store = {g: store[:, self._gene_off[c]:self._gene_off[c + 1]] for c, g in enumerate(self.genes)}
+        self._tau_star_cat, self._tau_store_cat = tau_star, store
+
+    def _tau_star_sweeps(self, dev, V, active, row_active, sweep_mask, ll_star, tau_star, store):
         for it in range(self.tau_iter):
             total = 0.0
             if V and active.any():
@@ -296,10 +315,6 @@ class Eta_Sampler:
                 for c in np.flatnonzero(active):
                     total += ll_star[self._gene_off[c]:self._gene_off[c + 1]].sum()
             logging.info('Tau star Iter %d, nll = %f' % (it, total))
-        self.gene_tau_star = {g: self._slice(tau_star, c) for c, g in enumerate(self.genes)}
-        self.gene_ll_tau_star = {g: self._slice(ll_star, c) for c, g in enumerate(self.genes)}
-        self.gene_tau_store = {g: store[:, self._gene_off[c]:self._gene_off[c + 1]] for c, g in enumerate(self.genes)}
-        self._tau_star_cat, self._tau_store_cat = tau_star, store
 
     def getTauStar(self, variants):
         """(tau_star, tau_mean, positions, gene of every row) over all genes in gene order.  Like the reference

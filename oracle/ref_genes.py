@@ -222,10 +222,13 @@ def kl_assign(cov, delta, eta, max_iter=10000, min_change=1.0e-4):
     return eta, it, div
 
 
-def calc_tau_star(rs, eta_self, eta_star, variants, gamma, eps, tau_iter, G):
-    """Eta_Sampler.calcTauStar (:397-452): NMFT start per gene (mask = the sampler's CURRENT eta, :421),
-    tau_iter sweeps masked by eta_star, per-variant best tau under the full multinomial log-pdf.
+def calc_tau_star(rs, eta_self, eta_star, variants, gamma, eps, tau_iter, G, gamma_sub=None, eps_sub=None):
+    """Eta_Sampler.calcTauStar (:397-452): NMFT start per gene (mask = the sampler's CURRENT eta and its own gamma, :420-421),
+    tau_iter sweeps masked by eta_star, per-variant best tau under the full multinomial log-pdf.  ``gamma_sub`` / ``eps_sub``
+    are the method's optional gamma / epsilon arguments: the sweeps and their likelihoods use them (:434-435), the start does not.
     Returns (tau_star list, ll_star list, tau_store list [tau_iter,V,G,4])."""
+    gamma_sw = gamma if gamma_sub is None else gamma_sub
+    eps_sw = eps if eps_sub is None else eps_sub
     C = len(variants)
     stars, lls, stores, taus = [], [], [], []
     for c in range(C):
@@ -242,11 +245,11 @@ def calc_tau_star(rs, eta_self, eta_star, variants, gamma, eps, tau_iter, G):
         for c in range(C):
             V = 0 if variants[c] is None else variants[c].shape[0]
             if V > 0 and eta_star[c].sum() > 0:
-                gr = mask_gamma(gamma, eta_star[c])
-                cbind.sample_tau(taus[c], np.ascontiguousarray(gr), eps, variants[c])
+                gr = mask_gamma(gamma_sw, eta_star[c])
+                cbind.sample_tau(taus[c], np.ascontiguousarray(gr), np.ascontiguousarray(eps_sw), variants[c])
                 x = variants[c]
                 n = x.sum(axis=2)
-                ll = (gammaln(n + 1.0) - gammaln(x + 1.0).sum(axis=2) + (x * np.log(site_prob(taus[c], gr, eps))).sum(axis=2)).sum(axis=1)
+                ll = (gammaln(n + 1.0) - gammaln(x + 1.0).sum(axis=2) + (x * np.log(site_prob(taus[c], gr, eps_sw))).sum(axis=2)).sum(axis=1)
                 better = ll > lls[c]
                 lls[c][better] = ll[better]
                 stars[c][better] = taus[c][better]

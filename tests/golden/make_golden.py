@@ -514,6 +514,17 @@ def gen_gene_assign(out, name="gene_assign", C=7, S=8, G=3, synth_kw=None):
         rec['tau_store'] = np.concatenate([smp.gene_tau_store[g] for g in smp.genes], axis=1).astype(np.int8)
         rec['pos'] = pos
         rec['contig_index'] = np.array(contig_index)
+        # calcTauStar once more, now with a substitute gamma / epsilon (Eta_Sampler.py:397-403: used by the sweeps and their
+        # likelihoods, the NMF start keeps the sampler's own gamma): continues both streams from where the first call left them
+        g2 = gm * (1.0 + 0.5 * np.cos(np.arange(gm.size).reshape(gm.shape)))
+        g2 = g2 / g2.sum(axis=1)[:, np.newaxis]
+        e2 = 0.88 * np.eye(4) + 0.03
+        smp.calcTauStar(smp.eta_star, gamma=g2, epsilon=e2)
+        ts2, tm2, _, _ = smp.getTauStar(var)
+        rec['sub_gamma'], rec['sub_epsilon'] = g2, e2
+        rec['sub_tau_star'] = ts2.astype(np.int8)
+        rec['sub_tau_star_ll'] = np.concatenate([smp.gene_ll_tau_star[g] for g in smp.genes])
+        rec['sub_tau_store'] = np.concatenate([smp.gene_tau_store[g] for g in smp.genes], axis=1).astype(np.int8)
         # the same run through main(): output files
         logging.getLogger().removeHandler(grab)
         stub = os.path.join(td, "ga")

@@ -70,6 +70,21 @@ def test_eta_sampler_reproduces_reference_run(name, tmp_path):
     live = ref > -1e300
     np.testing.assert_array_equal(live, mine > -1e300)
     np.testing.assert_allclose(mine[live], ref[live], rtol=1e-10)
+    # calcTauStar with a substitute gamma / epsilon (Eta_Sampler.py:397-403; used by the sweeps and their likelihoods only):
+    # continues both streams from the first call, as the run that wrote the fixture did
+    smp.calcTauStar(smp.eta_star, gamma=z['sub_gamma'], epsilon=z['sub_epsilon'])
+    tau_star2, _, _, _ = smp.getTauStar(var)
+    np.testing.assert_array_equal(tau_star2, z['sub_tau_star'])
+    np.testing.assert_array_equal(smp._tau_store_cat, z['sub_tau_store'])
+    ref, mine = z['sub_tau_star_ll'], np.concatenate([smp.gene_ll_tau_star[g] for g in smp.genes])
+    live = ref > -1e300
+    np.testing.assert_array_equal(live, mine > -1e300)
+    np.testing.assert_allclose(mine[live], ref[live], rtol=1e-10)
+    assert (tau_star2 != tau_star).any()                      # the substitute model does change the outcome
+    # ... and leaves the sampler's own model in place
+    np.testing.assert_array_equal(smp.gamma, k['gamma'])
+    with pytest.raises(ValueError):
+        smp.calcTauStar(smp.eta_star, gamma=z['sub_gamma'][:, :-1])
 
 
 @pytest.mark.parametrize("name", CASES)

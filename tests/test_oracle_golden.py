@@ -275,6 +275,14 @@ def test_gene_oracle_reproduces_reference_run(name):
     live = ref_ll > -1e300
     np.testing.assert_array_equal(live, mine > -1e300)
     np.testing.assert_allclose(mine[live], ref_ll[live], rtol=1e-11)
+    # the same call with a substitute gamma / epsilon (Eta_Sampler.py:397-403), continuing both streams
+    stars, lls, stores = rg.calc_tau_star(rs, eta, eta_star, k['variants'], k['gamma'], k['eps'], k['tau_iter'], G,
+                                          gamma_sub=z['sub_gamma'], eps_sub=z['sub_epsilon'])
+    np.testing.assert_array_equal(np.concatenate(stars), z['sub_tau_star'])
+    np.testing.assert_array_equal(np.concatenate(stores, axis=1), z['sub_tau_store'])
+    ref_ll, mine = z['sub_tau_star_ll'], np.concatenate(lls)
+    live = ref_ll > -1e300
+    np.testing.assert_allclose(mine[live], ref_ll[live], rtol=1e-11)
 
 
 def test_masked_row_sum_order_is_numpys():

@@ -240,6 +240,8 @@ def main():
     ap.add_argument("--rng", choices=["mt19937", "philox"], default="mt19937")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: print the cpu_baseline object and exit")
+    ap.add_argument("--true-G", type=int, default=None, help="strains the synthetic table is generated from (default: --G).  A G-sweep fits "
+                    "most of its chains with too few or too many haplotypes (BASELINE config 5: g = 2..12 on one table): their iterations cost more")
     ap.add_argument("--depth-scale", type=float, default=1.0, help="multiply the mean read depths of the synthetic tensor")
     ap.add_argument("--chains-per-gpu", type=int, default=1,
                     help="also time K concurrent chains on the GPU (extra key; the headline stays one chain per GPU)")
@@ -303,7 +305,9 @@ def main():
             data_label += ", -f filter kept %d" % counts.shape[0]
         V, S = counts.shape[0], counts.shape[1]
     else:
-        counts, _, _ = synth_counts(V, S, G, seed=1234 + rank, depth_scale=args.depth_scale)   # one independent chain per GPU
+        counts, _, _ = synth_counts(V, S, args.true_G or G, seed=1234 + rank, depth_scale=args.depth_scale)   # one independent chain per GPU
+        if args.true_G and args.true_G != G:
+            data_label = "synthetic, generated from %d strains" % args.true_G
     ctx = _lib.Context(dev)
     ctx.set_counts(counts)
     ctx.seed(rank)                                               # sampler seeds 0..N-1 (scripts/runDesman.sh:15-19)

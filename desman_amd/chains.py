@@ -22,11 +22,66 @@ import numpy as np
 REC_FIELDS = ("chain", "G", "seed", "G_final", "lp_star", "mean_dev", "iters", "wall_s", "failed")
 
 
-def chain_cost(V, S, G):
-    """relative cost of one Gibbs iteration, as measured on MI355X (profiles/r02_shape_scan.txt: V = 50k, S = 96 takes
-    0.32 / 0.41 / 0.45 / 0.73 ms at G = 2 / 4 / 5 / 12, i.e. ~0.25 + 0.04 G): the mu/E pass costs the same per cell
-    whatever G is, the tau sweep grows with G.  (Round 1's 4 G + G^2 over-weighted the large-G chains 7-fold.)"""
-    return float(V) * float(S) * (6.0 + float(G))
+def chain_cost(V, S, G, n_iter=None, nmf_updates=5000):
+    """estimated cost of a chain in microseconds on one MI355X (only ratios matter to the scheduler).
+
+    Fitted on the measurements of round 4 (profiles/r04_chain_cost_components.json: bench.py at V = 50k, S = 96, G = 2..12, and the
+    config-3 line; `scripts/fit_chain_cost.py --report` prints predicted vs measured): with kc = V S / 1000 (thousand cells)
+      one Gibbs iteration   38 + kc (0.0477 + 0.0063 G)  [+ 18 + 1.2e-4 2^G S from G = 10: stage 2 of the mu/E pass as its own launch]
+                            -- 0.328 / 0.405 / 0.513 / 0.691 ms at G = 2 / 4 / 8 / 12 there, 0.105 ms at config 3
+      one NMF update        12 + kc (0.0125 + 0.00306 ceil(G / 4))   -- 84 / 100 / 116 us at G <= 4 / <= 8 / <= 12 (K-blocks of four haplotypes)
+      host work per chain   0.2 s + 1.3 us per (position, haplotype): the result files (Output_Results)
+    and a chain runs 2 n_iter iterations (burn-in + sampling, bin/desman:212-232) after up to 5000 NMF updates (Init_NMFT.py:98-115:
+    the 1e-5 stop rarely fires).  n_iter = None: the cost of ONE iteration (chains of equal length compared).  Round 3's 6 + G had the
+    slope and nothing else.  What no shape-only estimate can know is how well G fits the table: chains with too few haplotypes draw
+    many more error reads, chains with too many run close races in the tau sweep (scripts/misfit_scan.py) -- up to twice the
+    time (config-5 data, six strains: G = 2 / 3 take 1.61 / 1.71 s, G = 4 1.26 s).  Hence the default schedule is the work queue
+    (WorkQueue below), which this estimate only orders, longest first."""
+    kc = float(V) * float(S) / 1000.0
+    gibbs = 38.0 + kc * (0.0477 + 0.0063 * G)
+    if G >= 10:
+        gibbs += 18.0 + 1.2e-4 * float(1 << min(int(G), 30)) * float(S)
+    if n_iter is None:
+        return gibbs
+    nmf = 12.0 + kc * (0.0125 + 0.00306 * float((int(G) + 3) // 4))
+    host = 0.2e6 + 1.3 * float(V) * float(G)
+    return 2.0 * float(n_iter) * gibbs + float(nmf_updates) * nmf + host
+
+
+class WorkQueue:
+    """Units of work handed out one at a time to whoever asks next -- across the ranks of ONE node (the only topology the path
+    has: scripts/runDesman.sh:15-21 starts its jobs on one machine).  A rank that drew short chains simply comes back sooner, so
+    the makespan does not hang on the cost estimate (it only orders the queue, longest first).  Three carriers of the counter:
+    a lock in this process (one rank), a small file under flock() (ranks started by desman_amd.launch.spawn_ranks, which makes the
+    file and passes its path in DESMAN_SWEEP_QUEUE), the rendezvous store of torch.distributed (`store.add`, ranks started by
+    torch.distributed.run).  next() returns 0, 1, 2, ... exactly once each over all callers."""
+
+    def __init__(self, file_path=None, store=None, key="desman_sweep_queue"):
+        import threading
+        self._lock = threading.Lock()
+        self._n = 0
+        self._path, self._store, self._key = file_path, store, key
+
+    def next(self):
+        if self._store is not None:
+            return int(self._store.add(self._key, 1)) - 1
+        if self._path is not None:
+            import fcntl
+            import struct
+            with self._lock, open(self._path, "r+b") as f:      # (the lock: flock is per open file description, threads share none here)
+                fcntl.flock(f, fcntl.LOCK_EX)
+                raw = f.read(8)
+                n = struct.unpack("<q", raw)[0] if len(raw) == 8 else 0
+                f.seek(0)
+                f.write(struct.pack("<q", n + 1))
+                f.flush()
+                os.fsync(f.fileno())
+                fcntl.flock(f, fcntl.LOCK_UN)
+            return n
+        with self._lock:
+            n = self._n
+            self._n += 1
+        return n
 
 
 def lpt_assign(costs, n_ranks):
@@ -42,12 +97,13 @@ def lpt_assign(costs, n_ranks):
     return bins
 
 
-def sweep_specs(g_values, n_reps, V, S):
-    """(G, seed) grid of a model-selection sweep: seeds 0..n_reps-1 per G (runDesman.sh:15-19)."""
+def sweep_specs(g_values, n_reps, V, S, n_iter=None):
+    """(G, seed) grid of a model-selection sweep: seeds 0..n_reps-1 per G (runDesman.sh:15-19); n_iter = the chains' -i (the whole
+    chain is then costed: NMF start + 2 n_iter iterations + result files)."""
     specs = []
     for G in g_values:
         for r in range(n_reps):
-            specs.append(dict(chain=len(specs), G=int(G), seed=int(r), cost=chain_cost(V, S, G)))
+            specs.append(dict(chain=len(specs), G=int(G), seed=int(r), cost=chain_cost(V, S, G, n_iter)))
     return specs
 
 
@@ -66,13 +122,18 @@ def group_units(specs, batch):
     return units
 
 
-def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=None, batch=1, comm=None):
+def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=None, batch=1, comm=None, queue=None):
     """Run `run_fn(spec) -> dict(REC_FIELDS...)` for this rank's share of `specs` and gather
     every chain's record on all ranks.  `dist` = an initialised torch.distributed module
     (or None for a single process).  `concurrency` chains of a rank run at the same time in
     threads (each on its own context / HIP streams; ctypes releases the GIL while a launch
     sequence is in flight): small-V chains are latency-bound, so several of them share a GPU
     well.  Returns the records sorted by chain id.
+
+    Which rank runs which chain: `queue` = None -- the static plan, longest-processing-time-first over the cost estimates
+    (lpt_assign; the same on every rank, nothing exchanged); `queue` = a WorkQueue shared by the ranks -- every worker thread
+    of every rank takes the next unit of the list (sorted by decreasing estimate) when it is free.  A chain's result does not
+    depend on where it ran (its seeds are its own), so both schedules write the same files.
 
     Failure handling ("a failed GPU's chains are simply re-queued"): a chain whose run_fn raises
     is re-queued ONCE on the same rank after the rank's other chains; if it fails again its record carries
@@ -86,11 +147,14 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
     else:
         world = dist.get_world_size() if dist is not None else 1
         rank = dist.get_rank() if dist is not None else 0
+    batched = batch_fn is not None and batch > 1
     units = group_units(specs, batch if batch_fn is not None else 1)
-    unit_bins = lpt_assign([sum(specs[i]["cost"] for i in u) for u in units], world)
-    bins = [[i for ui in ub for i in units[ui]] for ub in unit_bins]          # chain ids per rank, unit by unit
+    ucost = [sum(specs[i]["cost"] for i in u) for u in units]
+    unit_bins = lpt_assign(ucost, world)
+    bins = [[i for ui in ub for i in units[ui]] for ub in unit_bins]          # chain ids per rank, unit by unit (static plan)
 
     import logging
+    import threading
     log = logging.getLogger("desman_amd.chains")
 
     def one(cid):
@@ -114,56 +178,79 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
                    mean_dev=np.nan, iters=0, wall_s=np.nan, failed=1.0)
         return [float(rec[k]) for k in REC_FIELDS]
 
-    if batch_fn is not None and batch > 1:
-        # the units of this rank one after the other, each as one batched run; a unit whose batched run raises falls back to
-        # its chains one by one (and those to the re-queue / failed-record rule below)
-        def unit(ui):
-            ids = units[ui]
-            out = []
-            recs = None
-            if len(ids) > 1:
-                t0 = time.perf_counter()
-                try:
-                    recs = [dict(r) for r in batch_fn([specs[i] for i in ids])]
-                    if len(recs) != len(ids):
-                        raise RuntimeError("batch_fn returned %d records for %d chains" % (len(recs), len(ids)))
-                except (Exception, SystemExit) as e:         # noqa: BLE001
-                    log.warning("batched unit %s failed on rank %d (%s: %s): its chains run one by one", ids, rank, type(e).__name__, e)
-                    recs = None
-                if recs is not None:
-                    for cid, rec in zip(ids, recs):
-                        rec.setdefault("wall_s", (time.perf_counter() - t0) / len(ids))
-                        rec["chain"] = cid
-                        rec.setdefault("failed", 0.0)
-                        out.append([float(rec[k]) for k in REC_FIELDS])
-            if recs is None:
-                out += [one(cid) for cid in ids]
-            return out
-        if concurrency > 1 and len(unit_bins[rank]) > 1:         # units (different G) side by side: their host work overlaps
-            from concurrent.futures import ThreadPoolExecutor
-            os.environ.setdefault("DESMAN_HIP_ONE_STREAM", "1")  # one hardware queue per chain (see below)
-            with ThreadPoolExecutor(max_workers=concurrency) as pool:
-                first = [r for rs in pool.map(unit, unit_bins[rank]) for r in rs]
-        else:
-            first = [r for ui in unit_bins[rank] for r in unit(ui)]
-    elif concurrency > 1 and len(bins[rank]) > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        os.environ.setdefault("DESMAN_HIP_NMFT_GRAPH", "1")      # replayed NMFT batches: see api.hip (dsm_nmft_factorize)
+    def unit(ui):
+        """[(chain id, record or exception)] of one unit: a batched run of its chains where that applies (a unit whose batched run
+        raises falls back to its chains one by one, and those to the re-queue / failed-record rule below), else chain by chain"""
+        ids = units[ui]
+        if batched and len(ids) > 1:
+            t0 = time.perf_counter()
+            try:
+                recs = [dict(r) for r in batch_fn([specs[i] for i in ids])]
+                if len(recs) != len(ids):
+                    raise RuntimeError("batch_fn returned %d records for %d chains" % (len(recs), len(ids)))
+            except (Exception, SystemExit) as e:             # noqa: BLE001
+                log.warning("batched unit %s failed on rank %d (%s: %s): its chains run one by one", ids, rank, type(e).__name__, e)
+                recs = None
+            if recs is not None:
+                out = []
+                for cid, rec in zip(ids, recs):
+                    rec.setdefault("wall_s", (time.perf_counter() - t0) / len(ids))
+                    rec["chain"] = cid
+                    rec.setdefault("failed", 0.0)
+                    out.append((cid, [float(rec[k]) for k in REC_FIELDS]))
+                return out
+        return [(cid, one(cid)) for cid in ids]
+
+    # where this rank's next unit comes from
+    take_lock = threading.Lock()
+    if queue is None:
+        pending = list(unit_bins[rank])                      # LPT order within the rank: longest units start first
+        n_mine = len(pending)
+
+        def take():
+            with take_lock:
+                return pending.pop(0) if pending else None
+    else:
+        order = sorted(range(len(units)), key=lambda u: (-ucost[u], u))      # the same list on every rank
+        n_mine = len(order)                                  # (an upper bound: what this rank could end up running)
+
+        def take():
+            k = queue.next()
+            return order[k] if k < len(order) else None
+
+    done = []                                                # (chain id, record or exception), in order of completion
+
+    def worker():
+        while True:
+            ui = take()
+            if ui is None:
+                return
+            res = unit(ui)
+            with take_lock:
+                done.extend(res)
+
+    n_workers = max(1, min(int(concurrency), n_mine))
+    if n_workers > 1:
+        if not batched:
+            os.environ.setdefault("DESMAN_HIP_NMFT_GRAPH", "1")  # replayed NMFT batches: see api.hip (dsm_nmft_factorize)
         # more than four live hardware queues stretch every small kernel to ~55 us (DESIGN.md sec. 7): the MT19937 refill of
         # a chain then runs on the chain's own stream (35-chain sweep at V = 1000, 8 at a time: 4.2 -> 2.6 s)
         os.environ.setdefault("DESMAN_HIP_ONE_STREAM", "1")
-        with ThreadPoolExecutor(max_workers=concurrency) as pool:
-            first = list(pool.map(one, bins[rank]))          # LPT order: longest chains start first
+        threads = [threading.Thread(target=worker, name="desman-chain-%d" % k) for k in range(n_workers)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
     else:
-        first = [one(cid) for cid in bins[rank]]
+        worker()
     mine = []
-    for cid, res in zip(bins[rank], first):
+    for cid, res in sorted(done, key=lambda x: x[0]):
         if isinstance(res, BaseException):                   # second and last attempt, alone on the device
             res = one(cid)
             if isinstance(res, BaseException):
                 res = failed_record(cid)
         mine.append(res)
-    width = max(len(b) for b in bins) if specs else 0
+    width = (max(len(b) for b in bins) if queue is None else len(specs)) if specs else 0
     buf = np.full((max(width, 1), len(REC_FIELDS)), np.nan)
     if mine:
         buf[:len(mine)] = np.array(mine)
@@ -302,6 +389,9 @@ def main(argv=None):
     ap.add_argument("-c", "--concurrency", type=int, default=4, help="chains running at the same time per GPU")
     ap.add_argument("-b", "--batch", type=int, default=1, help="replicate chains of a G value (up to 8) share every kernel "
                     "launch of the Gibbs loop instead of running as separate chains (small tables: several times the throughput)")
+    ap.add_argument("--schedule", choices=["queue", "plan"], default="queue", help="queue (default): every rank takes the next chain of "
+                    "one list, longest estimate first, when it is free (a counter file under flock / the torch rendezvous store) -- chains "
+                    "that fit the table badly take up to twice their estimate; plan: the static longest-processing-time-first assignment")
     ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node to spread the chains over (one process each). "
                     "A plain `desman-sweep --gpus N` starts its own N ranks; under torch.distributed.run the world must be N")
     ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl", help="who carries the final gather of the fit records: rccl = "
@@ -332,7 +422,17 @@ def main(argv=None):
             launch._die("desman-sweep", "communicator of %d ranks, --gpus %d" % (comm.world, args.gpus))
     frame = p.read_csv(args.variant_file, header=0, index_col=0)
     V, S = frame.shape[0], (frame.shape[1] - 1) // 4
-    specs = sweep_specs(range(args.gmin, args.gmax + 1), args.reps, V, S)
+    specs = sweep_specs(range(args.gmin, args.gmax + 1), args.reps, V, S, n_iter=args.no_iter)
+    queue = None
+    if args.schedule == "queue" and world > 1:
+        if comm is not None:
+            if not os.environ.get("DESMAN_SWEEP_QUEUE"):
+                launch._die("desman-sweep", "--schedule queue needs the launcher's counter file (DESMAN_SWEEP_QUEUE): start the ranks "
+                            "with `desman-sweep --gpus N` or `python -m desman_amd.launch`, or pass --schedule plan")
+            queue = WorkQueue(file_path=os.environ["DESMAN_SWEEP_QUEUE"])
+        else:
+            from torch.distributed.distributed_c10d import _get_default_store
+            queue = WorkQueue(store=_get_default_store())
     extra = ["-m", str(args.min_coverage)] + (["-r", str(args.random_select)] if args.random_select else [])
     if args.batch > 1:
         # batched units draw mu/E from the aggregated specification; chains of this sweep that run one by one (a unit of one
@@ -340,7 +440,7 @@ def main(argv=None):
         os.environ["DESMAN_HIP_STATS_SPEC"] = "2"
     runner = gibbs_chain_runner(args.variant_file, args.no_iter, local, args.output_stub, extra)
     recs = run_chains(specs, runner, dist, device=dev_t, concurrency=args.concurrency, batch_fn=runner.batch if args.batch > 1 else None,
-                      batch=min(args.batch, 8), comm=comm)
+                      batch=min(args.batch, 8), comm=comm, queue=queue)
     if (comm.rank if comm is not None else (0 if dist is None else dist.get_rank())) == 0:
         write_dev_csv(args.output_stub + "_Dev.csv", recs)
         print(json.dumps(recs))

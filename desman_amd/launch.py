@@ -116,12 +116,18 @@ def spawn_ranks(n, cmd, env=None, port=None):
     each child's environment (what desman_amd/comm.py: Comm.from_env reads), stdout / stderr inherited.  Waits for all; when one rank
     fails the others are terminated (they would wait in a collective for ever).  Returns the first non-zero exit status, or 0."""
     import subprocess
+    import tempfile
     import time
     port = port or free_port()
     procs = []
+    # the counter of the chain scheduler's work queue (desman_amd/chains.py: WorkQueue): a fresh 8-byte file per launch, the
+    # ranks take numbers from it under flock().  One node, one file system: the path's only topology (scripts/runDesman.sh:15-21).
+    qfd, qpath = tempfile.mkstemp(prefix="desman_queue_")
+    os.write(qfd, b"\0" * 8)
+    os.close(qfd)
     for r in range(n):
         e = dict(os.environ if env is None else env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                 MASTER_PORT=str(port))
+                 MASTER_PORT=str(port), DESMAN_SWEEP_QUEUE=qpath)
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         e.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen(list(cmd), env=e))
@@ -138,6 +144,10 @@ def spawn_ranks(n, cmd, env=None, port=None):
                 for q in live:                                 # exact PIDs we started
                     procs[q].terminate()
         time.sleep(0.05)
+    try:
+        os.unlink(qpath)
+    except OSError:
+        pass
     return rc
 
 

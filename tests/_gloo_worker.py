@@ -53,6 +53,23 @@ if __name__ == "__main__":
             json.dump(dict(recs=recs, recs_b=recs_b, one=one, batched=list(ran)), f)
         dist.destroy_process_group()
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "queue":
+        # the work-queue schedule: rank 1 is "slow" (every chain sleeps ten times longer there), the counter lives in the rendezvous
+        # store; one chain fails once (re-queued on the rank that drew it).  Every chain must run exactly once over both ranks.
+        import time
+        from torch.distributed.distributed_c10d import _get_default_store
+        ran = []
+
+        def timed_run(spec):
+            ran.append(spec["chain"])
+            time.sleep(0.004 * (10 if dist.get_rank() == 1 else 1))
+            return flaky_run(spec) if (spec["G"], spec["seed"]) == (5, 2) else fake_run(spec)
+        q = chains.WorkQueue(store=_get_default_store(), key="q_test")
+        recs = chains.run_chains(specs, timed_run, dist, queue=q, concurrency=2)
+        with open(os.path.join(sys.argv[1], "queue%d.json" % dist.get_rank()), "w") as f:
+            json.dump(dict(recs=recs, ran=ran), f)
+        dist.destroy_process_group()
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "flaky":
         recs = chains.run_chains(specs, flaky_run, dist)
         with open(os.path.join(sys.argv[1], "flaky%d.json" % dist.get_rank()), "w") as f:

@@ -193,3 +193,65 @@ def test_two_rank_gloo_gene_gather(tmp_path):
     assert r0["eta"] == list(range(41))                                  # genes in global order
     assert r0["tau"] == list(range(int(rows.sum())))                     # variant rows in global order
     assert r0["bounds"][0] == 0 and r0["bounds"][-1] == 41
+
+
+def test_two_rank_gloo_work_queue_runs_every_chain_once_and_follows_the_faster_rank(tmp_path):
+    """--schedule queue: the ranks draw chains from one counter (here the rendezvous store).  The slow rank ends up with fewer
+    chains, every chain runs exactly once (the one that fails once is retried where it was drawn), both ranks gather all records"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29671", os.path.join(HERE, "_gloo_worker.py"), str(tmp_path), "queue"]
+    subprocess.run(cmd, check=True, env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r0 = json.load(open(tmp_path / "queue0.json"))
+    r1 = json.load(open(tmp_path / "queue1.json"))
+    assert r0["recs"] == r1["recs"] and [int(r["chain"]) for r in r0["recs"]] == list(range(15))
+    assert not any(r["failed"] for r in r0["recs"])
+    first = lambda ran: list(dict.fromkeys(ran))                          # (the retried chain appears twice on its rank)
+    assert sorted(first(r0["ran"]) + first(r1["ran"])) == list(range(15))
+    assert len(first(r0["ran"])) > len(first(r1["ran"]))                  # the fast rank took more of the list
+    specs = chains.sweep_specs(range(2, 7), 3, V=1000, S=16)
+    for r, s in zip(r0["recs"], specs):                                  # the records of the static plan, whoever ran the chain
+        assert (r["G"], r["seed"], r["lp_star"]) == (s["G"], s["seed"], -1000.0 * s["G"] - s["seed"])
+
+
+def test_work_queue_file_counter_over_processes_and_threads(tmp_path):
+    """the flock()ed counter file desman_amd.launch.spawn_ranks hands to its ranks: three processes x four threads draw 0..N-1
+    exactly once each"""
+    from desman_amd import launch
+    prog = tmp_path / "draw.py"
+    prog.write_text("import os, sys, threading\n"
+                    "sys.path.insert(0, %r)\n"
+                    "from desman_amd.chains import WorkQueue\n"
+                    "q = WorkQueue(file_path=os.environ['DESMAN_SWEEP_QUEUE']); got = []\n"
+                    "def w():\n"
+                    "    while True:\n"
+                    "        k = q.next()\n"
+                    "        if k >= 600: return\n"
+                    "        got.append(k)\n"
+                    "th = [threading.Thread(target=w) for _ in range(4)]\n"
+                    "[t.start() for t in th]; [t.join() for t in th]\n"
+                    "open(os.path.join(sys.argv[1], 'got%%s' %% os.environ['RANK']), 'w').write(' '.join(map(str, got)))\n"
+                    % os.path.dirname(HERE))
+    assert launch.spawn_ranks(3, [sys.executable, str(prog), str(tmp_path)]) == 0
+    got = [int(x) for r in range(3) for x in open(tmp_path / ("got%d" % r)).read().split()]
+    assert sorted(got) == list(range(600))
+    q = chains.WorkQueue()                                               # the in-process carrier
+    assert [q.next() for _ in range(5)] == [0, 1, 2, 3, 4]
+
+
+def test_cost_model_matches_the_round4_measurements():
+    """chain_cost against what bench.py measured at V = 50k, S = 96 (profiles/r04_chain_cost_components.json): every G within 5 %
+    for the Gibbs iteration and 8 % for the NMF update; whole chains within 10 % where G fits the table (chains with too few or too
+    many haplotypes cost more than any shape-only estimate says -- scripts/misfit_scan.py -- which is the reason for the work queue)"""
+    prof = os.path.join(os.path.dirname(HERE), "profiles", "r04_chain_cost_components.json")
+    d = json.load(open(prof))["per_G"]
+    V, S = 50000, 96
+    for g, row in d.items():
+        g = int(g)
+        assert abs(chains.chain_cost(V, S, g) / (1e3 * row["gibbs_ms_per_iter"]) - 1.0) < 0.05, g
+        nmf = (chains.chain_cost(V, S, g, n_iter=0, nmf_updates=1) - chains.chain_cost(V, S, g, n_iter=0, nmf_updates=0))
+        assert abs(nmf / row["nmft_us_per_update"] - 1.0) < 0.08, g
+    # whole `desman -i 500` chains on the six-strain config-5 table (profiles/r04_chain_phases.txt, seconds): the chains that fit
+    wall = {4: 1.26, 6: 1.44}
+    for g in wall:
+        assert abs(chains.chain_cost(V, S, g, n_iter=500, nmf_updates=4900) * 1e-6 / wall[g] - 1.0) < 0.10, g

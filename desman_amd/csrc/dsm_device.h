@@ -307,14 +307,43 @@ __device__ __forceinline__ void group_allreduce_sum4_f32(float &v0, float &v1, f
     v3 = dpp_mov_t<float, 0xFF>(k);
 }
 
+// ---- when do the fp32 totals of a step settle the fp64 draw?  (round 4: with the uniform taken into account)
+// c32 = the four candidate totals in log2 units, each off its exact value by at most
+//     E = [ X 1.4427 (G + 4) + |l| (4 NSL + 11) ] 2^-24          X = the variant's reads over all samples, |l| = the total's magnitude:
+// every mixture value carries <= (G + 4) roundings of 2^-24 (fp32 inputs, one per link of the chain), i.e. 1.4427 (G + 4) 2^-24 on its
+// log2, times its count; the hardware log2 is good to 1 ulp of its result (pinned by tests/test_gpu_edges.py) and the products, the
+// lane's running sum and the cross-lane butterfly add <= 4 NSL + 9 roundings of 2^-24 relative to |l|.  A gap between two totals is
+// therefore known to 2 E, and with best = the largest total the three others together weigh, relative to it, at most
+//     t = 3 x 2^-(gap to the second best - 2 E).
+// sweep_draw (c_sample_tau.c:48-91) picks `best` whenever u sum falls inside its CDF interval: the edges below it sum to <= t, its own
+// edge is >= 1, sum <= 1 + t -- so t < u < 1 - t suffices, whatever the exact values are.  Round 3 certified only gaps above 64 nats
+// (t ~ 1e-28: every u but 0).  That left the low-abundance haplotypes of an over-fitted chain -- gamma ~ 1e-2, gaps of 8 ... 64 nats,
+// half the steps of a G = 12 chain on a six-strain table (scripts/dbg/flat_diag.py) -- to the fp64 code, and with more than half of a
+// sweep there the screen was suspended altogether: 572 us per sweep instead of 264 (scripts/misfit_scan.py).  A gap of 8 nats now
+// certifies for all but 0.2 % of the uniforms.  The comparisons carry fp32 slack; NaN (the poisoned totals) fails them.
+template <int NSL>
+__device__ __forceinline__ bool screen_certify(const float (&c32)[4], float xtot, int G, uint32_t uw, int &best)
+{
+    best = 0;
+    float m = c32[0];
+#pragma unroll
+    for (int a = 1; a < 4; ++a) if (c32[a] > m) { m = c32[a]; best = a; }
+    float second = -3.0e38f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) second = (a == best) ? second : fmaxf(second, c32[a]);
+    const float e2 = (xtot * (1.4427f * (float)(G + 4)) + (fabsf(m) + 128.0f) * (float)(4 * NSL + 11)) * 1.1920929e-7f;   // 2 E (2^-23)
+    const float t = 3.0003f * __builtin_amdgcn_exp2f(fminf(second - m + e2, 0.0f));        // <= 3.0003 when the race is open
+    const float u = (float)uw * 2.3283064365386963e-10f;                                   // rounded to 24 bits (may reach 1.0)
+    return (fabsf(m) < 3.0e38f) && (u * 0.9999995f > t) && (u * 1.0000005f < 1.0f - t);
+}
+
 // ---- the screening pass of a sweep step (tau_kernel, gene_sweep_kernel).  The four candidate
 // log-probabilities in fp32 (packed arithmetic, hardware log2) from the fp64 prefix `pre`, the links h > g and gamma_g; true when
-// this lane's group can take `best` without the fp64 evaluation: the best total leads every other by more than 64 + 2^-13 |l|
-// (natural units; the fp32 error is below 0.1 + 1e-6 |l|), every mixture value is inside fp32's normal range, and the uniform
-// word is not 0.  gT32 = this group's gamma [G][SP] in fp32 (zero rows add nothing), eS32 = eta [16] then its column minima [4].
+// this lane's group can take `best` without the fp64 evaluation: the totals and the uniform word settle the draw (screen_certify above)
+// and every mixture value is inside fp32's normal range.  xtot = the variant's reads over all samples (an upper bound).  gT32 = this group's gamma [G][SP] in fp32 (zero rows add nothing), eS32 = eta [16] then its column minima [4].
 template <int LPV, int NSL>
 __device__ __forceinline__ bool sweep_screen(const double (&pre)[NSL][4], const int (&xi)[NSL][4], uint64_t t, int g, int G, int lig,
-                                             uint32_t uw, const float *__restrict__ gT32, const float *__restrict__ eS32, int &best)
+                                             uint32_t uw, const float *__restrict__ gT32, const float *__restrict__ eS32, float xtot, int &best)
 {
     constexpr int SP = LPV * NSL;
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -360,22 +389,14 @@ __device__ __forceinline__ bool sweep_screen(const double (&pre)[NSL][4], const 
     for (int a = 0; a < 4; ++a) c32[a] = acc2[a].x + acc2[a].y;
     if (!(lbmin >= 1.0e-30f)) c32[0] = __builtin_nanf("");          // poisons the totals of the whole group
     group_allreduce_sum4_f32<LPV>(c32[0], c32[1], c32[2], c32[3]);    // log2 units
-    best = 0;
-    float m = c32[0];
-#pragma unroll
-    for (int a = 1; a < 4; ++a) if (c32[a] > m) { m = c32[a]; best = a; }
-    const float need = 93.0f + 1.3e-4f * fabsf(m);                   // (64 + 2^-13 |l|) / ln 2
-    bool cert = (uw != 0u) && (fabsf(m) < 3.0e38f);
-#pragma unroll
-    for (int a = 0; a < 4; ++a) cert = cert && (a == best || m - c32[a] > need);
-    return cert;
+    return screen_certify<NSL>(c32, xtot, G, uw, best);
 }
 
 // the same from a prefix carried in fp32 ([sample slot][base pair]): the register-lean form of the sweep (kernels_gibbs.hip: tau_body, LEAN)
 typedef float dsm_f2 __attribute__((ext_vector_type(2)));
 template <int LPV, int NSL>
 __device__ __forceinline__ bool sweep_screen32(const dsm_f2 (&pre32)[NSL][2], const float (&xi)[NSL][4], uint64_t t, int g, int G, int lig,
-                                             uint32_t uw, const float *__restrict__ gT32, const float *__restrict__ eS32, int &best)
+                                             uint32_t uw, const float *__restrict__ gT32, const float *__restrict__ eS32, float xtot, int &best)
 {
     constexpr int SP = LPV * NSL;
     typedef dsm_f2 f2;
@@ -421,15 +442,7 @@ __device__ __forceinline__ bool sweep_screen32(const dsm_f2 (&pre32)[NSL][2], co
     for (int a = 0; a < 4; ++a) c32[a] = acc2[a].x + acc2[a].y;
     if (!(lbmin >= 1.0e-30f)) c32[0] = __builtin_nanf("");          // poisons the totals of the whole group
     group_allreduce_sum4_f32<LPV>(c32[0], c32[1], c32[2], c32[3]);    // log2 units
-    best = 0;
-    float m = c32[0];
-#pragma unroll
-    for (int a = 1; a < 4; ++a) if (c32[a] > m) { m = c32[a]; best = a; }
-    const float need = 93.0f + 1.3e-4f * fabsf(m);                   // (64 + 2^-13 |l|) / ln 2
-    bool cert = (uw != 0u) && (fabsf(m) < 3.0e38f);
-#pragma unroll
-    for (int a = 0; a < 4; ++a) cert = cert && (a == best || m - c32[a] > need);
-    return cert;
+    return screen_certify<NSL>(c32, xtot, G, uw, best);
 }
 
 template <typename T, int NV, int CNT, int OFF>

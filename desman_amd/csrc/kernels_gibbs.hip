@@ -771,6 +771,17 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
             bool have_cur = false;               // l_cur is the log-probability of the current configuration (wave-uniform)
             n_steps += G;
             const bool screen = screen_on;
+            // the variant's reads over all its samples, rounded up: the error bound of the screening pass scales with it (screen_certify)
+            float xtot = 0.0f;
+            if (screen) {
+#pragma unroll
+                for (int j = 0; j < NSL; ++j)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) { if constexpr (LEAN) xtot += xs[j][b]; else xtot += (float)xi[j][b]; }
+                float z1 = 0.0f, z2 = 0.0f, z3 = 0.0f;
+                group_allreduce_sum4_f32<LPV>(xtot, z1, z2, z3);
+                xtot *= 1.0001f;
+            }
             for (int g = 0; g < G; ++g) {
                 double gg[NSL];
                 if constexpr (!LEAN) {
@@ -801,8 +812,8 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                     // converged chain and ~97 % right after the NMFT initialisation take the short way.
                     int best = 0;
                     bool cert;
-                    if constexpr (LEAN) cert = sweep_screen32<LPV, NSL>(pre32, xs, t, g, G, lig, uw, gT32, eS32, best);
-                    else cert = sweep_screen<LPV, NSL>(pre, xi, t, g, G, lig, uw, gT32, eS32, best);
+                    if constexpr (LEAN) cert = sweep_screen32<LPV, NSL>(pre32, xs, t, g, G, lig, uw, gT32, eS32, xtot, best);
+                    else cert = sweep_screen<LPV, NSL>(pre, xi, t, g, G, lig, uw, gT32, eS32, xtot, best);
                     if (__builtin_amdgcn_ballot_w64(cert) == __builtin_amdgcn_ballot_w64(true)) { tn = best; decided = true; }
                 }
                 if (!decided) {

@@ -74,6 +74,55 @@ def test_tau_sweep_vs_oracle(ctx, V, S, G):
         np.testing.assert_allclose(logp, logp_ref, rtol=1e-12, atol=1e-8)
 
 
+@pytest.mark.parametrize("kind", ["low", "floor"])
+@pytest.mark.parametrize("V,S,G,spare", [(3000, 64, 8, (2, 5, 7)), (2000, 96, 12, (0, 3, 4, 8, 10, 11)), (1500, 16, 5, (1, 4)),
+                                         (600, 200, 6, (0, 5)), (400, 300, 4, (2,)), (500, 40, 3, (0,)), (800, 130, 7, (3, 6)),
+                                         (1000, 64, 8, (0, 1, 2, 3, 4, 5, 6))])
+def test_tau_sweep_of_an_overfitted_chain_vs_oracle(ctx, V, S, G, spare, kind):
+    """A chain with more haplotypes than the table has strains keeps the spare ones at low abundance (gamma ~ 1e-3 ... 1e-2: they soak
+    up errors; scripts/dbg/flat_diag.py) or at the floor (gamma = epsilon = 1e-6 in every sample, HaploSNP_Sampler.py:271-273).  The
+    steps of the first kind are races of a few to a few dozen nats: the screening pass settles them from the totals AND the uniform
+    (dsm_device.h: screen_certify), so few are left to fp64; the steps of the second kind are near-ties and go to the fp64 code.
+    Either way the draws are the oracle's, screens on or off."""
+    live = [g for g in range(G) if g not in spare]
+    counts, _, _ = synth_counts(V, S, max(len(live), 2), seed=V + S + G)
+    tau, gamma, eta = random_state(V, S, G, seed=G + 100)
+    gamma = gamma.copy()
+    rng = np.random.default_rng(V + G)
+    gamma[:, list(spare)] = 1.0e-6 if kind == "floor" else rng.uniform(2.0e-4, 2.0e-3, size=(S, len(spare)))
+    gamma[:, live] *= ((1.0 - gamma[:, list(spare)].sum(axis=1)) / gamma[:, live].sum(axis=1))[:, None]
+    gamma = np.ascontiguousarray(gamma / gamma.sum(axis=1)[:, None])
+    n_sw = 4
+    gs, es = np.ascontiguousarray(np.broadcast_to(gamma, (n_sw,) + gamma.shape)), np.ascontiguousarray(np.broadcast_to(eta, (n_sw, 4, 4)))
+    _load(ctx, counts, tau, gamma, eta, mt_seed=777)
+    ctx.sweep_stats(reset=True)
+    mt = cbind.MT19937(777)
+    ref = tau.copy()
+    for sweep in range(2):                                        # single sweeps (dsm_ctx_sample_tau), screened
+        n_ref = cbind.sample_tau_u(ref, gamma, eta, counts, mt.uniform(V * G))
+        n = ctx.sample_tau()
+        got, _, _ = ctx.get_state()
+        assert n == n_ref and np.array_equal(got, ref)
+    ctx.update_tau(gs, es)                                        # ... and the tau-only loop, whose finalize step keeps the counts
+    for it in range(n_sw):
+        cbind.sample_tau_u(ref, gamma, eta, counts, mt.uniform(V * G))
+        assert np.array_equal(ctx.get_tau_at(it), ref)
+    steps, exact = ctx.sweep_stats()
+    assert steps > 0
+    if kind == "low" and len(live) > 1 and S >= 40:
+        assert exact / steps < 0.25, (steps, exact)               # (round 3's rule -- gaps above 64 nats only -- left len(spare) / G of them)
+    # the same sweeps with the screen switched off: the same haplotypes
+    _load(ctx, counts, tau, gamma, eta, mt_seed=777)
+    ctx.set_tau_screen(False)
+    try:
+        for sweep in range(2):
+            ctx.sample_tau()
+        ctx.update_tau(gs, es)
+        assert np.array_equal(ctx.get_tau_at(n_sw - 1), ref)
+    finally:
+        ctx.set_tau_screen(True)
+
+
 def test_tau_sweep_zero_counts_and_deep_counts(ctx):
     V, S, G = 40, 16, 3
     counts, _, _ = synth_counts(V, S, G, seed=3)

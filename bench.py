@@ -242,6 +242,8 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: print the cpu_baseline object and exit")
     ap.add_argument("--true-G", type=int, default=None, help="strains the synthetic table is generated from (default: --G).  A G-sweep fits "
                     "most of its chains with too few or too many haplotypes (BASELINE config 5: g = 2..12 on one table): their iterations cost more")
+    ap.add_argument("--stats-spec", type=int, default=0, choices=[0, 1, 2, 3, 4], help="force a mu/E specification (0 = the shape rule; "
+                    "4 = stage 1 over tau words)")
     ap.add_argument("--depth-scale", type=float, default=1.0, help="multiply the mean read depths of the synthetic tensor")
     ap.add_argument("--chains-per-gpu", type=int, default=1,
                     help="also time K concurrent chains on the GPU (extra key; the headline stays one chain per GPU)")
@@ -312,6 +314,8 @@ def main():
     ctx.set_counts(counts)
     ctx.seed(rank)                                               # sampler seeds 0..N-1 (scripts/runDesman.sh:15-19)
     ctx.set_tau_rng(_lib.RNG_MT19937 if args.rng == "mt19937" else _lib.RNG_PHILOX)
+    if args.stats_spec:
+        ctx.force_stats_spec(args.stats_spec)
 
     # NMFT initialisation (untimed here; reported separately)
     rs = np.random.RandomState(rank)
@@ -479,7 +483,7 @@ def main():
     # fp32 screening pass (hardware log2); the steps it cannot decide (tau_steps_fp64_frac) are re-evaluated in fp64, 12 of 16
     n_logs = 16.0 * V * G * S + 4.0 * V * S
     traffic, valu = {}, {}
-    stats_kname = "stats_agg_kernel" if spec >= 2 else "stats_kernel"
+    stats_kname = "stats_pat_kernel" if spec == 4 else "stats_agg_kernel" if spec >= 2 else "stats_kernel"
     tj, traffic_source = None, None
     pmc_error = None
     if args.pmc is None:                             # default: measure in this run when that is possible

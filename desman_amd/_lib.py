@@ -18,7 +18,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "desman_hip.h")
 DSM_OK = 0
 RNG_MT19937, RNG_PHILOX = 0, 1
 STATS_AGG = 2        # version of the aggregated mu/E specification that runs by default (oracle/stats_agg.c); 3 = the table exp / log variant
-K_NAMES = ("stats", "dirichlet", "tau", "finalize", "mt", "nmft_a", "nmft_gamma", "nmft_b", "stats2", "stats_big")
+K_NAMES = ("stats", "dirichlet", "tau", "finalize", "mt", "nmft_a", "nmft_gamma", "nmft_b", "stats2", "stats_big", "stats_pat")
 
 
 class DesmanHipError(RuntimeError):

@@ -34,7 +34,7 @@ extern "C" int dsm_device_count(void)
 
 static const char *const k_names[] = {"stats_kernel", "dirichlet_kernel", "tau_kernel", "finalize_kernel",
                                       "mt_fill_kernel", "nmft_pass_a", "nmft_gamma", "nmft_pass_b",
-                                      "stats_stage2_kernel", "stats_big_kernel"};
+                                      "stats_stage2_kernel", "stats_big_kernel", "pat_rep_kernel + pat_agg_kernel"};
 static_assert(sizeof(k_names) / sizeof(k_names[0]) == DSM_K_COUNT, "one name per DSM_K_* id");
 extern "C" const char *dsm_kernel_name(int k) { return (k >= 0 && k < DSM_K_COUNT) ? k_names[k] : "?"; }
 
@@ -221,6 +221,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     free_traces(c);
     dev_free(&c->cnt_vs); dev_free(&c->items); dev_free(&c->nitems); dev_free(&c->tau);
+    dev_free(&c->pat_rep); dev_free(&c->pat_x); c->pat_rep_len = c->pat_x_len = 0;
     dev_free(&c->blk_tab); dev_free(&c->ntab_raw); c->ntab = nullptr; dev_free(&c->big_list); dev_free(&c->big_count);
     dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
@@ -283,6 +284,7 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     c->max_items = 0;
     c->blk_gmax = 0;
     c->stats_grid = 0;
+    dev_free(&c->pat_x); c->pat_x_len = 0;      // the aggregated counts of the old table's positions
     TRY(reset_blk_order(c));              // another table, another grid: no block order of the old one survives
     HIP_TRY(hipMemsetAsync(c->screen_ctl, 0, 4 * sizeof(uint32_t), c->stream));
     dev_free(&c->items);
@@ -674,7 +676,7 @@ extern "C" int dsm_ctx_stats_spec(dsm_ctx *c)
 
 extern "C" int dsm_ctx_force_stats_spec(dsm_ctx *c, int spec)
 {
-    if (!c || spec < 0 || spec > 3) { dsm_set_error("force_stats_spec: 0 (rule), 1, 2 or 3"); return DSM_ERR_ARG; }
+    if (!c || spec < 0 || spec > 4) { dsm_set_error("force_stats_spec: 0 (rule), 1, 2, 3 or 4"); return DSM_ERR_ARG; }
     c->force_stats_spec = spec;
     return DSM_OK;
 }

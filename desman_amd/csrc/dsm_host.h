@@ -80,6 +80,11 @@ struct dsm_ctx {
                                     // the aggregated pass wherever it applies, small problems too
     uint32_t *ntab = nullptr;       // [2^G][S] subset counts of the aggregated mu/E pass (spec v2), zero between passes
     size_t ntab_len = 0;
+    // pattern-aggregated stage 1 (spec 4, kernels_stats.hip): positions that share their packed tau word share one stage-1 cell per sample
+    unsigned long long *pat_rep = nullptr;   // [4^G] (~generation << 32 | lowest position that carries the word); atomicMin, never cleared
+    uint32_t *pat_x = nullptr;               // [V][4][S] counts summed per (representative position, base, sample); zero between passes
+    size_t pat_rep_len = 0, pat_x_len = 0;
+    uint32_t pat_gen = 0;
     uint32_t *ntab_raw = nullptr;   // the allocation `ntab` points into (kernels_stats.hip: ensure_ntab places the table inside it)
     uint32_t *ntab_base = nullptr;  // first place the table can start at (4 KB aligned)
     size_t ntab_off = 0;            // where past ntab_base the table starts (stats_place_ntab)
@@ -195,7 +200,8 @@ int stats_place_ntab(dsm_ctx *c);         // measures where the subset table sho
 #define DSM_NTAB_PAD 0               // words added to a row of the subset table when S is a multiple of 64 (stats_ntab_ld)
 int stats_ntab_ld(int S);
 int stats_ntab_rep(const dsm_ctx *c);       // copies of the subset table the stage-1 atomics are spread over
-int stats_spec(const dsm_ctx *c);           // 2 = aggregated sampler (oracle/stats_agg.c), 1 = per-read (orc_stats_counter)
+int stats_spec(const dsm_ctx *c);           // 2 / 3 = aggregated sampler (oracle/stats_agg.c), 4 = the same over tau patterns, 1 = per-read (orc_stats_counter)
+static inline int stats_draw_version(int spec) { return spec == 4 ? 2 : spec; }   // which version of the samplers (dsm_binom.h: SPEC) a specification draws with
 int k_stats(dsm_ctx *c, uint32_t iter);
 int k_stats_stage1(dsm_ctx *c, uint32_t iter);
 int k_stats_stage2(dsm_ctx *c, uint32_t iter);

@@ -1224,7 +1224,7 @@ int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trac
     q.alpha = c->alpha; q.delta = c->delta; q.epsilon = c->epsilon; q.lgc_gamma = lg; q.lgc_eta = le;
     q.k0 = k0; q.k1 = k1; q.iter = iter; q.zero_after = 1;
     q.gamma_out = gamma_out; q.gamma_trace = gamma_trace; q.eta_out = eta_out; q.eta_trace = eta_trace; q.rowprior = prior_out;
-    q.do_fin = do_fin; q.fin = fin; q.do_s2 = do_s2 ? stats_spec(c) : 0; q.s2 = s2;
+    q.do_fin = do_fin; q.fin = fin; q.do_s2 = do_s2 ? stats_draw_version(stats_spec(c)) : 0; q.s2 = s2;
     if (g_batch.K == 0) {
         const S2Plan plan = do_s2 ? make_stage2_plan(c->G) : S2Plan{};
         hipLaunchKernelGGL(dirichlet_kernel, dim3(c->S + 4 + do_fin), dim3(256), 0, c->stream, q, plan);

@@ -55,6 +55,10 @@ struct StatsAggParams {
                                     // subsets over the memory channels whatever the table's address
     int xcd;                        // 1: the table has a copy per XCD (rep = 8 k); a workgroup adds to a copy of ITS XCD (HW_REG_XCC_ID) with
                                     // workgroup-scope atomics, which execute in that XCD's L2 instead of at the memory side
+    // spec 4 (pattern-aggregated stage 1): non-null -> only the REPRESENTATIVE positions (lowest position of each packed tau word:
+    // pat_rep[word] & 0xFFFFFFFF) carry cells, with the counts of all positions of their word summed in pat_x [V][4][S]
+    const unsigned long long *pat_rep;
+    uint32_t *pat_x;
     int dbg;                        // timing experiments only (DESMAN_HIP_STATS_DBG; compiled out of the product kernel: STATS_DBG above): bit 0 no draws, 1 no item seeding, 2 no E/N atomics, 3 no cell Philox
 };
 
@@ -69,7 +73,7 @@ __device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t x)
 // SPEC: 2 or 3 (dsm_binom.h).  REGG: S <= LPV and G <= 8 -- a lane keeps its sample for the whole launch, so its G abundances
 // live in registers (no LDS tile of gamma: the 4 KB it took at config 3 now hold the log / exp tables of spec 3 at the same six
 // workgroups per CU) and the haplotype loop of a cell is scalar compares + one add per haplotype, no LDS read.
-template <int LPV, int SPEC, bool REGG>
+template <int LPV, int SPEC, bool REGG, bool PAT = false>
 __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_s[];
@@ -116,10 +120,21 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
         const bool tv = task < ntask;
         const int v = tv ? task / NCH : 0, j = tv ? task - v * NCH : 0;
         const int s = j * LPV + lig;
-        const bool active = tv && s < S;
+        bool active = tv && s < S;
         uint64_t t = p.tau[v];
         int4 c = make_int4(0, 0, 0, 0);
-        if (active) c = reinterpret_cast<const int4 *>(p.cnt_vs)[(size_t)v * S + s];
+        if constexpr (PAT) {
+            // a position that is not the representative of its tau word has no cell of its own: its reads were added to the
+            // representative's (pat_agg_kernel).  One variant per wavefront: the whole pass is skipped on a scalar branch.
+            const bool isrep = (uint32_t)p.pat_rep[t & ((1ull << (2 * G)) - 1ull)] == (uint32_t)v;
+            active = active && isrep;
+            // (most positions are not representatives: a pass none of whose lane groups holds one ends here, on a scalar branch)
+            if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
+            if (active) {
+                const uint32_t *xr = p.pat_x + (size_t)v * 4 * S + s;
+                c.x = (int)xr[0]; c.y = (int)xr[(size_t)S]; c.z = (int)xr[2 * (size_t)S]; c.w = (int)xr[3 * (size_t)S];
+            }
+        } else if (active) c = reinterpret_cast<const int4 *>(p.cnt_vs)[(size_t)v * S + s];
         // haplotype sets of the four bases and the abundance each base carries in this sample; t is uniform over a lane
         // group, so the base of haplotype g and the branches below are scalar -- one group after the other when the
         // wavefront holds several
@@ -164,7 +179,7 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
         uint32_t nacc[4] = {0, 0, 0, 0};
 #pragma unroll 1
         for (int b = 0; b < 4; ++b) {
-            const int xb = (b == 0) ? c.x : (b == 1) ? c.y : (b == 2) ? c.z : c.w;
+            const uint32_t xb = (uint32_t)((b == 0) ? c.x : (b == 1) ? c.y : (b == 2) ? c.z : c.w);     // (aggregated counts may pass 2^31)
             if (xb > 0) {
                 double W[4];
 #pragma unroll
@@ -180,6 +195,9 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
                 int kind = 0;
                 if (STATS_DBG(p, 1)) { n[0] = (uint32_t)xb + (uint32_t)(W[0] > W[1]) + rng.s0; n[1] = n[2] = n[3] = 0; }
                 else mult4<false, SPEC>(rng, (uint32_t)xb, W, n, rcp, ltab, defer, p.lean_cap, &kind);
+                // an aggregated count is consumed exactly once -- here, or by the compacted kernel when the item is handed over -- and
+                // whoever consumes it leaves zero behind for the next pass
+                if constexpr (PAT) { if (!defer) p.pat_x[((size_t)v * 4 + b) * S + s] = 0u; }
                 if (__builtin_expect(defer, 0)) {
                     // needs the rejection sampler: the compacted kernel re-does this item from its own stream
                     // (one atomic per wavefront: the deferring lanes take consecutive slots)
@@ -250,6 +268,93 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
 // six wavefronts per SIMD (the persistent grid's six workgroups per CU): the register allocation must leave room for them
 template <int LPV, int SPEC, bool REGG>
 __global__ __launch_bounds__(256, 6) void stats_agg_kernel(StatsAggParams p) { stats_agg_body<LPV, SPEC, REGG>(p); }
+template <int LPV>      // (five workgroups per CU: at six the 16- and 32-lane forms spill)
+__global__ __launch_bounds__(256, 5) void stats_pat_kernel(StatsAggParams p) { stats_agg_body<LPV, 2, false, true>(p); }
+
+// ---- spec 4: the two small passes ahead of stage 1 ------------------------------------------------------------------------
+// Cells (v, s) and (v', s) of positions with the same packed tau word have the same weights W_a = eta[a,b] Gamma_a for every
+// observed base b, and only sums over positions are consumed (Esum, N[H][s]): Multinomial(x; W) + Multinomial(x'; W) is
+// Multinomial(x + x'; W), so the counts are summed per (word, sample, base) first and stage 1 runs once per word instead of once per
+// position -- the same law (oracle twin: cbind.stats_agg(spec=4) sums the counts the same way and calls the spec-2 code), other draws.
+// Which position stands for a word must not depend on the order the hardware runs things in (the cell's Philox key is built from
+// it): the LOWEST position carrying the word, found by atomicMin.  Table entries are (~generation << 32 | position): a later pass
+// always writes smaller values than anything an earlier one left, so the table is never cleared.
+__global__ __launch_bounds__(256) void pat_rep_kernel(const uint64_t *__restrict__ tau, int V, int G, unsigned long long *__restrict__ rep, uint32_t hi)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    atomicMin(&rep[tau[v] & ((1ull << (2 * G)) - 1ull)], ((unsigned long long)hi << 32) | (unsigned long long)(uint32_t)v);
+}
+// up to 4096 words (G <= 6): thousands of positions per word would queue on the same few addresses (16 words in two cache lines at
+// G = 2: ~100 us for V = 50k), so a 1024-thread workgroup takes the minimum of its share of the positions in LDS first and sends
+// one atomicMin per word it met
+__global__ __launch_bounds__(1024) void pat_rep_lds_kernel(const uint64_t *__restrict__ tau, int V, int G, unsigned long long *__restrict__ rep, uint32_t hi)
+{
+    __shared__ uint32_t lo[4096];
+    const int words = 1 << (2 * G), tid = threadIdx.x;
+    for (int i = tid; i < words; i += 1024) lo[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint64_t mask = (1ull << (2 * G)) - 1ull;
+    for (int v = blockIdx.x * 1024 + tid; v < V; v += gridDim.x * 1024) atomicMin(&lo[tau[v] & mask], (uint32_t)v);
+    __syncthreads();
+    for (int i = tid; i < words; i += 1024)
+        if (lo[i] != 0xFFFFFFFFu) atomicMin(&rep[i], ((unsigned long long)hi << 32) | (unsigned long long)lo[i]);
+}
+// Few words (G <= 3 with 64-sample chunks, G = 4 with 32-sample chunks): thousands of positions add to the same few blocks, and
+// same-address global atomics resolve one after the other (V = 50k, S = 96: 248 us at G = 2, 153 at G = 3 with pat_agg_kernel).
+// Here a 1024-thread workgroup pools its share of the positions in LDS first -- table [4^G][4][LPW], indexed by the word itself, so
+// no look-up on the way in -- and adds the table to the representatives' blocks once at the end: workgroups x 4^G x 4 LPW global
+// atomics instead of V x S x 4.  LPW = lanes per position (64: one position per wavefront pass; 32: two).
+template <int LPW>
+__global__ __launch_bounds__(1024) void pat_agg_lds_kernel(const int32_t *__restrict__ cnt_vs, const uint64_t *__restrict__ tau, int V, int S, int G,
+                                                           const unsigned long long *__restrict__ rep, uint32_t *__restrict__ x, int nvsplit)
+{
+    extern __shared__ uint32_t ptab[];                       // [words][4][LPW]
+    const int words = 1 << (2 * G);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < words * 4 * LPW; i += 1024) ptab[i] = 0u;
+    __syncthreads();
+    constexpr int PPW = 64 / LPW;                            // positions per wavefront pass
+    const int chunk = (int)blockIdx.x / nvsplit, part = (int)blockIdx.x % nvsplit;      // sample chunk, share of the positions
+    const int s = chunk * LPW + (lane % LPW);
+    const uint64_t mask = (1ull << (2 * G)) - 1ull;
+    for (int v0 = (part * 16 + wv) * PPW; v0 < V; v0 += nvsplit * 16 * PPW) {
+        const int v = v0 + lane / LPW;
+        if (v < V && s < S) {
+            const int4 c = reinterpret_cast<const int4 *>(cnt_vs)[(size_t)v * S + s];
+            uint32_t *row = ptab + (size_t)(tau[v] & mask) * 4 * LPW + (lane % LPW);
+            if (c.x) atomicAdd(row, (uint32_t)c.x);
+            if (c.y) atomicAdd(row + LPW, (uint32_t)c.y);
+            if (c.z) atomicAdd(row + 2 * LPW, (uint32_t)c.z);
+            if (c.w) atomicAdd(row + 3 * LPW, (uint32_t)c.w);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < words * 4 * LPW; i += 1024) {
+        const uint32_t n = ptab[i];
+        if (!n) continue;
+        const int w = i / (4 * LPW), b = (i / LPW) & 3, sl = chunk * LPW + i % LPW;
+        atomicAdd(x + ((size_t)(uint32_t)rep[w] * 4 + b) * S + sl, n);      // (n != 0: some position carries the word, so it has a representative)
+    }
+}
+
+// thread = (position, sample): the slab's four counts are added to the representative's [4][S] block -- lanes are consecutive samples,
+// so an instruction's atomics fall on consecutive words.  Integer sums: the order of the adds changes nothing.
+__global__ __launch_bounds__(256) void pat_agg_kernel(const int32_t *__restrict__ cnt_vs, const uint64_t *__restrict__ tau, int V, int S, int G,
+                                                      const unsigned long long *__restrict__ rep, uint32_t *__restrict__ x)
+{
+    const size_t n = (size_t)V * S;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int v = (int)(i / (size_t)S), s = (int)(i - (size_t)v * S);
+        const int4 c = reinterpret_cast<const int4 *>(cnt_vs)[i];
+        const uint32_t r = (uint32_t)rep[tau[v] & ((1ull << (2 * G)) - 1ull)];
+        uint32_t *xr = x + (size_t)r * 4 * S + s;
+        if (c.x) atomicAdd(xr, (uint32_t)c.x);
+        if (c.y) atomicAdd(xr + S, (uint32_t)c.y);
+        if (c.z) atomicAdd(xr + 2 * (size_t)S, (uint32_t)c.z);
+        if (c.w) atomicAdd(xr + 3 * (size_t)S, (uint32_t)c.w);
+    }
+}
 template <int LPV, int SPEC, bool REGG>
 __global__ __launch_bounds__(256, 6) void stats_agg_kernel_b(BatchArgs<StatsAggParams> b) { stats_agg_body<LPV, SPEC, REGG>(b.p[blockIdx.y]); }
 
@@ -285,7 +390,9 @@ __device__ __forceinline__ void stats_big_body(const StatsAggParams &p)
         const int b = (int)(item & 3ull);
         const int s = (int)(cell / (uint32_t)p.V_tot), v = (int)(cell - (uint32_t)s * (uint32_t)p.V_tot) - p.v_off;
         const uint64_t t = p.tau[v];
-        const int xb = p.cnt_vs[((size_t)v * S + s) * 4 + b];
+        uint32_t xb;
+        if (p.pat_x) { uint32_t *xw = p.pat_x + ((size_t)v * 4 + b) * S + s; xb = *xw; *xw = 0u; }     // spec 4: consumed here (see stats_agg_body)
+        else xb = (uint32_t)p.cnt_vs[((size_t)v * S + s) * 4 + b];
         uint32_t H[4] = {0, 0, 0, 0};
         double Gam[4] = {0.0, 0.0, 0.0, 0.0};
         for (int g = 0; g < G; ++g) {
@@ -306,7 +413,7 @@ __device__ __forceinline__ void stats_big_body(const StatsAggParams &p)
         philox4x32_10(cell, 0u, p.iter, DSM_STREAM_STA1, p.k0, p.k1, cbase);
         Xo128 rng = item_seed<SPEC>(cbase, (uint32_t)b, p.k0, p.k1);
         bool defer = false;
-        mult4<true, SPEC>(rng, (uint32_t)xb, W, n, rcp, ltab, defer);
+        mult4<true, SPEC>(rng, xb, W, n, rcp, ltab, defer);
         uint32_t *erow = eacc + (b * 4) * 256 + tid;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -400,12 +507,17 @@ int stats_spec(const dsm_ctx *c)
     int force = c->force_stats_spec;
     if (force == 0) {                       // DESMAN_HIP_STATS_SPEC=1|2: the choice for every context that has none of its own
         const char *e = getenv("DESMAN_HIP_STATS_SPEC");   // (2 = the draws of a batched run, also for chains run one by one)
-        if (e && (e[0] == '1' || e[0] == '2' || e[0] == '3') && e[1] == 0) force = e[0] - '0';
+        if (e && (e[0] == '1' || e[0] == '2' || e[0] == '3' || e[0] == '4') && e[1] == 0) force = e[0] - '0';
     }
     if (force == 1) return 1;
     if (c->G < 1 || c->G > 16) return 1;
     if (((size_t)1 << c->G) * (size_t)c->S * 4 > ((size_t)64 << 20)) return 1;
     if (c->max_depth >= ((uint64_t)1 << 32)) return 1;
+    // spec 4 = spec 2's samplers over tau PATTERNS (positions sharing their packed word share a cell per sample; pat_rep_kernel above).
+    // It needs the direct-address table of 4^G words (G <= 8), a chain that is neither sharded by positions (representatives would
+    // be per shard) nor part of a batch (the batched launches are spec 2's); asked for where it does not apply, spec 2 runs.
+    const bool pat_ok = c->G <= 8 && !c->shard_on && g_batch.K == 0;
+    if (force == 4) return pat_ok ? 4 : 2;
     if (force >= 2) return force;                        // 2 = the default version of the aggregated draws, 3 = the table exp/log variant
     double reads = 0.0;
     for (int64_t d : c->depth) reads += (double)d;
@@ -417,6 +529,16 @@ int stats_spec(const dsm_ctx *c)
     const int rep = stats_ntab_rep(c);
     const double per = 3.0 * (double)c->V / (double)(1u << c->G);                // atomics per counter of the subset table
     const double t2 = 24.0 + stage2 + 0.062e-3 * cells + (rep == 1 ? 0.03 * per : 0.003 * per / rep);   // with copies: no measurable penalty
+    // over tau words (spec 4): one more pass over the counts (~60 us per 77 MB incl. its atomics) + a small launch, then stage 1 over at
+    // most 4^G words instead of V positions.  What it saves is stage 1's per-cell work, not its per-error-read work (the pooled cells
+    // hold the same reads), so it pays on large tables with few words -- measured on the six-strain 50k x 96 table
+    // (profiles/r04_misfit_scan_spec4.txt, ms per iteration, spec 4 vs 2): G = 2 0.27 vs 0.91, 3 0.27 vs 0.84, 4 0.29 vs 0.42, 5 0.39 vs
+    // 0.44, 6 0.41 vs 0.47 (forced at 7 / 8: 0.46 vs 0.49, 0.48 vs 0.51) -- and loses on small ones (10k x 64: 0.12-0.15 vs 0.09-0.12 at
+    // G = 2..5: the passes' fixed latencies).  By rule where the word count alone -- whatever the data -- leaves a quarter of the cells
+    // or fewer AND the table has 2.5 million cells; tables whose positions share words beyond that (biallelic data: at most
+    // 12 (2^G - 2) + 4 words) can ask for it (dsm_ctx_force_stats_spec(4), DESMAN_HIP_STATS_SPEC=4).
+    const double words = (double)((size_t)1 << (2 * c->G));
+    if (pat_ok && force == 0 && 4.0 * words <= (double)c->V && cells >= 2.5e6 && t2 < t1) return 4;
     return t2 < t1 ? DSM_STATS_AGG : 1;
 }
 
@@ -579,6 +701,28 @@ static int ensure_big_list(dsm_ctx *c, size_t seg)
     return DSM_OK;
 }
 
+// spec 4: the word table (4^G entries, all ones = "no pass has written here") and the aggregated counts (zero between passes)
+static int ensure_pat(dsm_ctx *c)
+{
+    const size_t nrep = (size_t)1 << (2 * c->G), nx = (size_t)c->V * 4 * (size_t)c->S;
+    if (!c->pat_rep || c->pat_rep_len != nrep) {
+        if (c->pat_rep) { (void)hipFree(c->pat_rep); c->pat_rep = nullptr; }
+        hipError_t e = hipMalloc((void **)&c->pat_rep, nrep * sizeof(unsigned long long));
+        if (e != hipSuccess) { dsm_set_error("hipMalloc(%zu B) failed: %s", nrep * 8, hipGetErrorString(e)); return DSM_ERR_NOMEM; }
+        c->pat_rep_len = nrep;
+        c->pat_gen = 0;
+        HIP_TRY(hipMemsetAsync(c->pat_rep, 0xFF, nrep * sizeof(unsigned long long), c->stream));
+    }
+    if (!c->pat_x || c->pat_x_len != nx) {
+        if (c->pat_x) { (void)hipFree(c->pat_x); c->pat_x = nullptr; }
+        hipError_t e = hipMalloc((void **)&c->pat_x, nx * sizeof(uint32_t));
+        if (e != hipSuccess) { dsm_set_error("hipMalloc(%zu B) failed: %s", nx * 4, hipGetErrorString(e)); return DSM_ERR_NOMEM; }
+        c->pat_x_len = nx;
+        HIP_TRY(hipMemsetAsync(c->pat_x, 0, nx * sizeof(uint32_t), c->stream));
+    }
+    return DSM_OK;
+}
+
 int k_stats_stage1(dsm_ctx *c, uint32_t iter)
 {
     int r = ensure_ntab(c);
@@ -586,11 +730,13 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     const int S = c->S, G = c->G, V = c->V;
     const int LPV = stats_agg_lpv(S);
     const int NCH = (S + LPV - 1) / LPV, SP = NCH * LPV, NG = 64 / LPV;
-    const int spec = stats_spec(c);                       // 2 or 3 (the caller checked that the aggregated pass applies)
+    const int spec_full = stats_spec(c);                  // 2, 3 or 4 (the caller checked that the aggregated pass applies)
+    const bool pat = spec_full == 4;
+    const int spec = stats_draw_version(spec_full);
     static const int regg_env = DSM_AB_ENV("DESMAN_HIP_STATS_REGG") ? atoi(DSM_AB_ENV("DESMAN_HIP_STATS_REGG")) : -1;   // A/B switch
     // (gamma in registers where a lane keeps its sample, instead of the LDS tile: measured slower -- 87-91 VGPRs, i.e. five
     // wavefronts per SIMD, or spills at six: 54-57 us against 48-49; kept as an A/B switch)
-    const bool regg = NCH == 1 && G <= 8 && regg_env == 1;
+    const bool regg = NCH == 1 && G <= 8 && regg_env == 1 && !pat;
     const size_t sh = ((regg ? 0 : (size_t)G * SP) + (spec >= 3 ? 2 * DSM_LOG_TAB_N + DSM_EXP_TAB_N : 0) + DSM_RCP_TAB_N + 16) * sizeof(double) +
                       16 * 256 * sizeof(uint32_t);
     if (sh > 160 * 1024) { dsm_set_error("stats_agg: gamma tile (%zu B) exceeds LDS", sh); return DSM_ERR_UNSUPPORTED; }
@@ -601,8 +747,12 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     AGG_CASE(16, 2, false) AGG_CASE(16, 2, true) AGG_CASE(32, 2, false) AGG_CASE(32, 2, true) AGG_CASE(64, 2, false) AGG_CASE(64, 2, true)
     AGG_CASE(16, 3, false) AGG_CASE(16, 3, true) AGG_CASE(32, 3, false) AGG_CASE(32, 3, true) AGG_CASE(64, 3, false) AGG_CASE(64, 3, true)
 #undef AGG_CASE
+    if (pat) {
+        fn = LPV == 16 ? (const void *)stats_pat_kernel<16> : LPV == 32 ? (const void *)stats_pat_kernel<32> : (const void *)stats_pat_kernel<64>;
+        fn_b = nullptr;
+    }
     if (!fn) { dsm_set_error("stats_agg: no kernel for spec %d", spec); return DSM_ERR_UNSUPPORTED; }
-    if (c->stats_grid == 0 || c->stats_grid_key != (spec * 2 + (regg ? 1 : 0))) {
+    if (c->stats_grid == 0 || c->stats_grid_key != (spec_full * 2 + (regg ? 1 : 0))) {
         int occ = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, sh));
         hipDeviceProp_t prop;
@@ -620,7 +770,7 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
         const long passes4 = (((long)V * NCH + NG - 1) / NG) / std::max(1L, (long)std::min(wgs_env, std::max(1, occ)) * prop.multiProcessorCount);   // workgroup = 4 wavefronts: passes x 4
         const int leave = leave_env >= 0 ? leave_env : ((c->tau_rng == DSM_RNG_MT19937 && passes4 <= 12) ? n_xcd : 0);
         c->stats_grid = std::min(wgs_env, std::max(1, occ)) * std::max(1, prop.multiProcessorCount - leave);   // six workgroups per CU: measured optimum (below)
-        c->stats_grid_key = spec * 2 + (regg ? 1 : 0);
+        c->stats_grid_key = spec_full * 2 + (regg ? 1 : 0);
     }
     const long ntask = ((long)V * NCH + NG - 1) / NG;            // wavefront passes (NG lane groups = NG tasks each)
     // a persistent grid of six workgroups (24 wavefronts) per CU, passes dealt round-robin: the kernel is issue-bound, and a SIMD
@@ -644,6 +794,34 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     p.xcd = stats_ntab_xcd(c) ? 1 : 0;
     p.hmul = stats_ntab_hmul();
     p.big_list = c->big_list; p.big_count = c->big_count;
+    p.pat_rep = nullptr; p.pat_x = nullptr;
+    if (pat) {
+        r = ensure_pat(c);
+        if (r != DSM_OK) return r;
+        p.pat_rep = c->pat_rep; p.pat_x = c->pat_x;
+        KTimer tm(c, DSM_K_STATSPAT);
+        const uint32_t hi = 0xFFFFFFFFu - (++c->pat_gen);             // later passes write smaller entries: nothing to clear
+        if (G <= 6) hipLaunchKernelGGL(pat_rep_lds_kernel, dim3(std::max(1, std::min(64, V / 4096))), dim3(1024), 0, c->stream, c->tau, V, G, c->pat_rep, hi);
+        else hipLaunchKernelGGL(pat_rep_kernel, dim3((V + 255) / 256), dim3(256), 0, c->stream, c->tau, V, G, c->pat_rep, hi);
+        const size_t ncell = (size_t)V * S;
+        // few words: pooled in LDS first (one 1024-thread workgroup per CU and share of the positions); else straight to the blocks
+        const int lpw = G <= 3 ? 64 : 32;
+        const size_t lds = ((size_t)1 << (2 * G)) * 4 * lpw * sizeof(uint32_t);
+        if (G <= 4 && lds <= 128 * 1024 && V >= 4096) {
+            const int nchunk = (S + lpw - 1) / lpw;
+            const int nvsplit = std::max(1, std::min(256 / nchunk, V / (16 * (64 / lpw) * 8)));     // >= 8 passes per wavefront
+            const void *fl = lpw == 64 ? (const void *)pat_agg_lds_kernel<64> : (const void *)pat_agg_lds_kernel<32>;
+            static bool attr_done[2] = {false, false};
+            if (!attr_done[lpw == 32]) { HIP_TRY(hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr_done[lpw == 32] = true; }
+            const int32_t *cv = c->cnt_vs; const uint64_t *tp = c->tau; const unsigned long long *rp = c->pat_rep; uint32_t *xp = c->pat_x;
+            int Vv = V, Ss = S, Gg = G, nvs = nvsplit;
+            void *args[] = {(void *)&cv, (void *)&tp, (void *)&Vv, (void *)&Ss, (void *)&Gg, (void *)&rp, (void *)&xp, (void *)&nvs};
+            HIP_TRY(hipLaunchKernel(fl, dim3(nchunk * nvsplit), dim3(1024), args, lds, c->stream));
+        } else
+            hipLaunchKernelGGL(pat_agg_kernel, dim3((unsigned)std::min<size_t>((ncell + 255) / 256, 16384)), dim3(256), 0, c->stream,
+                               c->cnt_vs, c->tau, V, S, G, c->pat_rep, c->pat_x);
+        HIP_TRY(hipGetLastError());
+    }
     {
         // who draws an item, not what is drawn: an item whose rarer outcome has a mean above lean_cap goes to the compacted
         // kernel although inversion still applies to it -- its search would hold its 63 neighbours of the wavefront for

@@ -284,7 +284,8 @@ int dsm_kl_assign(int device, const double *cov, const double *delta, double *et
 #define DSM_K_NMFT_B   7
 #define DSM_K_STATS2   8         /* stage 2 of the aggregated mu/E pass       */
 #define DSM_K_STATSBIG 9         /* deferred stage-1 items (stats_big_kernel) */
-#define DSM_K_COUNT    10
+#define DSM_K_STATSPAT 10        /* spec 4: word table + per-word count sums ahead of stage 1 (pat_rep_kernel, pat_agg_kernel) */
+#define DSM_K_COUNT    11
 /* evidence for the screening pass of the tau sweep: wavefront-steps run / left to the fp64 code, over the sweeps
    of dsm_ctx_gibbs_update and dsm_ctx_update_tau so far.  mode 1 = read and zero, 0 = read */
 int dsm_ctx_sweep_stats(dsm_ctx *ctx, uint64_t *steps, uint64_t *exact_steps, int mode);

@@ -242,10 +242,28 @@ def dirichlet_counter(sum_mu, esum, seed, it, alpha=0.1, delta=0.1, epsilon=1e-6
 STATS_AGG = 2          # the aggregated specification the product runs by default (3 = the table exp / log variant, selectable)
 
 
+def aggregate_over_patterns(tau_idx, variants):
+    """spec 4's first step: positions with the same tau row (the same packed word) pool their counts in the LOWEST such position,
+    every other position of the word is left without reads.  Cells (v, s), (v', s) of one word have the same weights for every
+    observed base, and a sum of multinomials with one probability vector is one multinomial of the summed count: the mu/E sums keep
+    their law (HaploSNP_Sampler.py:284-309 consumed as sums, :266,:276) while stage 1 draws once per word instead of once per position."""
+    tau_idx = np.asarray(tau_idx)
+    _, first, inv = np.unique(tau_idx, axis=0, return_index=True, return_inverse=True)
+    rep = first[np.asarray(inv).reshape(-1)]                 # lowest position carrying each position's word
+    out = np.zeros_like(variants)
+    np.add.at(out, rep, variants)
+    return out
+
+
 def stats_agg(tau_idx, gamma, eta, variants, seed, it, want_ntab=False, spec=STATS_AGG):
-    """the aggregated specification of the mu/E sums (oracle/stats_agg.c; spec 2 or 3): (sum_mu [S,G], Esum [4,4][, ntab [S,2^G]])."""
+    """the aggregated specification of the mu/E sums (oracle/stats_agg.c; spec 2 or 3): (sum_mu [S,G], Esum [4,4][, ntab [S,2^G]]).
+    spec 4 = spec 2 on the counts pooled per tau word (aggregate_over_patterns); like the device it is spec 2 itself for G > 8."""
     V, S, _ = variants.shape
     G = tau_idx.shape[1]
+    if spec == 4:
+        if G <= 8:
+            variants = np.ascontiguousarray(aggregate_over_patterns(tau_idx, variants))
+        spec = 2
     mu = np.zeros((S, G), dtype=np.uint64)
     E = np.zeros((4, 4), dtype=np.uint64)
     nt = np.zeros((S, 1 << G), dtype=np.uint32) if want_ntab else None

@@ -16,12 +16,13 @@ ap.add_argument("--S", type=int, default=96)
 ap.add_argument("--true-G", type=int, default=6)
 ap.add_argument("--gs", default="2,3,4,6,8,10,12")
 ap.add_argument("--warmup", type=int, default=300)
+ap.add_argument("--stats-spec", type=int, default=0)
 ap.add_argument("--out", default="gpurun_out/r04/misfit_scan.json")
 a = ap.parse_args()
 rows = {}
 for G in [int(x) for x in a.gs.split(",")]:
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--V", str(a.V), "--S", str(a.S), "--G", str(G), "--true-G", str(a.true_G),
-                        "--steps", "60", "--warmup", str(a.warmup), "--repeats", "3", "--no-pmc", "--no-cpu-baseline", "--batch", "0"],
+                        "--stats-spec", str(a.stats_spec), "--steps", "60", "--warmup", str(a.warmup), "--repeats", "3", "--no-pmc", "--no-cpu-baseline", "--batch", "0"],
                        capture_output=True, text=True)
     try:
         d = json.loads(r.stdout.strip().splitlines()[-1])

@@ -98,6 +98,7 @@ LAW_CASES = {
     "G12": (12, 2, 12, 1.0, "random"),
     "deep": (20, 4, 4, 15.0, "random"),                 # x 15 depth: BTRS in stage 1, deferred lists, stats_big_kernel
     "converged": (40, 4, 4, 4.0, "truth"),              # eta ~ 0.97 I, tau = the generating haplotypes: rare-outcome inversion
+    "words": (80, 4, 2, 3.0, "truth"),                  # 80 positions on at most 16 tau words: what spec 4 pools (5 positions a word)
 }
 
 

@@ -26,7 +26,7 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(params=[2, 3, 1], ids=["aggregated-muE", "aggregated-muE-v3", "per-read-muE"])
+@pytest.fixture(params=[2, 3, 1, 4], ids=["aggregated-muE", "aggregated-muE-v3", "per-read-muE", "aggregated-over-words"])
 def spec_ctx(ctx, request):
     """the shared context with one of the two mu/E specifications forced (small test shapes would all take the
     per-read pass by the shape rule): the law / chain-level tests must hold for both"""
@@ -272,9 +272,9 @@ def test_stats_bit_exact_vs_spec(ctx, V, S, G):
     ctx.seed(1, ctr_seed=0xABCDEF0123456789)
     idx = cbind.onehot_to_idx(tau)
     assert ctx.stats_spec() == 1                                 # small problem: per-read pass by the shape rule
-    for force in ((3, 2, 1) if G <= 16 else (0,)):                # both versions of the aggregated specification, and the per-read one
+    for force in ((3, 2, 1, 4) if G <= 16 else (0,)):             # the versions of the aggregated specification, and the per-read one
         ctx.force_stats_spec(force)
-        assert ctx.stats_spec() == (force if force >= 2 else 1)
+        assert ctx.stats_spec() == ((2 if G > 8 else 4) if force == 4 else force if force >= 2 else 1)
         for it in (0, 1, 77):
             mu, E = ctx.sample_stats(it)
             mu_ref, E_ref = (cbind.stats_agg(idx, gamma, eta, counts, 0xABCDEF0123456789, it, spec=force) if force >= 2 else
@@ -310,7 +310,7 @@ def test_stats_stage1_matches_spec(ctx, V, S, G, scale):
         _load(ctx, counts, tau, gamma, eta)
         ctx.seed(1, ctr_seed=seed)
         idx = cbind.onehot_to_idx(tau)
-        for spec in (3, 2):
+        for spec in (3, 2, 4):
             ctx.force_stats_spec(spec)
             for it in (0, 5):
                 nt, E = ctx.debug_stage1(it)
@@ -320,6 +320,57 @@ def test_stats_stage1_matches_spec(ctx, V, S, G, scale):
                 mu, E2 = ctx.sample_stats(it)
                 assert np.array_equal(mu, mu_ref) and np.array_equal(E2, E_ref)
     ctx.force_stats_spec(0)
+
+
+@pytest.mark.parametrize("V,S,G,scale,biallelic", [(5000, 64, 3, 1.0, False), (3000, 96, 2, 1.0, False), (2000, 16, 4, 1.0, False),
+                                                   (1500, 40, 5, 1.0, False), (800, 130, 2, 1.0, False), (1200, 64, 8, 1.0, True),
+                                                   (2500, 64, 3, 25.0, False), (1000, 33, 6, 8.0, True), (333, 200, 1, 1.0, False),
+                                                   # pooled in LDS first (V >= 4096, G <= 4): 64- and 32-lane position groups, ragged S and V
+                                                   (6000, 96, 4, 1.0, False), (4099, 40, 4, 1.0, False), (9001, 100, 2, 1.0, False), (4500, 7, 1, 1.0, False)])
+def test_stats_over_tau_words_matches_twin(ctx, V, S, G, scale, biallelic):
+    """spec 4: positions that share their packed tau word share one stage-1 cell per sample (pat_rep_kernel / pat_agg_kernel /
+    stats_pat_kernel) -- against the twin (cbind.stats_agg(spec=4): counts pooled in the lowest position of the word, then the spec-2
+    code), bit for bit: subset counts, Esum, sum_mu; deep tables push pooled items onto the deferred lists (stats_big_kernel reads
+    and clears the pooled counts); a pass leaves the pooled counts zero, so passes repeat."""
+    counts, tau_true, gamma_true = synth_counts(V, S, max(G, 2), seed=V + G, depth_scale=scale)
+    rng = np.random.default_rng(V)
+    if biallelic:                                                 # every position has two alleles: at most 12 (2^G - 2) + 4 words
+        a0, a1 = rng.integers(0, 4, size=V), rng.integers(1, 4, size=V)
+        idx = np.where(rng.random((V, G)) < 0.5, a0[:, None], ((a0 + a1) % 4)[:, None]).astype(np.uint8)
+        tau = cbind.idx_to_onehot(idx)
+        _, gamma, eta = random_state(V, S, G, seed=5)
+    else:
+        tau, gamma, eta = random_state(V, S, G, seed=G + 7)
+    _load(ctx, counts, tau, gamma, eta)
+    seed = 0x00C0FFEE12345678
+    ctx.seed(1, ctr_seed=seed)
+    idx = cbind.onehot_to_idx(tau)
+    n_words = len(np.unique(idx, axis=0))
+    assert n_words < V
+    ctx.force_stats_spec(4)
+    try:
+        assert ctx.stats_spec() == 4
+        first = None
+        for it in (0, 3, 0):
+            nt, E = ctx.debug_stage1(it)
+            mu_ref, E_ref, nt_ref = cbind.stats_agg(idx, gamma, eta, counts, seed, it, want_ntab=True, spec=4)
+            assert np.array_equal(E, E_ref) and np.array_equal(nt, nt_ref)
+            mu, E2 = ctx.sample_stats(it)
+            assert np.array_equal(mu, mu_ref) and np.array_equal(E2, E_ref)
+            assert int(mu.sum()) == int(counts.sum()) and np.array_equal(E.sum(axis=1), counts.sum(axis=(0, 1)).astype(np.uint64))
+            if it == 0:
+                if first is None:
+                    first = mu.copy()
+                else:
+                    assert np.array_equal(first, mu)
+        # another state on the same context: the word table carries nothing over from the pass before
+        tau2, _, _ = random_state(V, S, G, seed=G + 99)
+        ctx.set_state(tau2, gamma, eta)
+        mu, E = ctx.sample_stats(1)
+        mu_ref, E_ref = cbind.stats_agg(cbind.onehot_to_idx(tau2), gamma, eta, counts, seed, 1, spec=4)
+        assert np.array_equal(mu, mu_ref) and np.array_equal(E, E_ref)
+    finally:
+        ctx.force_stats_spec(0)
 
 
 def test_stats_degenerate_eta_and_gamma(ctx):
@@ -333,7 +384,7 @@ def test_stats_degenerate_eta_and_gamma(ctx):
     _load(ctx, counts, tau, gamma, eta)
     ctx.seed(1, ctr_seed=9)
     idx = cbind.onehot_to_idx(tau)
-    for spec in (3, 2):
+    for spec in (3, 2, 4):
         ctx.force_stats_spec(spec)
         mu, E = ctx.sample_stats(2)
         ctx.force_stats_spec(0)
@@ -479,7 +530,7 @@ def test_gibbs_chain_recovers_asymmetric_eta(spec_ctx):
 
 
 # ---------------------------------------------------------------- A6 full iteration
-@pytest.mark.parametrize("spec", [3, 2, 1])
+@pytest.mark.parametrize("spec", [3, 2, 1, 4])
 @pytest.mark.parametrize("V,S,G,n_iter", [(400, 16, 5, 12), (600, 64, 8, 8), (150, 96, 3, 6), (200, 20, 11, 4), (900, 10, 2, 4)])
 def test_gibbs_update_is_self_consistent_with_oracle(ctx, V, S, G, n_iter, spec):
     """every piece of every iteration of the device loop against the oracle, in the reference's order

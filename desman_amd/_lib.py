@@ -374,7 +374,7 @@ class Context:
 
     def force_stats_spec(self, spec=0):
         """0 = shape rule, 1 = per-read draws everywhere, 2 (STATS_AGG) / 3 = that version of the aggregated sampler on small
-        problems too (G <= 16)."""
+        problems too (G <= 16), 4 = spec 2 over tau words (G <= 8; spec 2 where it does not apply)."""
         check(self.lib.dsm_ctx_force_stats_spec(self._h, int(spec)))
 
     def debug_stage1(self, it):

@@ -124,11 +124,15 @@ int dsm_ctx_sample_stats(dsm_ctx *ctx, uint32_t iter, uint64_t *sum_mu, uint64_t
  * 2 = aggregated sampler (oracle/stats_agg.c, spec 2; needs G <= 16, a subset table of at most 64 MB and every sample's
  * depth < 2^32), 3 = a variant of it (same law; the start of the inversion search from a table exp / log instead of
  * repeated squaring, item streams two Philox rounds off the cell's block instead of three -- selectable, not the default:
- * measured no faster), 1 = per-read draws (oracle/desman_oracle.c: orc_stats_counter).  Where the aggregated pass applies
+ * measured no faster), 4 = spec 2's samplers over tau WORDS: positions whose packed tau words are equal pool their counts in the
+ * lowest such position and stage 1 draws once per (word, sample) -- the same law (a sum of multinomials with one probability vector),
+ * restated by oracle/cbind.py: stats_agg(spec=4); G <= 8, not for sharded or batched chains (they run spec 2); by rule on tables of
+ * >= 2.5 million cells whose word count 4^G is at most a quarter of their positions --,
+ * 1 = per-read draws (oracle/desman_oracle.c: orc_stats_counter).  Where the aggregated pass applies
  * the cheaper of it and the per-read pass runs, by a cost model over the read total, the cells V x S (padded to the
  * kernel's lane groups) and the atomics per subset counter (kernels_stats.hip: stats_spec) -- a function of the shape and
- * the read totals only, the same on every run.  dsm_ctx_force_stats_spec: 0 = that rule, 1 = always spec 1, 2 / 3 = that
- * version of the aggregated sampler wherever it applies, small problems too (environment: DESMAN_HIP_STATS_SPEC=1|2|3 for
+ * the read totals only, the same on every run.  dsm_ctx_force_stats_spec: 0 = that rule, 1 = always spec 1, 2 / 3 / 4 = that
+ * version of the aggregated sampler wherever it applies, small problems too (environment: DESMAN_HIP_STATS_SPEC=1|2|3|4 for
  * contexts without a choice of their own).  A batch (dsm_batch_gibbs_update) always takes the aggregated sampler: spec 2,
  * or 3 if its first chain asks.  */
 int dsm_ctx_stats_spec(dsm_ctx *ctx);

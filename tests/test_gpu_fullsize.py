@@ -36,8 +36,10 @@ def test_full_size_sweep_loglik_and_stats_invariants(V, S, G):
     # per-read pass: every read is assigned exactly once, observed-base totals are preserved,
     # identical (seed, iter) -> identical sums, different iter -> different sums
     mu, E = ctx.sample_stats(3)
-    assert ctx.stats_spec() == _lib.STATS_AGG == cbind.STATS_AGG     # full sizes run the aggregated sampler ...
-    mu_ref, E_ref = cbind.stats_agg(cbind.onehot_to_idx(got), gamma, eta, counts, 42, 3)
+    # full sizes run the aggregated sampler: over tau words where at most a quarter as many words as positions exist (spec 4) ...
+    spec = ctx.stats_spec()
+    assert spec == (4 if (4 * 4 ** G <= V and V * S >= 2.5e6) else _lib.STATS_AGG) and _lib.STATS_AGG == cbind.STATS_AGG
+    mu_ref, E_ref = cbind.stats_agg(cbind.onehot_to_idx(got), gamma, eta, counts, 42, 3, spec=spec)
     assert np.array_equal(mu, mu_ref) and np.array_equal(E, E_ref)   # ... bit for bit as restated in oracle/stats_agg.c
     assert int(mu.sum()) == int(counts.sum())
     assert np.array_equal(mu.sum(axis=1), counts.sum(axis=(0, 2)).astype(np.uint64))        # reads per sample
@@ -56,7 +58,7 @@ def test_full_size_sweep_loglik_and_stats_invariants(V, S, G):
     ctx.seed(31337, ctr_seed=42)
     ctx.gibbs_update(3)
     tr = ctx.get_trace()
-    mu0, E0 = cbind.stats_agg(cbind.onehot_to_idx(got), gamma, eta, counts, 42, 0)
+    mu0, E0 = cbind.stats_agg(cbind.onehot_to_idx(got), gamma, eta, counts, 42, 0, spec=spec)
     g0, e0, _ = cbind.dirichlet_counter(mu0, E0, 42, 0)
     np.testing.assert_allclose(tr["gamma"][0], g0, rtol=1e-13, atol=0)
     np.testing.assert_allclose(tr["eta"][0], e0, rtol=1e-13, atol=0)

@@ -28,7 +28,8 @@ def chain_cost(V, S, G, n_iter=None, nmf_updates=5000):
     Fitted on the measurements of round 4 (profiles/r04_chain_cost_components.json: bench.py at V = 50k, S = 96, G = 2..12, and the
     config-3 line; `scripts/fit_chain_cost.py --report` prints predicted vs measured): with kc = V S / 1000 (thousand cells)
       one Gibbs iteration   38 + kc (0.0477 + 0.0063 G)  [+ 18 + 1.2e-4 2^G S from G = 10: stage 2 of the mu/E pass as its own launch]
-                            -- 0.328 / 0.405 / 0.513 / 0.691 ms at G = 2 / 4 / 8 / 12 there, 0.105 ms at config 3
+                            -- 0.513 / 0.691 ms at G = 8 / 12 there, 0.105 ms at config 3; less where the mu/E pass runs over tau words
+                            (large tables, 4 x 4^G <= V: a measured coefficient per G, below)
       one NMF update        12 + kc (0.0125 + 0.00306 ceil(G / 4))   -- 84 / 100 / 116 us at G <= 4 / <= 8 / <= 12 (K-blocks of four haplotypes)
       host work per chain   0.2 s + 1.3 us per (position, haplotype): the result files (Output_Results)
     and a chain runs 2 n_iter iterations (burn-in + sampling, bin/desman:212-232) after up to 5000 NMF updates (Init_NMFT.py:98-115:
@@ -39,6 +40,10 @@ def chain_cost(V, S, G, n_iter=None, nmf_updates=5000):
     (WorkQueue below), which this estimate only orders, longest first."""
     kc = float(V) * float(S) / 1000.0
     gibbs = 38.0 + kc * (0.0477 + 0.0063 * G)
+    if 4 * 4 ** int(G) <= V and kc >= 2500.0 and G <= 8:
+        # the mu/E pass over tau words (kernels_stats.hip: stats_spec, spec 4) where few words cover many positions: measured
+        # 0.173 / 0.220 / 0.280 / 0.368 / 0.415 ms per iteration at G = 2 ... 6 (V = 50k, S = 96; 0.328 ... 0.465 position by position)
+        gibbs = 38.0 + kc * {1: 0.022, 2: 0.0280, 3: 0.0379, 4: 0.0504, 5: 0.0688, 6: 0.0785}.get(int(G), 0.0477 + 0.0063 * G)
     if G >= 10:
         gibbs += 18.0 + 1.2e-4 * float(1 << min(int(G), 30)) * float(S)
     if n_iter is None:

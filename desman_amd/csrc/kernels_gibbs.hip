@@ -692,7 +692,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
     int *redi = reinterpret_cast<int *>(red + 4);        // [4] (+4 pad)
     double2 *ltab = reinterpret_cast<double2 *>(red + 6);// [256] log table
     float *gT32 = reinterpret_cast<float *>(ltab + DSM_LOG_TAB_N);   // [G][SP] fp32 copies for the screening pass
-    float *eS32 = gT32 + (size_t)p.G * SP;               // [16] eta_sweep, [4] its column minima
+    float *eS32 = gT32 + (size_t)p.G * SP;               // [16] eta_sweep, [4] its column minima, [4] its column maxima (rounded up)
     const int tid = threadIdx.x, G = p.G, S = p.S;
     if (tid < DSM_LOG_TAB_N) ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
     for (int i = tid; i < G * SP; i += 256) {
@@ -703,9 +703,10 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
     }
     if (tid < 16) { eS[tid] = p.eta_sweep[tid]; eL[tid] = p.eta_ll[tid]; if (SWEEP) eS32[tid] = (float)p.eta_sweep[tid]; }
     if (SWEEP && tid < 4) {
-        float m = (float)p.eta_sweep[tid];
-        for (int a = 1; a < 4; ++a) m = fminf(m, (float)p.eta_sweep[a * 4 + tid]);
+        float m = (float)p.eta_sweep[tid], mx = m;
+        for (int a = 1; a < 4; ++a) { m = fminf(m, (float)p.eta_sweep[a * 4 + tid]); mx = fmaxf(mx, (float)p.eta_sweep[a * 4 + tid]); }
         eS32[16 + tid] = m;
+        eS32[20 + tid] = mx * 1.000001f;                  // (it enters an error bound: sweep_neartie_core)
     }
     __syncthreads();
 
@@ -815,6 +816,16 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                     if constexpr (LEAN) cert = sweep_screen32<LPV, NSL>(pre32, xs, t, g, G, lig, uw, gT32, eS32, xtot, best);
                     else cert = sweep_screen<LPV, NSL>(pre, xi, t, g, G, lig, uw, gT32, eS32, xtot, best);
                     if (__builtin_amdgcn_ballot_w64(cert) == __builtin_amdgcn_ballot_w64(true)) { tn = best; decided = true; }
+                    // ---- not settled by the totals: a near-tie?  The step of a haplotype that is rare in every sample (the spare
+                    // haplotypes of an over-fitted chain, gamma ~ 1e-3) is screened once more, on the DIFFERENCES of the candidates
+                    // (dsm_device.h: sweep_neartie_core); only what that leaves open runs the fp64 code.  Normal chains never get here.
+                    if (!decided && neartie_candidate<LPV, NSL>(g, lig, S, gT32)) {
+                        int tf = 0;
+                        bool c2;
+                        if constexpr (LEAN) c2 = sweep_neartie32<LPV, NSL>(pre32, xs, t, g, G, lig, uw, gT32, eS32, tf);
+                        else c2 = sweep_neartie<LPV, NSL>(pre, xi, t, g, G, lig, uw, gT32, eS32, tf);
+                        if (__builtin_amdgcn_ballot_w64(c2) == __builtin_amdgcn_ballot_w64(true)) { tn = tf; decided = true; }
+                    }
                 }
                 if (!decided) {
                 const bool reuse = have_cur;
@@ -1324,7 +1335,7 @@ static int tau_shape(int S, int *lpv, int *nsl)
 static size_t tau_lds_bytes(int G, int LPV, int NSL)
 {
     return ((size_t)G * LPV * NSL + 16 + 16 + 6 + 2 * DSM_LOG_TAB_N) * sizeof(double) +
-           ((size_t)G * LPV * NSL + 20) * sizeof(float);                  // + fp32 copies of gamma / eta for the screening pass
+           ((size_t)G * LPV * NSL + 24) * sizeof(float);                  // + fp32 copies of gamma / eta (+ column minima / maxima) for the screening passes
 }
 
 int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_sweep, const double *eta_ll,

@@ -437,9 +437,12 @@ __device__ void finalize_body(const FinalParams &p, double *red, double *redp, i
         for (int i = tid; i < p.SG; i += nthr) p.gamma_star[i] = p.gamma_src[i];
         if (tid < 16) p.eta_star[tid] = p.eta_src[tid];
     }
-    // the screening pass of the tau sweep is worth its ~20 % only while it decides most steps: a sweep that
-    // left more than half of its wavefront-steps to the fp64 code (very shallow data, a handful of samples, the first
-    // iterations from a random state) switches it off for the next 15 sweeps, then it is tried again.  Which steps are screened
+    // the screening pass of the tau sweep is worth its ~20 % only while it decides enough steps: a screened
+    // step costs ~720 issue cycles, an fp64 step ~3 700, one that takes both 4 420 -- the screen pays while it leaves fewer than
+    // (3 700 - 720) / 3 700 = 0.8 of the steps open.  A sweep that left MORE than four fifths of its wavefront-steps to the fp64
+    // code (very shallow data, a handful of samples) switches it off for the next 15 sweeps, then it is tried again.  (Round 3
+    // switched at one half: the chains of a G-sweep with twice as many haplotypes as strains sit right there -- their spare
+    // haplotypes, gamma ~ 1e-3, make near-ties of half the steps -- and ran most of their sweeps all-fp64: scripts/dbg/chain_fp64.py.)  Which steps are screened
     // changes no draw outside near-ties: a step after a screened one evaluates the current base's log-probability afresh where
     // an all-fp64 sweep re-uses the previous step's value -- the same number up to its last bits (a flip needs the uniform
     // within ~1e-13 of a CDF edge).  The rule itself is deterministic (counts of the previous launches only).
@@ -463,7 +466,7 @@ __device__ void finalize_body(const FinalParams &p, double *red, double *redp, i
             p.sweep_stats[0] += (unsigned long long)red[0];
             p.sweep_stats[1] += (unsigned long long)redp[0];
             if (any_plain) { if (p.screen_ctl[0] > 0) p.screen_ctl[0] -= 1; }
-            else if (2.0 * redp[0] > red[0]) p.screen_ctl[0] = 15;
+            else if (5.0 * redp[0] > 4.0 * red[0]) p.screen_ctl[0] = 15;
         }
         // The rare fp64 step of a sweep is long, and a workgroup that meets one late in the launch is the launch's tail (2.4 us of 36.8 at
         // config 3).  Close races stay close from sweep to sweep, so the blocks that met one go FIRST next time: a stable
@@ -692,7 +695,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
     int *redi = reinterpret_cast<int *>(red + 4);        // [4] (+4 pad)
     double2 *ltab = reinterpret_cast<double2 *>(red + 6);// [256] log table
     float *gT32 = reinterpret_cast<float *>(ltab + DSM_LOG_TAB_N);   // [G][SP] fp32 copies for the screening pass
-    float *eS32 = gT32 + (size_t)p.G * SP;               // [16] eta_sweep, [4] its column minima, [4] its column maxima (rounded up)
+    float *eS32 = gT32 + (size_t)p.G * SP;               // [16] eta_sweep, [4] its column minima
     const int tid = threadIdx.x, G = p.G, S = p.S;
     if (tid < DSM_LOG_TAB_N) ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
     for (int i = tid; i < G * SP; i += 256) {
@@ -703,10 +706,9 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
     }
     if (tid < 16) { eS[tid] = p.eta_sweep[tid]; eL[tid] = p.eta_ll[tid]; if (SWEEP) eS32[tid] = (float)p.eta_sweep[tid]; }
     if (SWEEP && tid < 4) {
-        float m = (float)p.eta_sweep[tid], mx = m;
-        for (int a = 1; a < 4; ++a) { m = fminf(m, (float)p.eta_sweep[a * 4 + tid]); mx = fmaxf(mx, (float)p.eta_sweep[a * 4 + tid]); }
+        float m = (float)p.eta_sweep[tid];
+        for (int a = 1; a < 4; ++a) m = fminf(m, (float)p.eta_sweep[a * 4 + tid]);
         eS32[16 + tid] = m;
-        eS32[20 + tid] = mx * 1.000001f;                  // (it enters an error bound: sweep_neartie_core)
     }
     __syncthreads();
 
@@ -816,16 +818,6 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                     if constexpr (LEAN) cert = sweep_screen32<LPV, NSL>(pre32, xs, t, g, G, lig, uw, gT32, eS32, xtot, best);
                     else cert = sweep_screen<LPV, NSL>(pre, xi, t, g, G, lig, uw, gT32, eS32, xtot, best);
                     if (__builtin_amdgcn_ballot_w64(cert) == __builtin_amdgcn_ballot_w64(true)) { tn = best; decided = true; }
-                    // ---- not settled by the totals: a near-tie?  The step of a haplotype that is rare in every sample (the spare
-                    // haplotypes of an over-fitted chain, gamma ~ 1e-3) is screened once more, on the DIFFERENCES of the candidates
-                    // (dsm_device.h: sweep_neartie_core); only what that leaves open runs the fp64 code.  Normal chains never get here.
-                    if (!decided && neartie_candidate<LPV, NSL>(g, lig, S, gT32)) {
-                        int tf = 0;
-                        bool c2;
-                        if constexpr (LEAN) c2 = sweep_neartie32<LPV, NSL>(pre32, xs, t, g, G, lig, uw, gT32, eS32, tf);
-                        else c2 = sweep_neartie<LPV, NSL>(pre, xi, t, g, G, lig, uw, gT32, eS32, tf);
-                        if (__builtin_amdgcn_ballot_w64(c2) == __builtin_amdgcn_ballot_w64(true)) { tn = tf; decided = true; }
-                    }
                 }
                 if (!decided) {
                 const bool reuse = have_cur;
@@ -1335,7 +1327,7 @@ static int tau_shape(int S, int *lpv, int *nsl)
 static size_t tau_lds_bytes(int G, int LPV, int NSL)
 {
     return ((size_t)G * LPV * NSL + 16 + 16 + 6 + 2 * DSM_LOG_TAB_N) * sizeof(double) +
-           ((size_t)G * LPV * NSL + 24) * sizeof(float);                  // + fp32 copies of gamma / eta (+ column minima / maxima) for the screening passes
+           ((size_t)G * LPV * NSL + 20) * sizeof(float);                  // + fp32 copies of gamma / eta for the screening pass
 }
 
 int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_sweep, const double *eta_ll,

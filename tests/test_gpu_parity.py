@@ -74,22 +74,23 @@ def test_tau_sweep_vs_oracle(ctx, V, S, G):
         np.testing.assert_allclose(logp, logp_ref, rtol=1e-12, atol=1e-8)
 
 
-@pytest.mark.parametrize("kind", ["low", "floor"])
+@pytest.mark.parametrize("kind", ["low", "rare", "floor"])
 @pytest.mark.parametrize("V,S,G,spare", [(3000, 64, 8, (2, 5, 7)), (2000, 96, 12, (0, 3, 4, 8, 10, 11)), (1500, 16, 5, (1, 4)),
                                          (600, 200, 6, (0, 5)), (400, 300, 4, (2,)), (500, 40, 3, (0,)), (800, 130, 7, (3, 6)),
                                          (1000, 64, 8, (0, 1, 2, 3, 4, 5, 6))])
 def test_tau_sweep_of_an_overfitted_chain_vs_oracle(ctx, V, S, G, spare, kind):
-    """A chain with more haplotypes than the table has strains keeps the spare ones at low abundance (gamma ~ 1e-3 ... 1e-2: they soak
-    up errors; scripts/dbg/flat_diag.py, chain_fp64.py) or at the floor (gamma = epsilon = 1e-6 in every sample,
-    HaploSNP_Sampler.py:271-273).  Their steps are races of a few nats or near-ties: the screening pass settles them from the totals
-    AND the uniform (dsm_device.h: screen_certify) or from the differences of the candidates (sweep_neartie_core), so few are left
-    to fp64.  Either way the draws are the oracle's, screens on or off."""
+    """A chain with more haplotypes than the table has strains keeps the spare ones at low abundance -- gamma ~ 1e-2 early on
+    ("low": races of 8 ... 64 nats, scripts/dbg/flat_diag.py), ~ 1e-3 once the chain has settled ("rare": near-ties,
+    scripts/dbg/chain_fp64.py) -- or at the floor (gamma = epsilon = 1e-6 in every sample, HaploSNP_Sampler.py:271-273).  The first
+    kind is settled by the screening pass from the totals AND the uniform (dsm_device.h: screen_certify: few steps left to fp64); the
+    near-ties of the other two go to the fp64 code.  Either way the draws are the oracle's, screens on or off."""
     live = [g for g in range(G) if g not in spare]
     counts, _, _ = synth_counts(V, S, max(len(live), 2), seed=V + S + G)
     tau, gamma, eta = random_state(V, S, G, seed=G + 100)
     gamma = gamma.copy()
     rng = np.random.default_rng(V + G)
-    gamma[:, list(spare)] = 1.0e-6 if kind == "floor" else rng.uniform(2.0e-4, 2.0e-3, size=(S, len(spare)))
+    gamma[:, list(spare)] = 1.0e-6 if kind == "floor" else rng.uniform(2.0e-4, 2.0e-3, size=(S, len(spare))) if kind == "rare" else \
+        rng.uniform(1.0e-2, 4.0e-2, size=(S, len(spare)))
     gamma[:, live] *= ((1.0 - gamma[:, list(spare)].sum(axis=1)) / gamma[:, live].sum(axis=1))[:, None]
     gamma = np.ascontiguousarray(gamma / gamma.sum(axis=1)[:, None])
     n_sw = 4
@@ -109,7 +110,7 @@ def test_tau_sweep_of_an_overfitted_chain_vs_oracle(ctx, V, S, G, spare, kind):
         assert np.array_equal(ctx.get_tau_at(it), ref)
     steps, exact = ctx.sweep_stats()
     assert steps > 0
-    if len(live) > 1 and S >= 40:
+    if kind != "floor" and len(live) > 1 and S >= 40 and (kind == "rare" or len(spare) * 0.04 < 0.5):   # (from a random tau the races are wide)
         assert exact / steps < 0.25, (kind, steps, exact)         # (round 3's rule -- gaps above 64 nats only -- left len(spare) / G of them)
     # the same sweeps with the screen switched off: the same haplotypes
     _load(ctx, counts, tau, gamma, eta, mt_seed=777)

@@ -40,10 +40,10 @@ def chain_cost(V, S, G, n_iter=None, nmf_updates=5000):
     (WorkQueue below), which this estimate only orders, longest first."""
     kc = float(V) * float(S) / 1000.0
     gibbs = 38.0 + kc * (0.0477 + 0.0063 * G)
-    if 4 * 4 ** int(G) <= V and kc >= 2500.0 and G <= 8:
-        # the mu/E pass over tau words (kernels_stats.hip: stats_spec, spec 4) where few words cover many positions: measured
-        # 0.173 / 0.220 / 0.280 / 0.368 / 0.415 ms per iteration at G = 2 ... 6 (V = 50k, S = 96; 0.328 ... 0.465 position by position)
-        gibbs = 38.0 + kc * {1: 0.022, 2: 0.0280, 3: 0.0379, 4: 0.0504, 5: 0.0688, 6: 0.0785}.get(int(G), 0.0477 + 0.0063 * G)
+    if (G <= 2 and kc >= 500.0) or (G == 3 and kc >= 1000.0) or (4 <= G <= 8 and kc >= 2500.0 and 64 * 2 ** int(G) <= V):
+        # the mu/E pass over tau words (kernels_stats.hip: stats_spec, spec 4) where few words cover many positions: a measured
+        # coefficient per G (V = 50k, S = 96, profiles/r04_chain_cost_components.json; 0.328 ... 0.513 ms position by position)
+        gibbs = 38.0 + kc * PAT_COEF.get(int(G), 0.0477 + 0.0063 * G)
     if G >= 10:
         gibbs += 18.0 + 1.2e-4 * float(1 << min(int(G), 30)) * float(S)
     if n_iter is None:
@@ -51,6 +51,10 @@ def chain_cost(V, S, G, n_iter=None, nmf_updates=5000):
     nmf = 12.0 + kc * (0.0125 + 0.00306 * float((int(G) + 3) // 4))
     host = 0.2e6 + 1.3 * float(V) * float(G)
     return 2.0 * float(n_iter) * gibbs + float(nmf_updates) * nmf + host
+
+
+# us per thousand cells and Gibbs iteration where the mu/E pass runs over tau words (chain_cost), G -> coefficient
+PAT_COEF = {1: 0.022, 2: 0.0280, 3: 0.0379, 4: 0.0504, 5: 0.0688, 6: 0.0785, 7: 0.085, 8: 0.090}
 
 
 class WorkQueue:

@@ -83,6 +83,7 @@ struct dsm_ctx {
     // pattern-aggregated stage 1 (spec 4, kernels_stats.hip): positions that share their packed tau word share one stage-1 cell per sample
     unsigned long long *pat_rep = nullptr;   // [4^G] (~generation << 32 | lowest position that carries the word); atomicMin, never cleared
     uint32_t *pat_x = nullptr;               // [V][4][S] counts summed per (representative position, base, sample); zero between passes
+    uint32_t *pat_list = nullptr;            // [4^G] the representatives of this pass, in no particular order, then [2] their number (by pass parity)
     size_t pat_rep_len = 0, pat_x_len = 0;
     uint32_t pat_gen = 0;
     uint32_t *ntab_raw = nullptr;   // the allocation `ntab` points into (kernels_stats.hip: ensure_ntab places the table inside it)

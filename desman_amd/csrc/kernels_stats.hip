@@ -59,6 +59,7 @@ struct StatsAggParams {
     // pat_rep[word] & 0xFFFFFFFF) carry cells, with the counts of all positions of their word summed in pat_x [V][4][S]
     const unsigned long long *pat_rep;
     uint32_t *pat_x;
+    const uint32_t *pat_list, *pat_n;   // the representatives of this pass (any order) and their number: stage 1 walks this list
     int dbg;                        // timing experiments only (DESMAN_HIP_STATS_DBG; compiled out of the product kernel: STATS_DBG above): bit 0 no draws, 1 no item seeding, 2 no E/N atomics, 3 no cell Philox
 };
 
@@ -113,23 +114,21 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
     // which copy of the subset table this workgroup adds to
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;                // HW_REG_XCC_ID[3:0] (gfx942 / gfx950)
     const unsigned copy = p.xcd ? xcc + 8u * ((blockIdx.x >> 3) % (unsigned)(p.rep >> 3)) : blockIdx.x % (unsigned)p.rep;
-    const int ntask = V * NCH;                                        // (variant, chunk of LPV samples)
+    // spec 4: only the representatives carry cells -- the tasks are (entry of the pass's list, chunk); the list is in no
+    // particular order (atomic appends), which changes no sum: a cell's stream is keyed by its position, the sums are integers
+    const int nunit = PAT ? (int)__builtin_amdgcn_readfirstlane((int)*p.pat_n) : V;
+    const int ntask = nunit * NCH;                                    // (variant, chunk of LPV samples)
     const int nslot = (ntask + NG - 1) / NG;                          // NG tasks per wavefront pass
     for (int slot = wid; slot < nslot; slot += nwaves) {
         const int task = slot * NG + grp;
         const bool tv = task < ntask;
-        const int v = tv ? task / NCH : 0, j = tv ? task - v * NCH : 0;
+        const int u = tv ? task / NCH : 0, j = tv ? task - u * NCH : 0;
+        const int v = PAT ? (int)p.pat_list[u] : u;
         const int s = j * LPV + lig;
-        bool active = tv && s < S;
+        const bool active = tv && s < S;
         uint64_t t = p.tau[v];
         int4 c = make_int4(0, 0, 0, 0);
         if constexpr (PAT) {
-            // a position that is not the representative of its tau word has no cell of its own: its reads were added to the
-            // representative's (pat_agg_kernel).  One variant per wavefront: the whole pass is skipped on a scalar branch.
-            const bool isrep = (uint32_t)p.pat_rep[t & ((1ull << (2 * G)) - 1ull)] == (uint32_t)v;
-            active = active && isrep;
-            // (most positions are not representatives: a pass none of whose lane groups holds one ends here, on a scalar branch)
-            if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
             if (active) {
                 const uint32_t *xr = p.pat_x + (size_t)v * 4 * S + s;
                 c.x = (int)xr[0]; c.y = (int)xr[(size_t)S]; c.z = (int)xr[2 * (size_t)S]; c.w = (int)xr[3 * (size_t)S];
@@ -338,6 +337,19 @@ __global__ __launch_bounds__(1024) void pat_agg_lds_kernel(const int32_t *__rest
     }
 }
 
+// the representatives of the pass as a list (one thread per word; appended in whatever order the atomics resolve): stage 1 then has
+// an even share of them per wavefront -- walking the positions instead, the lowest positions of the words (all within the first few
+// thousand) made a few wavefronts do most of the work (V = 50k, S = 96, G = 6: 175 us).  The counter of the NEXT pass is cleared here.
+__global__ __launch_bounds__(256) void pat_list_kernel(const unsigned long long *__restrict__ rep, int words, uint32_t hi, uint32_t *__restrict__ list,
+                                                       uint32_t *__restrict__ n_this, uint32_t *__restrict__ n_next)
+{
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w == 0) *n_next = 0u;
+    if (w >= words) return;
+    const unsigned long long e = rep[w];
+    if ((uint32_t)(e >> 32) == hi) list[atomicAdd(n_this, 1u)] = (uint32_t)e;
+}
+
 // thread = (position, sample): the slab's four counts are added to the representative's [4][S] block -- lanes are consecutive samples,
 // so an instruction's atomics fall on consecutive words.  Integer sums: the order of the adds changes nothing.
 __global__ __launch_bounds__(256) void pat_agg_kernel(const int32_t *__restrict__ cnt_vs, const uint64_t *__restrict__ tau, int V, int S, int G,
@@ -529,16 +541,22 @@ int stats_spec(const dsm_ctx *c)
     const int rep = stats_ntab_rep(c);
     const double per = 3.0 * (double)c->V / (double)(1u << c->G);                // atomics per counter of the subset table
     const double t2 = 24.0 + stage2 + 0.062e-3 * cells + (rep == 1 ? 0.03 * per : 0.003 * per / rep);   // with copies: no measurable penalty
-    // over tau words (spec 4): one more pass over the counts (~60 us per 77 MB incl. its atomics) + a small launch, then stage 1 over at
-    // most 4^G words instead of V positions.  What it saves is stage 1's per-cell work, not its per-error-read work (the pooled cells
-    // hold the same reads), so it pays on large tables with few words -- measured on the six-strain 50k x 96 table
-    // (profiles/r04_misfit_scan_spec4.txt, ms per iteration, spec 4 vs 2): G = 2 0.27 vs 0.91, 3 0.27 vs 0.84, 4 0.29 vs 0.42, 5 0.39 vs
-    // 0.44, 6 0.41 vs 0.47 (forced at 7 / 8: 0.46 vs 0.49, 0.48 vs 0.51) -- and loses on small ones (10k x 64: 0.12-0.15 vs 0.09-0.12 at
-    // G = 2..5: the passes' fixed latencies).  By rule where the word count alone -- whatever the data -- leaves a quarter of the cells
-    // or fewer AND the table has 2.5 million cells; tables whose positions share words beyond that (biallelic data: at most
-    // 12 (2^G - 2) + 4 words) can ask for it (dsm_ctx_force_stats_spec(4), DESMAN_HIP_STATS_SPEC=4).
-    const double words = (double)((size_t)1 << (2 * c->G));
-    if (pat_ok && force == 0 && 4.0 * words <= (double)c->V && cells >= 2.5e6 && t2 < t1) return 4;
+    // over tau words (spec 4): one more pass over the counts (~60 us per 77 MB incl. its atomics) + two small launches, then stage 1 over
+    // the words the chain's tau actually holds instead of its V positions.  What it saves is stage 1's per-cell work, not its
+    // per-error-read work (the pooled cells hold the same reads), so it pays on large tables with few words -- and most where stage 1 is
+    // most expensive, in the chains of a G-sweep that have fewer haplotypes than the table has strains.  Measured, ms per iteration,
+    // spec 4 vs 2 (profiles/r04_misfit_scan_spec4.txt): six-strain 50k x 96 table G = 2 0.14 vs 0.91, 3 0.21 vs 0.84, 4 0.27 vs 0.42,
+    // 5 0.33 vs 0.44, 6 0.34 vs 0.47, 7 0.41 vs 0.49, 8 0.42 vs 0.51 (at 7 and 8 the six real strains keep the words few although
+    // 4^G > V); four-strain 20k x 64: 0.10 vs 0.22, 0.15 vs 0.18, then 0.16 vs 0.13, 0.17 vs 0.14; 10k x 64: 0.10 vs 0.12, 0.13 vs 0.12,
+    // 0.14 vs 0.09.  A table whose words are all different pays the pooling pass for nothing (+12 % at 50k x 96).  The rule -- shape
+    // only, like everything here: G <= 2 from half a million cells, G = 3 from a million, G = 4 ... 8 from 2.5 million cells where
+    // even 64 x 2^G words (several times what biallelic positions can form: 12 (2^G - 2) + 4) stay below V.  Anything else can ask for
+    // it (dsm_ctx_force_stats_spec(4), DESMAN_HIP_STATS_SPEC=4).
+    if (pat_ok && force == 0 && t2 < t1) {
+        const bool small_g = (c->G <= 2 && cells >= 0.5e6) || (c->G == 3 && cells >= 1.0e6);
+        const bool mid_g = c->G >= 4 && cells >= 2.5e6 && 64.0 * (double)((size_t)1 << c->G) <= (double)c->V;
+        if (small_g || mid_g) return 4;
+    }
     return t2 < t1 ? DSM_STATS_AGG : 1;
 }
 
@@ -713,6 +731,12 @@ static int ensure_pat(dsm_ctx *c)
         c->pat_gen = 0;
         HIP_TRY(hipMemsetAsync(c->pat_rep, 0xFF, nrep * sizeof(unsigned long long), c->stream));
     }
+    if (!c->pat_list || c->pat_rep_len != nrep || c->pat_gen == 0) {
+        if (c->pat_list) { (void)hipFree(c->pat_list); c->pat_list = nullptr; }
+        hipError_t e = hipMalloc((void **)&c->pat_list, (nrep + 2) * sizeof(uint32_t));
+        if (e != hipSuccess) { dsm_set_error("hipMalloc(%zu B) failed: %s", (nrep + 2) * 4, hipGetErrorString(e)); return DSM_ERR_NOMEM; }
+        HIP_TRY(hipMemsetAsync(c->pat_list + nrep, 0, 2 * sizeof(uint32_t), c->stream));
+    }
     if (!c->pat_x || c->pat_x_len != nx) {
         if (c->pat_x) { (void)hipFree(c->pat_x); c->pat_x = nullptr; }
         hipError_t e = hipMalloc((void **)&c->pat_x, nx * sizeof(uint32_t));
@@ -794,15 +818,19 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     p.xcd = stats_ntab_xcd(c) ? 1 : 0;
     p.hmul = stats_ntab_hmul();
     p.big_list = c->big_list; p.big_count = c->big_count;
-    p.pat_rep = nullptr; p.pat_x = nullptr;
+    p.pat_rep = nullptr; p.pat_x = nullptr; p.pat_list = nullptr; p.pat_n = nullptr;
     if (pat) {
         r = ensure_pat(c);
         if (r != DSM_OK) return r;
         p.pat_rep = c->pat_rep; p.pat_x = c->pat_x;
         KTimer tm(c, DSM_K_STATSPAT);
         const uint32_t hi = 0xFFFFFFFFu - (++c->pat_gen);             // later passes write smaller entries: nothing to clear
+        const int words = 1 << (2 * G);
+        uint32_t *n_this = c->pat_list + words + (c->pat_gen & 1u), *n_next = c->pat_list + words + ((c->pat_gen + 1u) & 1u);
+        p.pat_list = c->pat_list; p.pat_n = n_this;
         if (G <= 6) hipLaunchKernelGGL(pat_rep_lds_kernel, dim3(std::max(1, std::min(64, V / 4096))), dim3(1024), 0, c->stream, c->tau, V, G, c->pat_rep, hi);
         else hipLaunchKernelGGL(pat_rep_kernel, dim3((V + 255) / 256), dim3(256), 0, c->stream, c->tau, V, G, c->pat_rep, hi);
+        hipLaunchKernelGGL(pat_list_kernel, dim3((words + 255) / 256), dim3(256), 0, c->stream, c->pat_rep, words, hi, c->pat_list, n_this, n_next);
         const size_t ncell = (size_t)V * S;
         // few words: pooled in LDS first (one 1024-thread workgroup per CU and share of the positions); else straight to the blocks
         const int lpw = G <= 3 ? 64 : 32;

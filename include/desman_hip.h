@@ -126,8 +126,8 @@ int dsm_ctx_sample_stats(dsm_ctx *ctx, uint32_t iter, uint64_t *sum_mu, uint64_t
  * repeated squaring, item streams two Philox rounds off the cell's block instead of three -- selectable, not the default:
  * measured no faster), 4 = spec 2's samplers over tau WORDS: positions whose packed tau words are equal pool their counts in the
  * lowest such position and stage 1 draws once per (word, sample) -- the same law (a sum of multinomials with one probability vector),
- * restated by oracle/cbind.py: stats_agg(spec=4); G <= 8, not for sharded or batched chains (they run spec 2); by rule on tables of
- * >= 2.5 million cells whose word count 4^G is at most a quarter of their positions --,
+ * restated by oracle/cbind.py: stats_agg(spec=4); G <= 8, not for sharded or batched chains (they run spec 2); by rule on large tables
+ * (G <= 2 from half a million cells, G = 3 from a million, G = 4 ... 8 from 2.5 million cells with 64 x 2^G <= V) --,
  * 1 = per-read draws (oracle/desman_oracle.c: orc_stats_counter).  Where the aggregated pass applies
  * the cheaper of it and the per-read pass runs, by a cost model over the read total, the cells V x S (padded to the
  * kernel's lane groups) and the atomics per subset counter (kernels_stats.hip: stats_spec) -- a function of the shape and

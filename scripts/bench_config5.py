@@ -40,7 +40,7 @@ def run_sweep(freq, a, stub, extra):
 
 def plan_check(recs, V, S, n_bins=8, batch=1):
     """LPT plan of the driver for n_bins GPUs from chain_cost; bin loads predicted (cost units) and measured (seconds)"""
-    specs = chains.sweep_specs(sorted({int(r["G"]) for r in recs}), 1 + max(int(r["seed"]) for r in recs), V, S)
+    specs = chains.sweep_specs(sorted({int(r["G"]) for r in recs}), 1 + max(int(r["seed"]) for r in recs), V, S, n_iter=500)
     wall = {(int(r["G"]), int(r["seed"])): r["wall_s"] for r in recs}
     units = chains.group_units(specs, batch)
     bins = chains.lpt_assign([sum(specs[i]["cost"] for i in u) for u in units], n_bins)
@@ -49,8 +49,16 @@ def plan_check(recs, V, S, n_bins=8, batch=1):
     # the best the same greedy rule could do had it known the measured times
     ub = chains.lpt_assign([sum(wall[(specs[i]["G"], specs[i]["seed"])] for i in u) for u in units], n_bins)
     best = [sum(wall[(specs[i]["G"], specs[i]["seed"])] for ui in b for i in units[ui]) for b in ub]
+    # the work queue (desman-sweep --schedule queue, the default): every rank takes the next unit of the list (decreasing estimate) when
+    # it is free -- simulated with the measured times
+    order = sorted(range(len(units)), key=lambda u: (-sum(specs[i]["cost"] for i in units[u]), u))
+    free = [0.0] * n_bins
+    for u in order:
+        k = min(range(n_bins), key=lambda r: (free[r], r))
+        free[k] += sum(wall[(specs[i]["G"], specs[i]["seed"])] for i in units[u])
     return dict(bins=n_bins, predicted_max_over_mean=max(pred) / (sum(pred) / n_bins), measured_max_over_mean=max(meas) / (sum(meas) / n_bins),
-                measured_makespan_s=max(meas), lpt_on_measured_times_makespan_s=max(best), sum_s=sum(meas))
+                measured_makespan_s=max(meas), lpt_on_measured_times_makespan_s=max(best), sum_s=sum(meas),
+                work_queue_makespan_s=max(free), work_queue_max_over_mean=max(free) / (sum(meas) / n_bins))
 
 
 def main():
@@ -87,7 +95,7 @@ def main():
             per_g = {}
             for r in recs:
                 per_g.setdefault(int(r["G"]), []).append(r["wall_s"])
-            cost = {g: chains.chain_cost(a.V, a.S, g) for g in per_g}
+            cost = {g: chains.chain_cost(a.V, a.S, g, n_iter=a.iters) for g in per_g}
             tot_w, tot_c = sum(np.mean(v) for v in per_g.values()), sum(cost.values())
             res = dict(wall_s=wall, failed=int(sum(r["failed"] for r in recs)),
                        per_G_mean_chain_wall_s={g: float(np.mean(v)) for g, v in sorted(per_g.items())},

@@ -38,7 +38,9 @@ def test_full_size_sweep_loglik_and_stats_invariants(V, S, G):
     mu, E = ctx.sample_stats(3)
     # full sizes run the aggregated sampler: over tau words where at most a quarter as many words as positions exist (spec 4) ...
     spec = ctx.stats_spec()
-    assert spec == (4 if (4 * 4 ** G <= V and V * S >= 2.5e6) else _lib.STATS_AGG) and _lib.STATS_AGG == cbind.STATS_AGG
+    cells = V * S
+    by_rule = 4 if ((G <= 2 and cells >= 0.5e6) or (G == 3 and cells >= 1e6) or (4 <= G <= 8 and cells >= 2.5e6 and 64 * 2 ** G <= V)) else _lib.STATS_AGG
+    assert spec == by_rule and _lib.STATS_AGG == cbind.STATS_AGG
     mu_ref, E_ref = cbind.stats_agg(cbind.onehot_to_idx(got), gamma, eta, counts, 42, 3, spec=spec)
     assert np.array_equal(mu, mu_ref) and np.array_equal(E, E_ref)   # ... bit for bit as restated in oracle/stats_agg.c
     assert int(mu.sum()) == int(counts.sum())

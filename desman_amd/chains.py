@@ -54,7 +54,7 @@ def chain_cost(V, S, G, n_iter=None, nmf_updates=5000):
 
 
 # us per thousand cells and Gibbs iteration where the mu/E pass runs over tau words (chain_cost), G -> coefficient
-PAT_COEF = {1: 0.022, 2: 0.0280, 3: 0.0379, 4: 0.0504, 5: 0.0688, 6: 0.0785, 7: 0.085, 8: 0.090}
+PAT_COEF = {1: 0.022, 2: 0.0289, 3: 0.0385, 4: 0.0505, 5: 0.0598, 6: 0.0624, 7: 0.0806, 8: 0.1060}
 
 
 class WorkQueue:

@@ -66,6 +66,7 @@ SIGNATURES = {
     "dsm_ctx_stats_spec": (_i, [_vp]),
     "dsm_ctx_sweep_stats": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _i]),
     "dsm_ctx_set_tau_screen": (_i, [_vp, _i]),
+    "dsm_ctx_set_tau_neartie": (_i, [_vp, _i]),
     "dsm_ctx_set_nmft_fused": (_i, [_vp, _i]),
     "dsm_ctx_set_nmft_persist": (_i, [_vp, _i]),
     "dsm_ctx_tau_launch_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
@@ -339,6 +340,11 @@ class Context:
         out = np.empty_like(x)
         check(self.lib.dsm_ctx_debug_log2f(self._h, x.ctypes.data, out.ctypes.data, x.size))
         return out
+
+    def set_tau_neartie(self, mode=-1):
+        """which instantiation of the Gibbs loop's tau sweep runs: -1 = the one with the near-tie screen when the chain holds a haplotype
+        that is rare in every sample (decided at the start of each gibbs_update call), 0 = never, 1 = always; same draws either way"""
+        check(self.lib.dsm_ctx_set_tau_neartie(self._h, int(mode)))
 
     def set_tau_screen(self, on):
         """A/B switch: False = every step of the tau sweep in fp64 (same draws except in ~1e-13 near-ties)"""

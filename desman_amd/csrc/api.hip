@@ -796,6 +796,7 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
     // entry state: ll, lp, storeStarState(0)  (HaploSNP_Sampler.py:336-338)
     TRY(eval_state(c, c->gamma, c->eta, c->tau_trace, 1));
     TRY(stats_place_ntab(c));                            // first call with this table: where its atomics cost least (kernels_stats.hip)
+    TRY(k_tau_neartie_hint(c));                          // which instantiation of the sweep this call runs (same draws either way)
     double *const P[2] = {c->prior, c->prior + (DSM_MAX_S + 4)};
     int nb_prev = 0;
     // the MT19937 words of the sweeps are generated on the side stream, chunks of sweeps ahead (never beyond the last sweep
@@ -803,6 +804,9 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
     SweepWords words(c, n_iter);
     TRY(words.prefetch());
     for (int it = 0; it < n_iter; ++it) {
+        // (the abundances move during a burn-in: the choice of the sweep's instantiation is looked at again now and then -- a stream
+        // synchronisation and a 4-byte read-back every 64 iterations; the draws do not depend on it)
+        if (it && (it & 63) == 0 && c->tau_neartie_mode == -1) TRY(k_tau_neartie_hint(c));
         const uint32_t ic = c->iter_ctr++;
         // sampleMu (:341): spec v2 = stage 1 here, stage 2 inside the Dirichlet launch; spec v1 = the per-read pass
         const bool agg = stats_spec(c) >= 2;
@@ -1209,6 +1213,13 @@ extern "C" int dsm_ctx_set_nmft_fused(dsm_ctx *c, int mode)
 
 // A/B switch for tests and measurements: with on = 0 every sweep step is evaluated in fp64 (the same draws except in near-ties:
 // the two modes evaluate the current base's log-probability along different FMA chains, a flip needs u within ~1e-13 of a CDF edge)
+extern "C" int dsm_ctx_set_tau_neartie(dsm_ctx *c, int mode)
+{
+    if (!c || mode < -1 || mode > 1) { dsm_set_error("set_tau_neartie: -1 (by the abundances), 0 or 1"); return DSM_ERR_ARG; }
+    c->tau_neartie_mode = mode;
+    return DSM_OK;
+}
+
 extern "C" int dsm_ctx_set_tau_screen(dsm_ctx *c, int on)
 {
     if (!c) { dsm_set_error("set_tau_screen: null context"); return DSM_ERR_ARG; }

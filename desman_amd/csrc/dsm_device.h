@@ -446,6 +446,124 @@ __device__ __forceinline__ bool sweep_screen32(const dsm_f2 (&pre32)[NSL][2], co
     return screen_certify<NSL>(c32, xtot, G, uw, best);
 }
 
+// ---- the screening pass of a NEAR-TIE step (round 4): the differences l_a - l_0 instead of the totals.
+// The spare haplotypes of a chain with more haplotypes than the table has strains end up at gamma_sg ~ 1e-3 in every sample (a real
+// `desman` chain at G = 12 on a six-strain table: six of them, scripts/dbg/chain_fp64.py): which base such a haplotype carries moves the
+// likelihood by a fraction of a nat, its step is a near-tie that no bound on the TOTALS can settle, half of the sweep's steps ran the
+// fp64 code: 675 us per sweep instead of 264.  This screen lives in a SECOND instantiation of the sweep kernel (tau_body: NT), chosen
+// per call from the chain's own abundances: inside the one kernel its mere presence cost the normal path 5 % (profiles/r04_neartie_ab.txt).  With R = the rest mixture (haplotypes h != g),
+//     l_a - l_0 = sum_{s,b} x_sb [log1p(r_ab) - log1p(r_0b)],      r_ab = e_ab gamma_sg / R_sb   (<~ 1e-2),
+// and log1p(r) = r - r^2/2 + r^3/3 - [0, r^4/4]: a cubic in fp32 where the cell's largest r is below 1/32, the hardware log2 of 1 + r
+// above (a base that no abundant haplotype carries has R ~ 0.01 and r ~ 0.1: few reads sit there, so the log's absolute error
+// (2^-22, pinned by tests/test_gpu_edges.py, + the rounding of 1 + r) costs little, while the cubic's r^4 would not be small);
+// D_a = sum x (f(r_ab) - f(r_0b)), together with a bound T >= sum x (r_max^4 / 4 or 3e-7, + 5e-6 r_max: at most G + 8 <= 40 roundings of 2^-24, twice over) on what any candidate's sum is
+// off by (truncation / the log; the fp32 roundings of R, of the quotient, of the cubic and of the accumulation; r_max from the column
+// maxima of eta, rounded up).  Every exp(l_a - max) the fp64 code forms
+// (sweep_draw) is then known to a relative 2 T + 2e-6, and its comparison u sum < C_k comes out the same way as long as
+// |u sum - C_k| > (8 T + 2e-5) sum for the three edges (twice the bound).  Returns true when this lane's group may take `tn` without
+// the fp64 evaluation; false -- an edge too close, T not small (a haplotype that is not rare in some sample), a mixture value outside
+// fp32's normal range, NaN -- leaves the step to the fp64 code as before.
+// s32 = the rest mixture [sample slot][base pair], gq = gamma_g of the slots, e2 = eta in fp32 as [a][base pair], emax2 = its column maxima.
+template <int LPV, int NSL>
+__device__ __forceinline__ bool sweep_neartie_core(const dsm_f2 (&s32)[NSL][2], const float (&xs)[NSL][4], const float (&gq)[NSL], uint32_t uw,
+                                                   const dsm_f2 *__restrict__ e2, const dsm_f2 *__restrict__ emax2, int &tn)
+{
+    typedef dsm_f2 f2;
+    const f2 third = (f2){0.33333334f, 0.33333334f}, half = (f2){0.5f, 0.5f}, one = (f2){1.0f, 1.0f};
+    f2 acc[4] = {(f2){0.0f, 0.0f}, (f2){0.0f, 0.0f}, (f2){0.0f, 0.0f}, (f2){0.0f, 0.0f}};
+    f2 tb = (f2){0.0f, 0.0f};
+    float smin = 1.0f;
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+#pragma unroll
+        for (int bp = 0; bp < 2; ++bp) {
+            const f2 R = s32[j][bp];
+            smin = fminf(smin, fminf(R.x, R.y));
+            const f2 q = (f2){gq[j] * __builtin_amdgcn_rcpf(R.x), gq[j] * __builtin_amdgcn_rcpf(R.y)};     // gamma / R
+            const f2 x2 = (f2){xs[j][2 * bp], xs[j][2 * bp + 1]};
+            const f2 rm = emax2[bp] * q;                                                                     // the largest r of this cell
+            const bool px = rm.x < 0.03125f, py = rm.y < 0.03125f;                                           // cubic or hardware log
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f2 r = e2[a * 2 + bp] * q;
+                f2 f = r * __builtin_elementwise_fma(r, __builtin_elementwise_fma(r, third, -half), one);         // r - r^2/2 + r^3/3
+                if (!px) f.x = __builtin_amdgcn_logf(1.0f + r.x) * 0.69314718f;
+                if (!py) f.y = __builtin_amdgcn_logf(1.0f + r.y) * 0.69314718f;
+                acc[a] = __builtin_elementwise_fma(x2, f, acc[a]);
+            }
+            const f2 rm2 = rm * rm;
+            f2 eb = rm2 * rm2 * (f2){0.25f, 0.25f};                                                          // per read: the cubic's truncation ...
+            eb.x = px ? eb.x : 3.0e-7f; eb.y = py ? eb.y : 3.0e-7f;                                          // ... or the log's absolute error
+            tb = __builtin_elementwise_fma(x2, __builtin_elementwise_fma(rm, (f2){5.0e-6f, 5.0e-6f}, eb), tb);
+        }
+    }
+    float d1 = (acc[1].x - acc[0].x) + (acc[1].y - acc[0].y), d2 = (acc[2].x - acc[0].x) + (acc[2].y - acc[0].y),
+          d3 = (acc[3].x - acc[0].x) + (acc[3].y - acc[0].y), T = tb.x + tb.y;
+    if (!(smin >= 1.0e-30f)) T = __builtin_nanf("");                // poisons the bound of the whole group
+    group_allreduce_sum4_f32<LPV>(d1, d2, d3, T);                     // natural units
+    const float m = fmaxf(fmaxf(0.0f, d1), fmaxf(d2, d3));
+    const float e0 = __builtin_amdgcn_exp2f((0.0f - m) * 1.44269504f), e1 = __builtin_amdgcn_exp2f((d1 - m) * 1.44269504f);
+    const float e2x = __builtin_amdgcn_exp2f((d2 - m) * 1.44269504f), e3 = __builtin_amdgcn_exp2f((d3 - m) * 1.44269504f);
+    const float c0 = e0, c1 = c0 + e1, c2 = c1 + e2x, sum = c2 + e3;
+    const float us = ((float)uw * 2.3283064365386963e-10f) * sum;
+    tn = (us < c0) ? 0 : (us < c1) ? 1 : (us < c2) ? 2 : 3;
+    const float margin = (8.08f * T + 2.0e-5f) * sum;                // (T itself is an fp32 sum: + 1 %)
+    const float gap = fminf(fminf(fabsf(us - c0), fabsf(us - c1)), fabsf(us - c2));
+    return (T < 1.0e-2f) && (gap > margin);                          // NaN fails both comparisons
+}
+
+// the rest mixture of step g in fp32: the carried prefix (links h < g) + the links h > g (what sweep_screen builds for itself)
+template <int LPV, int NSL>
+__device__ __forceinline__ void screen_chain(dsm_f2 (&s32)[NSL][2], uint64_t t, int g, int G, int lig, const float *__restrict__ gT32,
+                                             const float *__restrict__ eS32)
+{
+    constexpr int SP = LPV * NSL;
+    typedef dsm_f2 f2;
+#pragma unroll 4
+    for (int h = g + 1; h < G; ++h) {
+        const f2 *er = reinterpret_cast<const f2 *>(eS32 + (int)((t >> (2 * h)) & 3) * 4);
+        const f2 e01 = er[0], e23 = er[1];
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            const float gm = gT32[h * SP + lig + j * LPV];
+            const f2 gm2 = (f2){gm, gm};
+            s32[j][0] = __builtin_elementwise_fma(e01, gm2, s32[j][0]);
+            s32[j][1] = __builtin_elementwise_fma(e23, gm2, s32[j][1]);
+        }
+    }
+}
+template <int LPV, int NSL>
+__device__ __forceinline__ bool sweep_neartie(const double (&pre)[NSL][4], const int (&xi)[NSL][4], uint64_t t, int g, int G, int lig,
+                                              uint32_t uw, const float *__restrict__ gT32, const float *__restrict__ eS32, int &tn)
+{
+    dsm_f2 s32[NSL][2];
+    float xs[NSL][4], gf[NSL];
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+        gf[j] = gT32[g * (LPV * NSL) + lig + j * LPV];
+#pragma unroll
+        for (int bp = 0; bp < 2; ++bp) s32[j][bp] = (dsm_f2){(float)pre[j][2 * bp], (float)pre[j][2 * bp + 1]};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) xs[j][b] = (float)xi[j][b];
+    }
+    screen_chain<LPV, NSL>(s32, t, g, G, lig, gT32, eS32);
+    return sweep_neartie_core<LPV, NSL>(s32, xs, gf, uw, reinterpret_cast<const dsm_f2 *>(eS32), reinterpret_cast<const dsm_f2 *>(eS32 + 20), tn);
+}
+template <int LPV, int NSL>
+__device__ __forceinline__ bool sweep_neartie32(const dsm_f2 (&pre32)[NSL][2], const float (&xs)[NSL][4], uint64_t t, int g, int G, int lig,
+                                                uint32_t uw, const float *__restrict__ gT32, const float *__restrict__ eS32, int &tn)
+{
+    dsm_f2 s32[NSL][2];
+    float gf[NSL];
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+        gf[j] = gT32[g * (LPV * NSL) + lig + j * LPV];
+        s32[j][0] = pre32[j][0]; s32[j][1] = pre32[j][1];
+    }
+    screen_chain<LPV, NSL>(s32, t, g, G, lig, gT32, eS32);
+    return sweep_neartie_core<LPV, NSL>(s32, xs, gf, uw, reinterpret_cast<const dsm_f2 *>(eS32), reinterpret_cast<const dsm_f2 *>(eS32 + 20), tn);
+}
+
 template <typename T, int NV, int CNT, int OFF>
 __device__ __forceinline__ void transpose_reduce_step(T (&v)[NV], int lane)
 {

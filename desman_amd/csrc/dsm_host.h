@@ -134,6 +134,8 @@ struct dsm_ctx {
     uint32_t *step_cnt = nullptr;   // [2 slots][DSM_MAX_GRID][2] per-workgroup wavefront-steps of a tau launch: run / left to fp64
     uint32_t *screen_ctl = nullptr; // [4] [0] = sweeps still to run without the screening pass (set by finalize_body)
     bool tau_screen = true;         // dsm_ctx_set_tau_screen: the fp32 screening pass of the tau sweep may run
+    int tau_neartie_mode = -1;      // dsm_ctx_set_tau_neartie: -1 = by the chain's abundances at the start of each Gibbs call, 0 = never, 1 = always
+    bool tau_neartie_on = false;    // this call runs the sweep's instantiation with the near-tie screen (kernels_gibbs.hip: k_tau_neartie_hint)
     double *prior_all = nullptr;    // [n_iter][S + 4] priors of the stored states of updateTau
     double *prior = nullptr;        // [2][DSM_MAX_S + 4] per-row Dirichlet log-prior terms, by iteration parity
     double *scalars = nullptr;      // [8] misc device scalars
@@ -203,6 +205,7 @@ int stats_ntab_ld(int S);
 int stats_ntab_rep(const dsm_ctx *c);       // copies of the subset table the stage-1 atomics are spread over
 int stats_spec(const dsm_ctx *c);           // 2 / 3 = aggregated sampler (oracle/stats_agg.c), 4 = the same over tau patterns, 1 = per-read (orc_stats_counter)
 static inline int stats_draw_version(int spec) { return spec == 4 ? 2 : spec; }   // which version of the samplers (dsm_binom.h: SPEC) a specification draws with
+int k_tau_neartie_hint(dsm_ctx *c);
 int k_stats(dsm_ctx *c, uint32_t iter);
 int k_stats_stage1(dsm_ctx *c, uint32_t iter);
 int k_stats_stage2(dsm_ctx *c, uint32_t iter);

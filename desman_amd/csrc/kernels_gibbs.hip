@@ -674,7 +674,10 @@ struct TauParams {
 #define TAU_LEAN(LPV, NSL) ((LPV) >= 32 && ((NSL) == 3 || (NSL) == 6 || (NSL) == 8))
 #endif
 #endif
-template <int LPV, int NSL, bool SWEEP, bool LL>
+// NT: the instantiation with the near-tie screen (dsm_device.h: sweep_neartie_core) for chains that carry haplotypes rare in every
+// sample -- chosen per call by k_tau_sweep from the chain's own abundances (dsm_host.h: tau_neartie_on).  Both instantiations make the
+// draws of the fp64 code, so which one runs is a matter of speed only.
+template <int LPV, int NSL, bool SWEEP, bool LL, bool NT = false>
 __device__ __forceinline__ void tau_body(const TauParams &p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_t[];
@@ -695,20 +698,27 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
     int *redi = reinterpret_cast<int *>(red + 4);        // [4] (+4 pad)
     double2 *ltab = reinterpret_cast<double2 *>(red + 6);// [256] log table
     float *gT32 = reinterpret_cast<float *>(ltab + DSM_LOG_TAB_N);   // [G][SP] fp32 copies for the screening pass
-    float *eS32 = gT32 + (size_t)p.G * SP;               // [16] eta_sweep, [4] its column minima
+    float *eS32 = gT32 + (size_t)p.G * SP;               // [16] eta_sweep, [4] its column minima; NT: [4] its column maxima (rounded up)
+    uint32_t *gmaxb = reinterpret_cast<uint32_t *>(eS32 + 24);       // NT: [32] bits of max_s (float)gamma_sg (positive floats order like their bits)
     const int tid = threadIdx.x, G = p.G, S = p.S;
     if (tid < DSM_LOG_TAB_N) ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
+    if constexpr (NT) {
+        if (tid < 32) gmaxb[tid] = 0u;
+        __syncthreads();
+    }
     for (int i = tid; i < G * SP; i += 256) {
         const int g = i / SP, s = i % SP;
         const double x = (s < S) ? p.gamma[(size_t)s * G + g] : 1.0;   // pad: p > 0, count = 0
         gT[i] = x;
         if (SWEEP) gT32[i] = (float)x;
+        if constexpr (NT) { if (s < S && g < 32) atomicMax(&gmaxb[g], __float_as_uint((float)x)); }
     }
     if (tid < 16) { eS[tid] = p.eta_sweep[tid]; eL[tid] = p.eta_ll[tid]; if (SWEEP) eS32[tid] = (float)p.eta_sweep[tid]; }
     if (SWEEP && tid < 4) {
-        float m = (float)p.eta_sweep[tid];
-        for (int a = 1; a < 4; ++a) m = fminf(m, (float)p.eta_sweep[a * 4 + tid]);
+        float m = (float)p.eta_sweep[tid], mx = m;
+        for (int a = 1; a < 4; ++a) { m = fminf(m, (float)p.eta_sweep[a * 4 + tid]); mx = fmaxf(mx, (float)p.eta_sweep[a * 4 + tid]); }
         eS32[16 + tid] = m;
+        if constexpr (NT) eS32[20 + tid] = mx * 1.000001f;          // (it enters an error bound: sweep_neartie_core)
     }
     __syncthreads();
 
@@ -804,7 +814,22 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                 }
                 int tn = 0;
                 bool decided = false;
-                if (screen) {
+                // NT: a haplotype that is rare in every sample (max_s gamma_sg <= 0.01: the spare haplotypes of an over-fitted chain) makes
+                // near-ties, which the totals below cannot settle: its step is screened on the differences of the candidates first;
+                // what that leaves open is tried on the totals and then goes to the fp64 code like any other step.  Known per haplotype,
+                // wave-uniform.
+                bool rare = false;
+                if constexpr (NT) rare = screen && g < 32 && __builtin_amdgcn_readfirstlane(gmaxb[g]) <= 0x3C23D70Au;      // bits of 0.01f
+                if constexpr (NT) {
+                    if (rare) {
+                        int tf = 0;
+                        bool c2;
+                        if constexpr (LEAN) c2 = sweep_neartie32<LPV, NSL>(pre32, xs, t, g, G, lig, uw, gT32, eS32, tf);
+                        else c2 = sweep_neartie<LPV, NSL>(pre, xi, t, g, G, lig, uw, gT32, eS32, tf);
+                        if (__builtin_amdgcn_ballot_w64(c2) == __builtin_amdgcn_ballot_w64(true)) { tn = tf; decided = true; }
+                    }
+                }
+                if (screen && !decided) {
                     // ---- screening pass in fp32 (hardware log2): the four candidate log-probabilities to ~1e-6 relative.
                     // If the best one leads every other by more than 64 + 2^-13 |l| (natural units; the fp32 error is below
                     // 0.1 + 1e-6 |l|), the fp64 evaluation below would find exp(l_a - l_best) < e^-30 for the others, and its
@@ -1015,6 +1040,8 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
 #define TAU_MIN_WGS(LPV, NSL) (TAU_LEAN(LPV, NSL) ? ((NSL) == 2 ? 4 : (NSL) == 3 ? 3 : 2) : 1)
 template <int LPV, int NSL, bool SWEEP, bool LL>
 __global__ __launch_bounds__(256, TAU_MIN_WGS(LPV, NSL)) void tau_kernel(TauParams p) { tau_body<LPV, NSL, SWEEP, LL>(p); }
+template <int LPV, int NSL>
+__global__ __launch_bounds__(256, TAU_MIN_WGS(LPV, NSL)) void tau_kernel_nt(TauParams p) { tau_body<LPV, NSL, true, true, true>(p); }
 // K chains of one shape, chain = blockIdx.y (dsm_host.h: BatchCtl)
 template <int LPV, int NSL, bool SWEEP, bool LL>
 __global__ __launch_bounds__(256, TAU_MIN_WGS(LPV, NSL)) void tau_kernel_b(BatchArgs<TauParams> b) { tau_body<LPV, NSL, SWEEP, LL>(b.p[blockIdx.y]); }
@@ -1287,6 +1314,37 @@ int k_prior(dsm_ctx *c, const double *gamma, const double *eta, double *prior_ou
     return DSM_OK;
 }
 
+// how many haplotypes are rare in every sample (max_s gamma_sg <= 0.01): the chain then runs the sweep's NT instantiation for this call
+__global__ __launch_bounds__(256) void gamma_rare_kernel(const double *__restrict__ gamma, int S, int G, int *__restrict__ out)
+{
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += 256) {
+        double m = 0.0;
+        for (int s = 0; s < S; ++s) m = fmax(m, gamma[(size_t)s * G + g]);
+        if ((float)m <= 0.01f) atomicAdd(&cnt, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *out = cnt;
+}
+// called at the start of a Gibbs call (api.hip): decides which instantiation of the sweep the call runs.  -1 = by the abundances
+// (one tiny launch and a 4-byte read-back per call), 0 / 1 = forced (dsm_ctx_set_tau_neartie).  Never for a batch or a sharded chain.
+int k_tau_neartie_hint(dsm_ctx *c)
+{
+    c->tau_neartie_on = false;
+    if (c->tau_neartie_mode == 0 || g_batch.K || c->shard_on || !c->tau_screen || c->G < 2) return DSM_OK;
+    if (c->tau_neartie_mode == 1) { c->tau_neartie_on = true; return DSM_OK; }
+    int n = 0;
+    hipLaunchKernelGGL(gamma_rare_kernel, dim3(1), dim3(256), 0, c->stream, c->gamma, c->S, c->G, c->nchange + 1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&n, c->nchange + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemsetAsync(c->nchange + 1, 0, sizeof(int), c->stream));
+    c->tau_neartie_on = n > 0 && n < c->G;
+    return DSM_OK;
+}
+
 template <int LPV, int NSL>
 static void launch_tau(dsm_ctx *c, int mode, const TauParams &p, int grid, size_t sh)
 {
@@ -1298,7 +1356,8 @@ static void launch_tau(dsm_ctx *c, int mode, const TauParams &p, int grid, size_
             hipLaunchKernelGGL((tau_kernel_b<LPV, NSL, true, true>), dim3(g2, g_batch.K), dim3(256), sh, c->stream, acc);
         return;
     }
-    if (mode == 3) hipLaunchKernelGGL((tau_kernel<LPV, NSL, true, true>), dim3(g2), dim3(256), sh, c->stream, p);
+    if (mode == 3 && c->tau_neartie_on) hipLaunchKernelGGL((tau_kernel_nt<LPV, NSL>), dim3(g2), dim3(256), sh, c->stream, p);
+    else if (mode == 3) hipLaunchKernelGGL((tau_kernel<LPV, NSL, true, true>), dim3(g2), dim3(256), sh, c->stream, p);
     else if (mode == 1) hipLaunchKernelGGL((tau_kernel<LPV, NSL, true, false>), dim3(g2), dim3(256), sh, c->stream, p);
     else hipLaunchKernelGGL((tau_kernel<LPV, NSL, false, true>), dim3(g2), dim3(256), sh, c->stream, p);
 }
@@ -1327,7 +1386,7 @@ static int tau_shape(int S, int *lpv, int *nsl)
 static size_t tau_lds_bytes(int G, int LPV, int NSL)
 {
     return ((size_t)G * LPV * NSL + 16 + 16 + 6 + 2 * DSM_LOG_TAB_N) * sizeof(double) +
-           ((size_t)G * LPV * NSL + 20) * sizeof(float);                  // + fp32 copies of gamma / eta for the screening pass
+           ((size_t)G * LPV * NSL + 24 + 32) * sizeof(float);             // + fp32 copies of gamma / eta for the screening passes (+ the NT kernel's column maxima and per-haplotype maxima)
 }
 
 int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_sweep, const double *eta_ll,

@@ -124,6 +124,62 @@ def test_tau_sweep_of_an_overfitted_chain_vs_oracle(ctx, V, S, G, spare, kind):
         ctx.set_tau_screen(True)
 
 
+@pytest.mark.parametrize("V,S,G,spare,scale", [(3000, 64, 8, (2, 5, 7), 1e-3), (2000, 96, 12, (0, 3, 4, 8, 10, 11), 1e-3), (1500, 16, 5, (1, 4), 2e-3),
+                                               (600, 200, 6, (0, 5), 5e-4), (400, 300, 4, (2,), 1e-3), (800, 130, 7, (3, 6), 1e-2),
+                                               (1200, 40, 6, (0, 1, 2, 3), 1e-6), (900, 500, 3, (1,), 1e-3)])
+def test_gibbs_loop_with_the_neartie_sweep_is_the_same_chain(ctx, V, S, G, spare, scale):
+    """The Gibbs loop's sweep has a second instantiation with a screen on the DIFFERENCES of the candidates for the steps of haplotypes
+    that are rare in every sample (tau_kernel_nt; dsm_ctx_set_tau_neartie).  Forced on, forced off or chosen by the chain's abundances,
+    the chain is the same chain bit for bit -- haplotypes of every iteration, gamma / eta traces, ll / lp, MAP record -- and equals the
+    oracle's sweeps; and the screen does settle the near-ties (fewer steps left to fp64 than without it)."""
+    live = [g for g in range(G) if g not in spare]
+    counts, tau_true, gamma_true = synth_counts(V, S, max(len(live), 2), seed=V + G)
+    rng = np.random.default_rng(V + S)
+    # a settled over-fitted state: the live haplotypes carry the generating tau, the spare ones random bases at low abundance
+    tau_idx = rng.integers(0, 4, size=(V, G)).astype(np.uint8)
+    tau_idx[:, live] = tau_true[:, :len(live)]
+    tau = cbind.idx_to_onehot(tau_idx)
+    gamma = np.full((S, G), 0.0)
+    gamma[:, list(spare)] = rng.uniform(0.2 * scale, 2.0 * scale, size=(S, len(spare)))
+    gamma[:, live] = gamma_true[:, :len(live)] * (1.0 - gamma[:, list(spare)].sum(axis=1))[:, None] / gamma_true[:, :len(live)].sum(axis=1)[:, None]
+    gamma = np.ascontiguousarray(gamma / gamma.sum(axis=1)[:, None])
+    eta = 0.96 * np.eye(4) + 0.01
+    n_it = 5
+    runs = {}
+    for mode in (0, 1, -1):
+        _load(ctx, counts, tau, gamma, eta, mt_seed=4711)
+        ctx.seed(4711, ctr_seed=0xFEEDFACE)
+        ctx.force_stats_spec(2)
+        ctx.set_tau_neartie(mode)
+        ctx.sweep_stats(reset=True)
+        try:
+            ctx.gibbs_update(n_it)
+        finally:
+            ctx.set_tau_neartie(-1)
+            ctx.force_stats_spec(0)
+        tr = ctx.get_trace()
+        runs[mode] = dict(tr=tr, taus=[ctx.get_tau_at(i) for i in range(n_it)], star=ctx.get_star(), stats=ctx.sweep_stats())
+    for mode in (1, -1):
+        for k in ("gamma", "eta", "ll", "lp", "nchange"):
+            assert np.array_equal(runs[0]["tr"][k], runs[mode]["tr"][k]), (mode, k)
+        assert all(np.array_equal(a, b) for a, b in zip(runs[0]["taus"], runs[mode]["taus"]))
+        assert runs[0]["star"]["lp"] == runs[mode]["star"]["lp"] and np.array_equal(runs[0]["star"]["tau"], runs[mode]["star"]["tau"])
+    # every sweep of the loop against the oracle, on the GSL stream: tau_it from (tau_{it-1}, gamma_it, eta_{it-1})
+    mt = cbind.MT19937(4711)
+    ref, eta_prev = tau.copy(), eta
+    for it in range(n_it):
+        cbind.sample_tau_u(ref, np.ascontiguousarray(runs[1]["tr"]["gamma"][it]), np.ascontiguousarray(eta_prev), counts, mt.uniform(V * G))
+        assert np.array_equal(runs[1]["taus"][it], ref), it
+        eta_prev = runs[1]["tr"]["eta"][it]
+    (st0, ex0), (st1, ex1) = runs[0]["stats"], runs[1]["stats"]
+    assert st0 == st1 > 0
+    assert ex1 <= ex0 + 0.01 * st1, (ex0, ex1, st1)               # never worse than the totals alone ...
+    if S >= 40 and len(live) > 1 and scale <= 2e-3:
+        assert ex1 < 0.5 * ex0 + 0.02 * st1, (ex0, ex1, st1)      # ... and the near-ties no longer go to fp64
+    if scale <= 2e-3:
+        assert runs[-1]["stats"] == runs[1]["stats"]              # the abundances of such a state switch it on by themselves
+
+
 def test_tau_sweep_zero_counts_and_deep_counts(ctx):
     V, S, G = 40, 16, 3
     counts, _, _ = synth_counts(V, S, G, seed=3)

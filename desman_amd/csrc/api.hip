@@ -850,6 +850,7 @@ int comm_device(const dsm_comm *m);
 static int gibbs_update_sharded(dsm_ctx *c, int n_iter, int v_offset, int v_total, dsm_exchange_fn exchange, void *user, dsm_comm *comm)
 {
     TRY(need(c, true, true));
+    c->tau_neartie_on = false;                           // (a sharded chain runs the sweep's plain instantiation)
     if (n_iter < 0 || (!exchange && !comm) || v_offset < 0 || v_total < v_offset + c->V) { dsm_set_error("gibbs_update_sharded: bad arguments"); return DSM_ERR_ARG; }
     if (comm && comm_device(comm) != c->device) { dsm_set_error("gibbs_update_sharded: the communicator lives on device %d, the context on %d", comm_device(comm), c->device); return DSM_ERR_ARG; }
     if (c->tau_rng != DSM_RNG_PHILOX) { dsm_set_error("gibbs_update_sharded: needs counter-based tau uniforms (DSM_RNG_PHILOX)"); return DSM_ERR_STATE; }

@@ -674,6 +674,9 @@ struct TauParams {
 #define TAU_LEAN(LPV, NSL) ((LPV) >= 32 && ((NSL) == 3 || (NSL) == 6 || (NSL) == 8))
 #endif
 #endif
+#ifndef DSM_NT_RARE
+#define DSM_NT_RARE 0.01f     /* a haplotype whose abundance is at most this in every sample is "rare": its steps take the near-tie screen first */
+#endif
 // NT: the instantiation with the near-tie screen (dsm_device.h: sweep_neartie_core) for chains that carry haplotypes rare in every
 // sample -- chosen per call by k_tau_sweep from the chain's own abundances (dsm_host.h: tau_neartie_on).  Both instantiations make the
 // draws of the fp64 code, so which one runs is a matter of speed only.
@@ -819,7 +822,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                 // what that leaves open is tried on the totals and then goes to the fp64 code like any other step.  Known per haplotype,
                 // wave-uniform.
                 bool rare = false;
-                if constexpr (NT) rare = screen && g < 32 && __builtin_amdgcn_readfirstlane(gmaxb[g]) <= 0x3C23D70Au;      // bits of 0.01f
+                if constexpr (NT) rare = screen && g < 32 && __builtin_amdgcn_readfirstlane(gmaxb[g]) <= __builtin_bit_cast(uint32_t, (float)DSM_NT_RARE);
                 if constexpr (NT) {
                     if (rare) {
                         int tf = 0;
@@ -1323,7 +1326,7 @@ __global__ __launch_bounds__(256) void gamma_rare_kernel(const double *__restric
     for (int g = threadIdx.x; g < G; g += 256) {
         double m = 0.0;
         for (int s = 0; s < S; ++s) m = fmax(m, gamma[(size_t)s * G + g]);
-        if ((float)m <= 0.01f) atomicAdd(&cnt, 1);
+        if ((float)m <= (float)DSM_NT_RARE) atomicAdd(&cnt, 1);
     }
     __syncthreads();
     if (threadIdx.x == 0) *out = cnt;

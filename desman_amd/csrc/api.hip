@@ -222,6 +222,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     free_traces(c);
     dev_free(&c->cnt_vs); dev_free(&c->items); dev_free(&c->nitems); dev_free(&c->tau);
     dev_free(&c->pat_rep); dev_free(&c->pat_x); dev_free(&c->pat_list); c->pat_rep_len = c->pat_x_len = 0;
+    if (c->h_rare) { (void)hipHostFree(c->h_rare); c->h_rare = nullptr; }
     dev_free(&c->blk_tab); dev_free(&c->ntab_raw); c->ntab = nullptr; dev_free(&c->big_list); dev_free(&c->big_count);
     dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
@@ -406,6 +407,7 @@ extern "C" int dsm_ctx_set_state(dsm_ctx *c, const int64_t *tau, const double *g
     HIP_TRY(hipMemcpyAsync(d_t, tau, nt * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     TRY(k_pack_tau(c, d_t, c->tau, c->V, G));
     HIP_TRY(hipMemcpyAsync(c->gamma, gamma, (size_t)c->S * G * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->tau_rare_n = tau_rare_from_host(gamma, c->S, G);
     HIP_TRY(hipMemcpyAsync(c->eta, eta, 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_state = true;
@@ -417,6 +419,7 @@ extern "C" int dsm_ctx_set_gamma_eta(dsm_ctx *c, const double *gamma, const doub
     TRY(need(c, true, true));
     BIND(c);
     if (gamma) HIP_TRY(hipMemcpyAsync(c->gamma, gamma, (size_t)c->S * c->G * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (gamma) c->tau_rare_n = tau_rare_from_host(gamma, c->S, c->G);
     if (eta) HIP_TRY(hipMemcpyAsync(c->eta, eta, 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DSM_OK;
@@ -806,7 +809,7 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
     for (int it = 0; it < n_iter; ++it) {
         // (the abundances move during a burn-in: the choice of the sweep's instantiation is looked at again now and then -- a stream
         // synchronisation and a 4-byte read-back every 64 iterations; the draws do not depend on it)
-        if (it && (it & 63) == 0 && c->tau_neartie_mode == -1) TRY(k_tau_neartie_hint(c));
+        if (it && (it & 63) == 0 && c->tau_neartie_mode == -1) { TRY(k_tau_rare_count(c, true)); TRY(k_tau_neartie_hint(c)); }
         const uint32_t ic = c->iter_ctr++;
         // sampleMu (:341): spec v2 = stage 1 here, stage 2 inside the Dirichlet launch; spec v1 = the per-read pass
         const bool agg = stats_spec(c) >= 2;
@@ -827,7 +830,9 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
     if (n_iter > 0)
         TRY(k_finalize(c, nb_prev, n_iter - 1, 0, P[(n_iter - 1) & 1], c->gamma_trace + (size_t)(n_iter - 1) * sg,
                        c->eta_trace + (size_t)(n_iter - 1) * 16));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n_iter > 0 && c->tau_neartie_mode == -1) TRY(k_tau_rare_count(c, false));      // what the next call will go by: rides on this call's own
+    HIP_TRY(hipStreamSynchronize(c->stream));                                            // synchronisation
+    if (n_iter > 0 && c->tau_neartie_mode == -1 && c->h_rare) c->tau_rare_n = *c->h_rare;
     return DSM_OK;
 }
 

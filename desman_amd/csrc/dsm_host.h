@@ -136,6 +136,9 @@ struct dsm_ctx {
     bool tau_screen = true;         // dsm_ctx_set_tau_screen: the fp32 screening pass of the tau sweep may run
     int tau_neartie_mode = -1;      // dsm_ctx_set_tau_neartie: -1 = by the chain's abundances at the start of each Gibbs call, 0 = never, 1 = always
     bool tau_neartie_on = false;    // this call runs the sweep's instantiation with the near-tie screen (kernels_gibbs.hip: k_tau_neartie_hint)
+    int tau_rare_n = 0;             // haplotypes at or below DSM_NT_RARE in every sample, as last known: from the host's gamma (set_state /
+                                    // set_gamma_eta), from the device's at the end of a Gibbs call and every 64 iterations inside one
+    int *h_rare = nullptr;          // pinned word the count is read back into (no synchronisation of its own at the end of a call)
     double *prior_all = nullptr;    // [n_iter][S + 4] priors of the stored states of updateTau
     double *prior = nullptr;        // [2][DSM_MAX_S + 4] per-row Dirichlet log-prior terms, by iteration parity
     double *scalars = nullptr;      // [8] misc device scalars
@@ -206,6 +209,8 @@ int stats_ntab_rep(const dsm_ctx *c);       // copies of the subset table the st
 int stats_spec(const dsm_ctx *c);           // 2 / 3 = aggregated sampler (oracle/stats_agg.c), 4 = the same over tau patterns, 1 = per-read (orc_stats_counter)
 static inline int stats_draw_version(int spec) { return spec == 4 ? 2 : spec; }   // which version of the samplers (dsm_binom.h: SPEC) a specification draws with
 int k_tau_neartie_hint(dsm_ctx *c);
+int k_tau_rare_count(dsm_ctx *c, bool wait);         // enqueue the count of rare haplotypes of the resident gamma -> *h_rare (wait: and take it)
+int tau_rare_from_host(const double *gamma, int S, int G);
 int k_stats(dsm_ctx *c, uint32_t iter);
 int k_stats_stage1(dsm_ctx *c, uint32_t iter);
 int k_stats_stage2(dsm_ctx *c, uint32_t iter);

@@ -1331,20 +1331,35 @@ __global__ __launch_bounds__(256) void gamma_rare_kernel(const double *__restric
     __syncthreads();
     if (threadIdx.x == 0) *out = cnt;
 }
-// called at the start of a Gibbs call (api.hip): decides which instantiation of the sweep the call runs.  -1 = by the abundances
-// (one tiny launch and a 4-byte read-back per call), 0 / 1 = forced (dsm_ctx_set_tau_neartie).  Never for a batch or a sharded chain.
+// Which instantiation of the sweep a Gibbs call runs: -1 = by the abundances as last known (dsm_host.h: tau_rare_n -- no device work
+// here), 0 / 1 = forced (dsm_ctx_set_tau_neartie).  Never for a batch or a sharded chain.
 int k_tau_neartie_hint(dsm_ctx *c)
 {
     c->tau_neartie_on = false;
     if (c->tau_neartie_mode == 0 || g_batch.K || c->shard_on || !c->tau_screen || c->G < 2) return DSM_OK;
-    if (c->tau_neartie_mode == 1) { c->tau_neartie_on = true; return DSM_OK; }
+    c->tau_neartie_on = c->tau_neartie_mode == 1 || (c->tau_rare_n > 0 && c->tau_rare_n < c->G);
+    return DSM_OK;
+}
+int tau_rare_from_host(const double *gamma, int S, int G)
+{
     int n = 0;
+    for (int g = 0; g < G; ++g) {
+        double m = 0.0;
+        for (int s = 0; s < S; ++s) m = std::max(m, gamma[(size_t)s * G + g]);
+        n += (float)m <= (float)DSM_NT_RARE;
+    }
+    return n;
+}
+// the same count from the resident gamma, read back into pinned memory: enqueued before a synchronisation the caller makes anyway
+// (end of a Gibbs call), or with one of its own (wait: every 64 iterations inside a call)
+int k_tau_rare_count(dsm_ctx *c, bool wait)
+{
+    if (!c->h_rare) HIP_TRY(hipHostMalloc((void **)&c->h_rare, sizeof(int), hipHostMallocDefault));
     hipLaunchKernelGGL(gamma_rare_kernel, dim3(1), dim3(256), 0, c->stream, c->gamma, c->S, c->G, c->nchange + 1);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&n, c->nchange + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_rare, c->nchange + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemsetAsync(c->nchange + 1, 0, sizeof(int), c->stream));
-    c->tau_neartie_on = n > 0 && n < c->G;
+    if (wait) { HIP_TRY(hipStreamSynchronize(c->stream)); c->tau_rare_n = *c->h_rare; }
     return DSM_OK;
 }
 

@@ -311,7 +311,7 @@ int dsm_ctx_set_tau_screen(dsm_ctx *ctx, int on);
 /* the tau sweep of dsm_ctx_gibbs_update has a second instantiation with one more screen, for the steps of haplotypes that are rare in
    every sample (max_s gamma_sg <= 0.01: the spare haplotypes of a chain with more haplotypes than the table has strains -- their steps
    are near-ties that only the DIFFERENCES of the candidates can settle short of fp64).  mode -1 (default): a call runs it while the
-   chain's abundances hold such a haplotype (looked at when the call starts and every 64 iterations); 0 = never; 1 = always.  The draws are those of the fp64 code
+   chain's abundances hold such a haplotype (as set by dsm_ctx_set_state / left by the previous call, and looked at every 64 iterations); 0 = never; 1 = always.  The draws are those of the fp64 code
    either way (tests/test_gpu_parity.py); not used for batches and sharded chains. */
 int dsm_ctx_set_tau_neartie(dsm_ctx *ctx, int mode);
 /* workgroups one tau sweep of the resident shape launches, and how many of them the device holds at once (occupancy of the

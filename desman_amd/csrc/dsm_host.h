@@ -86,6 +86,7 @@ struct dsm_ctx {
     uint32_t *pat_list = nullptr;            // [4^G] the representatives of this pass, in no particular order, then [2] their number (by pass parity)
     size_t pat_rep_len = 0, pat_x_len = 0;
     uint32_t pat_gen = 0;
+    uint32_t *s2_scratch = nullptr; // stage 2 as its own launch with a sample's root level shared by several workgroups (kernels_stats.hip: k_stats_stage2)
     uint32_t *ntab_raw = nullptr;   // the allocation `ntab` points into (kernels_stats.hip: ensure_ntab places the table inside it)
     uint32_t *ntab_base = nullptr;  // first place the table can start at (4 KB aligned)
     size_t ntab_off = 0;            // where past ntab_base the table starts (stats_place_ntab)

@@ -32,6 +32,8 @@ struct Stage2Params {
     uint32_t k0, k1, iter;
     uint32_t hmul;                  // row of subset H in ntab: (H * hmul) mod 2^G (kernels_stats.hip: stats_ntab_hmul)
     uint32_t *big_count;            // work-list counter of stage 1: consumed by now, reset here for the next pass (or null)
+    int nsplit;                     // workgroups that share a sample's root level (stand-alone kernel, G >= 11), else 1
+    uint32_t *scratch, *ticket;     // [S][S2_TAB_ENTRIES] level-1 tables handed over, [S] arrival counters; zero between passes
 };                                  // the plan of the halving tree (a function of G) travels beside it: one per launch
 
 S2Plan make_stage2_plan(int G);     // kernels_stats.hip
@@ -41,7 +43,7 @@ S2Plan make_stage2_plan(int G);     // kernels_stats.hip
 // leaf counts end in LDS (returned pointer, [G] u32, valid after the function's final barrier); to_global also adds
 // them to p.sum_mu[s][.]
 template <int SPEC>
-__device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, const S2Plan &pl, int s, char *smem, bool to_global)
+__device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, const S2Plan &pl, int s, char *smem, bool to_global, int part = 0)
 {
     const int G = p.G, tid = threadIdx.x, nthr = blockDim.x;      // 256 (fused form) or 1024 (many subsets)
     double2 *ltab = reinterpret_cast<double2 *>(smem);                         // [256] log table, then [64] exp table
@@ -53,7 +55,8 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
     int *n_lo = reinterpret_cast<int *>(leaf + 32);                            // the plan's node arrays (lane-indexed below)
     int *n_hi = n_lo + S2_MAX_NODES, *n_off = n_hi + S2_MAX_NODES, *n_idx = n_off + S2_MAX_NODES, *n_child = n_idx + S2_MAX_NODES;
 
-    if (s == 0 && tid < DSM_BIG_NT * DSM_BIG_NL && p.big_count) p.big_count[tid * DSM_BIG_STRIDE] = 0u;
+    const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
+    if (s == 0 && part == 0 && tid < DSM_BIG_NT * DSM_BIG_NL && p.big_count) p.big_count[tid * DSM_BIG_STRIDE] = 0u;
     if (tid < DSM_LOG_TAB_N) ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
     if (tid < DSM_EXP_TAB_N) etab[tid] = p.log_tab[2 * DSM_LOG_TAB_N + tid];
     for (int k = tid; k < DSM_RCP_TAB_N; k += nthr) rcp[k] = k ? 1.0 / (double)k : 0.0;
@@ -71,7 +74,10 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
         const int n0 = pl.level_start[level], n1 = pl.level_start[level + 1];
         const int base = pl.off[n0];
         const int total = (level == 0) ? (1 << G) : (pl.off[n1 - 1] + (1 << (pl.hi[n1 - 1] - pl.lo[n1 - 1]))) - base;
-        for (int j = tid; j < total; j += nthr) {
+        // (the root level of a sample that several workgroups share: this one's contiguous share of the subsets)
+        const int share = (level == 0 && nsplit > 1) ? (total + nsplit - 1) / nsplit : total;
+        const int j_lo = (level == 0 && nsplit > 1) ? part * share : 0, j_hi = (level == 0 && nsplit > 1) ? min(total, j_lo + share) : total;
+        for (int j = j_lo + tid; j < j_hi; j += nthr) {
             int i = n0;
             for (int k = n0 + 1; k < n1; ++k) if (j + base >= pl.off[k]) i = k;      // scalar plan, <= 16 nodes per level
             const int lo = n_lo[i], hi = n_hi[i], w = hi - lo;
@@ -122,6 +128,26 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
             if (n - k) atomicAdd(&R[HR], n - k);
         }
         __syncthreads();
+        if (level == 0 && nsplit > 1) {
+            // hand the level-1 tables over: device-scope atomics onto the sample's scratch rows (they execute at the memory side, so
+            // the reader below sees every one of them), then a ticket; whoever draws the last ticket owns the rest of the tree
+            const int l1 = pl.level_start[1], l2 = pl.level_start[2];
+            const int b1 = pl.off[l1], n1 = (pl.off[l2 - 1] + (1 << (pl.hi[l2 - 1] - pl.lo[l2 - 1]))) - b1;
+            uint32_t *row = p.scratch + (size_t)s * S2_TAB_ENTRIES;
+            // (the adds RETURN their old value: a thread passes the barrier below only when its adds have been performed, so the
+            // ticket -- issued after the barrier -- is ordered behind every add of this workgroup without a cache-flushing fence)
+            uint32_t sink = 0;
+            for (int i = tid; i < n1; i += nthr) { const uint32_t v = tab[b1 + i]; if (v) sink += atomicAdd(&row[i], v); }
+            asm volatile("" :: "v"(sink));
+            __syncthreads();
+            __shared__ int last_wg;
+            if (tid == 0) last_wg = (atomicAdd(&p.ticket[s], 1u) == (uint32_t)(nsplit - 1)) ? 1 : 0;
+            __syncthreads();
+            if (!last_wg) return leaf;                         // (callers of the split form use nothing of the returned tables)
+            for (int i = tid; i < n1; i += nthr) tab[b1 + i] = atomicExch(&row[i], 0u);      // read at the memory side, left zero for the next pass
+            if (tid == 0) p.ticket[s] = 0u;
+            __syncthreads();
+        }
     }
     return leaf;
 }

@@ -457,7 +457,7 @@ template <int SPEC>
 __global__ __launch_bounds__(1024) void stats_stage2_kernel(Stage2Params p, S2Plan plan)
 {
     __shared__ __attribute__((aligned(16))) char smem2[S2_SMEM_BYTES];
-    stage2_sample<SPEC>(p, plan, blockIdx.x, smem2, true);
+    stage2_sample<SPEC>(p, plan, (int)blockIdx.x / p.nsplit, smem2, true, (int)blockIdx.x % p.nsplit);
 }
 template <int SPEC>
 __global__ __launch_bounds__(1024) void stats_stage2_kernel_b(Stage2Batch b)
@@ -930,10 +930,24 @@ int k_stats_stage2(dsm_ctx *c, uint32_t iter)
     p.big_count = c->big_count;
     // 2^G subsets per sample at the root: 256 threads up to G = 9, 1024 above
     const int nthr = c->G >= 10 ? 1024 : 256;
-    const bool v3 = stats_spec(c) >= 3;
+    const bool v3 = stats_draw_version(stats_spec(c)) >= 3;          // (spec 4 draws with version 2's samplers)
+    // many subsets per sample (G >= 11): the root level -- one large-count binomial per subset that straddles the halves, 2^G / 1024 of
+    // them per thread one after the other -- is dealt over `nsplit` workgroups per sample; the last one to finish takes the level-1
+    // tables the others left in `s2_scratch` and runs the lower levels (dsm_stage2.h).  Same draws: a binomial's stream is keyed by
+    // (subset, sample, node, level), the tables are integer sums.
+    p.nsplit = 1; p.scratch = nullptr; p.ticket = nullptr;
+    if (g_batch.K == 0 && c->G >= 11) {
+        if (!c->s2_scratch) {
+            hipError_t e = hipMalloc((void **)&c->s2_scratch, ((size_t)DSM_MAX_S * (S2_TAB_ENTRIES + 1)) * sizeof(uint32_t));
+            if (e != hipSuccess) { dsm_set_error("hipMalloc failed: %s", hipGetErrorString(e)); return DSM_ERR_NOMEM; }
+            HIP_TRY(hipMemsetAsync(c->s2_scratch, 0, ((size_t)DSM_MAX_S * (S2_TAB_ENTRIES + 1)) * sizeof(uint32_t), c->stream));
+        }
+        p.nsplit = c->G >= 12 ? 4 : 2;
+        p.scratch = c->s2_scratch; p.ticket = c->s2_scratch + (size_t)DSM_MAX_S * S2_TAB_ENTRIES;
+    }
     if (g_batch.K == 0) {
-        if (v3) hipLaunchKernelGGL(stats_stage2_kernel<3>, dim3(c->S), dim3(nthr), 0, c->stream, p, make_stage2_plan(c->G));
-        else hipLaunchKernelGGL(stats_stage2_kernel<2>, dim3(c->S), dim3(nthr), 0, c->stream, p, make_stage2_plan(c->G));
+        if (v3) hipLaunchKernelGGL(stats_stage2_kernel<3>, dim3(c->S * p.nsplit), dim3(nthr), 0, c->stream, p, make_stage2_plan(c->G));
+        else hipLaunchKernelGGL(stats_stage2_kernel<2>, dim3(c->S * p.nsplit), dim3(nthr), 0, c->stream, p, make_stage2_plan(c->G));
     } else {
         static thread_local Stage2Batch acc;
         acc.p[g_batch.k] = p;

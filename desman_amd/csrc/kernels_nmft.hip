@@ -893,6 +893,74 @@ __device__ __forceinline__ double row16_transpose_reduce(double (&v)[16], int n)
     return v[0];
 }
 
+// ---- tau numerators on the matrix cores (round 4) --------------------------------------------------------------------------
+// num[i][g] = sum_s Q'[i][s] gamma_raw[g][s] contracts over SAMPLES, which the L2 layout keeps in the low four lane bits -- where
+// the instruction wants a free index.  Rounds 2-3 therefore ran it on the VALU (16 FMAs per tile and K-block on per-lane LDS
+// operands, then a 15-add / 30-DPP transposing butterfly per K-block: a quarter of the update kernel's VALU instructions at
+// S = 96, G = 12).  Now a tile of Q' (16 rows x 16 samples) crosses the wavefront's own 2.3 KB of LDS once -- written in L2 (four
+// conflict-free 512 B row groups), read back as A[i = lane % 16][k = lane / 16] = Q'[i][4 k + j], j = 0..3 (two 16 B reads) -- and
+// meets B_j[k][g] = gamma_raw[g][16 t + 4 k + j] in four MFMAs per tile.  D[i][g] returns on lane g + 16 vv, element e (i = 4 e +
+// vv): the four bases of a (variant, haplotype) pair end in ONE lane, so the renormalisation over bases needs no exchange at all.
+// Columns g >= G of D are never read; their lanes supply any in-range operand.
+#define NM_XS 18                      // row stride of the transposition tile in doubles (16 + 2: the 16 B reads of a row group spread over the banks)
+#define NM_XQ (16 * NM_XS)            // doubles per wavefront
+
+// gamma operands in LDS: ONE zero-padded matrix [GP][LDG = SPAD + 1] per factor serves both contractions that read it -- the odd row
+// stride puts the 4 rows x 16 samples of an R-operand fetch and the 16 rows x 4 samples of a numerator-operand fetch on every bank
+// exactly four times (512 B each: the minimum) -- where rounds 2-3 kept a plain copy and two fragment-ordered copies (a third of the
+// kernel's LDS at S = 96, G = 12: two workgroups per CU; now three).
+__device__ __forceinline__ void nm_stage_gamma_p(double *graw_p, double *ggam_p, const double *__restrict__ graw, const double *__restrict__ ggam,
+                                                 int GP, int LDG, int G, int S, int tid, int nthr)
+{
+    for (int i = tid; i < GP * LDG; i += nthr) {
+        const int g = i / LDG, sidx = i - g * LDG;
+        const bool in = g < G && sidx < S;
+        graw_p[i] = in ? graw[(size_t)g * S + sidx] : 0.0;
+        ggam_p[i] = in ? ggam[(size_t)g * S + sidx] : 0.0;
+    }
+}
+
+// one tile: qv = Q' of tile t in L2 -> num += Q'_t . gamma_raw_t^T; graw_t = graw_p + 16 t
+template <int KB>
+__device__ __forceinline__ double4_t nm_num_tile(double4_t num, const double4_t &qv, double *xq, const double *graw_t, int LDG, int n, int q)
+{
+    constexpr int GP = 4 * KB;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xq[(4 * e + q) * NM_XS + n] = qv[e];
+    __builtin_amdgcn_wave_barrier();
+    const double2 lo = *reinterpret_cast<const double2 *>(xq + n * NM_XS + 4 * q);
+    const double2 hi = *reinterpret_cast<const double2 *>(xq + n * NM_XS + 4 * q + 2);
+    __builtin_amdgcn_wave_barrier();
+    const double *bl = graw_t + (n < GP ? n : GP - 1) * LDG + 4 * q;          // B_j[k = q][g = n] = gamma_raw[g][16 t + 4 k + j]
+    num = __builtin_amdgcn_mfma_f64_16x16x4f64(lo.x, bl[0], num, 0, 0, 0);
+    num = __builtin_amdgcn_mfma_f64_16x16x4f64(lo.y, bl[1], num, 0, 0, 0);
+    num = __builtin_amdgcn_mfma_f64_16x16x4f64(hi.x, bl[2], num, 0, 0, 0);
+    num = __builtin_amdgcn_mfma_f64_16x16x4f64(hi.y, bl[3], num, 0, 0, 0);
+    return num;
+}
+
+// the tau rows of the quad from their numerators (Init_NMFT.py:171-181, :88-91): lane (g = n, vv = q) holds the four bases
+template <int KB, bool TO_GLOBAL>
+__device__ __forceinline__ void nm_tau_finish(const double4_t &num, const double *told, double *tnew, const double *t1, int G, int n, int q,
+                                              int adjust, bool vok, double *tau_v /* tau + (v0 + q) * 4 * G, or null */)
+{
+    constexpr int GP = 4 * KB;
+    const bool okg = n < G;
+    double tn[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tn[e] = okg ? told[(4 * e + q) * GP + n] * fdiv(nzd(num[e]), nzd(t1[okg ? n : 0])) : 0.0;   // :171-172
+    const double tot = ((tn[0] + tn[1]) + tn[2]) + tn[3];                                                                  // :176-178
+    if (okg) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            double x = fdiv(tn[e], tot);                                                                                   // :180-181
+            if (adjust && x < DSM_EPS) x = DSM_EPS;                                                                        // :88-91
+            if (TO_GLOBAL && vok) tau_v[(size_t)e * G + n] = x;
+            tnew[(4 * e + q) * GP + n] = vok ? x : 0.0;
+        }
+    }
+}
+
 struct NmftMfmaParams {
     const double *F; double *tau; const double *gam_raw, *gam;
     int V, S, G, adjust, do_update;
@@ -911,31 +979,21 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
     const int nblk = gridDim.x;
     double2 *ltab = reinterpret_cast<double2 *>(smem_m);                        // [256]
-    double *gr = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);              // [GP][SPAD] gamma_raw (product operands)
-    double *braw = gr + GP * SPAD;                                              // [NT][KB][64] B fragments of gamma_raw
-    double *bgam = braw + NT * KB * 64;                                         // [NT][KB][64] B fragments of gamma
-    double *t1 = bgam + NT * KB * 64;                                           // [GP] rowsum(gamma_raw)
+    constexpr int LDG = SPAD + 1;
+    double *graw_p = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);          // [GP][LDG] gamma_raw, zero-padded (nm_stage_gamma_p)
+    double *ggam_p = graw_p + GP * LDG;                                         // [GP][LDG] gamma
+    double *t1 = ggam_p + GP * LDG;                                             // [GP] rowsum(gamma_raw)
     double *told = t1 + GP + wv * (2 * 16 * GP);                                // per wavefront [16][GP], row i = 4 r + vv
     double *tnew = told + 16 * GP;                                              // per wavefront [16][GP]
+    double *xq = t1 + GP + 4 * (2 * 16 * GP) + wv * NM_XQ;                      // per wavefront [16][NM_XS] transposition tile of Q'
     double *red = reinterpret_cast<double *>(smem_m);                           // [4][GP + 2][SPAD] end-of-kernel reduction: takes the place
                                                                                 // of everything above once the quads are done (at S = 96, G = 12 its
                                                                                 // 43 KB on top of the rest made 87 KB = ONE workgroup per CU)
     ltab[tid] = reinterpret_cast<const double2 *>(log_tab)[tid];
-    for (int i = tid; i < GP * SPAD; i += 256) {
-        const int g = i / SPAD, s = i % SPAD;
-        gr[i] = (g < G && s < S) ? gam_raw[(size_t)g * S + s] : 0.0;
-    }
-    for (int i = tid; i < NT * KB * 64; i += 256) {
-        const int l = i & 63, kb = (i >> 6) % KB, t = (i >> 6) / KB;
-        const int g = 4 * kb + (l >> 4), s = 16 * t + (l & 15);
-        const bool in = g < G && s < S;
-        braw[i] = in ? gam_raw[(size_t)g * S + s] : 0.0;
-        bgam[i] = in ? gam[(size_t)g * S + s] : 0.0;
-    }
-    __syncthreads();
+    nm_stage_gamma_p(graw_p, ggam_p, gam_raw, gam, GP, LDG, G, S, tid, 256);
     for (int g = wv; g < GP; g += 4) {                                          // gamma.sum(1) (:170), lane-parallel
         double a = 0.0;
-        for (int s = lane; s < SPAD; s += 64) a += gr[g * SPAD + s];
+        for (int s = lane; s < SPAD; s += 64) a += (g < G && s < S) ? gam_raw[(size_t)g * S + s] : 0.0;
         a = group_allreduce_sum<64>(a);
         if (lane == 0) t1[g] = a;
     }
@@ -946,8 +1004,6 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
     double obj = 0.0, h1 = 0.0;
-    const bool b0 = n & 1, b1 = n & 2, b2 = n & 4, b3 = n & 8;
-    const int my_e = (b0 ? 2 : 0) + (b1 ? 1 : 0), my_gg = (b3 ? 2 : 0) + (b2 ? 1 : 0);
 
     const int nquad = (V + 3) >> 2;
     for (int qd = blockIdx.x * 4 + wv; qd < nquad; qd += nblk * 4) {
@@ -980,44 +1036,19 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
             double a_old[KB];
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) a_old[kb] = told[n * GP + 4 * kb + q];
-            double4_t qp[NT];
+            double4_t num = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_old[kb], braw[(t * KB + kb) * 64 + lane], R, 0, 0, 0);
+                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_old[kb], graw_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
                 const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
+                double4_t qv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qp[t][e] = fdiv(ft[e], nzd(R[e]));          // nm_tile_q2: F > 0; lanes without a cell stay finite
+                for (int e = 0; e < 4; ++e) qv[e] = fdiv(ft[e], nzd(R[e]));             // nm_tile_q2: F > 0; lanes without a cell stay finite
+                num = nm_num_tile<KB>(num, qv, xq, graw_p + 16 * t, LDG, n, q);
             }
-#pragma unroll
-            for (int c = 0; c < KB; ++c) {
-                double p[16];                                                   // value index j = 4 e + gg
-#pragma unroll
-                for (int j = 0; j < 16; ++j) p[j] = 0.0;
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) {
-                        const double gm = gr[(4 * c + gg) * SPAD + 16 * t + n];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) p[4 * e + gg] = fma(qp[t][e], gm, p[4 * e + gg]);
-                    }
-                const double tot_rg = row16_transpose_reduce(p, n);             // num[(my_e, vv = q)][g]
-                const int g = 4 * c + my_gg;
-                const bool ok = g < G;
-                double tn = 0.0;
-                if (ok) tn = told[(4 * my_e + q) * GP + g] * fdiv(nzd(tot_rg), nzd(t1[g]));       // :171-172
-                const double t_a0 = dpp_mov<0x00>(tn), t_a1 = dpp_mov<0xAA>(tn);              // e = 0 / 1 live in quad lanes 0 / 2
-                const double t_a2 = dpp_mov<0x55>(tn), t_a3 = dpp_mov<0xFF>(tn);              // e = 2 / 3            quad lanes 1 / 3
-                const double tot = ((t_a0 + t_a1) + t_a2) + t_a3;                              // :176-178
-                if (ok) {
-                    double x = fdiv(tn, tot);                                                      // :180-181
-                    if (adjust && x < DSM_EPS) x = DSM_EPS;                                    // :88-91
-                    if (vok) tau[((size_t)(v0 + q) * 4 + my_e) * G + g] = x;
-                    tnew[(4 * my_e + q) * GP + g] = vok ? x : 0.0;
-                }
-            }
+            nm_tau_finish<KB, true>(num, told, tnew, t1, G, n, q, adjust, vok, tau + (size_t)(v0 + q) * 4 * G);
             __builtin_amdgcn_wave_barrier();
         }
         // statistics of the (new) state: R2, objective, Q2, gamma numerators, H1
@@ -1031,7 +1062,7 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
         for (int t = 0; t < NT; ++t) {
             double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_new[kb], bgam[(t * KB + kb) * 64 + lane], R, 0, 0, 0);
+            for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_new[kb], ggam_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
             double4_t q2;
             const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
             q2 = nm_tile_q2(ft, R, live[t], ltab, obj);
@@ -1077,6 +1108,7 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
     }
 }
 
+constexpr int nmft_mfma_wgs(int NT, int KB) { return NT <= 4 ? (KB <= 3 ? 4 : 3) : (KB <= 3 ? 3 : 2); }
 static bool mfma_shape(const dsm_ctx *c, int *nt, int *kb)
 {
     *nt = (c->S + 15) / 16;
@@ -1097,20 +1129,23 @@ int nmft_mfma_grid(const dsm_ctx *c)
     int nt, kb, cus = 256;
     (void)mfma_shape(c, &nt, &kb);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) cus = 256;
-    const int cap = (nt <= 4 ? 3 : 2) * cus;
+    const int cap = nmft_mfma_wgs(nt, kb) * cus;
     if (g > cap) g = cap;
     return g < 1 ? 1 : g;
 }
 static size_t mfma_lds_bytes(int NT, int KB)
 {
     const size_t GP = 4 * KB, SPAD = 16 * NT;
-    const size_t loop = 2 * DSM_LOG_TAB_N + GP * SPAD + 2 * (size_t)NT * KB * 64 + GP + 4 * 2 * 16 * GP, red = 4 * (GP + 2) * SPAD;
+    const size_t loop = 2 * DSM_LOG_TAB_N + 2 * GP * (SPAD + 1) + GP + 4 * 2 * 16 * GP + 4 * NM_XQ, red = 4 * (GP + 2) * SPAD;
     return std::max(loop, red) * sizeof(double);
 }
+// workgroups per CU the register allocation leaves room for (round 4, with the numerators on the matrix cores -- no qp[NT], no
+// butterfly -- and one padded gamma matrix per factor in LDS): four up to four sample tiles (three at sixteen haplotypes), three from
+// five tiles on (two at sixteen haplotypes: LDS)
 template <int NT, int KB, bool KEEPF>
-__global__ __launch_bounds__(256, (NT <= 4 ? 3 : 2)) void nmft_mfma_kernel(NmftMfmaParams q) { nmft_mfma_body<NT, KB, KEEPF>(q); }
+__global__ __launch_bounds__(256, nmft_mfma_wgs(NT, KB)) void nmft_mfma_kernel(NmftMfmaParams q) { nmft_mfma_body<NT, KB, KEEPF>(q); }
 template <int NT, int KB, bool KEEPF>
-__global__ __launch_bounds__(256, (NT <= 4 ? 3 : 2)) void nmft_mfma_kernel_b(BatchArgs<NmftMfmaParams> b)
+__global__ __launch_bounds__(256, nmft_mfma_wgs(NT, KB)) void nmft_mfma_kernel_b(BatchArgs<NmftMfmaParams> b)
 {
     nmft_mfma_body<NT, KB, KEEPF>(b.p[blockIdx.y]);
 }
@@ -1503,13 +1538,16 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
     const int nwg = gridDim.x, wg = blockIdx.x;
     const int nout = G * S + G + 1;
     double2 *ltab = reinterpret_cast<double2 *>(smem_p);                        // [256]
-    double *gr = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);              // [GP][SPAD] gamma_raw (product operands)
-    double *braw = gr + GP * SPAD;                                              // [NT][KB][64] B fragments of gamma_raw
-    double *bgam = braw + NT * KB * 64;                                         // [NT][KB][64] B fragments of gamma
-    double *t1 = bgam + NT * KB * 64;                                           // [GP] rowsum(gamma_raw)
+    constexpr int LDG = SPAD + 1;
+    double *graw_p = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);          // [GP][LDG] gamma_raw, zero-padded (nm_stage_gamma_p)
+    double *ggam_p = graw_p + GP * LDG;                                         // [GP][LDG] gamma
+    double *t1 = ggam_p + GP * LDG;                                             // [GP] rowsum(gamma_raw)
     double *tl = t1 + GP;                                                       // per wavefront [2][16][GP]: tau rows, old and new
-    double *red = tl + NW * (2 * 16 * GP);                                      // [NW][GP + 2][SPAD] cross-wavefront reduction, also scratch
-    double *stat = red + NW * (GP + 2) * SPAD;                                  // [nout] the reduced statistics
+    constexpr int REDW = ((GP + 2) * SPAD > NM_XQ) ? (GP + 2) * SPAD : NM_XQ;   // doubles per wavefront of the region below
+    double *red = tl + NW * (2 * 16 * GP);                                      // [NW][GP + 2][SPAD] cross-wavefront reduction, also scratch; in the
+                                                                                // tau half (nothing of it is live then) wavefront w's transposition
+                                                                                // tile of Q' (nm_num_tile) sits at red + w * NM_XQ
+    double *stat = red + NW * REDW;                                             // [nout] the reduced statistics
     double *gm = stat + ((nout + 1) & ~1);                                      // [G][S] gamma after _adjustment
     double *grw = gm + G * S;                                                   // [G][S] normalised gamma before _adjustment
     int *ok_s = reinterpret_cast<int *>(grw + G * S);                           // [1] verdict of a barrier for the whole workgroup
@@ -1528,8 +1566,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
             tnew[(4 * r + vv) * GP + g] = (v0 + vv < V) ? prm.tau[(size_t)v0 * 4 * G + k] : 0.0;
         }
     }
-    const bool b0 = n & 1, b1 = n & 2, b2 = n & 4, b3 = n & 8;
-    const int my_e = (b0 ? 2 : 0) + (b1 ? 1 : 0), my_gg = (b3 ? 2 : 0) + (b2 ? 1 : 0);
+    double *xq = red + wv * NM_XQ;
     bool live[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) live[t] = vok && (16 * t + n < S);
@@ -1546,21 +1583,10 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
     }
     // MFMA operands of the current gamma: gr / braw from grw, bgam from gm, t1 = rowsum(grw)
     auto stage_gamma = [&]() {
-        for (int i = tid; i < GP * SPAD; i += NTHR) {
-            const int g = i / SPAD, s = i % SPAD;
-            gr[i] = (g < G && s < S) ? grw[g * S + s] : 0.0;
-        }
-        for (int i = tid; i < NT * KB * 64; i += NTHR) {
-            const int l = i & 63, kb = (i >> 6) % KB, t = (i >> 6) / KB;
-            const int g = 4 * kb + (l >> 4), s = 16 * t + (l & 15);
-            const bool in = g < G && s < S;
-            braw[i] = in ? grw[g * S + s] : 0.0;
-            bgam[i] = in ? gm[g * S + s] : 0.0;
-        }
-        __syncthreads();
+        nm_stage_gamma_p(graw_p, ggam_p, grw, gm, GP, LDG, G, S, tid, NTHR);
         for (int g = wv; g < GP; g += NW) {                                     // gamma.sum(1) (:170), lane-parallel
             double a = 0.0;
-            for (int s = lane; s < SPAD; s += 64) a += gr[g * SPAD + s];
+            for (int s = lane; s < SPAD; s += 64) a += (g < G && s < S) ? grw[g * S + s] : 0.0;
             a = group_allreduce_sum<64>(a);
             if (lane == 0) t1[g] = a;
         }
@@ -1592,7 +1618,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
             for (int t = 0; t < NT; ++t) {
                 double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_new[kb], bgam[(t * KB + kb) * 64 + lane], R, 0, 0, 0);
+                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_new[kb], ggam_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
                 double4_t q2;
                 const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
                 q2 = nm_tile_q2(ft, R, live[t], ltab, obj);
@@ -1708,43 +1734,19 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
             double a_old[KB];
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) a_old[kb] = told[n * GP + 4 * kb + q];
-            double4_t qp[NT];
+            double4_t num = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_old[kb], braw[(t * KB + kb) * 64 + lane], R, 0, 0, 0);
+                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_old[kb], graw_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
                 const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
+                double4_t qv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qp[t][e] = fdiv(ft[e], nzd(R[e]));          // nm_tile_q2: F > 0; lanes without a cell stay finite
+                for (int e = 0; e < 4; ++e) qv[e] = fdiv(ft[e], nzd(R[e]));             // nm_tile_q2: F > 0; lanes without a cell stay finite
+                num = nm_num_tile<KB>(num, qv, xq, graw_p + 16 * t, LDG, n, q);
             }
-#pragma unroll
-            for (int c = 0; c < KB; ++c) {
-                double p[16];                                                   // value index j = 4 e + gg
-#pragma unroll
-                for (int j = 0; j < 16; ++j) p[j] = 0.0;
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) {
-                        const double gmv = gr[(4 * c + gg) * SPAD + 16 * t + n];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) p[4 * e + gg] = fma(qp[t][e], gmv, p[4 * e + gg]);
-                    }
-                const double tot_rg = row16_transpose_reduce(p, n);             // num[(my_e, vv = q)][g]
-                const int g = 4 * c + my_gg;
-                const bool ok = g < G;
-                double tn = 0.0;
-                if (ok) tn = told[(4 * my_e + q) * GP + g] * fdiv(nzd(tot_rg), nzd(t1[g]));       // :171-172
-                const double t_a0 = dpp_mov<0x00>(tn), t_a1 = dpp_mov<0xAA>(tn);
-                const double t_a2 = dpp_mov<0x55>(tn), t_a3 = dpp_mov<0xFF>(tn);
-                const double tot = ((t_a0 + t_a1) + t_a2) + t_a3;                              // :176-178
-                if (ok) {
-                    double x = fdiv(tn, tot);                                                      // :180-181
-                    if (adjust && x < DSM_EPS) x = DSM_EPS;                                    // :88-91
-                    tnew[(4 * my_e + q) * GP + g] = vok ? x : 0.0;
-                }
-            }
+            nm_tau_finish<KB, false>(num, told, tnew, t1, G, n, q, adjust, vok, nullptr);
             __builtin_amdgcn_wave_barrier();
         }
         NM_STAMP(8);
@@ -1816,8 +1818,8 @@ int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, i
     if (grid < 2 || grid > cus) return DSM_OK;              // (neither form holds more than one workgroup per CU worth of table: no buffers
                                                             //  are allocated for tables that cannot take this path)
     const int GP = 4 * kb, SPAD = 16 * nt;
-    const size_t sh = (2 * DSM_LOG_TAB_N + (size_t)GP * SPAD + 2 * (size_t)nt * kb * 64 + GP + (size_t)nwv * 2 * 16 * GP +
-                       (size_t)nwv * (GP + 2) * SPAD + ((nout + 1) & ~1) + 2 * (size_t)G * S + 2) * sizeof(double);
+    const size_t sh = (2 * DSM_LOG_TAB_N + 2 * (size_t)GP * (SPAD + 1) + GP + (size_t)nwv * 2 * 16 * GP +
+                       (size_t)nwv * std::max<size_t>((size_t)(GP + 2) * SPAD, NM_XQ) + ((nout + 1) & ~1) + 2 * (size_t)G * S + 2) * sizeof(double);
     if (sh > 160 * 1024) return DSM_OK;
     // exchange buffers + barrier words (zeroed before every launch)
     // ... + a copy of the factors as they are now: should the launch not come to an end (a barrier timed out: its workgroups

@@ -1108,7 +1108,13 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
     }
 }
 
-constexpr int nmft_mfma_wgs(int NT, int KB) { return NT <= 4 ? (KB <= 3 ? 4 : 3) : (KB <= 3 ? 3 : 2); }
+constexpr int nmft_mfma_wgs(int NT, int KB)
+{
+    // ((3, 2) and (4, 3) need 129 registers: at four wavefronts per SIMD they would spill one -- and a kernel with scratch pays its
+    // first launch ~120 us for the allocation)
+    return NT <= 4 ? ((KB <= 3 && !(NT == 3 && KB == 2) && !(NT == 4 && KB == 3)) ? 4 : 3) : (KB <= 3 ? 3 : 2);
+}
+
 static bool mfma_shape(const dsm_ctx *c, int *nt, int *kb)
 {
     *nt = (c->S + 15) / 16;
@@ -1788,7 +1794,7 @@ static PersistGate g_persist_gate[16];
 template <int NT, int KB, int NWV>
 static int launch_persist(dsm_ctx *c, const NmftPersistParams &q, int grid, size_t sh, int *fits)
 {
-    auto fn = nmft_persist_kernel<NT, KB, (NT <= 2), NWV>;    // F kept in registers up to 32 samples (three tiles spill at 3 wavefronts per SIMD)
+    auto fn = nmft_persist_kernel<NT, KB, true, NWV>;          // F stays in registers for the whole loop (round 4: the tau numerators on the matrix cores freed the registers; before, three tiles spilled at 3 wavefronts per SIMD and F was re-read from L2 twice per update)
     int occ = 0, cus = 0;
     HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64 * NWV, sh));

@@ -17,7 +17,7 @@ pats = sys.argv[1:] or [r"^(void )?tau_kernel<(32|64), (2|3|4|6|8), true, true>"
                         r"^(void )?stats_stage2_kernel<2>"]
 rows = []
 with tempfile.TemporaryDirectory() as d:
-    for o in sorted(glob.glob(os.path.join(ROOT, "desman_amd", "lib", "obj", "*.o"))):
+    for o in sorted(glob.glob(os.path.join(ROOT, "desman_amd", "lib", os.environ.get("DSM_OBJDIR", "obj"), "*.o"))):
         t = os.path.join(d, os.path.basename(o))
         shutil.copy(o, t)
         subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", t], capture_output=True)

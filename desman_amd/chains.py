@@ -30,7 +30,8 @@ def chain_cost(V, S, G, n_iter=None, nmf_updates=5000):
       one Gibbs iteration   38 + kc (0.0477 + 0.0063 G)  [+ 18 + 1.2e-4 2^G S from G = 10: stage 2 of the mu/E pass as its own launch]
                             -- 0.513 / 0.691 ms at G = 8 / 12 there, 0.105 ms at config 3; less where the mu/E pass runs over tau words
                             (large tables, 4 x 4^G <= V: a measured coefficient per G, below)
-      one NMF update        12 + kc (0.0125 + 0.00306 ceil(G / 4))   -- 84 / 100 / 116 us at G <= 4 / <= 8 / <= 12 (K-blocks of four haplotypes)
+      one NMF update        12 + kc (0.0129 + 0.00229 ceil(G / 4))   -- 85 / 96 / 107 us at G <= 4 / <= 8 / <= 12 (K-blocks of four haplotypes;
+                            refitted after the tau numerators moved to the matrix cores: 84 / 100 / 116 before), 23 us at config 3
       host work per chain   0.2 s + 1.3 us per (position, haplotype): the result files (Output_Results)
     and a chain runs 2 n_iter iterations (burn-in + sampling, bin/desman:212-232) after up to 5000 NMF updates (Init_NMFT.py:98-115:
     the 1e-5 stop rarely fires).  n_iter = None: the cost of ONE iteration (chains of equal length compared).  Round 3's 6 + G had the
@@ -48,7 +49,7 @@ def chain_cost(V, S, G, n_iter=None, nmf_updates=5000):
         gibbs += 18.0 + 1.2e-4 * float(1 << min(int(G), 30)) * float(S)
     if n_iter is None:
         return gibbs
-    nmf = 12.0 + kc * (0.0125 + 0.00306 * float((int(G) + 3) // 4))
+    nmf = 12.0 + kc * (0.0129 + 0.00229 * float((int(G) + 3) // 4))
     host = 0.2e6 + 1.3 * float(V) * float(G)
     return 2.0 * float(n_iter) * gibbs + float(nmf_updates) * nmf + host
 

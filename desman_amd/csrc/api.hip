@@ -1364,10 +1364,11 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     double *ctl = c->nstat + (size_t)G * S + 2 * G;
     Scratch<double> d_trace;
     TRY(d_trace.alloc((size_t)max_iter + 1));
-    struct TraceGuard { dsm_ctx *c; ~TraceGuard() { c->ndiv_trace = nullptr; } } trace_guard{c};
+    struct TraceGuard { dsm_ctx *c; ~TraceGuard() { c->ndiv_trace = nullptr; c->nmft_fix_gamma = 0; } } trace_guard{c};
     HIP_TRY(hipMemsetAsync(ctl, 0, 16 * sizeof(double), c->stream));
     const int adjust = fix_gamma ? 0 : 1;
     c->ndiv_trace = d_trace;
+    c->nmft_fix_gamma = fix_gamma ? 1 : 0;               // the update kernels leave out what only a gamma update reads (kernels_nmft.hip)
     // factorize applies _adjustment once before the first objective (Init_NMFT.py:102)
     if (adjust) TRY(k_nmft_clamp(c));
     const int BATCH = 64;
@@ -1474,7 +1475,7 @@ extern "C" int dsm_batch_nmft_factorize(dsm_ctx *const *ctxs, int K, int max_ite
         g_batch = BatchCtl{};
         for (int k = 0; k < K; ++k) {
             ctxs[k]->stream = saved[k].st; ctxs[k]->timing = saved[k].timing; ctxs[k]->nmft_fused = saved[k].fused;
-            ctxs[k]->ndiv_trace = nullptr;
+            ctxs[k]->ndiv_trace = nullptr; ctxs[k]->nmft_fix_gamma = 0;
         }
     };
 #define BTRY(expr) do { int _r = (expr); if (_r != DSM_OK) { (void)hipStreamSynchronize(lead->stream); restore(); return _r; } } while (0)
@@ -1485,6 +1486,7 @@ extern "C" int dsm_batch_nmft_factorize(dsm_ctx *const *ctxs, int K, int max_ite
         dsm_ctx *c = ctxs[k];
         BTRY(traces[k].alloc((size_t)max_iter + 1));
         c->ndiv_trace = traces[k];
+        c->nmft_fix_gamma = fix_gamma ? 1 : 0;
         BHIP(hipMemsetAsync(ctl_of(c), 0, 16 * sizeof(double), c->stream));
         if (adjust) BTRY(k_nmft_clamp(c));
     }

@@ -176,6 +176,7 @@ struct dsm_ctx {
     double *np_part = nullptr;      // its exchange buffers: partials [nout][workgroups] + totals [nout]
     size_t np_cap = 0;
     unsigned *np_bar = nullptr;     // its barrier words
+    int nmft_fix_gamma = 0;         // set for the duration of a factorize_tau loop (api.hip: dsm_nmft_factorize): the update kernels then leave out the gamma numerators
     int nmft_fused = -1;            // reduce + gamma/control of an update as one launch: -1 = by size (<= 128 partials), 0 = never, 1 = always
     // timing
     bool timing = false;

@@ -251,6 +251,32 @@ __device__ __forceinline__ void nmft_gamma_body(const NmftGammaParams &q)
 __global__ __launch_bounds__(1024) void nmft_gamma_kernel(NmftGammaParams q) { nmft_gamma_body(q); }
 __global__ __launch_bounds__(1024) void nmft_gamma_kernel_b(BatchArgs<NmftGammaParams> b) { nmft_gamma_body(b.p[blockIdx.y]); }
 
+// gamma fixed (factorize_tau, and the stand-alone objective): of the statistics only the objective is wanted, so the reduction of
+// the partials and the control step are ONE launch of one wavefront -- the objective's partials summed as every reduction of this
+// file sums them (nmft_sum_partials), then the stop test of nmft_gamma_body.  An update is then two launches, not three.
+struct NmftObjCtlParams { const double *partial; int nblk, nout, max_iter; double min_change; double *stat, *ctl, *div_trace; };
+__device__ __forceinline__ void nmft_objctl_body(const NmftObjCtlParams &q)
+{
+    double *__restrict__ ctl = q.ctl;
+    if (ctl[2] != 0.0) return;
+    const int lane = threadIdx.x & 63;
+    const double div = nmft_sum_partials(q.partial + (size_t)(q.nout - 1) * q.nblk, q.nblk, lane);
+    if (lane == 0) {
+        q.stat[q.nout - 1] = div;
+        const int it = (int)ctl[6];
+        ctl[6] = (double)(it + 1);
+        const double prev = (it == 0) ? 0.0 : ctl[4 + ((it - 1) & 1)];
+        const bool go = (it < q.max_iter) && (fabs(prev - div) > q.min_change);     // Init_NMFT.py:140
+        ctl[0] = div;
+        ctl[4 + (it & 1)] = div;
+        ctl[3] = (double)it;
+        if (!go) ctl[2] = 1.0;
+        if (q.div_trace) q.div_trace[it] = div;
+    }
+}
+__global__ __launch_bounds__(64) void nmft_objctl_kernel(NmftObjCtlParams q) { nmft_objctl_body(q); }
+__global__ __launch_bounds__(64) void nmft_objctl_kernel_b(BatchArgs<NmftObjCtlParams> b) { nmft_objctl_body(b.p[blockIdx.y]); }
+
 // ---------------------------------------------------------------------------
 // reduce + gamma / control in ONE launch of NMFT_RG_WGS workgroups (an update is then two dependent launches, not three).
 // Workgroup b owns the sample columns [b cw, (b+1) cw): it sums the workgroup partials of the statistics it needs -- its
@@ -285,7 +311,7 @@ __device__ __forceinline__ void nmft_rg_body(const NmftRgParams &q)
     const int nwg = (int)gridDim.x, cw = (S + nwg - 1) / nwg, s_lo = (int)blockIdx.x * cw;
     const int ncol = s_lo < S ? (S - s_lo < cw ? S - s_lo : cw) : 0;
     const int nown = G * ncol, nneed = nown + G + 1;
-    for (int i = wv; i < nneed; i += 16) {
+    for (int i = (q.fix_gamma ? nown + G : 0) + wv; i < nneed; i += 16) {            // (gamma fixed: the objective alone)
         // statistic number `out` of the update kernels' partial table: numerator (g, s) = g S + s, row sum g = G S + g,
         // objective = G S + G
         int out;
@@ -679,8 +705,17 @@ int k_nmft_gamma(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int
     // launch (config 3: 34 us per update; fused, with one workgroup per sample column, 35).
     // dsm_ctx_set_nmft_fused overrides the size rule per context (tests assert that the two forms agree bit for bit).
     const bool fuse = c->nmft_fused < 0 ? c->npart_cols <= 128 : c->nmft_fused != 0;
+    if (fix_gamma && !fuse) {
+        // gamma fixed: the objective's reduction and the control step as one launch of one wavefront (nmft_objctl_kernel)
+        const NmftObjCtlParams q{c->npart, c->npart_cols, nout, max_iter, min_change, c->nstat, NMFT_CTL(c), c->ndiv_trace};
+        LAUNCH_OR_COLLECT(NmftObjCtlParams, q,
+                          hipLaunchKernelGGL(nmft_objctl_kernel, dim3(1), dim3(64), 0, c->stream, q),
+                          hipLaunchKernelGGL(nmft_objctl_kernel_b, dim3(1, K), dim3(64), 0, c->stream, acc));
+        HIP_TRY(hipGetLastError());
+        return DSM_OK;
+    }
     if (fuse) {
-        const int nwg = std::min(c->S, 32);
+        const int nwg = fix_gamma ? 1 : std::min(c->S, 32);       // (gamma fixed: every workgroup would sum the same objective)
         const int cw = (c->S + nwg - 1) / nwg;
         const size_t sh = ((size_t)c->nG * cw + c->nG + 1 + 1024) * sizeof(double);
         const NmftRgParams q{c->npart, c->npart_cols, c->nstat, c->S, c->nG, max_iter, min_change, fix_gamma, adjust, parity,
@@ -965,6 +1000,9 @@ struct NmftMfmaParams {
     const double *F; double *tau; const double *gam_raw, *gam;
     int V, S, G, adjust, do_update;
     const double *ctl, *log_tab; double *partial;
+    int fix_gamma;      // factorize_tau (Init_NMFT.py:134-149; the `-r` path, bin/desman:181-206): gamma stays as it is, so only the objective
+                        // of the statistics is wanted -- no gamma numerators (24 of a quad's 84 MFMAs at six tiles), no row sums, one partial
+                        // per workgroup instead of G S + G + 1
 };
 template <int NT, int KB, bool KEEPF>
 __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
@@ -973,6 +1011,7 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
     double *__restrict__ tau = prm.tau, *__restrict__ partial = prm.partial;
     const double *__restrict__ ctl = prm.ctl, *__restrict__ log_tab = prm.log_tab;
     const int V = prm.V, S = prm.S, G = prm.G, adjust = prm.adjust, do_update = prm.do_update;
+    const bool gnum = prm.fix_gamma == 0;                                       // the gamma numerators and row sums are wanted
     extern __shared__ __attribute__((aligned(16))) char smem_m[];
     if (ctl[2] != 0.0) return;
     constexpr int GP = 4 * KB, SPAD = 16 * NT;
@@ -1057,7 +1096,7 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
         for (int kb = 0; kb < KB; ++kb) a_new[kb] = tnew[n * GP + 4 * kb + q];
         double a_g[4];                                                          // A of the row contraction: tau_new[vv = q][e][g = n]
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { a_g[e] = (n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; h1 += a_g[e]; }
+        for (int e = 0; e < 4; ++e) { a_g[e] = (gnum && n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; h1 += a_g[e]; }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -1066,20 +1105,24 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
             double4_t q2;
             const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
             q2 = nm_tile_q2(ft, R, live[t], ltab, obj);
+            if (gnum) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
     // workgroup reduction over the 4 wavefronts (fixed order) -> transposed partials.  acc[t][e]: g = 4 e + q, s = 16 t + n
     __syncthreads();
+    if (gnum) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int g = 4 * e + q;
-            if (g < GP) red[((size_t)wv * (GP + 2) + g) * SPAD + 16 * t + n] = acc[t][e];
-        }
+            for (int e = 0; e < 4; ++e) {
+                const int g = 4 * e + q;
+                if (g < GP) red[((size_t)wv * (GP + 2) + g) * SPAD + 16 * t + n] = acc[t][e];
+            }
+    }
     // objective: one value per lane; H1: lane (n = g, q) holds the sum over bases and this lane's variants of tau_new[.][g]
     {
         const double o = group_allreduce_sum<64>(obj);
@@ -1090,13 +1133,13 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
         if (lane < GP) red[((size_t)wv * (GP + 2) + GP + 1) * SPAD + lane] = hh;
     }
     __syncthreads();
-    for (int i = tid; i < G * S; i += 256) {
+    for (int i = tid; gnum && i < G * S; i += 256) {
         const int g = i / S, s = i % S;
         double a = 0.0;
         for (int k = 0; k < 4; ++k) a += red[((size_t)k * (GP + 2) + g) * SPAD + s];
         partial[(size_t)i * nblk + blockIdx.x] = a;
     }
-    if (tid < G) {
+    if (gnum && tid < G) {
         double a = 0.0;
         for (int k = 0; k < 4; ++k) a += red[((size_t)k * (GP + 2) + GP + 1) * SPAD + tid];
         partial[((size_t)G * S + tid) * nblk + blockIdx.x] = a;
@@ -1160,7 +1203,7 @@ template <int NT, int KB>
 static void launch_mfma(dsm_ctx *c, int adjust, int do_update, int grid)
 {
     const size_t sh = mfma_lds_bytes(NT, KB);
-    const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart};
+    const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart, c->nmft_fix_gamma};
     LAUNCH_OR_COLLECT(NmftMfmaParams, q,
                       hipLaunchKernelGGL((nmft_mfma_kernel<NT, KB, (NT <= 3 || NT == 5 || NT == 6)>), dim3(grid), dim3(256), sh, c->stream, q),
                       hipLaunchKernelGGL((nmft_mfma_kernel_b<NT, KB, (NT <= 3 || NT == 5 || NT == 6)>), dim3(grid, K), dim3(256), sh, c->stream, acc));
@@ -1423,7 +1466,7 @@ static int launch_wide(dsm_ctx *c, int adjust, int do_update, int grid)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&nmft_wide_kernel<NT, KB, NCB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart};
+    const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart, c->nmft_fix_gamma};
     hipLaunchKernelGGL((nmft_wide_kernel<NT, KB, NCB>), dim3(grid), dim3(64 * (8 / NCB) * NCB), sh, c->stream, q);
     return DSM_OK;
 }
@@ -1613,13 +1656,14 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
         double obj = 0.0, h1 = 0.0;
+        const bool gnum = prm.fix_gamma == 0;                                   // gamma fixed (factorize_tau): the objective alone
         if (have) {
             double a_new[KB];
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) a_new[kb] = tnew[n * GP + 4 * kb + q];
             double a_g[4];                                                      // A of the row contraction: tau_new[vv = q][e][g = n]
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { a_g[e] = (n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; h1 += a_g[e]; }
+            for (int e = 0; e < 4; ++e) { a_g[e] = (gnum && n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; h1 += a_g[e]; }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -1628,8 +1672,10 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
                 double4_t q2;
                 const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
                 q2 = nm_tile_q2(ft, R, live[t], ltab, obj);
+                if (gnum) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
+                }
             }
         }
         NM_STAMP(1);
@@ -1641,6 +1687,54 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
         hh += __shfl_xor(hh, 16, 64);
         hh += __shfl_xor(hh, 32, 64);
         __syncthreads();
+        double div;
+        if (!gnum) {
+            // gamma fixed: ONE value crosses the machine per update -- the workgroup's objective (the same triple sum of its wavefronts'
+            // parts as below), published in the row of this update's parity (a workgroup that is through the barrier may publish its
+            // next value while a slower one still reads this update's: two rows, the barrier keeps them at most one update apart);
+            // ONE barrier; then every workgroup sums the row for itself exactly as the reduction below sums statistic G S + G --
+            // the same bits everywhere, the same bits as the three-launch path.  No second barrier, no read-back of 521 totals.
+            if (lane == 0) red[((size_t)wv * (GP + 2) + GP) * SPAD] = o_w;
+            __syncthreads();
+            double *const orow = prm.partial + (size_t)(it & 1) * nwg;
+            if (tid == 0) {
+                double x[NW / 4];
+#pragma unroll
+                for (int r = 0; r < NW / 4; ++r) {
+                    double a = 0.0;
+                    for (int k = 0; k < 4; ++k) a += red[((size_t)(4 * r + k) * (GP + 2) + GP) * SPAD];
+                    x[r] = a;
+                }
+                double ps = x[0];
+                if constexpr (NW == 12) ps = (x[0] + x[1]) + x[2];
+                nm_store(orow + wg, ps);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            NM_STAMP(2);
+            alive = nm_grid_barrier(prm.bar, ++epoch, tid, ok_s);
+            if (!alive) break;
+            NM_STAMP(3);
+            if (wv == 0) {
+                double a = 0.0;
+                if constexpr (NW == 12) {
+                    for (int b = lane; b < nwg; b += 64) a += nm_load(orow + b);
+                } else {
+                    const int ntrip = (nwg + 2) / 3;
+                    for (int t = lane; t < ntrip; t += 64) {
+                        const int b = 3 * t;
+                        double x = nm_load(orow + b);
+                        if (b + 1 < nwg) x += nm_load(orow + b + 1);
+                        if (b + 2 < nwg) x += nm_load(orow + b + 2);
+                        a += x;
+                    }
+                }
+                a = group_allreduce_sum<64>(a);
+                if (lane == 0) stat[G * S + G] = a;
+            }
+            __syncthreads();
+            NM_STAMP(6);
+            div = stat[G * S + G];
+        } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -1701,8 +1795,9 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
         NM_STAMP(5);
         for (int i = tid; i < nout; i += NTHR) stat[i] = nm_load(prm.stat + i);
         __syncthreads();
+        div = stat[G * S + G];
+        }
         // ---- the stop test of the factorize loop (Init_NMFT.py:106), by every workgroup for itself
-        const double div = stat[G * S + G];
         const bool go = (it < prm.max_iter) && (fabs(prev - div) > prm.min_change);
         if (wg == 0 && tid == 0) {
             if (prm.div_trace) prm.div_trace[it] = div;

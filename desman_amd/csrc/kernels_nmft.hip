@@ -853,14 +853,15 @@ int k_nmft_get_tau(dsm_ctx *c, uint64_t *d_packed)
 // ===========================================================================
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// a / b for the operands of the update (positive, far from the ends of the exponent range): hardware reciprocal, two
-// Newton steps, one residual correction -- 8 instructions / ~50 issue cycles instead of the 11 / ~80 of the IEEE expansion
+// a / b for the operands of the update (positive, far from the ends of the exponent range): hardware reciprocal, one
+// Newton step, one residual correction -- 6 instructions / ~40 issue cycles instead of the 11 / ~80 of the IEEE expansion
 // (no v_div_scale / v_div_fmas / v_div_fixup).  The quotient is within 1 ulp of a / b (faithful, not always correctly
 // rounded); the factors stay within the 1e-7 of the reference goldens after 100 updates that the tests ask for.
 __device__ __forceinline__ double fdiv(double a, double b)
 {
+    // v_rcp_f64 is good to ~2^-23; one Newton step makes 2^-46, and the residual correction of the QUOTIENT below is itself a
+    // Newton step on it (its error is the product of r's and q's: 2^-92) -- a second step on r (rounds 2-3) bought nothing
     double r = __builtin_amdgcn_rcp(b);
-    r = fma(fma(-b, r, 1.0), r, r);
     r = fma(fma(-b, r, 1.0), r, r);
     const double q = a * r;
     return fma(fma(-b, q, a), r, q);

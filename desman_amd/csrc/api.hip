@@ -228,7 +228,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
     dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->sweep_stats); dev_free(&c->step_cnt); dev_free(&c->blk_order); dev_free(&c->screen_ctl); dev_free(&c->prior); dev_free(&c->prior_all); dev_free(&c->scalars); dev_free(&c->star);
-    dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->shard_vec); dev_free(&c->np_part); if (c->np_bar) { (void)hipFree(c->np_bar); c->np_bar = nullptr; } dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); dev_free(&c->ngam_raw);
+    dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->shard_vec); dev_free(&c->np_part); if (c->np_bar) { (void)hipFree(c->np_bar); c->np_bar = nullptr; } dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ntau2); dev_free(&c->ngam); dev_free(&c->ngam_raw);
     dev_free(&c->npart); dev_free(&c->nstat);
     for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ev_u_ready[i]); (void)hipEventDestroy(c->ev_u_free[i]); }
     if (c->stream_rng != c->stream) (void)hipStreamDestroy(c->stream_rng);
@@ -262,7 +262,7 @@ extern "C" int dsm_ctx_set_counts(dsm_ctx *c, const int64_t *variants, int V, in
     TRY(dev_alloc(&c->cnt_vs, n * 4));
     TRY(dev_alloc(&c->nitems, (size_t)S));
     TRY(dev_alloc(&c->tau, (size_t)V));
-    dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ngam); dev_free(&c->ngam_raw); c->nG = 0;
+    dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ntau2); dev_free(&c->ngam); dev_free(&c->ngam_raw); c->nG = 0;
     free_traces(c);
     Scratch<int64_t> d_in; Scratch<int> d_flag; Scratch<double> d_part; Scratch<unsigned long long> d_depth;
     const int nblk = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
@@ -1369,6 +1369,13 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     const int adjust = fix_gamma ? 0 : 1;
     c->ndiv_trace = d_trace;
     c->nmft_fix_gamma = fix_gamma ? 1 : 0;               // the update kernels leave out what only a gamma update reads (kernels_nmft.hip)
+    // ... and on the matrix-core kernel an update is ONE fused pass (objective of the current rows + candidate rows of the next update
+    // into a second buffer, accepted or not by the control step that follows: NmftMfmaParams.fix_gamma == 2)
+    const bool fusedfix = fix_gamma && nmft_use_mfma(c);
+    if (fusedfix) {
+        if (!c->ntau2) TRY(dev_alloc(&c->ntau2, (size_t)c->V * 4 * G));
+        c->nmft_fix_gamma = 2;
+    }
     // factorize applies _adjustment once before the first objective (Init_NMFT.py:102)
     if (adjust) TRY(k_nmft_clamp(c));
     const int BATCH = 64;
@@ -1392,7 +1399,7 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     const bool wave = nmft_use_wave(c);
     // one-pass path: statistics of the initial state, then every update launch also produces the
     // statistics of the next iteration; two-pass path (large S*G): pass A + pass B per iteration
-    if (wave) TRY(k_nmft_wave(c, adjust, 0));
+    if (wave && !fusedfix) TRY(k_nmft_wave(c, adjust, 0));
     // One iteration = the same 2-3 launches every time (the iteration index and the stop flag live in
     // device memory), so BATCH iterations can be captured once into a hipGraph and replayed.  Measured on
     // MI355X / ROCm 7.2: a replayed kernel node costs ~10 us, more than a stream-ordered launch (V=10k: 70 vs
@@ -1402,6 +1409,10 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     // time: 4.2 s eager -> 2.2 s replayed.  desman_amd.chains opts in through DESMAN_HIP_NMFT_GRAPH=1.
     // (Timing mode records events per launch -> eager.)
     auto enqueue_iteration = [&](int n) -> int {                                     // n = launch number of this call (parity slot)
+        if (fusedfix) {                                                              // the pass first: its objective is what the control step tests
+            TRY(k_nmft_wave(c, adjust, 1));
+            return k_nmft_gamma(c, max_iter, min_change, fix_gamma, adjust, n & 1);
+        }
         if (!wave) TRY(k_nmft_pass_a(c));
         // the control kernel decides ON THE DEVICE whether this update runs at all (Init_NMFT.py:106)
         TRY(k_nmft_gamma(c, max_iter, min_change, fix_gamma, adjust, n & 1));       // also records div_trace[it]
@@ -1432,6 +1443,13 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     }
     const int done = (int)h[3];
     if (n_done) *n_done = done;
+    if (fusedfix) {
+        // an odd number of accepted candidates: the current rows are in the second buffer
+        double par = 0.0;
+        HIP_TRY(hipMemcpyAsync(&par, ctl + 10, sizeof par, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (par != 0.0) HIP_TRY(hipMemcpyAsync(c->ntau, c->ntau2, (size_t)c->V * 4 * G * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
     if (div_trace) {
         HIP_TRY(hipMemcpyAsync(div_trace, d_trace, ((size_t)done + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1486,30 +1504,36 @@ extern "C" int dsm_batch_nmft_factorize(dsm_ctx *const *ctxs, int K, int max_ite
         dsm_ctx *c = ctxs[k];
         BTRY(traces[k].alloc((size_t)max_iter + 1));
         c->ndiv_trace = traces[k];
-        c->nmft_fix_gamma = fix_gamma ? 1 : 0;
+        c->nmft_fix_gamma = fix_gamma ? 2 : 0;          // gamma fixed: the fused pass (dsm_nmft_factorize; the batch is matrix-core only)
+        if (fix_gamma && !c->ntau2) BTRY(dev_alloc(&c->ntau2, (size_t)c->V * 4 * G));
         BHIP(hipMemsetAsync(ctl_of(c), 0, 16 * sizeof(double), c->stream));
         if (adjust) BTRY(k_nmft_clamp(c));
     }
     g_batch.K = K;
-    for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_wave(ctxs[k], adjust, 0)); }
+    if (!fix_gamma) for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_wave(ctxs[k], adjust, 0)); }
     const int BATCH = 64;
-    std::vector<double> h((size_t)K * 7, 0.0);
+    std::vector<double> h((size_t)K * 11, 0.0);
     for (int launched = 0; launched <= max_iter;) {
         for (int i = 0; i < BATCH && launched <= max_iter; ++i, ++launched) {
+            if (fix_gamma)                              // the fused pass first: its objective is what the control step tests
+                for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_wave(ctxs[k], adjust, 1)); }
             for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_gamma(ctxs[k], max_iter, min_change, fix_gamma, adjust, launched & 1)); }
-            for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_wave(ctxs[k], adjust, 1)); }
+            if (!fix_gamma)
+                for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_wave(ctxs[k], adjust, 1)); }
         }
         for (int k = 0; k < K; ++k)
-            BHIP(hipMemcpyAsync(h.data() + (size_t)k * 7, ctl_of(ctxs[k]), 7 * sizeof(double), hipMemcpyDeviceToHost, lead->stream));
+            BHIP(hipMemcpyAsync(h.data() + (size_t)k * 11, ctl_of(ctxs[k]), 11 * sizeof(double), hipMemcpyDeviceToHost, lead->stream));
         BHIP(hipStreamSynchronize(lead->stream));
         bool all = true;
-        for (int k = 0; k < K; ++k) all = all && h[(size_t)k * 7 + 2] != 0.0;
+        for (int k = 0; k < K; ++k) all = all && h[(size_t)k * 11 + 2] != 0.0;
         if (all) break;
     }
     g_batch = BatchCtl{};
     for (int k = 0; k < K; ++k) {
-        const int done = (int)h[(size_t)k * 7 + 3];
+        const int done = (int)h[(size_t)k * 11 + 3];
         if (n_done) n_done[k] = done;
+        if (fix_gamma && h[(size_t)k * 11 + 10] != 0.0)          // an odd number of accepted candidates: the current rows are in the second buffer
+            BHIP(hipMemcpyAsync(ctxs[k]->ntau, ctxs[k]->ntau2, (size_t)ctxs[k]->V * 4 * G * sizeof(double), hipMemcpyDeviceToDevice, lead->stream));
         if (div_traces)
             BHIP(hipMemcpyAsync(div_traces + (size_t)k * ((size_t)max_iter + 1), traces[k], ((size_t)done + 1) * sizeof(double),
                                 hipMemcpyDeviceToHost, lead->stream));

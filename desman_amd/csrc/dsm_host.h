@@ -164,6 +164,7 @@ struct dsm_ctx {
     // NMFT
     double *F = nullptr;            // [V][4][S]
     double *ntau = nullptr;         // [V][4][G]
+    double *ntau2 = nullptr;        // [V][4][G] the other buffer of factorize_tau's fused pass (kernels_nmft.hip: NmftMfmaParams.fix_gamma == 2), made on first use
     double *ngam = nullptr;         // [G][S] (after _adjustment)
     double *ngam_raw = nullptr;     // [G][S] normalised gamma of the running update, before _adjustment
     int npart_cols = 0;             // workgroup partials currently held by npart

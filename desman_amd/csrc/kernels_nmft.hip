@@ -271,6 +271,7 @@ __device__ __forceinline__ void nmft_objctl_body(const NmftObjCtlParams &q)
         ctl[4 + (it & 1)] = div;
         ctl[3] = (double)it;
         if (!go) ctl[2] = 1.0;
+        else ctl[10] = 1.0 - ctl[10];                  // the fused pass's candidate rows become the current ones (NmftMfmaParams.fix_gamma == 2; unused otherwise)
         if (q.div_trace) q.div_trace[it] = div;
     }
 }
@@ -335,6 +336,7 @@ __device__ __forceinline__ void nmft_rg_body(const NmftRgParams &q)
         ctl[6 + (1 - p)] = (double)(it + 1);
         ctl[3] = (double)it;
         if (!go) { ctl[2] = 1.0; ctl[8 + (1 - p)] = 1.0; }       // [2]: read by the update kernels of later launches and by the host
+        else if (q.fix_gamma) ctl[10] = 1.0 - ctl[10];           // gamma fixed: the fused pass's candidate rows become the current ones
         if (q.div_trace) q.div_trace[it] = div;
     }
     if (!go || q.fix_gamma) return;                                               // uniform over the workgroup
@@ -1001,20 +1003,33 @@ struct NmftMfmaParams {
     const double *F; double *tau; const double *gam_raw, *gam;
     int V, S, G, adjust, do_update;
     const double *ctl, *log_tab; double *partial;
+    double *tau2;       // fix_gamma == 2: the second tau buffer of the fused pass (below)
     int fix_gamma;      // factorize_tau (Init_NMFT.py:134-149; the `-r` path, bin/desman:181-206): gamma stays as it is, so only the objective
                         // of the statistics is wanted -- no gamma numerators (24 of a quad's 84 MFMAs at six tiles), no row sums, one partial
-                        // per workgroup instead of G S + G + 1
+                        // per workgroup instead of G S + G + 1.
+                        // 2 = the FUSED pass (this kernel; the persistent loop has its own): with gamma unchanged the product tau . gamma that
+                        // an update's tau half divides F by is the very product its predecessor's statistics half took the objective of, so one
+                        // pass per update does both -- R = tau_k . gamma, objective of tau_k AND Q = F (/) R -> numerators -> candidate
+                        // tau_(k+1), written to the OTHER buffer; the control step that follows (stop test on the objective of tau_k) accepts
+                        // the candidate by flipping the parity word ctl[10], or stops and leaves tau_k current.  One contraction, 4 NT divisions
+                        // and a pass over the quad's LDS rows less per update; the same objective trace, update count and factors bit for bit
+                        // (nm_tile_q2's quotient IS the tau half's: both divide by R with elop's zero rule).
 };
-template <int NT, int KB, bool KEEPF>
+template <int NT, int KB, bool KEEPF, bool FIXF = false>      // FIXF: the fused pass of factorize_tau as an instantiation of its own (registers)
 __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
 {
     const double *__restrict__ F = prm.F, *__restrict__ gam_raw = prm.gam_raw, *__restrict__ gam = prm.gam;
-    double *__restrict__ tau = prm.tau, *__restrict__ partial = prm.partial;
+    double *tau = prm.tau, *__restrict__ partial = prm.partial;
     const double *__restrict__ ctl = prm.ctl, *__restrict__ log_tab = prm.log_tab;
     const int V = prm.V, S = prm.S, G = prm.G, adjust = prm.adjust, do_update = prm.do_update;
     const bool gnum = prm.fix_gamma == 0;                                       // the gamma numerators and row sums are wanted
+    constexpr bool fusedfix = FIXF;                                             // gamma fixed: one pass per update (NmftMfmaParams)
     extern __shared__ __attribute__((aligned(16))) char smem_m[];
     if (ctl[2] != 0.0) return;
+    // fused pass: which buffer holds the current rows (flipped by the control step when it accepts a candidate)
+    const bool par1 = fusedfix && ctl[10] != 0.0;
+    const double *tau_in = par1 ? prm.tau2 : prm.tau;
+    double *tau_out = fusedfix ? (par1 ? prm.tau : prm.tau2) : prm.tau;
     constexpr int GP = 4 * KB, SPAD = 16 * NT;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
     const int nblk = gridDim.x;
@@ -1033,7 +1048,7 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
     nm_stage_gamma_p(graw_p, ggam_p, gam_raw, gam, GP, LDG, G, S, tid, 256);
     for (int g = wv; g < GP; g += 4) {                                          // gamma.sum(1) (:170), lane-parallel
         double a = 0.0;
-        for (int s = lane; s < SPAD; s += 64) a += (g < G && s < S) ? gam_raw[(size_t)g * S + s] : 0.0;
+        for (int s = lane; s < SPAD; s += 64) a += (g < G && s < S) ? (fusedfix ? gam : gam_raw)[(size_t)g * S + s] : 0.0;
         a = group_allreduce_sum<64>(a);
         if (lane == 0) t1[g] = a;
     }
@@ -1052,7 +1067,7 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
         // the 16 tau rows of the quad (contiguous in HBM: [vv][r][g]) -> LDS [i = 4 r + vv][g]
         for (int k = lane; k < 16 * G; k += 64) {
             const int vv = k / (4 * G), r = (k / G) & 3, g = k % G;
-            const double x = (v0 + vv < V) ? tau[(size_t)v0 * 4 * G + k] : 0.0;
+            const double x = (v0 + vv < V) ? tau_in[(size_t)v0 * 4 * G + k] : 0.0;
             told[(4 * r + vv) * GP + g] = x;
             if (!do_update) tnew[(4 * r + vv) * GP + g] = x;
         }
@@ -1072,6 +1087,24 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
             if constexpr (KEEPF) f[t] = load_f(t);
         }
         __builtin_amdgcn_wave_barrier();
+        if constexpr (fusedfix) {
+            // gamma fixed: objective of the current rows and the candidate rows of the next update from ONE product
+            double a_cur[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) a_cur[kb] = told[n * GP + 4 * kb + q];
+            double4_t num = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[kb], ggam_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
+                const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
+                const double4_t q2 = nm_tile_q2(ft, R, live[t], ltab, obj);
+                num = nm_num_tile<KB>(num, q2, xq, ggam_p + 16 * t, LDG, n, q);
+            }
+            nm_tau_finish<KB, true>(num, told, tnew, t1, G, n, q, adjust, vok, tau_out + (size_t)(v0 + q) * 4 * G);
+            __builtin_amdgcn_wave_barrier();
+        } else {
         if (do_update) {
             double a_old[KB];
 #pragma unroll
@@ -1112,6 +1145,7 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
             }
         }
         __builtin_amdgcn_wave_barrier();
+        }       // (not the fused pass)
     }
     // workgroup reduction over the 4 wavefronts (fixed order) -> transposed partials.  acc[t][e]: g = 4 e + q, s = 16 t + n
     __syncthreads();
@@ -1195,6 +1229,13 @@ static size_t mfma_lds_bytes(int NT, int KB)
 template <int NT, int KB, bool KEEPF>
 __global__ __launch_bounds__(256, nmft_mfma_wgs(NT, KB)) void nmft_mfma_kernel(NmftMfmaParams q) { nmft_mfma_body<NT, KB, KEEPF>(q); }
 template <int NT, int KB, bool KEEPF>
+__global__ __launch_bounds__(256, nmft_mfma_wgs(NT, KB)) void nmft_mfma_fix_kernel(NmftMfmaParams q) { nmft_mfma_body<NT, KB, KEEPF, true>(q); }
+template <int NT, int KB, bool KEEPF>
+__global__ __launch_bounds__(256, nmft_mfma_wgs(NT, KB)) void nmft_mfma_fix_kernel_b(BatchArgs<NmftMfmaParams> b)
+{
+    nmft_mfma_body<NT, KB, KEEPF, true>(b.p[blockIdx.y]);
+}
+template <int NT, int KB, bool KEEPF>
 __global__ __launch_bounds__(256, nmft_mfma_wgs(NT, KB)) void nmft_mfma_kernel_b(BatchArgs<NmftMfmaParams> b)
 {
     nmft_mfma_body<NT, KB, KEEPF>(b.p[blockIdx.y]);
@@ -1204,7 +1245,13 @@ template <int NT, int KB>
 static void launch_mfma(dsm_ctx *c, int adjust, int do_update, int grid)
 {
     const size_t sh = mfma_lds_bytes(NT, KB);
-    const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart, c->nmft_fix_gamma};
+    const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart, c->ntau2, c->nmft_fix_gamma};
+    if (c->nmft_fix_gamma == 2 && do_update) {           // gamma fixed: the fused pass (its own instantiation)
+        LAUNCH_OR_COLLECT(NmftMfmaParams, q,
+                          hipLaunchKernelGGL((nmft_mfma_fix_kernel<NT, KB, (NT <= 3 || NT == 5 || NT == 6)>), dim3(grid), dim3(256), sh, c->stream, q),
+                          hipLaunchKernelGGL((nmft_mfma_fix_kernel_b<NT, KB, (NT <= 3 || NT == 5 || NT == 6)>), dim3(grid, K), dim3(256), sh, c->stream, acc));
+        return;
+    }
     LAUNCH_OR_COLLECT(NmftMfmaParams, q,
                       hipLaunchKernelGGL((nmft_mfma_kernel<NT, KB, (NT <= 3 || NT == 5 || NT == 6)>), dim3(grid), dim3(256), sh, c->stream, q),
                       hipLaunchKernelGGL((nmft_mfma_kernel_b<NT, KB, (NT <= 3 || NT == 5 || NT == 6)>), dim3(grid, K), dim3(256), sh, c->stream, acc));
@@ -1467,7 +1514,7 @@ static int launch_wide(dsm_ctx *c, int adjust, int do_update, int grid)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&nmft_wide_kernel<NT, KB, NCB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart, c->nmft_fix_gamma};
+    const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart, c->ntau2, c->nmft_fix_gamma};
     hipLaunchKernelGGL((nmft_wide_kernel<NT, KB, NCB>), dim3(grid), dim3(64 * (8 / NCB) * NCB), sh, c->stream, q);
     return DSM_OK;
 }
@@ -1636,7 +1683,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
         nm_stage_gamma_p(graw_p, ggam_p, grw, gm, GP, LDG, G, S, tid, NTHR);
         for (int g = wv; g < GP; g += NW) {                                     // gamma.sum(1) (:170), lane-parallel
             double a = 0.0;
-            for (int s = lane; s < SPAD; s += 64) a += (g < G && s < S) ? grw[g * S + s] : 0.0;
+            for (int s = lane; s < SPAD; s += 64) a += (g < G && s < S) ? (prm.fix_gamma ? gm : grw)[g * S + s] : 0.0;
             a = group_allreduce_sum<64>(a);
             if (lane == 0) t1[g] = a;
         }
@@ -1665,6 +1712,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
             double a_g[4];                                                      // A of the row contraction: tau_new[vv = q][e][g = n]
 #pragma unroll
             for (int e = 0; e < 4; ++e) { a_g[e] = (gnum && n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; h1 += a_g[e]; }
+            double4_t num = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -1676,8 +1724,13 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
                 if (gnum) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
+                } else {
+                    // gamma fixed: this product is also the one the tau half of the update divides F by (NmftMfmaParams.fix_gamma == 2):
+                    // the candidate rows of the next update come out of the same pass
+                    num = nm_num_tile<KB>(num, q2, xq, ggam_p + 16 * t, LDG, n, q);
                 }
             }
+            if (!gnum) nm_tau_finish<KB, false>(num, tnew, told, t1, G, n, q, adjust, vok, nullptr);     // candidate -> the spare rows
         }
         NM_STAMP(1);
         // Workgroup reduction: wavefronts 4 r .. 4 r + 3 are workgroup 3 wg + r of the three-launch kernel (the same four quads, summed
@@ -1830,7 +1883,10 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
         }
         NM_STAMP(7);
         // ---- tau half of the update on this wavefront's quad (tau rows stay in LDS)
-        if (have) {
+        if (have && prm.fix_gamma) {                                             // the candidate rows are the current ones now
+            double *tsw = told; told = tnew; tnew = tsw;
+            __builtin_amdgcn_wave_barrier();
+        } else if (have) {
             double *tsw = told; told = tnew; tnew = tsw;                         // the rows of the last update are the old ones now
             __builtin_amdgcn_wave_barrier();
             double a_old[KB];

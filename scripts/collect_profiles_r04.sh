@@ -17,6 +17,7 @@ done
 timeout 600 python bench.py --V 50000 --S 96 --G 4 --steps 100 --warmup 20 --no-cpu-baseline --batch 0 > $O/r04_bench_V50000_S96_G4.json 2>> $O/bench.err
 cp gpurun_out/pmc_traffic_by_shape.json $O/pmc_traffic_by_shape.json
 for shp in "50000 96 12" "200000 64 8" "10000 64 8"; do python scripts/bench_vshard_comm.py $shp 100; done > $O/r04_vshard_comm.txt 2>&1
+for shp in "1000 64 5" "3000 64 5" "10000 64 8" "30000 64 6" "50000 96 8" "50000 96 12"; do python scripts/dbg/prof_nmft_tau.py $shp 2>&1 | tail -1; done > $O/r04_nmft_factorize_tau.txt
 python scripts/chain_phases.py --out $O/r04_chain_phases.json 2>&1 | grep "G=" > $O/r04_chain_phases.txt
 python scripts/fit_chain_cost.py --out $O/r04_chain_cost_components.json > $O/r04_chain_cost_components.txt 2>&1
 python scripts/kernel_regs.py > $O/r04_kernel_regs.txt 2>&1

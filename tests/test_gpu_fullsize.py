@@ -227,3 +227,32 @@ np.savez(sys.argv[1], n=n, tr=tr, t=t, g=g)
             outs.append(np.load(path))
         a, b = outs
         assert int(a["n"]) == int(b["n"]) == 15 and np.array_equal(a["tr"], b["tr"]) and np.array_equal(a["t"], b["t"]) and np.array_equal(a["g"], b["g"])
+
+
+@pytest.mark.parametrize("fix_gamma", [False, True])
+def test_nmft_graph_replay_equals_the_eager_loop(fix_gamma, monkeypatch):
+    """DESMAN_HIP_NMFT_GRAPH=1 (desman_amd.chains sets it): batches of 64 updates of the three-launch loop captured once and replayed --
+    the same launches, so the same factors, update count and objective trace as the eager loop; with gamma fixed an update is the
+    update kernel + the one-wavefront objective / control launch (nmft_objctl_kernel).  S > 64: the persistent loop does not apply."""
+    from oracle import ref_numpy as rn
+    V, S, G = 1000, 100, 4
+    counts, _, _ = synth_counts(V, S, G, seed=11)
+    tau0, gam0 = rn.nmft_random_initialize(np.random.RandomState(12), V, S, G)
+    outs = []
+    for graph in ("0", "1"):
+        monkeypatch.setenv("DESMAN_HIP_NMFT_GRAPH", graph)
+        c = _lib.Context(0)
+        c.set_counts(counts)
+        c.nmft_set(tau0, gam0)
+        n, tr = c.nmft_factorize(max_iter=150, min_change=1e-5, fix_gamma=fix_gamma)
+        t, g = c.nmft_get()
+        outs.append((n, np.asarray(tr), t, g))
+        c.close()
+    (n0, tr0, t0, g0), (n1, tr1, t1, g1) = outs
+    assert n0 == n1 and np.array_equal(tr0, tr1) and np.array_equal(t0, t1) and np.array_equal(g0, g1)
+    F = cbind.nmft_freq(counts)
+    tc, gc = tau0.copy(), gam0.copy()
+    n_ref, tr_ref = (cbind.nmft_factorize_tau if fix_gamma else cbind.nmft_factorize)(F, tc, gc, max_iter=150, min_change=1e-5)
+    assert n0 == n_ref
+    np.testing.assert_allclose(tr0, tr_ref, rtol=1e-9)
+    np.testing.assert_allclose(t0, tc, rtol=1e-6, atol=1e-12)

@@ -1319,7 +1319,7 @@ extern "C" int dsm_nmft_set(dsm_ctx *c, const double *tau, const double *gamma, 
     TRY(dev_alloc(&c->ntau, (size_t)V * 4 * G));
     TRY(dev_alloc(&c->ngam, (size_t)G * S));
     TRY(dev_alloc(&c->ngam_raw, (size_t)G * S));
-    TRY(dev_alloc(&c->npart, (size_t)std::max(std::max(c->nmft_blocks, nmft_wave_grid(c)), nmft_use_mfma(c) ? nmft_mfma_grid(c) : 0) * ((size_t)G * S + G + 1)));
+    TRY(dev_alloc(&c->npart, (size_t)std::max(std::max(c->nmft_blocks, nmft_wave_grid(c)), nmft_use_mfma(c) ? std::max(nmft_mfma_grid(c, false), nmft_mfma_grid(c, true)) : 0) * ((size_t)G * S + G + 1)));
     TRY(dev_alloc(&c->nstat, (size_t)G * S + 2 * G + 16));
     // reference layout tau[v + a*V][g] -> device layout [v][a][g]
     std::vector<double> t((size_t)V * 4 * G);

@@ -245,6 +245,6 @@ int nmft_grid(dsm_ctx *c);
 bool nmft_use_wave(const dsm_ctx *c);
 bool nmft_use_mfma(const dsm_ctx *c);
 int nmft_wave_grid(const dsm_ctx *c);
-int nmft_mfma_grid(const dsm_ctx *c);     // up to four workgroups per CU
+int nmft_mfma_grid(const dsm_ctx *c, bool fix = false);     // up to four workgroups per CU (five for the fused pass of factorize_tau)
 int k_nmft_wave(dsm_ctx *c, int adjust, int do_update);
 int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int adjust, int *used);

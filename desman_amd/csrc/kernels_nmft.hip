@@ -1022,7 +1022,7 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
     double *tau = prm.tau, *__restrict__ partial = prm.partial;
     const double *__restrict__ ctl = prm.ctl, *__restrict__ log_tab = prm.log_tab;
     const int V = prm.V, S = prm.S, G = prm.G, adjust = prm.adjust, do_update = prm.do_update;
-    const bool gnum = prm.fix_gamma == 0;                                       // the gamma numerators and row sums are wanted
+    const bool gnum = !FIXF && prm.fix_gamma == 0;                              // the gamma numerators and row sums are wanted
     constexpr bool fusedfix = FIXF;                                             // gamma fixed: one pass per update (NmftMfmaParams)
     extern __shared__ __attribute__((aligned(16))) char smem_m[];
     if (ctl[2] != 0.0) return;
@@ -1036,7 +1036,7 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
     double2 *ltab = reinterpret_cast<double2 *>(smem_m);                        // [256]
     constexpr int LDG = SPAD + 1;
     double *graw_p = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);          // [GP][LDG] gamma_raw, zero-padded (nm_stage_gamma_p)
-    double *ggam_p = graw_p + GP * LDG;                                         // [GP][LDG] gamma
+    double *ggam_p = graw_p + (FIXF ? 0 : GP * LDG);                            // [GP][LDG] gamma (the fused pass reads no other: one matrix)
     double *t1 = ggam_p + GP * LDG;                                             // [GP] rowsum(gamma_raw)
     double *told = t1 + GP + wv * (2 * 16 * GP);                                // per wavefront [16][GP], row i = 4 r + vv
     double *tnew = told + 16 * GP;                                              // per wavefront [16][GP]
@@ -1045,7 +1045,8 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
                                                                                 // of everything above once the quads are done (at S = 96, G = 12 its
                                                                                 // 43 KB on top of the rest made 87 KB = ONE workgroup per CU)
     ltab[tid] = reinterpret_cast<const double2 *>(log_tab)[tid];
-    nm_stage_gamma_p(graw_p, ggam_p, gam_raw, gam, GP, LDG, G, S, tid, 256);
+    if constexpr (FIXF) nm_stage_gamma_p(ggam_p, ggam_p, gam, gam, GP, LDG, G, S, tid, 256);
+    else nm_stage_gamma_p(graw_p, ggam_p, gam_raw, gam, GP, LDG, G, S, tid, 256);
     for (int g = wv; g < GP; g += 4) {                                          // gamma.sum(1) (:170), lane-parallel
         double a = 0.0;
         for (int s = lane; s < SPAD; s += 64) a += (g < G && s < S) ? (fusedfix ? gam : gam_raw)[(size_t)g * S + s] : 0.0;
@@ -1164,8 +1165,8 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
         double hh = h1;                                                        // sum over q (lanes n, n + 16, n + 32, n + 48)
         hh += __shfl_xor(hh, 16, 64);
         hh += __shfl_xor(hh, 32, 64);
-        if (lane == 0) red[((size_t)wv * (GP + 2) + GP) * SPAD] = o;
-        if (lane < GP) red[((size_t)wv * (GP + 2) + GP + 1) * SPAD + lane] = hh;
+        if (lane == 0) red[FIXF ? (size_t)wv : ((size_t)wv * (GP + 2) + GP) * SPAD] = o;     // (the fused pass reduces nothing else: four words)
+        if (gnum && lane < GP) red[((size_t)wv * (GP + 2) + GP + 1) * SPAD + lane] = hh;
     }
     __syncthreads();
     for (int i = tid; gnum && i < G * S; i += 256) {
@@ -1181,7 +1182,7 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
     }
     if (tid == 64) {
         double a = 0.0;
-        for (int k = 0; k < 4; ++k) a += red[((size_t)k * (GP + 2) + GP) * SPAD];
+        for (int k = 0; k < 4; ++k) a += red[FIXF ? (size_t)k : ((size_t)k * (GP + 2) + GP) * SPAD];
         partial[((size_t)G * S + G) * nblk + blockIdx.x] = a;
     }
 }
@@ -1193,6 +1194,9 @@ constexpr int nmft_mfma_wgs(int NT, int KB)
     return NT <= 4 ? ((KB <= 3 && !(NT == 3 && KB == 2) && !(NT == 4 && KB == 3)) ? 4 : 3) : (KB <= 3 ? 3 : 2);
 }
 
+// the fused pass of factorize_tau (no gamma numerators in registers, one gamma matrix and a four-word reduction in LDS): one
+// workgroup per CU more
+constexpr int nmft_mfma_fix_wgs(int NT, int KB) { return NT <= 4 ? (KB <= 3 ? 5 : 4) : (KB <= 3 ? 4 : 3); }
 static bool mfma_shape(const dsm_ctx *c, int *nt, int *kb)
 {
     *nt = (c->S + 15) / 16;
@@ -1205,7 +1209,7 @@ static bool mfma_shape(const dsm_ctx *c, int *nt, int *kb)
 
 bool nmft_use_mfma(const dsm_ctx *c) { int a, b; return mfma_shape(c, &a, &b); }
 
-int nmft_mfma_grid(const dsm_ctx *c)
+int nmft_mfma_grid(const dsm_ctx *c, bool fix)
 {
     int g = ((c->V + 3) / 4 + 3) / 4;             // quads / 4 wavefronts
     // at most the workgroups that are resident at once (the quad loop is grid-strided): three per CU by registers up to four
@@ -1213,14 +1217,15 @@ int nmft_mfma_grid(const dsm_ctx *c)
     int nt, kb, cus = 256;
     (void)mfma_shape(c, &nt, &kb);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) cus = 256;
-    const int cap = nmft_mfma_wgs(nt, kb) * cus;
+    // (a context's partial table is laid out for the larger of the two grids: dsm_nmft_set asks with fix = true)
+    const int cap = (fix ? nmft_mfma_fix_wgs(nt, kb) : nmft_mfma_wgs(nt, kb)) * cus;
     if (g > cap) g = cap;
     return g < 1 ? 1 : g;
 }
-static size_t mfma_lds_bytes(int NT, int KB)
+static size_t mfma_lds_bytes(int NT, int KB, bool fix = false)
 {
     const size_t GP = 4 * KB, SPAD = 16 * NT;
-    const size_t loop = 2 * DSM_LOG_TAB_N + 2 * GP * (SPAD + 1) + GP + 4 * 2 * 16 * GP + 4 * NM_XQ, red = 4 * (GP + 2) * SPAD;
+    const size_t loop = 2 * DSM_LOG_TAB_N + (fix ? 1 : 2) * GP * (SPAD + 1) + GP + 4 * 2 * 16 * GP + 4 * NM_XQ, red = fix ? 4 : 4 * (GP + 2) * SPAD;
     return std::max(loop, red) * sizeof(double);
 }
 // workgroups per CU the register allocation leaves room for (round 4, with the numerators on the matrix cores -- no qp[NT], no
@@ -1229,9 +1234,9 @@ static size_t mfma_lds_bytes(int NT, int KB)
 template <int NT, int KB, bool KEEPF>
 __global__ __launch_bounds__(256, nmft_mfma_wgs(NT, KB)) void nmft_mfma_kernel(NmftMfmaParams q) { nmft_mfma_body<NT, KB, KEEPF>(q); }
 template <int NT, int KB, bool KEEPF>
-__global__ __launch_bounds__(256, nmft_mfma_wgs(NT, KB)) void nmft_mfma_fix_kernel(NmftMfmaParams q) { nmft_mfma_body<NT, KB, KEEPF, true>(q); }
+__global__ __launch_bounds__(256, nmft_mfma_fix_wgs(NT, KB)) void nmft_mfma_fix_kernel(NmftMfmaParams q) { nmft_mfma_body<NT, KB, KEEPF, true>(q); }
 template <int NT, int KB, bool KEEPF>
-__global__ __launch_bounds__(256, nmft_mfma_wgs(NT, KB)) void nmft_mfma_fix_kernel_b(BatchArgs<NmftMfmaParams> b)
+__global__ __launch_bounds__(256, nmft_mfma_fix_wgs(NT, KB)) void nmft_mfma_fix_kernel_b(BatchArgs<NmftMfmaParams> b)
 {
     nmft_mfma_body<NT, KB, KEEPF, true>(b.p[blockIdx.y]);
 }
@@ -1247,9 +1252,10 @@ static void launch_mfma(dsm_ctx *c, int adjust, int do_update, int grid)
     const size_t sh = mfma_lds_bytes(NT, KB);
     const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart, c->ntau2, c->nmft_fix_gamma};
     if (c->nmft_fix_gamma == 2 && do_update) {           // gamma fixed: the fused pass (its own instantiation)
+        const size_t shf = mfma_lds_bytes(NT, KB, true);
         LAUNCH_OR_COLLECT(NmftMfmaParams, q,
-                          hipLaunchKernelGGL((nmft_mfma_fix_kernel<NT, KB, (NT <= 3 || NT == 5 || NT == 6)>), dim3(grid), dim3(256), sh, c->stream, q),
-                          hipLaunchKernelGGL((nmft_mfma_fix_kernel_b<NT, KB, (NT <= 3 || NT == 5 || NT == 6)>), dim3(grid, K), dim3(256), sh, c->stream, acc));
+                          hipLaunchKernelGGL((nmft_mfma_fix_kernel<NT, KB, (NT <= 3 || NT == 5 || NT == 6)>), dim3(grid), dim3(256), shf, c->stream, q),
+                          hipLaunchKernelGGL((nmft_mfma_fix_kernel_b<NT, KB, (NT <= 3 || NT == 5 || NT == 6)>), dim3(grid, K), dim3(256), shf, c->stream, acc));
         return;
     }
     LAUNCH_OR_COLLECT(NmftMfmaParams, q,
@@ -1262,7 +1268,7 @@ int k_nmft_mfma(dsm_ctx *c, int adjust, int do_update)
     KTimer tm(c, do_update ? DSM_K_NMFT_B : DSM_K_NMFT_A);
     int nt, kb;
     if (!mfma_shape(c, &nt, &kb)) { dsm_set_error("nmft_mfma: unsupported shape"); return DSM_ERR_UNSUPPORTED; }
-    const int grid = nmft_mfma_grid(c);
+    const int grid = nmft_mfma_grid(c, c->nmft_fix_gamma == 2 && do_update);
 #define MCASE(N, K) if (nt == N && kb == K) launch_mfma<N, K>(c, adjust, do_update, grid)
     MCASE(1, 1); MCASE(1, 2); MCASE(2, 1); MCASE(2, 2); MCASE(3, 1); MCASE(3, 2); MCASE(4, 1); MCASE(4, 2);
     MCASE(1, 3); MCASE(2, 3); MCASE(3, 3); MCASE(4, 3); MCASE(5, 1); MCASE(5, 2); MCASE(5, 3); MCASE(6, 1); MCASE(6, 2); MCASE(6, 3);

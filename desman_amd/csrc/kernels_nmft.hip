@@ -1971,12 +1971,16 @@ int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, i
     *used = 0;
     static const bool off = DSM_AB_ENV("DESMAN_HIP_NMFT_NO_PERSIST") != nullptr;
     int nt, kb;
-    if (off || c->nmft_persist == 0 || !mfma_shape(c, &nt, &kb) || nt > 4 || kb > 3 || c->timing || g_batch.K) return DSM_OK;
+    if (off || c->nmft_persist == 0 || !mfma_shape(c, &nt, &kb) || nt > 6 || kb > 3 || c->timing || g_batch.K) return DSM_OK;
     int cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     const int G = c->nG, S = c->S, nquad = (c->V + 3) / 4, nblk = (nquad + 3) / 4;
     // up to one update-kernel workgroup per CU: four wavefronts per workgroup; above: twelve (three of those workgroups each)
     const int nwv = nblk <= cus ? 4 : NMFT_P_WAVES;
+    // 65..96 samples: the four-wavefront form (V <= 16 x compute units; LDS), and only with gamma fixed -- one value per workgroup
+    // crosses the machine then (12.8 against 20.7 us per update at 3000 x 96 x 8); with G S + G + 1 statistics to exchange the loop is
+    // no faster than three launches there (22.7 vs 22.6)
+    if (nt > 4 && (nwv != 4 || !fix_gamma)) return DSM_OK;
     const int grid = (nquad + nwv - 1) / nwv;
     const int nout = G * S + G + 1;
     if (grid < 2 || grid > cus) return DSM_OK;              // (neither form holds more than one workgroup per CU worth of table: no buffers
@@ -2019,6 +2023,9 @@ int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, i
     KTimer tm(c, DSM_K_NMFT_B);
 #define PCASE(N, K) if (nt == N && kb == K) rc = (nwv == 4) ? launch_persist<N, K, 4>(c, q, grid, sh, &fits) : launch_persist<N, K, NMFT_P_WAVES>(c, q, grid, sh, &fits)
     PCASE(1, 1); PCASE(1, 2); PCASE(1, 3); PCASE(2, 1); PCASE(2, 2); PCASE(2, 3); PCASE(3, 1); PCASE(3, 2); PCASE(3, 3); PCASE(4, 1); PCASE(4, 2); PCASE(4, 3);
+#define PCASE4(N, K) if (nt == N && kb == K) rc = launch_persist<N, K, 4>(c, q, grid, sh, &fits)
+    PCASE4(5, 1); PCASE4(5, 2); PCASE4(5, 3); PCASE4(6, 1); PCASE4(6, 2); PCASE4(6, 3);
+#undef PCASE4
 #undef PCASE
     if (rc != DSM_OK) return rc;
     if (!fits) return DSM_OK;

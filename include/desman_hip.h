@@ -300,7 +300,7 @@ int dsm_ctx_debug_log2f(dsm_ctx *ctx, const float *in, float *out, size_t n);
    update counts and objective traces do not depend on it (tests/test_gpu_fullsize.py asserts bit-equality). */
 int dsm_ctx_set_nmft_fused(dsm_ctx *ctx, int mode);
 /* dsm_nmft_factorize as ONE persistent launch (resident workgroups, in-kernel grid barriers, tau rows kept in LDS) where the
-   table fits the machine (S <= 64, G <= 12, V <= 48 x compute units): -1 / 1 = wherever it applies (default), 0 = never (the
+   table fits the machine (S <= 64, G <= 12, V <= 48 x compute units; factorize_tau also S <= 96 with V <= 16 x compute units): -1 / 1 = wherever it applies (default), 0 = never (the
    three-launch loop).  Same stopping rule, update counts, objective trace and factors, bit for bit: every path sums the workgroup
    partials in one canonical order (kernels_nmft.hip: nmft_sum_partials; tests/test_gpu_fullsize.py asserts the equality). */
 int dsm_ctx_set_nmft_persist(dsm_ctx *ctx, int mode);

@@ -98,7 +98,8 @@ def _nmft_run(counts, tau0, gam0, fused, fix_gamma, max_iter=20, persist=0):
 
 @pytest.mark.parametrize("V,S,G", [(10000, 64, 8), (50000, 96, 12), (3000, 64, 8), (2000, 32, 5), (13000, 40, 3), (12288, 48, 12), (933, 64, 5),
                                    (97, 20, 2), (5000, 128, 8), (2500, 110, 12), (14001, 100, 3), (3000, 64, 16), (6000, 96, 13), (2000, 128, 15),
-                                   (3000, 300, 8), (1001, 130, 3), (801, 512, 16), (2000, 200, 12), (1500, 260, 5), (37, 400, 2)])
+                                   (3000, 300, 8), (1001, 130, 3), (801, 512, 16), (2000, 200, 12), (1500, 260, 5), (37, 400, 2),
+                                   (3000, 96, 8), (1500, 80, 12), (4096, 90, 3)])      # 65..96 samples, V <= 4096: the persistent loop's four-wavefront form
 def test_full_size_nmft_factorize_matches_oracle(V, S, G):
     counts, tau0, gam0, F = _nmft_case(V, S, G)
     for fix_gamma in (False, True):

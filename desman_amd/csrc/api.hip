@@ -828,12 +828,15 @@ extern "C" int dsm_ctx_gibbs_update(dsm_ctx *c, int n_iter)
         TRY(words.release(it));
         std::swap(c->eta, c->eta_new);                                   // eta_new becomes the chain's eta
     }
+    // the last iteration's finalize launch also counts the haplotypes that are rare in every sample -- what the next call's choice of
+    // sweep instantiation goes by -- straight into the host's pinned word: it rides on this call's own launch and synchronisation
+    const bool want_rare = n_iter > 0 && c->tau_neartie_mode == -1;
+    if (want_rare && !c->h_rare) HIP_TRY(hipHostMalloc((void **)&c->h_rare, sizeof(int), hipHostMallocDefault));
     if (n_iter > 0)
         TRY(k_finalize(c, nb_prev, n_iter - 1, 0, P[(n_iter - 1) & 1], c->gamma_trace + (size_t)(n_iter - 1) * sg,
-                       c->eta_trace + (size_t)(n_iter - 1) * 16));
-    if (n_iter > 0 && c->tau_neartie_mode == -1) TRY(k_tau_rare_count(c, false));      // what the next call will go by: rides on this call's own
-    HIP_TRY(hipStreamSynchronize(c->stream));                                            // synchronisation
-    if (n_iter > 0 && c->tau_neartie_mode == -1 && c->h_rare) c->tau_rare_n = *c->h_rare;
+                       c->eta_trace + (size_t)(n_iter - 1) * 16, 0, want_rare ? c->h_rare : nullptr));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (want_rare) c->tau_rare_n = *c->h_rare;
     return DSM_OK;
 }
 

@@ -232,7 +232,7 @@ int tau_launch_info(dsm_ctx *c, int *launched, int *resident);
 int k_shard_pack(dsm_ctx *c, int nblocks);
 int k_shard_unpack(dsm_ctx *c);
 int k_finalize(dsm_ctx *c, int nblocks, int it, int star_mode, const double *prior, const double *gamma_src,
-               const double *eta_src, int slot = 0);
+               const double *eta_src, int slot = 0, int *rare_out = nullptr);
 
 // ---- launchers (kernels_nmft.hip)
 int k_nmft_freq(dsm_ctx *c);

@@ -390,6 +390,9 @@ __global__ __launch_bounds__(256) void stats_kernel(const int2 *__restrict__ ite
 // own single-workgroup kernel or as one extra workgroup of the NEXT iteration's
 // dirichlet launch (it only needs data that launch order already guarantees).
 // =====================================================================
+#ifndef DSM_NT_RARE
+#define DSM_NT_RARE 0.01f     /* a haplotype whose abundance is at most this in every sample is "rare": its steps take the near-tie screen first */
+#endif
 struct FinalParams {
     const double *ll_partial; int nblocks;
     double ll_const, tau_prior;
@@ -408,6 +411,9 @@ struct FinalParams {
     uint32_t *screen_ctl;         // [0] sweeps still to run without the screening pass
     uint32_t *blk_order;          // [nblocks] out (or null): the order the next sweep of this parity runs its blocks in -- those first that
                                   // left a step to the fp64 code in the finalized one (tau_body: `order`)
+    int *rare_out; int G;         // stand-alone launch at the end of a Gibbs call (or null): how many haplotypes of the finalized state are rare in
+                                  // every sample (gamma_rare_kernel's count), written straight to the host's pinned word -- what the NEXT call's
+                                  // choice of sweep instantiation goes by; as its own launch + copy + clear it was 15 us of every call
 };
 
 __device__ void finalize_body(const FinalParams &p, double *red, double *redp, int *flag, int tid, int nthr)
@@ -498,6 +504,18 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalParams p)
     __shared__ double red[256], redp[256];
     __shared__ int flag;
     finalize_body(p, red, redp, &flag, threadIdx.x, 256);
+    if (p.rare_out) {                                     // (gamma_rare_kernel's count on the finalized state's abundances)
+        __syncthreads();
+        if (threadIdx.x == 0) flag = 0;
+        __syncthreads();
+        for (int g = threadIdx.x; g < p.G; g += 256) {
+            double m = 0.0;
+            for (int s = 0; s < p.S; ++s) m = fmax(m, p.gamma_src[(size_t)s * p.G + g]);
+            if ((float)m <= (float)DSM_NT_RARE) atomicAdd(&flag, 1);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) *p.rare_out = flag;
+    }
 }
 
 // =====================================================================
@@ -674,9 +692,7 @@ struct TauParams {
 #define TAU_LEAN(LPV, NSL) ((LPV) >= 32 && ((NSL) == 3 || (NSL) == 6 || (NSL) == 8))
 #endif
 #endif
-#ifndef DSM_NT_RARE
-#define DSM_NT_RARE 0.01f     /* a haplotype whose abundance is at most this in every sample is "rare": its steps take the near-tie screen first */
-#endif
+
 // NT: the instantiation with the near-tie screen (dsm_device.h: sweep_neartie_core) for chains that carry haplotypes rare in every
 // sample -- chosen per call by k_tau_sweep from the chain's own abundances (dsm_host.h: tau_neartie_on).  Both instantiations make the
 // draws of the fp64 code, so which one runs is a matter of speed only.
@@ -1218,6 +1234,7 @@ static FinalParams make_final(dsm_ctx *c, int nblocks, int it, int star_mode, co
     p.step_cnt = c->step_cnt + (size_t)slot * 2 * DSM_MAX_GRID; p.sweep_stats = c->sweep_stats; p.screen_ctl = c->screen_ctl + slot;
     static const bool order_on = !(getenv("DESMAN_HIP_TAU_ORDER") && atoi(getenv("DESMAN_HIP_TAU_ORDER")) == 0);      // A/B switch
     p.blk_order = nullptr;
+    p.rare_out = nullptr; p.G = c->G;
     // (a launch whose workgroups are all resident at once has no tail to move the long steps out of: the order is left alone and the finalize
     // step stays short -- at config 2 it rides in a 8 us Dirichlet launch)
     if (order_on && c->blk_order && nblocks > 0 && nblocks <= DSM_MAX_GRID) {
@@ -1506,10 +1523,11 @@ int k_shard_unpack(dsm_ctx *c)
 }
 
 int k_finalize(dsm_ctx *c, int nblocks, int it, int star_mode, const double *prior, const double *gamma_src,
-               const double *eta_src, int slot)
+               const double *eta_src, int slot, int *rare_out)
 {
     KTimer tm(c, DSM_K_FINAL);
-    const FinalParams p = make_final(c, nblocks, it, star_mode, prior, gamma_src, eta_src, slot);
+    FinalParams p = make_final(c, nblocks, it, star_mode, prior, gamma_src, eta_src, slot);
+    p.rare_out = rare_out;
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, p);
     HIP_TRY(hipGetLastError());
     return DSM_OK;

@@ -348,6 +348,19 @@ def main():
         # 256 MB Infinity Cache, so the byte stream is MALL/L2 traffic, not HBM
         nmft["roofline"] = dict(bound="hbm", achieved=nmft["achieved_GBps"], peak=8000.0, unit="GB/s",
                                 frac=nmft["achieved_GBps"] / 8000.0)
+        # factorize_tau (gamma fixed: Init_NMFT.py:134-149, what the `-r` workflow runs over every position the sampler did not see):
+        # one fused pass per update -- a pass over F, tau read and written
+        _, g_fit = ctx.nmft_get()
+        ctx.nmft_set(tau0, g_fit)
+        ctx.nmft_factorize(max_iter=5, min_change=0.0, fix_gamma=True)      # warm
+        ctx.nmft_set(tau0, g_fit)
+        t0 = time.perf_counter()
+        n_ft, tr_ft = ctx.nmft_factorize(max_iter=n_nm, min_change=0.0, fix_gamma=True)
+        t_ft = time.perf_counter() - t0
+        ft_bytes = 4 * V * S * 8 + 2 * 4 * V * G * 8
+        nmft["factorize_tau"] = dict(iters=n_ft, ms_per_iter=1e3 * t_ft / max(n_ft, 1), div_last=float(tr_ft[-1]),
+                                     algorithmic_bytes_per_iter=ft_bytes,
+                                     achieved_GBps=ft_bytes / (t_ft / max(n_ft, 1)) / 1e9)
         ctx.nmft_set(tau0, gam0)
         ctx.nmft_factorize(max_iter=n_nm, min_change=0.0)
     tau_init = ctx.nmft_get_tau()

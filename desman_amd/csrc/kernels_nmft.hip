@@ -1304,6 +1304,7 @@ __global__ __launch_bounds__(64 * (8 / NCB) * NCB) void nmft_wide_kernel(NmftMfm
     double *__restrict__ tau = prm.tau, *__restrict__ partial = prm.partial;
     const double *__restrict__ ctl = prm.ctl, *__restrict__ log_tab = prm.log_tab;
     const int V = prm.V, S = prm.S, G = prm.G, adjust = prm.adjust, do_update = prm.do_update;
+    const bool gnum = prm.fix_gamma == 0;            // gamma fixed (factorize_tau): no gamma numerators, no row sums, the objective's partial alone
     extern __shared__ __attribute__((aligned(16))) char smem_w[];
     if (ctl[2] != 0.0) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
@@ -1424,7 +1425,7 @@ __global__ __launch_bounds__(64 * (8 / NCB) * NCB) void nmft_wide_kernel(NmftMfm
         for (int kb = 0; kb < KB; ++kb) a_new[kb] = tnew[n * GP + 4 * kb + q];
         double a_g[4];                                                          // A of the row contraction: tau_new[vv = q][e][g = n]
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { a_g[e] = (n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; h1 += a_g[e]; }
+        for (int e = 0; e < 4; ++e) { a_g[e] = (gnum && n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; h1 += a_g[e]; }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -1432,8 +1433,10 @@ __global__ __launch_bounds__(64 * (8 / NCB) * NCB) void nmft_wide_kernel(NmftMfm
             for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_new[kb], bgam[((cb * NT + t) * KB + kb) * 64 + lane], R, 0, 0, 0);
             const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
             const double4_t q2 = nm_tile_q2(ft, R, live[t], ltab, obj);
+            if (gnum) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
+            }
         }
         __syncthreads();                                                        // done with this trip's rows
     }
@@ -1448,7 +1451,7 @@ __global__ __launch_bounds__(64 * (8 / NCB) * NCB) void nmft_wide_kernel(NmftMfm
     }
     // gamma numerators: acc[t][e] is (g = 4 e + q, s = 16 tg + n) of this wavefront's columns; the quads in flight add up slot by slot
 #pragma unroll 1
-    for (int sl = 0; sl < NQ; ++sl) {
+    for (int sl = 0; gnum && sl < NQ; ++sl) {
         __syncthreads();
         if (slot == sl) {
 #pragma unroll
@@ -1464,11 +1467,11 @@ __global__ __launch_bounds__(64 * (8 / NCB) * NCB) void nmft_wide_kernel(NmftMfm
         }
     }
     __syncthreads();
-    for (int i = tid; i < G * S; i += NTHR) {
+    for (int i = tid; gnum && i < G * S; i += NTHR) {
         const int g = i / S, s2 = i % S;
         partial[(size_t)i * nblk + blockIdx.x] = red[(size_t)g * SPAD + s2];
     }
-    if (tid < G) {
+    if (gnum && tid < G) {
         double a = 0.0;
         for (int k = 0; k < NQ; ++k) a += h1w[k * GP + tid];
         partial[((size_t)G * S + tid) * nblk + blockIdx.x] = a;

@@ -35,8 +35,8 @@ def _table_bytes(flat, names, positions):
         return None
     if flat.dtype.kind == "f" and (flat.dtype != np.float64 or not np.isfinite(flat).all()):
         return None
-    if not all(type(n) is str and n and not any(c in n for c in ',"\r\n\0') for n in names):
-        return None
+    if not all(type(n) is str and n and n.isascii() and not any(c in n for c in ',"\r\n\0') for n in names):
+        return None                                       # (a non-ASCII contig name has no 'S' form: pandas writes it)
     n, nc = flat.shape
     if flat.dtype.kind == "f":                            # by bit pattern: 0.0 and -0.0 print differently
         inv, uniq = pd.factorize(np.ascontiguousarray(flat, dtype=np.float64).ravel().view(np.int64))

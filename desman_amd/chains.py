@@ -70,19 +70,30 @@ class WorkQueue:
         import threading
         self._lock = threading.Lock()
         self._n = 0
+        self._epoch = -1
         self._path, self._store, self._key = file_path, store, key
 
+    def begin(self):
+        """a new list of units (one per run_chains call; every rank makes the same calls in the same order): the counter
+        starts at 0 again -- its own 8 bytes of the file / its own key of the store, so a rank that is already in call k + 1
+        never takes numbers from call k's counter"""
+        with self._lock:
+            self._epoch += 1
+            self._n = 0
+
     def next(self):
+        epoch = max(self._epoch, 0)
         if self._store is not None:
-            return int(self._store.add(self._key, 1)) - 1
+            return int(self._store.add("%s/%d" % (self._key, epoch), 1)) - 1
         if self._path is not None:
             import fcntl
             import struct
             with self._lock, open(self._path, "r+b") as f:      # (the lock: flock is per open file description, threads share none here)
                 fcntl.flock(f, fcntl.LOCK_EX)
+                f.seek(8 * epoch)
                 raw = f.read(8)
                 n = struct.unpack("<q", raw)[0] if len(raw) == 8 else 0
-                f.seek(0)
+                f.seek(8 * epoch)
                 f.write(struct.pack("<q", n + 1))
                 f.flush()
                 os.fsync(f.fileno())
@@ -223,21 +234,28 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
     else:
         order = sorted(range(len(units)), key=lambda u: (-ucost[u], u))      # the same list on every rank
         n_mine = len(order)                                  # (an upper bound: what this rank could end up running)
+        queue.begin()
 
         def take():
             k = queue.next()
             return order[k] if k < len(order) else None
 
     done = []                                                # (chain id, record or exception), in order of completion
+    worker_errors = []                                       # what a worker thread died of outside a chain (the queue's carrier)
 
     def worker():
-        while True:
-            ui = take()
-            if ui is None:
-                return
-            res = unit(ui)
+        try:
+            while True:
+                ui = take()
+                if ui is None:
+                    return
+                res = unit(ui)
+                with take_lock:
+                    done.extend(res)
+        except BaseException as e:                           # noqa: BLE001 -- a thread must not die silently: see after the gather
+            log.error("worker thread of rank %d stopped: %s: %s", rank, type(e).__name__, e)
             with take_lock:
-                done.extend(res)
+                worker_errors.append(e)
 
     n_workers = max(1, min(int(concurrency), n_mine))
     if n_workers > 1:
@@ -276,6 +294,19 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
         rows = np.concatenate([o.cpu().numpy() for o in out], axis=0)
     rows = rows[~np.isnan(rows[:, 0])]
     rows = rows[np.argsort(rows[:, 0])]
+    # every chain exactly once -- after the gather, so that every rank reaches the collective and every rank sees the same hole.
+    # A unit a dead worker thread had taken (flock / store error in take()) is gone from the queue: its chains get failed
+    # records, model selection skips them, and the error is raised where it happened.
+    got = [int(r[0]) for r in rows]
+    if len(set(got)) != len(got):
+        raise RuntimeError("run_chains: chains gathered twice: %s" % sorted(c for c in set(got) if got.count(c) > 1))
+    missing = sorted(set(range(len(specs))) - set(got))
+    if missing:
+        log.error("run_chains: %d chain(s) ran nowhere (%s): failed records", len(missing), missing[:16])
+        rows = np.concatenate([rows, np.array([failed_record(c) for c in missing])], axis=0)
+        rows = rows[np.argsort(rows[:, 0])]
+    if worker_errors:
+        raise RuntimeError("run_chains: %d worker thread(s) of rank %d stopped outside a chain" % (len(worker_errors), rank)) from worker_errors[0]
     return [dict(zip(REC_FIELDS, r.tolist())) for r in rows]
 
 
@@ -433,13 +464,23 @@ def main(argv=None):
     frame = p.read_csv(args.variant_file, header=0, index_col=0)
     V, S = frame.shape[0], (frame.shape[1] - 1) // 4
     specs = sweep_specs(range(args.gmin, args.gmax + 1), args.reps, V, S, n_iter=args.no_iter)
-    queue = None
+    queue = queue_made = None
     if args.schedule == "queue" and world > 1:
         if comm is not None:
-            if not os.environ.get("DESMAN_SWEEP_QUEUE"):
-                launch._die("desman-sweep", "--schedule queue needs the launcher's counter file (DESMAN_SWEEP_QUEUE): start the ranks "
-                            "with `desman-sweep --gpus N` or `python -m desman_amd.launch`, or pass --schedule plan")
-            queue = WorkQueue(file_path=os.environ["DESMAN_SWEEP_QUEUE"])
+            qpath = os.environ.get("DESMAN_SWEEP_QUEUE")
+            if not qpath:
+                # ranks started by another launcher (python -m torch.distributed.run -m desman_amd.chains ...): no counter file
+                # was made for us.  One node, one file system: rank 0 makes it under a name every rank can form from the
+                # launch's rendezvous (address, port, run id), the communicator's barrier orders creation before first use.
+                import tempfile
+                qpath = queue_made = os.path.join(tempfile.gettempdir(), "desman_queue_%s_%s_%s" % (
+                    os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
+                    os.environ.get("TORCHELASTIC_RUN_ID", "none")))
+                if comm.rank == 0:
+                    with open(qpath, "wb") as f:
+                        f.write(b"\0" * 8)
+                comm.barrier()
+            queue = WorkQueue(file_path=qpath)
         else:
             from torch.distributed.distributed_c10d import _get_default_store
             queue = WorkQueue(store=_get_default_store())
@@ -459,6 +500,11 @@ def main(argv=None):
     if dist is not None:
         dist.destroy_process_group()
     if comm is not None:
+        if queue_made and comm.rank == 0:                  # (after the gather: nobody takes numbers any more)
+            try:
+                os.unlink(queue_made)
+            except OSError:
+                pass
         comm.close()
 
 

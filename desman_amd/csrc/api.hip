@@ -1320,6 +1320,7 @@ extern "C" int dsm_nmft_set(dsm_ctx *c, const double *tau, const double *gamma, 
     c->nG = G;
     c->nmft_blocks = nmft_grid(c);
     TRY(dev_alloc(&c->ntau, (size_t)V * 4 * G));
+    dev_free(&c->ntau2);                                  // sized by the previous G: factorize_tau's fused pass makes it again on first use
     TRY(dev_alloc(&c->ngam, (size_t)G * S));
     TRY(dev_alloc(&c->ngam_raw, (size_t)G * S));
     TRY(dev_alloc(&c->npart, (size_t)std::max(std::max(c->nmft_blocks, nmft_wave_grid(c)), nmft_use_mfma(c) ? std::max(nmft_mfma_grid(c, false), nmft_mfma_grid(c, true)) : 0) * ((size_t)G * S + G + 1)));

@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from desman_amd import chains
 
@@ -237,6 +238,30 @@ def test_work_queue_file_counter_over_processes_and_threads(tmp_path):
     assert sorted(got) == list(range(600))
     q = chains.WorkQueue()                                               # the in-process carrier
     assert [q.next() for _ in range(5)] == [0, 1, 2, 3, 4]
+
+
+def test_work_queue_serves_a_second_call_and_a_dead_worker_is_not_silent(tmp_path):
+    """(i) a second run_chains over the same queue gets its work (the counter belongs to the call: own 8 bytes of the
+    file / own key of the store); (ii) a worker thread that dies in take() (flock / store error) no longer yields a short gather in
+    silence: the chains it never ran come back as failed records and the error is raised"""
+    specs = chains.sweep_specs(range(2, 5), 2, V=100, S=8)
+    run = lambda sp: dict(G=sp["G"], seed=sp["seed"], G_final=sp["G"], lp_star=-1.0, mean_dev=2.0, iters=1)
+    qfile = tmp_path / "q"
+    qfile.write_bytes(b"\0" * 8)
+    for q in (chains.WorkQueue(), chains.WorkQueue(file_path=str(qfile))):
+        for _ in range(3):
+            recs = chains.run_chains(specs, run, queue=q, concurrency=2)
+            assert [int(r["chain"]) for r in recs] == list(range(len(specs))) and not any(r["failed"] for r in recs)
+
+    class Broken(chains.WorkQueue):
+        def next(self):
+            k = super().next()
+            if k == 2:
+                raise OSError("store went away")
+            return k
+
+    with pytest.raises(RuntimeError, match="worker thread"):
+        chains.run_chains(specs, run, queue=Broken(), concurrency=1)
 
 
 def test_cost_model_matches_the_round4_measurements():

@@ -749,6 +749,26 @@ def test_nmft_vs_oracle(ctx, V, S, G):
     assert np.array_equal(ctx.nmft_get_tau(), cbind.idx_to_onehot(cbind.nmft_get_tau(tc, G)))
 
 
+def test_factorize_tau_after_nmft_set_with_a_larger_rank_on_one_context(ctx):
+    """One context, nmft_set(G = 3) + factorize_tau, then nmft_set(G = 8) + factorize_tau: the fused pass's second tau buffer
+    follows the rank (it kept the first call's size: device writes past its end).  Both runs equal the oracle's."""
+    V, S = 600, 64
+    counts, _, _ = synth_counts(V, S, 8, seed=91)
+    ctx.set_counts(counts)
+    F = cbind.nmft_freq(counts)
+    for G in (3, 8, 2):
+        tau, gam = rn.nmft_random_initialize(np.random.RandomState(G), V, S, G)
+        ctx.nmft_set(tau, gam)
+        tc, gc = tau.copy(), gam.copy()
+        n_ref, tr_ref = cbind.nmft_factorize_tau(F, tc, gc, max_iter=31, min_change=1e-5)
+        n, tr = ctx.nmft_factorize(max_iter=31, min_change=1e-5, fix_gamma=True)
+        assert n == n_ref
+        np.testing.assert_allclose(tr, tr_ref, rtol=1e-9)
+        t, g = ctx.nmft_get()
+        np.testing.assert_allclose(t, tc, rtol=1e-6, atol=1e-12)
+        assert np.array_equal(g, gam)
+
+
 def test_chain_posterior_matches_reference_sampler_in_law(spec_ctx):
     """T1 parity at chain level: the HIP chain (counter-based mu/E, gamma, eta draws) and the oracle's
     RandomState-exact restatement of the reference's update() target the same posterior: posterior means of

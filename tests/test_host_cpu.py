@@ -154,6 +154,7 @@ def test_fast_haplotype_table_text_is_pandas_text(tmp_path):
         assert _table_bytes(flat, names, pos) == want
     ok = cases[1]
     assert _table_bytes(ok, ["a,b"] + names[1:], pos) is None                 # a name that needs quoting
+    assert _table_bytes(ok, ["contig_\u00e9"] + names[1:], pos) is None        # a non-ASCII name (raised UnicodeEncodeError: ADVICE r4)
     assert _table_bytes(ok, names, pos.astype(np.float64)) is None            # positions that are not integers
     assert _table_bytes(np.where(ok == 0, np.nan, 1.0), names, pos) is None   # missing values
     assert _table_bytes(rng.random((V, 300)), names, pos) is None             # too many distinct values to pay

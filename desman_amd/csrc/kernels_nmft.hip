@@ -870,26 +870,63 @@ __device__ __forceinline__ double fdiv(double a, double b)
 }
 // Q2 = F (/) max(R2, eps) and the objective terms of one 16-sample tile (Init_NMFT.py:152-156, du.elop), element e = base.
 // F is a count + 1 over a depth + 4, never zero: elop's zero test can only fire on R.  Lanes without a cell (padded samples,
-// variants past the end) carry F = 1, R = 0: their quotient 1 / eps is finite, meets a zero row of tau in the contraction that
-// follows (variants) or lands in a column nobody reads (samples), and is kept out of the objective by `live`.  The selects for
-// R < eps are taken only by a wavefront that holds such an element (with the adjustment on, tau >= eps and the columns of gamma sum
-// to one: never but in padded lanes); the operations on live elements and their order are those of the plain form.
+// variants past the end) carry some F of the table and R = 0: their quotient F / eps is finite, meets a zero row of tau in the
+// contraction that follows (variants) or lands in a column nobody reads (samples), and is kept out of the objective by `live`.
+//
+// Round 5: the tile is STRAIGHT-LINE code.  Rounds 2-4 tested every element for elop's rare cases (0 < R < eps divides by R itself;
+// a quotient outside the table logarithm's domain takes libm's) behind wave-uniform branches -- five basic-block ends per element,
+// an exposed LDS round trip per table look-up, the exec-mask bookkeeping of `if (live)`: 72 instructions per element, a third of
+// them scalar (profiles/r05_nmft_isa_counts.txt).  Now ONE test per tile -- a live lane with !(R >= eps), NaN included -- sends the
+// whole tile through the element-by-element code (nm_tile_q2_rare: never with the adjustment on, where tau >= eps and the columns of
+// gamma sum to one); the common path is four independent division / logarithm chains the scheduler interleaves, their table
+// look-ups in flight together.  The operations on live elements and their order are those of the element-by-element form: same bits.
+// log of any double without a call (libm's log as a callee costs the calling kernel its scratch-free register allocation): the table
+// logarithm where it applies, else subnormals rescaled by 2^64, log 0 = -inf, log of a negative number or NaN = NaN, log inf = inf
+__device__ __forceinline__ double nm_log_any(double x, const double2 *__restrict__ ltab)
+{
+    if (dsm_log_ok(x)) return dsm_log_core(x, ltab);
+    if (x > 0.0 && x < 0x1p-1022) return dsm_log_core(x * 0x1p64, ltab) - 64.0 * 0x1.62e42fefa39efp-1;
+    return x == 0.0 ? -__builtin_inf() : (x > 0.0 ? x : __builtin_nan(""));
+}
+// the element-by-element form of the tile (rounds 2-4), kept as a loop for the rare tile
+__device__ __forceinline__ double4_t nm_tile_q2_rare(const double4_t &ft, const double4_t &R, bool live, const double2 *__restrict__ ltab, double &obj)
+{
+    double4_t q2 = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int e = 0; e < 4; ++e) {
+        const double Re = e == 0 ? R[0] : e == 1 ? R[1] : e == 2 ? R[2] : R[3], fe = e == 0 ? ft[0] : e == 1 ? ft[1] : e == 2 ? ft[2] : ft[3];
+        const bool tiny = Re < DSM_EPS;
+        const double pa = tiny ? DSM_EPS : Re;
+        const double ratio = fdiv(fe, pa);
+        // elop divides by R itself when 0 < R < eps; nzd: the lanes without a cell have R = 0
+        const double qq = (tiny && Re != 0.0) ? fdiv(fe, nzd(Re)) : ratio;
+        q2[0] = e == 0 ? qq : q2[0]; q2[1] = e == 1 ? qq : q2[1]; q2[2] = e == 2 ? qq : q2[2]; q2[3] = e == 3 ? qq : q2[3];
+        const double o2 = obj + (fe * nm_log_any(ratio, ltab) - fe + pa);
+        obj = live ? o2 : obj;
+    }
+    return q2;
+}
 __device__ __forceinline__ double4_t nm_tile_q2(const double4_t &ft, const double4_t &R, bool live, const double2 *__restrict__ ltab,
                                                 double &obj)
 {
+    const bool ok = (R[0] >= DSM_EPS) & (R[1] >= DSM_EPS) & (R[2] >= DSM_EPS) & (R[3] >= DSM_EPS);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(live && !ok) != 0ull, 0)) {
+        return nm_tile_q2_rare(ft, R, live, ltab, obj);
+    }
     double4_t q2;
+    double term[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const bool tiny = R[e] < DSM_EPS;
-        const double pa = tiny ? DSM_EPS : R[e];
+        double pa;                                                              // max(R, eps) -- lanes without a cell: R = 0 -- as ONE instruction
+        asm("v_max_f64 %0, %1, %2" : "=v"(pa) : "v"(R[e]), "v"(DSM_EPS));       // (the builtin quiets a signalling NaN first: an instruction more)
         const double ratio = fdiv(ft[e], pa);
-        double qq = ratio;
-        // elop divides by R itself when 0 < R < eps (never with the adjustment on: tau >= eps and the gamma columns
-        // sum to one); a wave-uniform branch keeps that second division out of the common path
-        if (__builtin_amdgcn_ballot_w64(tiny && R[e] != 0.0) != 0ull) { if (tiny) qq = fdiv(ft[e], nzd(R[e])); }   // nzd: the lanes without a cell have R = 0
-        q2[e] = qq;
-        if (live) obj += ft[e] * dsm_log(ratio, ltab) - ft[e] + pa;
+        q2[e] = ratio;
+        term[e] = ft[e] * dsm_log_core(ratio, ltab) - ft[e] + pa;
     }
+    double o2 = obj;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o2 += term[e];
+    obj = live ? o2 : obj;
     return q2;
 }
 #define DSM_DPP_ROW_SHL4 0x104

@@ -1323,7 +1323,7 @@ extern "C" int dsm_nmft_set(dsm_ctx *c, const double *tau, const double *gamma, 
     dev_free(&c->ntau2);                                  // sized by the previous G: factorize_tau's fused pass makes it again on first use
     TRY(dev_alloc(&c->ngam, (size_t)G * S));
     TRY(dev_alloc(&c->ngam_raw, (size_t)G * S));
-    TRY(dev_alloc(&c->npart, (size_t)std::max(std::max(c->nmft_blocks, nmft_wave_grid(c)), nmft_use_mfma(c) ? std::max(nmft_mfma_grid(c, false), nmft_mfma_grid(c, true)) : 0) * ((size_t)G * S + G + 1)));
+    TRY(dev_alloc(&c->npart, (size_t)std::max(std::max(c->nmft_blocks, nmft_wave_grid(c)), std::max(nmft_wide_grid(c), nmft_use_mfma(c) ? std::max(nmft_mfma_grid(c, false), nmft_mfma_grid(c, true)) : 0)) * ((size_t)G * S + G + 1)));
     TRY(dev_alloc(&c->nstat, (size_t)G * S + 2 * G + 16));
     // reference layout tau[v + a*V][g] -> device layout [v][a][g]
     std::vector<double> t((size_t)V * 4 * G);
@@ -1479,7 +1479,7 @@ extern "C" int dsm_batch_nmft_factorize(dsm_ctx *const *ctxs, int K, int max_ite
             return DSM_ERR_ARG;
         }
         for (int j = 0; j < k; ++j) if (ctxs[j] == ctxs[k]) { dsm_set_error("batch: chain %d listed twice", k); return DSM_ERR_ARG; }
-        if (!nmft_use_mfma(b)) { dsm_set_error("batch: the matrix-core NMFT kernel does not apply to this shape (S <= 128, G <= 16)"); return DSM_ERR_UNSUPPORTED; }
+        if (!nmft_use_mfma(b) && !nmft_use_wide(b)) { dsm_set_error("batch: the matrix-core NMFT kernels do not apply to this shape (S <= 512, G <= 16)"); return DSM_ERR_UNSUPPORTED; }
     }
     dsm_ctx *const lead = ctxs[0];
     BIND(lead);
@@ -1503,26 +1503,27 @@ extern "C" int dsm_batch_nmft_factorize(dsm_ctx *const *ctxs, int K, int max_ite
 #define BTRY(expr) do { int _r = (expr); if (_r != DSM_OK) { (void)hipStreamSynchronize(lead->stream); restore(); return _r; } } while (0)
 #define BHIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { dsm_set_error("%s failed: %s", #expr, hipGetErrorString(_e)); (void)hipStreamSynchronize(lead->stream); restore(); return DSM_ERR_HIP; } } while (0)
     const int adjust = fix_gamma ? 0 : 1;
+    const bool fused = fix_gamma && nmft_use_mfma(lead);                  // (S > 128: nmft_split_kernel has no fused pass)
     auto ctl_of = [&](dsm_ctx *c) { return c->nstat + (size_t)G * S + 2 * G; };
     for (int k = 0; k < K; ++k) {                                  // per chain, once: control words, _adjustment, first statistics
         dsm_ctx *c = ctxs[k];
         BTRY(traces[k].alloc((size_t)max_iter + 1));
         c->ndiv_trace = traces[k];
-        c->nmft_fix_gamma = fix_gamma ? 2 : 0;          // gamma fixed: the fused pass (dsm_nmft_factorize; the batch is matrix-core only)
-        if (fix_gamma && !c->ntau2) BTRY(dev_alloc(&c->ntau2, (size_t)c->V * 4 * G));
+        c->nmft_fix_gamma = fused ? 2 : (fix_gamma ? 1 : 0);      // gamma fixed: the fused pass where the shape has one (dsm_nmft_factorize), else the two-half form without gamma numerators
+        if (fused && !c->ntau2) BTRY(dev_alloc(&c->ntau2, (size_t)c->V * 4 * G));
         BHIP(hipMemsetAsync(ctl_of(c), 0, 16 * sizeof(double), c->stream));
         if (adjust) BTRY(k_nmft_clamp(c));
     }
     g_batch.K = K;
-    if (!fix_gamma) for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_wave(ctxs[k], adjust, 0)); }
+    if (!fused) for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_wave(ctxs[k], adjust, 0)); }
     const int BATCH = 64;
     std::vector<double> h((size_t)K * 11, 0.0);
     for (int launched = 0; launched <= max_iter;) {
         for (int i = 0; i < BATCH && launched <= max_iter; ++i, ++launched) {
-            if (fix_gamma)                              // the fused pass first: its objective is what the control step tests
+            if (fused)                                  // the fused pass first: its objective is what the control step tests
                 for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_wave(ctxs[k], adjust, 1)); }
             for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_gamma(ctxs[k], max_iter, min_change, fix_gamma, adjust, launched & 1)); }
-            if (!fix_gamma)
+            if (!fused)
                 for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_nmft_wave(ctxs[k], adjust, 1)); }
         }
         for (int k = 0; k < K; ++k)
@@ -1536,7 +1537,7 @@ extern "C" int dsm_batch_nmft_factorize(dsm_ctx *const *ctxs, int K, int max_ite
     for (int k = 0; k < K; ++k) {
         const int done = (int)h[(size_t)k * 11 + 3];
         if (n_done) n_done[k] = done;
-        if (fix_gamma && h[(size_t)k * 11 + 10] != 0.0)          // an odd number of accepted candidates: the current rows are in the second buffer
+        if (fused && h[(size_t)k * 11 + 10] != 0.0)              // an odd number of accepted candidates: the current rows are in the second buffer
             BHIP(hipMemcpyAsync(ctxs[k]->ntau, ctxs[k]->ntau2, (size_t)ctxs[k]->V * 4 * G * sizeof(double), hipMemcpyDeviceToDevice, lead->stream));
         if (div_traces)
             BHIP(hipMemcpyAsync(div_traces + (size_t)k * ((size_t)max_iter + 1), traces[k], ((size_t)done + 1) * sizeof(double),

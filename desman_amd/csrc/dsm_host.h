@@ -244,6 +244,8 @@ int k_nmft_get_tau(dsm_ctx *c, uint64_t *d_packed);
 int nmft_grid(dsm_ctx *c);
 bool nmft_use_wave(const dsm_ctx *c);
 bool nmft_use_mfma(const dsm_ctx *c);
+bool nmft_use_wide(const dsm_ctx *c);                      // 128 < S <= 512: nmft_split_kernel
+int nmft_wide_grid(const dsm_ctx *c);
 int nmft_wave_grid(const dsm_ctx *c);
 int nmft_mfma_grid(const dsm_ctx *c, bool fix = false);     // up to four workgroups per CU (five for the fused pass of factorize_tau)
 int k_nmft_wave(dsm_ctx *c, int adjust, int do_update);

@@ -24,7 +24,12 @@
 
 #define NMFT_CTL(c) ((c)->nstat + (size_t)(c)->nG * (c)->S + 2 * (c)->nG)
 
-__device__ __forceinline__ double nzd(double x) { return x == 0.0 ? DSM_EPS : x; }   // du.elop
+// du.elop's zero rule: x == 0 ? eps : x.  eps = 2^-52 = 0x3CB00000'00000000 and a zero's low word is zero already, so one select on the high word does it
+__device__ __forceinline__ double nzd(double x)
+{
+    static_assert(DSM_EPS == 0x1p-52, "nzd: DSM_EPS is not 2^-52");
+    return __hiloint2double(x == 0.0 ? 0x3CB00000 : __double2hiint(x), __double2loint(x));
+}
 
 // F[v][a][s] = (x_vsa + 1) / (n_vs + 4)          (Init_NMFT.py:49-60)
 __global__ __launch_bounds__(256) void nmft_freq_kernel(const int32_t *__restrict__ cnt_vs, double *__restrict__ F,
@@ -801,7 +806,7 @@ int k_nmft_wide(dsm_ctx *c, int adjust, int do_update);
 int k_nmft_wave(dsm_ctx *c, int adjust, int do_update)
 {
     if (nmft_use_mfma(c)) return k_nmft_mfma(c, adjust, do_update);
-    if (nmft_use_wide(c) && !g_batch.K) return k_nmft_wide(c, adjust, do_update);
+    if (nmft_use_wide(c)) return k_nmft_wide(c, adjust, do_update);
     KTimer tm(c, do_update ? DSM_K_NMFT_B : DSM_K_NMFT_A);
     int nsl, gmax;
     if (!wave_shape(c, &nsl, &gmax)) { dsm_set_error("nmft_wave: unsupported shape"); return DSM_ERR_UNSUPPORTED; }
@@ -854,6 +859,17 @@ int k_nmft_get_tau(dsm_ctx *c, uint64_t *d_packed)
 // shapes run nmft_wave_kernel / the two-pass kernels.
 // ===========================================================================
 typedef double double4_t __attribute__((ext_vector_type(4)));
+#ifdef DSM_AB_SWITCHES           // phase clocks of the update kernel's quad loop (experiment build only; DESMAN_HIP_NMFT_STAMPS=1 prints them per launch)
+__device__ unsigned long long nm_dbg[12];
+#define NM_CLK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); nm_dbg[k] += _t - nm_t; nm_t = _t; } } while (0)
+#define NM_CLK0() unsigned long long nm_t = __builtin_amdgcn_s_memtime()
+#define NM_CLKQ() do { if (blockIdx.x == 0 && threadIdx.x == 0) nm_dbg[7] += 1; } while (0)
+#else
+#define NM_CLK(k) do { } while (0)
+#define NM_CLK0() do { } while (0)
+#define NM_CLKQ() do { } while (0)
+#endif
+#define NM_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z)
 
 // a / b for the operands of the update (positive, far from the ends of the exponent range): hardware reciprocal, one
 // Newton step, one residual correction -- 6 instructions / ~40 issue cycles instead of the 11 / ~80 of the IEEE expansion
@@ -861,6 +877,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // rounded); the factors stay within the 1e-7 of the reference goldens after 100 updates that the tests ask for.
 __device__ __forceinline__ double fdiv(double a, double b)
 {
+
     // v_rcp_f64 is good to ~2^-23; one Newton step makes 2^-46, and the residual correction of the QUOTIENT below is itself a
     // Newton step on it (its error is the product of r's and q's: 2^-92) -- a second step on r (rounds 2-3) bought nothing
     double r = __builtin_amdgcn_rcp(b);
@@ -1007,17 +1024,17 @@ __device__ __forceinline__ double4_t nm_num_tile(double4_t num, const double4_t 
     const double2 hi = *reinterpret_cast<const double2 *>(xq + n * NM_XS + 4 * q + 2);
     __builtin_amdgcn_wave_barrier();
     const double *bl = graw_t + (n < GP ? n : GP - 1) * LDG + 4 * q;          // B_j[k = q][g = n] = gamma_raw[g][16 t + 4 k + j]
-    num = __builtin_amdgcn_mfma_f64_16x16x4f64(lo.x, bl[0], num, 0, 0, 0);
-    num = __builtin_amdgcn_mfma_f64_16x16x4f64(lo.y, bl[1], num, 0, 0, 0);
-    num = __builtin_amdgcn_mfma_f64_16x16x4f64(hi.x, bl[2], num, 0, 0, 0);
-    num = __builtin_amdgcn_mfma_f64_16x16x4f64(hi.y, bl[3], num, 0, 0, 0);
+    num = NM_MFMA(lo.x, bl[0], num, 0, 0, 0);
+    num = NM_MFMA(lo.y, bl[1], num, 0, 0, 0);
+    num = NM_MFMA(hi.x, bl[2], num, 0, 0, 0);
+    num = NM_MFMA(hi.y, bl[3], num, 0, 0, 0);
     return num;
 }
 
 // the tau rows of the quad from their numerators (Init_NMFT.py:171-181, :88-91): lane (g = n, vv = q) holds the four bases
 template <int KB, bool TO_GLOBAL>
 __device__ __forceinline__ void nm_tau_finish(const double4_t &num, const double *told, double *tnew, const double *t1, int G, int n, int q,
-                                              int adjust, bool vok, double *tau_v /* tau + (v0 + q) * 4 * G, or null */)
+                                              int adjust, bool store, bool vok, double *tau_v /* tau + (v0 + q) * 4 * G, or null */)
 {
     constexpr int GP = 4 * KB;
     const bool okg = n < G;
@@ -1030,7 +1047,7 @@ __device__ __forceinline__ void nm_tau_finish(const double4_t &num, const double
         for (int e = 0; e < 4; ++e) {
             double x = fdiv(tn[e], tot);                                                                                   // :180-181
             if (adjust && x < DSM_EPS) x = DSM_EPS;                                                                        // :88-91
-            if (TO_GLOBAL && vok) tau_v[(size_t)e * G + n] = x;
+            if (TO_GLOBAL && store) tau_v[(size_t)e * G + n] = x;
             tnew[(4 * e + q) * GP + n] = vok ? x : 0.0;
         }
     }
@@ -1060,6 +1077,12 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
     const double *__restrict__ ctl = prm.ctl, *__restrict__ log_tab = prm.log_tab;
     const int V = prm.V, S = prm.S, G = prm.G, adjust = prm.adjust, do_update = prm.do_update;
     const bool gnum = !FIXF && prm.fix_gamma == 0;                              // the gamma numerators and row sums are wanted
+    // VC (round 5): up to four haplotypes on wide tables -- the two contractions that contract to or from HAPLOTYPES (tau numerators, gamma
+    // numerators) on the vector ALU.  A 16 x 16 x 4 matrix instruction fills 4 of its 16 columns there, costs ~75 cycles of the SIMD's fp64
+    // datapath all the same and overlaps no fp64 vector work (scripts/ubench/mfma_f64_rate.hip): 16 v_fma_f64 per tile do the useful
+    // quarter in 69.  R = tau . gamma (K = 4: no waste) stays on the matrix cores.
+    constexpr bool VC = !FIXF && KB == 1 && (NT == 5 || NT == 6);
+    constexpr bool PF = KEEPF && (NT == 5 || NT == 6);                          // the quad loop that looks ahead (below)
     constexpr bool fusedfix = FIXF;                                             // gamma fixed: one pass per update (NmftMfmaParams)
     extern __shared__ __attribute__((aligned(16))) char smem_m[];
     if (ctl[2] != 0.0) return;
@@ -1081,14 +1104,40 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
     double *red = reinterpret_cast<double *>(smem_m);                           // [4][GP + 2][SPAD] end-of-kernel reduction: takes the place
                                                                                 // of everything above once the quads are done (at S = 96, G = 12 its
                                                                                 // 43 KB on top of the rest made 87 KB = ONE workgroup per CU)
-    ltab[tid] = reinterpret_cast<const double2 *>(log_tab)[tid];
-    if constexpr (FIXF) nm_stage_gamma_p(ggam_p, ggam_p, gam, gam, GP, LDG, G, S, tid, 256);
-    else nm_stage_gamma_p(graw_p, ggam_p, gam_raw, gam, GP, LDG, G, S, tid, 256);
-    for (int g = wv; g < GP; g += 4) {                                          // gamma.sum(1) (:170), lane-parallel
-        double a = 0.0;
-        for (int s = lane; s < SPAD; s += 64) a += (g < G && s < S) ? (fusedfix ? gam : gam_raw)[(size_t)g * S + s] : 0.0;
-        a = group_allreduce_sum<64>(a);
-        if (lane == 0) t1[g] = a;
+#ifdef DSM_AB_SWITCHES
+    const unsigned long long nm_r0 = __builtin_amdgcn_s_memrealtime(), nm_m0 = __builtin_amdgcn_s_memtime();
+#endif
+    {
+        // operands of the whole launch: every load of a thread is issued before its first store (round 5: the staging loop and the row
+        // sums' own global reads were 9 400 cycles of a launch's start, one exposed latency after the other); the row sums
+        // gamma.sum(1) (:170) are then taken from the staged matrix -- the same numbers in the same order, lane-strided + butterfly
+        constexpr int NST = (GP * LDG + 255) / 256;
+        double gr[FIXF ? 1 : NST], gg[NST];
+        const double2 lt = reinterpret_cast<const double2 *>(log_tab)[tid];
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int i = tid + 256 * j, g = i / LDG, sidx = i - g * LDG;
+            const bool in = i < GP * LDG && g < G && sidx < S;
+            if constexpr (!FIXF) gr[j] = in ? gam_raw[(size_t)g * S + sidx] : 0.0;
+            gg[j] = in ? gam[(size_t)g * S + sidx] : 0.0;
+        }
+        ltab[tid] = lt;
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int i = tid + 256 * j;
+            if (i < GP * LDG) {
+                if constexpr (!FIXF) graw_p[i] = gr[j];
+                ggam_p[i] = gg[j];
+            }
+        }
+        __syncthreads();
+        const double *src = fusedfix ? ggam_p : graw_p;
+        for (int g = wv; g < GP; g += 4) {
+            double a = 0.0;
+            for (int s = lane; s < SPAD; s += 64) a += src[g * LDG + s];
+            a = group_allreduce_sum<64>(a);
+            if (lane == 0) t1[g] = a;
+        }
     }
     __syncthreads();
 
@@ -1098,8 +1147,126 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
     for (int t = 0; t < NT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
     double obj = 0.0, h1 = 0.0;
 
+    // ---- a quad's work: the tau half of the running update and the statistics of the next (or, gamma fixed, the fused pass), on F tiles
+    // handed in by tile(t); used(t) runs when tile t has been read for the last time, rows_read() when the quad's old tau rows have
     const int nquad = (V + 3) >> 2;
+    NM_CLK0();
+#ifdef DSM_AB_SWITCHES
+    if (blockIdx.x == 0 && threadIdx.x == 0) nm_dbg[5] += nm_t - nm_m0;        // prologue
+#endif
+    auto quad_work = [&](auto tile, auto livef, auto used, auto rows_read, const int v0, const bool vok) __attribute__((always_inline)) {
+        if constexpr (fusedfix) {
+            // gamma fixed: objective of the current rows and the candidate rows of the next update from ONE product
+            double a_cur[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) a_cur[kb] = told[n * GP + 4 * kb + q];
+            double4_t num = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) R = NM_MFMA(a_cur[kb], ggam_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
+                const double4_t ft = tile(t);
+                const double4_t q2 = nm_tile_q2(ft, R, livef(t), ltab, obj);
+                used(t);
+                num = nm_num_tile<KB>(num, q2, xq, ggam_p + 16 * t, LDG, n, q);
+            }
+            nm_tau_finish<KB, true>(num, told, tnew, t1, G, n, q, adjust, vok, vok, tau_out + (size_t)(v0 + q) * 4 * G);
+            __builtin_amdgcn_wave_barrier();
+            rows_read();
+        } else {
+        if (do_update) {
+            double a_old[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) a_old[kb] = told[n * GP + 4 * kb + q];
+            double4_t num = (double4_t){0.0, 0.0, 0.0, 0.0};
+            double p[VC ? 16 : 1];                                               // VC: this lane's part of num[(e, vv = q)][g], value index 4 e + g
+#pragma unroll
+            for (int j = 0; j < (VC ? 16 : 1); ++j) p[j] = 0.0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) R = NM_MFMA(a_old[kb], graw_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
+                const double4_t ft = tile(t);
+                double4_t qv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qv[e] = fdiv(ft[e], nzd(R[e]));             // nm_tile_q2: F > 0; lanes without a cell stay finite
+                if constexpr (VC) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const double gm = graw_p[g * LDG + 16 * t + n];                  // gamma_raw[g][16 t + n] (zero rows past G)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) p[4 * e + g] = fma(qv[e], gm, p[4 * e + g]);
+                    }
+                } else {
+                    num = nm_num_tile<KB>(num, qv, xq, graw_p + 16 * t, LDG, n, q);
+                }
+            }
+            if constexpr (VC) {
+                // the 16 lanes of a variant add up (transposing butterfly: lane n ends with value 8 b0 + 4 b1 + 2 b3 + b2 = 4 e + g), then
+                // the update on (base e, haplotype g) pairs: the four bases of a (variant, haplotype) sit in one quad
+                const bool b0 = n & 1, b1 = n & 2, b2 = n & 4, b3 = n & 8;
+                const int my_e = (b0 ? 2 : 0) + (b1 ? 1 : 0), g = (b3 ? 2 : 0) + (b2 ? 1 : 0);
+                const double part = row16_transpose_reduce(p, n);
+                const bool okg = g < G;
+                const double tn = okg ? told[(4 * my_e + q) * GP + g] * fdiv(nzd(part), nzd(t1[okg ? g : 0])) : 0.0;      // :171-172
+                const double t_a0 = dpp_mov<0x00>(tn), t_a1 = dpp_mov<0xAA>(tn);              // e = 0 / 1 live in quad lanes 0 / 2
+                const double t_a2 = dpp_mov<0x55>(tn), t_a3 = dpp_mov<0xFF>(tn);              // e = 2 / 3            quad lanes 1 / 3
+                const double tot = ((t_a0 + t_a1) + t_a2) + t_a3;                              // :176-178
+                if (okg) {
+                    double x = fdiv(tn, tot);                                                  // :180-181
+                    if (adjust && x < DSM_EPS) x = DSM_EPS;                                    // :88-91
+                    if (vok) tau[((size_t)(v0 + q) * 4 + my_e) * G + g] = x;
+                    tnew[(4 * my_e + q) * GP + g] = vok ? x : 0.0;
+                }
+            } else {
+                nm_tau_finish<KB, true>(num, told, tnew, t1, G, n, q, adjust, vok, vok, tau + (size_t)(v0 + q) * 4 * G);
+            }
+            __builtin_amdgcn_wave_barrier();
+            rows_read();
+            NM_CLK(3);
+        }
+        // statistics of the (new) state: R2, objective, Q2, gamma numerators, H1
+        double a_new[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) a_new[kb] = tnew[n * GP + 4 * kb + q];
+        double a_g[4];                                                          // A of the row contraction: tau_new[vv = q][e][g = n]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a_g[e] = (gnum && n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; h1 += a_g[e]; }
+        double4_t tn16[VC ? 4 : 1];                                             // VC: the new rows of this lane's variant, [e][g]
+        if constexpr (VC) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tn16[e] = *reinterpret_cast<const double4_t *>(tnew + (4 * e + q) * GP);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) R = NM_MFMA(a_new[kb], ggam_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
+            double4_t q2;
+            const double4_t ft = tile(t);
+            q2 = nm_tile_q2(ft, R, livef(t), ltab, obj);
+            used(t);
+            if constexpr (VC) {
+                if (gnum) {                                                     // acc[t][g] += sum_e tau_new[vv = q][e][g] Q2[e]: this lane's variant
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) acc[t][g] = fma(tn16[e][g], q2[e], acc[t][g]);
+                }
+            } else if (gnum) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t] = NM_MFMA(a_g[e], q2[e], acc[t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        NM_CLK(4);
+        }       // (not the fused pass)
+    };
+    if constexpr (!PF) {
     for (int qd = blockIdx.x * 4 + wv; qd < nquad; qd += nblk * 4) {
+        NM_CLK(0); NM_CLKQ();
         const int v0 = qd * 4;
         const bool vok = v0 + q < V;                                            // this lane's variant exists
         // the 16 tau rows of the quad (contiguous in HBM: [vv][r][g]) -> LDS [i = 4 r + vv][g]
@@ -1109,8 +1276,8 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
             told[(4 * r + vv) * GP + g] = x;
             if (!do_update) tnew[(4 * r + vv) * GP + g] = x;
         }
-        // F in L2: f[t][e] = F[variant v0 + q][base e][16 t + n]; kept in registers for both halves while NT <= 4,
-        // re-read (L2) by the second half for wider sample ranges
+        // F in L2: f[t][e] = F[variant v0 + q][base e][16 t + n]; kept in registers for both halves while NT <= 3,
+        // re-read (L2) by the second half at four, seven and eight tiles
         double4_t f[KEEPF ? NT : 1];
         bool live[NT];
         auto load_f = [&](int t) {
@@ -1125,75 +1292,103 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
             if constexpr (KEEPF) f[t] = load_f(t);
         }
         __builtin_amdgcn_wave_barrier();
-        if constexpr (fusedfix) {
-            // gamma fixed: objective of the current rows and the candidate rows of the next update from ONE product
-            double a_cur[KB];
+        NM_CLK(1);
+        quad_work([&](int t) { return KEEPF ? f[KEEPF ? t : 0] : load_f(t); }, [&](int t) { return live[t]; }, [](int) {}, []() {}, v0, vok);
+    }
+    } else {
+    // ---- five and six tiles (round 5): the loop that looks ahead.  Measured with the phase clocks of the experiment build
+    // (profiles/r05_nmft_phase_clocks.txt, one wavefront per SIMD, 50k x 96 x 12): of a quad's 21 000 cycles 4 300 went by at the TOP of
+    // the round -- the old tau rows fetched and staged with their latency exposed, 24 exec-masked loads with 64-bit vector address
+    // arithmetic each -- and 1 100 more waiting for the first F tile.  Now: (i) the next quad's tau rows are fetched at the start of the
+    // round and staged the moment this quad's have been read for the last time; (ii) tile t of the next quad is loaded into the
+    // registers tile t of this one has just left (the statistics half / the fused pass reads each tile once more and last); (iii) an
+    // address is a wave-uniform base (the quad's first row) + a 32-bit lane offset, no branch, no select: lanes without a cell read a
+    // cell that exists (the last variant, the last sample) -- R = 0 there and any finite F will do (nm_tile_q2).
+    const int qstride = nblk * 4;
+    int qd = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+    const uint32_t rowb = (uint32_t)S * 8u;
+    uint32_t so[NT];                                                            // byte offset of this lane's sample in tile t
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) a_cur[kb] = told[n * GP + 4 * kb + q];
-            double4_t num = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < NT; ++t) so[t] = (uint32_t)min(16 * t + n, S - 1) * 8u;
+    const bool slive_last = 16 * (NT - 1) + n < S;
+    auto f_off = [&](int qd_) -> uint32_t { return (uint32_t)min(q, V - 1 - 4 * qd_) * 4u * rowb; };      // variants past the end read the last one
+    auto load_tile = [&](int qd_, uint32_t off, int t) -> double4_t {
+        const char *base = reinterpret_cast<const char *>(F) + (size_t)qd_ * 16 * S * 8;
+        double4_t x;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
+        for (int e = 0; e < 4; ++e) x[e] = *reinterpret_cast<const double *>(base + (size_t)(off + (uint32_t)e * rowb + so[t]));
+        return x;
+    };
+    constexpr int TPRE = (16 * GP + 63) / 64;
+    int tk_src[TPRE], tk_vv[TPRE], tk_dst[TPRE];                                // value k = lane + 64 i of a quad's rows: where it is read, its variant, where it goes
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[kb], ggam_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
-                const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
-                const double4_t q2 = nm_tile_q2(ft, R, live[t], ltab, obj);
-                num = nm_num_tile<KB>(num, q2, xq, ggam_p + 16 * t, LDG, n, q);
-            }
-            nm_tau_finish<KB, true>(num, told, tnew, t1, G, n, q, adjust, vok, tau_out + (size_t)(v0 + q) * 4 * G);
-            __builtin_amdgcn_wave_barrier();
-        } else {
-        if (do_update) {
-            double a_old[KB];
+    for (int i = 0; i < TPRE; ++i) {
+        const int k = lane + 64 * i;
+        const int kc = k < 16 * G ? k : 16 * G - 1;
+        const int vv = kc / (4 * G), r = (kc / G) & 3, g = kc % G;
+        tk_src[i] = kc; tk_vv[i] = vv;
+        tk_dst[i] = k < 16 * G ? (4 * r + vv) * GP + g : -1;
+    }
+    auto tau_fetch = [&](int qd_, double (&tp)[TPRE]) {
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) a_old[kb] = told[n * GP + 4 * kb + q];
-            double4_t num = (double4_t){0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < TPRE; ++i) tp[i] = (4 * qd_ + tk_vv[i] < V) ? tau_in[(size_t)qd_ * 16 * G + tk_src[i]] : 0.0;
+    };
+    auto tau_stage = [&](const double (&tp)[TPRE]) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_old[kb], graw_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
-                const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
-                double4_t qv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) qv[e] = fdiv(ft[e], nzd(R[e]));             // nm_tile_q2: F > 0; lanes without a cell stay finite
-                num = nm_num_tile<KB>(num, qv, xq, graw_p + 16 * t, LDG, n, q);
-            }
-            nm_tau_finish<KB, true>(num, told, tnew, t1, G, n, q, adjust, vok, tau + (size_t)(v0 + q) * 4 * G);
-            __builtin_amdgcn_wave_barrier();
-        }
-        // statistics of the (new) state: R2, objective, Q2, gamma numerators, H1
-        double a_new[KB];
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) a_new[kb] = tnew[n * GP + 4 * kb + q];
-        double a_g[4];                                                          // A of the row contraction: tau_new[vv = q][e][g = n]
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { a_g[e] = (gnum && n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; h1 += a_g[e]; }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_new[kb], ggam_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
-            double4_t q2;
-            const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
-            q2 = nm_tile_q2(ft, R, live[t], ltab, obj);
-            if (gnum) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
+        for (int i = 0; i < TPRE; ++i) {
+            if (tk_dst[i] >= 0) {
+                told[tk_dst[i]] = tp[i];
+                if (!do_update) tnew[tk_dst[i]] = tp[i];
             }
         }
+    };
+    if (qd < nquad) {
+        uint32_t off = f_off(qd);
+        double4_t f[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) f[t] = load_tile(qd, off, t);
+        const bool ahead = fusedfix || do_update;            // (the statistics-only launch, once per factorize, reads the rows to the end of its round: it stages there)
+        double tp[TPRE];
+        tau_fetch(qd, tp);
+        tau_stage(tp);
         __builtin_amdgcn_wave_barrier();
-        }       // (not the fused pass)
+        for (;;) {
+            NM_CLK(0); NM_CLKQ();
+            const int qn = qd + qstride;
+            const bool more = qn < nquad;
+            const int qp = more ? qn : qd;                                      // what is fetched ahead (after the last quad: itself again, from cache)
+            const uint32_t offp = f_off(qp);
+            const int v0 = qd * 4;
+            const bool vok = v0 + q < V;                                        // this lane's variant exists
+            const bool live_last = vok && slive_last;
+            if (ahead) tau_fetch(qp, tp);
+            NM_CLK(1);
+            quad_work([&](int t) { return f[t]; }, [&](int t) { return t == NT - 1 ? live_last : vok; },
+                      [&](int t) { f[t] = load_tile(qp, offp, t); }, [&]() { if (ahead) { tau_stage(tp); __builtin_amdgcn_wave_barrier(); } }, v0, vok);
+            if (!ahead) { tau_fetch(qp, tp); tau_stage(tp); __builtin_amdgcn_wave_barrier(); }
+            if (!more) break;
+            qd = qn;
+            off = offp;
+        }
+    }
     }
     // workgroup reduction over the 4 wavefronts (fixed order) -> transposed partials.  acc[t][e]: g = 4 e + q, s = 16 t + n
+    NM_CLK(0);
     __syncthreads();
     if (gnum) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int g = 4 * e + q;
-                if (g < GP) red[((size_t)wv * (GP + 2) + g) * SPAD + 16 * t + n] = acc[t][e];
+                if constexpr (VC) {                                              // element = haplotype, this lane's variant: the four variants add up
+                    double a = acc[t][e];
+                    a += __shfl_xor(a, 16, 64);
+                    a += __shfl_xor(a, 32, 64);
+                    if (q == 0) red[((size_t)wv * (GP + 2) + e) * SPAD + 16 * t + n] = a;
+                } else {
+                    const int g = 4 * e + q;
+                    if (g < GP) red[((size_t)wv * (GP + 2) + g) * SPAD + 16 * t + n] = acc[t][e];
+                }
             }
     }
     // objective: one value per lane; H1: lane (n = g, q) holds the sum over bases and this lane's variants of tau_new[.][g]
@@ -1206,11 +1401,13 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
         if (gnum && lane < GP) red[((size_t)wv * (GP + 2) + GP + 1) * SPAD + lane] = hh;
     }
     __syncthreads();
-    for (int i = tid; gnum && i < G * S; i += 256) {
-        const int g = i / S, s = i % S;
-        double a = 0.0;
-        for (int k = 0; k < 4; ++k) a += red[((size_t)k * (GP + 2) + g) * SPAD + s];
-        partial[(size_t)i * nblk + blockIdx.x] = a;
+    for (int i = tid; gnum && i < GP * SPAD; i += 256) {                        // (walks the padded tile: the divisions are by constants)
+        const int g = i / SPAD, s = i - g * SPAD;
+        if (g < G && s < S) {
+            double a = 0.0;
+            for (int k = 0; k < 4; ++k) a += red[((size_t)k * (GP + 2) + g) * SPAD + s];
+            partial[((size_t)g * S + s) * nblk + blockIdx.x] = a;
+        }
     }
     if (gnum && tid < G) {
         double a = 0.0;
@@ -1222,18 +1419,30 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
         for (int k = 0; k < 4; ++k) a += red[FIXF ? (size_t)k : ((size_t)k * (GP + 2) + GP) * SPAD];
         partial[((size_t)G * S + G) * nblk + blockIdx.x] = a;
     }
+#ifdef DSM_AB_SWITCHES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NM_CLK(8);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { nm_dbg[9] += __builtin_amdgcn_s_memrealtime() - nm_r0; nm_dbg[10] += __builtin_amdgcn_s_memtime() - nm_m0; }
+#endif
 }
 
 constexpr int nmft_mfma_wgs(int NT, int KB)
 {
     // ((3, 2) and (4, 3) need 129 registers: at four wavefronts per SIMD they would spill one -- and a kernel with scratch pays its
     // first launch ~120 us for the allocation)
-    return NT <= 4 ? ((KB <= 3 && !(NT == 3 && KB == 2) && !(NT == 4 && KB == 3)) ? 4 : 3) : (KB <= 3 ? 3 : 2);
+#ifdef NM_WGS56
+    if (NT >= 5) return NM_WGS56;
+#endif
+    // five tiles and more: two (256 registers: the loop that looks ahead holds the next quad's rows and addresses too; measured at
+    // 50k x 96 x 12 before it: 101.7 us per update at two against 106.6 at three with 22 registers spilled)
+    // up to four tiles: four where 128 registers hold the kernel without scratch (round 5, with the statistics tile as straight-line code: not at
+    // (3, 1), (3, 2), (3, 3), (4, 2), (4, 3)), else three
+    return NT <= 4 ? ((KB <= 3 && NT <= 2) || (NT == 4 && KB == 1) ? 4 : 3) : 2;    // (five / six tiles, up to four haplotypes: the VC form holds 16 + 16 more values)
 }
 
 // the fused pass of factorize_tau (no gamma numerators in registers, one gamma matrix and a four-word reduction in LDS): one
 // workgroup per CU more
-constexpr int nmft_mfma_fix_wgs(int NT, int KB) { return NT <= 4 ? (KB <= 3 ? 5 : 4) : (KB <= 3 ? 4 : 3); }
+constexpr int nmft_mfma_fix_wgs(int NT, int KB) { return NT <= 4 ? ((KB <= 3 && !(NT == 3 && KB >= 2)) ? 5 : 4) : 3; }      // (five / six tiles: the loop that looks ahead)
 static bool mfma_shape(const dsm_ctx *c, int *nt, int *kb)
 {
     *nt = (c->S + 15) / 16;
@@ -1255,7 +1464,9 @@ int nmft_mfma_grid(const dsm_ctx *c, bool fix)
     (void)mfma_shape(c, &nt, &kb);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) cus = 256;
     // (a context's partial table is laid out for the larger of the two grids: dsm_nmft_set asks with fix = true)
-    const int cap = (fix ? nmft_mfma_fix_wgs(nt, kb) : nmft_mfma_wgs(nt, kb)) * cus;
+    int cap = (fix ? nmft_mfma_fix_wgs(nt, kb) : nmft_mfma_wgs(nt, kb)) * cus;
+    static const int wgs_env = DSM_AB_ENV("DESMAN_HIP_NMFT_WGS") ? atoi(DSM_AB_ENV("DESMAN_HIP_NMFT_WGS")) : 0;       // A/B switch: fewer resident workgroups per CU
+    if (wgs_env > 0 && wgs_env * cus < cap) cap = wgs_env * cus;
     if (g > cap) g = cap;
     return g < 1 ? 1 : g;
 }
@@ -1314,29 +1525,55 @@ int k_nmft_mfma(dsm_ctx *c, int adjust, int do_update)
 #undef MCASE
     HIP_TRY(hipGetLastError());
     c->npart_cols = grid;
+#ifdef DSM_AB_SWITCHES
+    if (DSM_AB_ENV("DESMAN_HIP_NMFT_STAMPS") && do_update) {
+        static int calls = 0;
+        unsigned long long h[12];
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(nm_dbg), sizeof h));
+        if (++calls == 20 && h[7]) {
+            const double qn = (double)h[7];
+            fprintf(stderr, "nmft_mfma quad loop, workgroup 0 wavefront 0, cycles per quad over %.0f quads: top+issue %.0f | load wait %.0f | tau half %.0f | statistics %.0f | loop %.0f\n",
+                    qn, h[1] / qn, h[2] / qn, h[3] / qn, h[4] / qn, h[0] / qn);
+            fprintf(stderr, "   whole kernel (that wavefront): %llu cycles = %.1f us (s_memrealtime), i.e. %.0f MHz; prologue %llu, epilogue (reduction + partials) %llu cycles\n",
+                    h[10], h[9] / 100.0, h[9] ? 100.0 * (double)h[10] / (double)h[9] : 0.0, h[5], h[8]);
+        }
+        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, (unsigned long long)(atoi(DSM_AB_ENV("DESMAN_HIP_NMFT_STAMPS")) > 1), 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(nm_dbg), z, sizeof z));
+    }
+#endif
     return DSM_OK;
 }
 
 // ===========================================================================
-// nmft_wide_kernel: the update of nmft_mfma_kernel for tables wider than eight sample tiles (128 < S <= 512), which the VALU
-// kernels ran at a third to a ninth of the matrix-core kernel's rate per element (profiles/r03_nmft_shape_scan.txt).
+// nmft_split_kernel (round 5; takes the place of round 3's nmft_wide_kernel): the update of nmft_mfma_kernel for tables wider than
+// eight sample tiles (128 < S <= 512).
 //
-// A wavefront cannot hold more than eight tiles of per-sample state, so a quad of variants is shared by NCB wavefronts, each
-// owning a block of NT consecutive sample tiles (tile tg = cb NT + t): everything per sample -- R', Q', R2, Q2, the objective
-// terms, the gamma numerators of its columns -- is the narrow kernel's code on the block.  The one quantity that crosses blocks
-// is the tau numerator num[row][g] = sum over ALL samples: every wavefront leaves its block's part in LDS, a barrier, and every
-// wavefront of the quad adds the NCB parts in block order and runs the (tiny) tau update for itself; block 0 stores it.  A
-// workgroup keeps NQ = 8 / NCB quads in flight (eight wavefronts = two per SIMD, what the registers allow) and ONE copy of the
-// two operand layouts of gamma for all of them -- 128 KB at S = 512, G = 16 -- so it is one workgroup per CU.
-// Statistics: a wavefront owns its columns' gamma numerators outright; the NQ quads in flight are added slot by slot through one
-// [GP][SPAD] buffer that takes the operands' place at the end.  Same partial layout as the other update kernels: the reduce /
-// gamma / control launches are shared.  No batched form: replicate chains of such a table run one by one.
+// A wavefront cannot hold more than eight tiles of per-sample state, so a quad of variants is SHARED by NCB = 4 wavefronts, each
+// owning a block of NT consecutive sample tiles (tile tg = cb NT + t): everything per sample -- R', Q', R2, Q2, the objective terms,
+// the gamma numerators of its columns -- is the narrow kernel's code on the block, in its round-5 form: tau numerators on the matrix
+// cores through the per-wavefront transposition tile (nm_num_tile; round 3's wide kernel ran them on the vector ALU with a butterfly
+// per K-block), ONE zero-padded gamma matrix per factor for every contraction that reads it (was: two fragment-ordered copies), the
+// statistics tile as straight-line code (nm_tile_q2), F addressed by a wave-uniform base + a 32-bit lane offset with clamped rows /
+// samples instead of exec-masked loads, and tile t of the NEXT quad loaded into the registers tile t of this one has just left.
+// 10k x 300 x 8 114 -> 75 us per update, 5k x 512 x 8 83 -> 74, 10k x 192 x 8 59 -> 52 (profiles/r05_nmft_split_ab.txt).
+//
+// What crosses blocks is the tau numerator num[row][g] = sum over ALL samples: every wavefront leaves its block's part in LDS,
+// ONE workgroup barrier per quad (round 3: three), and every wavefront of the quad adds the NCB parts in block order and runs the
+// (tiny) tau update for itself -- identical numbers in every block; block 0 stores them.  Everything else a block reads it wrote
+// itself or is written with identical values by its peers (the quad's tau rows: old rows in two buffers by quad parity, so that a
+// wavefront may stage the next quad's rows while a peer still reads this one's; new rows in one).  The exchange area doubles as
+// the transposition tile of nm_num_tile and alternates by quad parity for the same reason (XPAR; where LDS is short -- the widest
+// tables -- one buffer and a second barrier).
+// A workgroup is eight wavefronts = NQ = 8 / NCB quads in flight; every wavefront of it runs the same number of rounds (a slot
+// past the end works on a quad of absent variants).  Statistics: a wavefront owns its columns' gamma numerators outright; the NQ
+// quads in flight add up slot by slot through one [GP][SPAD] buffer that takes the operands' place at the end.  Same partial
+// layout as the other update kernels: the reduce / gamma / control launches are shared.  Batched entry: nmft_split_kernel_b.
 // ===========================================================================
-template <int NT, int KB, int NCB>
-__global__ __launch_bounds__(64 * (8 / NCB) * NCB) void nmft_wide_kernel(NmftMfmaParams prm)
+template <int NT, int KB, int NCB, bool XPAR>
+__device__ __forceinline__ void nmft_split_body(const NmftMfmaParams &prm)
 {
-    constexpr int NQ = 8 / NCB, NW = NQ * NCB, NTT = NT * NCB, GP = 4 * KB, SPAD = 16 * NTT, NTHR = 64 * NW;
-    constexpr bool KEEPF = NT <= 6;
+    constexpr int NQ = 8 / NCB, NW = 8, NTT = NT * NCB, GP = 4 * KB, SPAD = 16 * NTT, NTHR = 64 * NW, LDG = SPAD + 1;
     const double *__restrict__ F = prm.F, *__restrict__ gam_raw = prm.gam_raw, *__restrict__ gam = prm.gam;
     double *__restrict__ tau = prm.tau, *__restrict__ partial = prm.partial;
     const double *__restrict__ ctl = prm.ctl, *__restrict__ log_tab = prm.log_tab;
@@ -1344,27 +1581,23 @@ __global__ __launch_bounds__(64 * (8 / NCB) * NCB) void nmft_wide_kernel(NmftMfm
     const bool gnum = prm.fix_gamma == 0;            // gamma fixed (factorize_tau): no gamma numerators, no row sums, the objective's partial alone
     extern __shared__ __attribute__((aligned(16))) char smem_w[];
     if (ctl[2] != 0.0) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slot = wv / NCB, cb = wv % NCB, nblk = gridDim.x;
     double2 *ltab = reinterpret_cast<double2 *>(smem_w);                        // [256]
-    double *braw = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);            // [NTT][KB][64] B fragments of gamma_raw
-    double *bgam = braw + NTT * KB * 64;                                        // [NTT][KB][64] B fragments of gamma
-    double *t1 = bgam + NTT * KB * 64;                                          // [GP] rowsum(gamma_raw)
-    double *told = t1 + GP + slot * (2 * 16 * GP);                              // per quad in flight [16][GP], row i = 4 r + vv
-    double *tnew = told + 16 * GP;
-    double *nump = t1 + GP + NQ * (2 * 16 * GP) + slot * (NCB * 16 * GP);       // per quad in flight [NCB][16][GP]: the blocks' parts of num
-    double *objw = t1 + GP + NQ * (2 * 16 * GP) + NQ * (NCB * 16 * GP);         // [NW]
+    double *graw_p = reinterpret_cast<double *>(ltab + DSM_LOG_TAB_N);          // [GP][LDG] gamma_raw, zero-padded (nm_stage_gamma_p)
+    double *ggam_p = graw_p + GP * LDG;                                         // [GP][LDG] gamma
+    double *t1 = ggam_p + GP * LDG;                                             // [GP] rowsum(gamma_raw)
+    double *rows = t1 + GP + slot * (3 * 16 * GP);                              // per quad in flight: old rows x 2 (quad parity), new rows
+    double *tnew = rows + 2 * 16 * GP;
+    double *xall = t1 + GP + NQ * (3 * 16 * GP);                                // per wavefront [XPAR ? 2 : 1][NM_XQ]: transposition tile / part of num
+    constexpr int XW = (XPAR ? 2 : 1) * NM_XQ;
+    double *objw = xall + NW * XW;                                              // [NW]
     double *h1w = objw + NW;                                                    // [NQ][GP]
-    double *red = braw;                                                         // [GP][SPAD] at the end
+    double *red = graw_p;                                                       // [GP][SPAD] at the end
     for (int i = tid; i < DSM_LOG_TAB_N; i += NTHR) ltab[i] = reinterpret_cast<const double2 *>(log_tab)[i];
-    for (int i = tid; i < NTT * KB * 64; i += NTHR) {
-        const int l = i & 63, kb = (i >> 6) % KB, t = (i >> 6) / KB;
-        const int g = 4 * kb + (l >> 4), s2 = 16 * t + (l & 15);
-        const bool in = g < G && s2 < S;
-        braw[i] = in ? gam_raw[(size_t)g * S + s2] : 0.0;
-        bgam[i] = in ? gam[(size_t)g * S + s2] : 0.0;
-    }
-    for (int k = tid; k < NQ * 2 * 16 * GP; k += NTHR) t1[GP + k] = 0.0;        // told / tnew incl. the padded haplotype columns
+    nm_stage_gamma_p(graw_p, ggam_p, gam_raw, gam, GP, LDG, G, S, tid, NTHR);
+    for (int k = tid; k < NQ * 3 * 16 * GP; k += NTHR) t1[GP + k] = 0.0;        // the rows incl. the padded haplotype columns
     for (int g = wv; g < GP; g += NW) {                                         // gamma.sum(1) (:170), lane-parallel
         double a = 0.0;
         if (g < G) for (int s2 = lane; s2 < S; s2 += 64) a += gam_raw[(size_t)g * S + s2];
@@ -1377,84 +1610,109 @@ __global__ __launch_bounds__(64 * (8 / NCB) * NCB) void nmft_wide_kernel(NmftMfm
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
     double obj = 0.0, h1 = 0.0;
-    const bool b0 = n & 1, b1 = n & 2, b2 = n & 4, b3 = n & 8;
-    const int my_e = (b0 ? 2 : 0) + (b1 ? 1 : 0), my_gg = (b3 ? 2 : 0) + (b2 ? 1 : 0);
 
+    // F in L2 (nmft_mfma_kernel): f[t][e] = F[variant v0 + q][base e][16 tg + n].  Address = the quad's first row (wave-uniform) + a
+    // 32-bit lane offset; lanes without a cell read a cell that exists (the last variant, the last sample): R = 0 there, any finite
+    // F will do (nm_tile_q2).
     const int nquad = (V + 3) >> 2;
-    for (int qd0 = blockIdx.x * NQ; qd0 < nquad; qd0 += nblk * NQ) {           // every wavefront of the workgroup runs the same trips
-        const int v0 = (qd0 + slot) * 4;                                        // a slot past the end is a quad of absent variants
-        const bool vok = v0 + q < V;
-        for (int k = lane + 64 * cb; k < 16 * G; k += 64 * NCB) {
-            const int vv = k / (4 * G), r = (k / G) & 3, g = k % G;
-            const double x = (v0 + vv < V) ? tau[(size_t)v0 * 4 * G + k] : 0.0;
-            told[(4 * r + vv) * GP + g] = x;
-            if (!do_update) tnew[(4 * r + vv) * GP + g] = x;
-        }
-        double4_t f[KEEPF ? NT : 1];
-        bool live[NT];
-        auto load_f = [&](int t) {
-            double4_t x;
+    const int qstride = nblk * NQ;
+    const uint32_t rowb = (uint32_t)S * 8u;
+    uint32_t so[NT];                                                            // byte offset of this lane's sample in tile t of its block
+    bool slive[NT];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = live[t] ? F[((size_t)(v0 + q) * 4 + e) * S + 16 * (cb * NT + t) + n] : 1.0;
-            return x;
-        };
+    for (int t = 0; t < NT; ++t) {
+        const int s2 = 16 * (cb * NT + t) + n;
+        slive[t] = s2 < S;
+        so[t] = (uint32_t)(s2 < S ? s2 : S - 1) * 8u;
+    }
+    auto quad_addr = [&](int qd_) { return min(qd_, nquad - 1); };              // a slot past the end reads the last quad (and keeps nothing of it)
+    auto f_off = [&](int qa) -> uint32_t { return (uint32_t)min(q, V - 1 - 4 * qa) * 4u * rowb; };
+    auto load_tile = [&](int qa, uint32_t off, int t) -> double4_t {
+        const char *base = reinterpret_cast<const char *>(F) + (size_t)qa * 16 * S * 8;
+        double4_t x;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            live[t] = vok && (16 * (cb * NT + t) + n < S);
-            if constexpr (KEEPF) f[t] = load_f(t);
+        for (int e = 0; e < 4; ++e) x[e] = *reinterpret_cast<const double *>(base + (size_t)(off + (uint32_t)e * rowb + so[t]));
+        return x;
+    };
+    constexpr int TPRE = (16 * GP + 63) / 64;
+    auto tau_fetch = [&](int qd_, double (&tp)[TPRE]) {
+#pragma unroll
+        for (int i = 0; i < TPRE; ++i) {
+            const int k = lane + 64 * i;
+            const int kc = k < 16 * G ? k : 16 * G - 1;
+            const int vv = kc / (4 * G);
+            tp[i] = (4 * qd_ + vv < V) ? tau[(size_t)min(qd_, nquad - 1) * 16 * G + kc] : 0.0;
         }
-        __syncthreads();                                                        // the quad's rows are staged
+    };
+    auto tau_stage = [&](const double (&tp)[TPRE], double *told_, bool also_new) {
+#pragma unroll
+        for (int i = 0; i < TPRE; ++i) {
+            const int k = lane + 64 * i;
+            if (k < 16 * G) {
+                const int vv = k / (4 * G), r = (k / G) & 3, g = k % G;
+                told_[(4 * r + vv) * GP + g] = tp[i];
+                if (also_new) tnew[(4 * r + vv) * GP + g] = tp[i];
+            }
+        }
+    };
+
+    int qd = blockIdx.x * NQ + slot;                                            // wave-uniform
+    int par = 0;
+    {
+        double tp0[TPRE];
+        tau_fetch(qd, tp0);
+        tau_stage(tp0, rows, !do_update);
+    }
+    const int qa0 = quad_addr(qd);
+    uint32_t off = f_off(qa0);
+    double4_t f[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) f[t] = load_tile(qa0, off, t);
+    __builtin_amdgcn_wave_barrier();
+
+    for (int qd0 = blockIdx.x * NQ; qd0 < nquad; qd0 += qstride) {              // every wavefront of the workgroup runs the same rounds
+        const int qn = qd + qstride;
+        const int qpa = quad_addr(qn);
+        const uint32_t offp = f_off(qpa);
+        const int v0 = qd * 4;
+        const bool vok = v0 + q < V;                                            // this lane's variant exists
+        double *told = rows + par * (16 * GP), *toldn = rows + (par ^ 1) * (16 * GP);
+        double *xq = xall + wv * XW + (XPAR ? par * NM_XQ : 0);
+        double tp[TPRE];
         if (do_update) {
+            tau_fetch(qn, tp);                                                  // the next quad's rows: staged when this one's have been read for the last time
             double a_old[KB];
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) a_old[kb] = told[n * GP + 4 * kb + q];
-            double4_t qp[NT];
+            double4_t num = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
+                const int tg = cb * NT + t;
                 double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_old[kb], braw[((cb * NT + t) * KB + kb) * 64 + lane], R, 0, 0, 0);
-                const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
+                for (int kb = 0; kb < KB; ++kb) R = NM_MFMA(a_old[kb], graw_p[(4 * kb + q) * LDG + 16 * tg + n], R, 0, 0, 0);
+                double4_t qv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qp[t][e] = fdiv(ft[e], nzd(R[e]));          // nm_tile_q2: F > 0; lanes without a cell stay finite
+                for (int e = 0; e < 4; ++e) qv[e] = fdiv(f[t][e], nzd(R[e]));           // nm_tile_q2: F > 0; lanes without a cell stay finite
+                num = nm_num_tile<KB>(num, qv, xq, graw_p + 16 * tg, LDG, n, q);
             }
+            // this block's part of num -> LDS; all parts of the quad in block order
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int c = 0; c < KB; ++c) {
-                double p[16];                                                   // value index j = 4 e + gg
+            for (int e = 0; e < 4; ++e) xq[e * 64 + lane] = num[e];
+            __syncthreads();
+            double4_t tot = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int j = 0; j < 16; ++j) p[j] = 0.0;
+            for (int b = 0; b < NCB; ++b) {
+                const double *xb = xall + (slot * NCB + b) * XW + (XPAR ? par * NM_XQ : 0);
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) {
-                        const double gm = braw[((cb * NT + t) * KB + c) * 64 + n + 16 * gg];     // gamma_raw[4 c + gg][16 tg + n]
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) p[4 * e + gg] = fma(qp[t][e], gm, p[4 * e + gg]);
-                    }
-                const double part = row16_transpose_reduce(p, n);               // this block's part of num[(my_e, vv = q)][4 c + my_gg]
-                nump[(cb * 16 + 4 * my_e + q) * GP + 4 * c + my_gg] = part;
+                for (int e = 0; e < 4; ++e) tot[e] = (b == 0) ? xb[e * 64 + lane] : tot[e] + xb[e * 64 + lane];
             }
-            __syncthreads();                                                    // every block's part is there
-#pragma unroll
-            for (int c = 0; c < KB; ++c) {
-                const int g = 4 * c + my_gg;
-                const bool ok = g < G;
-                double tot_rg = 0.0;
-#pragma unroll
-                for (int b = 0; b < NCB; ++b) tot_rg += nump[(b * 16 + 4 * my_e + q) * GP + g];       // block order
-                double tn = 0.0;
-                if (ok) tn = told[(4 * my_e + q) * GP + g] * fdiv(nzd(tot_rg), nzd(t1[g]));       // :171-172
-                const double t_a0 = dpp_mov<0x00>(tn), t_a1 = dpp_mov<0xAA>(tn);              // e = 0 / 1 live in quad lanes 0 / 2
-                const double t_a2 = dpp_mov<0x55>(tn), t_a3 = dpp_mov<0xFF>(tn);              // e = 2 / 3            quad lanes 1 / 3
-                const double tot = ((t_a0 + t_a1) + t_a2) + t_a3;                              // :176-178
-                if (ok && cb == 0) {                                            // the same numbers in every block: block 0 stores them
-                    double x = fdiv(tn, tot);                                                      // :180-181
-                    if (adjust && x < DSM_EPS) x = DSM_EPS;                                    // :88-91
-                    if (vok) tau[((size_t)(v0 + q) * 4 + my_e) * G + g] = x;
-                    tnew[(4 * my_e + q) * GP + g] = vok ? x : 0.0;
-                }
-            }
-            __syncthreads();                                                    // the new rows are there
+            if constexpr (!XPAR) __syncthreads();                               // one buffer: nobody overwrites a part a peer has not read yet
+            nm_tau_finish<KB, true>(tot, told, tnew, t1, G, n, q, adjust, vok && cb == 0, vok, tau + (size_t)(v0 + q) * 4 * G);
+            __builtin_amdgcn_wave_barrier();
+            tau_stage(tp, toldn, false);
+            __builtin_amdgcn_wave_barrier();
         }
         // statistics of the (new) state on this block's columns: R2, objective, Q2, gamma numerators; H1 by block 0
         double a_new[KB];
@@ -1462,20 +1720,31 @@ __global__ __launch_bounds__(64 * (8 / NCB) * NCB) void nmft_wide_kernel(NmftMfm
         for (int kb = 0; kb < KB; ++kb) a_new[kb] = tnew[n * GP + 4 * kb + q];
         double a_g[4];                                                          // A of the row contraction: tau_new[vv = q][e][g = n]
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { a_g[e] = (gnum && n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; h1 += a_g[e]; }
+        for (int e = 0; e < 4; ++e) { a_g[e] = (gnum && n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; if (cb == 0) h1 += a_g[e]; }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            const int tg = cb * NT + t;
             double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_new[kb], bgam[((cb * NT + t) * KB + kb) * 64 + lane], R, 0, 0, 0);
-            const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
-            const double4_t q2 = nm_tile_q2(ft, R, live[t], ltab, obj);
+            for (int kb = 0; kb < KB; ++kb) R = NM_MFMA(a_new[kb], ggam_p[(4 * kb + q) * LDG + 16 * tg + n], R, 0, 0, 0);
+            const double4_t q2 = nm_tile_q2(f[t], R, vok && slive[t], ltab, obj);
+            f[t] = load_tile(qpa, offp, t);                                     // this tile of the next quad
             if (gnum) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) acc[t] = NM_MFMA(a_g[e], q2[e], acc[t], 0, 0, 0);
             }
         }
-        __syncthreads();                                                        // done with this trip's rows
+        __builtin_amdgcn_wave_barrier();
+        if (!do_update) {                                                       // statistics only (once per factorize): the next quad's rows, in place
+            __syncthreads();                                                    // every block of the quad has read the rows
+            tau_fetch(qn, tp);
+            tau_stage(tp, rows, true);
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            par ^= 1;
+        }
+        qd = qn;
+        off = offp;
     }
     // objective: per wavefront; H1: lane (n = g, q) of a block-0 wavefront holds the sum over bases and its variants of tau_new[.][g]
     {
@@ -1520,25 +1789,46 @@ __global__ __launch_bounds__(64 * (8 / NCB) * NCB) void nmft_wide_kernel(NmftMfm
     }
 }
 
-// 128 < S <= 512, G <= 16: blocks of six or eight tiles, two to four blocks -- the smallest tile count that holds S
+static size_t split_lds_bytes(int NT, int KB, int NCB, bool xpar)
+{
+    const size_t NQ = 8 / NCB, NTT = (size_t)NT * NCB, GP = 4 * KB, SPAD = 16 * NTT;
+    return (2 * DSM_LOG_TAB_N + 2 * GP * (SPAD + 1) + GP + NQ * 3 * 16 * GP + 8 * (xpar ? 2 : 1) * NM_XQ + 8 + NQ * GP) * sizeof(double);
+}
+// two exchange buffers where they fit beside two workgroups per CU's worth of everything else, or at least into the CU
+constexpr bool split_xpar(int NT, int KB, int NCB)
+{
+    return (2 * DSM_LOG_TAB_N + 2 * (4 * KB) * (16 * NT * NCB + 1) + 4 * KB + (8 / NCB) * 3 * 16 * (4 * KB) + 8 * 2 * NM_XQ + 8 + (8 / NCB) * 4 * KB) * 8 <= 160 * 1024;
+}
+// two wavefronts per SIMD (the second argument of HIP's __launch_bounds__) = one workgroup per CU, 256 registers: measured against four
+// (two workgroups per CU where three-tile blocks and the LDS allow it: 128 registers, 23-30 of them spilled) 52 vs 57 us per update at
+// 10k x 192 x 8, equal at 10k x 300 x 8 (profiles/r05_nmft_split_ab.txt)
+constexpr int split_wgs(int, int, int) { return 2; }
+template <int NT, int KB, int NCB>
+__global__ __launch_bounds__(512, split_wgs(NT, KB, NCB)) void nmft_split_kernel(NmftMfmaParams q) { nmft_split_body<NT, KB, NCB, split_xpar(NT, KB, NCB)>(q); }
+template <int NT, int KB, int NCB>
+__global__ __launch_bounds__(512, split_wgs(NT, KB, NCB)) void nmft_split_kernel_b(BatchArgs<NmftMfmaParams> b)
+{
+    nmft_split_body<NT, KB, NCB, split_xpar(NT, KB, NCB)>(b.p[blockIdx.y]);
+}
+
+// Which tables take the split kernel, and how: 128 < S <= 512 -- four blocks of three to eight tiles, the smallest that hold S.  G <= 16.
+// (Two blocks of three / four tiles for 64 < S <= 128 were measured too: 104 vs 103 us per update at 50k x 96 x 12, 70 vs 61 at
+// 30k x 80 x 10 with its padded tile -- one wavefront per quad stays the form there, profiles/r05_nmft_split_ab.txt.)
 static bool wide_shape(const dsm_ctx *c, int *nt, int *kb, int *ncb)
 {
     static const bool off = DSM_AB_ENV("DESMAN_HIP_NMFT_NO_MFMA") != nullptr || DSM_AB_ENV("DESMAN_HIP_NMFT_NO_WIDE") != nullptr;
     const int tiles = (c->S + 15) / 16;
     *kb = (c->nG + 3) / 4;
     if (off || tiles <= 8 || tiles > 32 || *kb < 1 || *kb > 4) return false;
-    static const int shapes[6][2] = {{6, 2}, {8, 2}, {6, 3}, {8, 3}, {6, 4}, {8, 4}};         // by capacity: 12, 16, 18, 24, 24, 32 tiles
-    for (int i = 0; i < 6; ++i)
-        if (shapes[i][0] * shapes[i][1] >= tiles) { *nt = shapes[i][0]; *ncb = shapes[i][1]; return true; }
+    static const int shapes[5][2] = {{3, 4}, {4, 4}, {5, 4}, {6, 4}, {8, 4}};       // by capacity: 12, 16, 20, 24, 32 tiles
+    for (int i = 0; i < 5; ++i)
+        if (shapes[i][0] * shapes[i][1] >= tiles) {
+            *nt = shapes[i][0]; *ncb = shapes[i][1];
+            return split_lds_bytes(*nt, *kb, *ncb, false) <= 160 * 1024;       // (not S > 384 with G > 12: two padded gamma matrices of 66 KB each; the two-pass kernels take it)
+        }
     return false;
 }
 bool nmft_use_wide(const dsm_ctx *c) { int a, b, d; return wide_shape(c, &a, &b, &d); }
-
-static size_t wide_lds_bytes(int NT, int KB, int NCB)
-{
-    const size_t NQ = 8 / NCB, NW = NQ * NCB, NTT = (size_t)NT * NCB, GP = 4 * KB;
-    return (2 * DSM_LOG_TAB_N + 2 * NTT * KB * 64 + GP + NQ * 2 * 16 * GP + NQ * NCB * 16 * GP + NW + NQ * GP) * sizeof(double);
-}
 
 int nmft_wide_grid(const dsm_ctx *c)
 {
@@ -1547,21 +1837,26 @@ int nmft_wide_grid(const dsm_ctx *c)
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) cus = 256;
     const int nq = 8 / ncb;
     int g = ((c->V + 3) / 4 + nq - 1) / nq;
-    if (g > cus) g = cus;                          // one workgroup per CU: eight wavefronts, the operands' LDS
+    const int cap = cus * (split_wgs(nt, kb, ncb) / 2);
+    if (g > cap) g = cap;                          // the workgroups that are resident at once (the rounds are grid-strided)
     return g < 1 ? 1 : g;
 }
 
 template <int NT, int KB, int NCB>
 static int launch_wide(dsm_ctx *c, int adjust, int do_update, int grid)
 {
-    const size_t sh = wide_lds_bytes(NT, KB, NCB);
+    const size_t sh = split_lds_bytes(NT, KB, NCB, split_xpar(NT, KB, NCB));
+    if (sh > 160 * 1024) { dsm_set_error("nmft_split: %zu B of LDS", sh); return DSM_ERR_UNSUPPORTED; }
     static bool attr_set = false;                  // more than 64 KB of dynamic LDS has to be asked for, once per instantiation
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&nmft_wide_kernel<NT, KB, NCB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&nmft_split_kernel<NT, KB, NCB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&nmft_split_kernel_b<NT, KB, NCB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart, c->ntau2, c->nmft_fix_gamma};
-    hipLaunchKernelGGL((nmft_wide_kernel<NT, KB, NCB>), dim3(grid), dim3(64 * (8 / NCB) * NCB), sh, c->stream, q);
+    LAUNCH_OR_COLLECT(NmftMfmaParams, q,
+                      hipLaunchKernelGGL((nmft_split_kernel<NT, KB, NCB>), dim3(grid), dim3(512), sh, c->stream, q),
+                      hipLaunchKernelGGL((nmft_split_kernel_b<NT, KB, NCB>), dim3(grid, K), dim3(512), sh, c->stream, acc));
     return DSM_OK;
 }
 
@@ -1569,14 +1864,12 @@ int k_nmft_wide(dsm_ctx *c, int adjust, int do_update)
 {
     KTimer tm(c, do_update ? DSM_K_NMFT_B : DSM_K_NMFT_A);
     int nt, kb, ncb;
-    if (!wide_shape(c, &nt, &kb, &ncb)) { dsm_set_error("nmft_wide: unsupported shape"); return DSM_ERR_UNSUPPORTED; }
-    if (g_batch.K) { dsm_set_error("nmft_wide: no batched form (S > 128)"); return DSM_ERR_UNSUPPORTED; }
+    if (!wide_shape(c, &nt, &kb, &ncb)) { dsm_set_error("nmft_split: unsupported shape"); return DSM_ERR_UNSUPPORTED; }
     const int grid = nmft_wide_grid(c);
     int rc = DSM_ERR_UNSUPPORTED;
-#define WCASE(N, K, B) if (nt == N && kb == K && ncb == B) rc = launch_wide<N, K, B>(c, adjust, do_update, grid)
-    WCASE(6, 1, 2); WCASE(6, 2, 2); WCASE(6, 3, 2); WCASE(6, 4, 2); WCASE(8, 1, 2); WCASE(8, 2, 2); WCASE(8, 3, 2); WCASE(8, 4, 2);
-    WCASE(6, 1, 3); WCASE(6, 2, 3); WCASE(6, 3, 3); WCASE(6, 4, 3); WCASE(8, 1, 3); WCASE(8, 2, 3); WCASE(8, 3, 3); WCASE(8, 4, 3);
-    WCASE(6, 1, 4); WCASE(6, 2, 4); WCASE(6, 3, 4); WCASE(6, 4, 4); WCASE(8, 1, 4); WCASE(8, 2, 4); WCASE(8, 3, 4); WCASE(8, 4, 4);
+#define WCASE(N, B) if (nt == N && ncb == B) { if (kb == 1) rc = launch_wide<N, 1, B>(c, adjust, do_update, grid); else if (kb == 2) rc = launch_wide<N, 2, B>(c, adjust, do_update, grid); \
+                                               else if (kb == 3) rc = launch_wide<N, 3, B>(c, adjust, do_update, grid); else rc = launch_wide<N, 4, B>(c, adjust, do_update, grid); }
+    WCASE(3, 4); WCASE(4, 4); WCASE(5, 4); WCASE(6, 4); WCASE(8, 4);
 #undef WCASE
     if (rc != DSM_OK) return rc;
     HIP_TRY(hipGetLastError());
@@ -1763,20 +2056,20 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
             for (int t = 0; t < NT; ++t) {
                 double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_new[kb], ggam_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
+                for (int kb = 0; kb < KB; ++kb) R = NM_MFMA(a_new[kb], ggam_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
                 double4_t q2;
                 const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
                 q2 = nm_tile_q2(ft, R, live[t], ltab, obj);
                 if (gnum) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g[e], q2[e], acc[t], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) acc[t] = NM_MFMA(a_g[e], q2[e], acc[t], 0, 0, 0);
                 } else {
                     // gamma fixed: this product is also the one the tau half of the update divides F by (NmftMfmaParams.fix_gamma == 2):
                     // the candidate rows of the next update come out of the same pass
                     num = nm_num_tile<KB>(num, q2, xq, ggam_p + 16 * t, LDG, n, q);
                 }
             }
-            if (!gnum) nm_tau_finish<KB, false>(num, tnew, told, t1, G, n, q, adjust, vok, nullptr);     // candidate -> the spare rows
+            if (!gnum) nm_tau_finish<KB, false>(num, tnew, told, t1, G, n, q, adjust, false, vok, nullptr);     // candidate -> the spare rows
         }
         NM_STAMP(1);
         // Workgroup reduction: wavefronts 4 r .. 4 r + 3 are workgroup 3 wg + r of the three-launch kernel (the same four quads, summed
@@ -1943,14 +2236,14 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
             for (int t = 0; t < NT; ++t) {
                 double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a_old[kb], graw_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
+                for (int kb = 0; kb < KB; ++kb) R = NM_MFMA(a_old[kb], graw_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
                 const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
                 double4_t qv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) qv[e] = fdiv(ft[e], nzd(R[e]));             // nm_tile_q2: F > 0; lanes without a cell stay finite
                 num = nm_num_tile<KB>(num, qv, xq, graw_p + 16 * t, LDG, n, q);
             }
-            nm_tau_finish<KB, false>(num, told, tnew, t1, G, n, q, adjust, vok, nullptr);
+            nm_tau_finish<KB, false>(num, told, tnew, t1, G, n, q, adjust, false, vok, nullptr);
             __builtin_amdgcn_wave_barrier();
         }
         NM_STAMP(8);

@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void k(double *out, long long *cyc, double a0,
     for (int i = 0; i < 4; ++i) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
     double v[8];
     for (int i = 0; i < 8; ++i) v[i] = a + i;
+    const long long r0 = __builtin_amdgcn_s_memrealtime();
     const long long t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
     for (int it = 0; it < N / 16; ++it) {
@@ -40,11 +41,12 @@ __global__ __launch_bounds__(256) void k(double *out, long long *cyc, double a0,
         }
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
+    const long long r1 = __builtin_amdgcn_s_memrealtime();
     double s = 0.0;
     for (int i = 0; i < 4; ++i) for (int e = 0; e < 4; ++e) s += acc[i][e];
     for (int i = 0; i < 8; ++i) s += v[i];
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
-    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = r1 - r0; }
 }
 
 template <int MODE, int K>
@@ -58,8 +60,8 @@ static int run(const char *name, int blocks, double *out, long long *cyc)
         CHK(hipEventRecord(e1, 0)); CHK(hipEventSynchronize(e1));
         CHK(hipEventElapsedTime(&ms, e0, e1));
     }
-    long long c = 0; CHK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
-    printf("%-28s %8.1f us   %7.1f memtime ticks per MFMA (one wavefront's view)   %6.1f ns per MFMA per wavefront\n", name, ms * 1e3, (double)c / N, ms * 1e6 / N);
+    long long cc[2] = {0, 0}; CHK(hipMemcpy(cc, cyc, 16, hipMemcpyDeviceToHost)); const long long c = cc[0];
+    printf("%-28s %8.1f us   %7.1f memtime ticks per MFMA (one wavefront's view)   %6.1f ns per MFMA per wavefront   s_memtime runs at %.0f MHz (against s_memrealtime = 100 MHz)\n", name, ms * 1e3, (double)c / N, ms * 1e6 / N, 100.0 * (double)cc[0] / (double)cc[1]);
     return 0;
 }
 
@@ -69,7 +71,7 @@ int main(int argc, char **argv)
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
     const int blocks = prop.multiProcessorCount * wps;
     double *out; long long *cyc;
-    CHK(hipMalloc(&out, (size_t)blocks * 256 * 8)); CHK(hipMalloc(&cyc, 8));
+    CHK(hipMalloc(&out, (size_t)blocks * 256 * 8)); CHK(hipMalloc(&cyc, 16));
     printf("%s, %d CUs, %d wavefront(s) per SIMD, %d MFMAs per wavefront, clock %d MHz\n", prop.gcnArchName, prop.multiProcessorCount, wps, N, prop.clockRate / 1000);
     if (run<0, 0>("dep (1 accumulator)", blocks, out, cyc)) return 1;
     if (run<1, 0>("ind4 (4 accumulators)", blocks, out, cyc)) return 1;

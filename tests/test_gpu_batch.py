@@ -82,10 +82,12 @@ def test_batch_argument_checks():
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("V,S,G,K", [(120, 16, 4, 3), (300, 64, 8, 5), (90, 96, 12, 2), (50, 7, 1, 4)])
+@pytest.mark.parametrize("V,S,G,K", [(120, 16, 4, 3), (300, 64, 8, 5), (90, 96, 12, 2), (50, 7, 1, 4), (90, 96, 3, 2), (70, 130, 4, 3),
+                                     (45, 300, 8, 2), (33, 500, 12, 2)])
 def test_batched_nmft_factorize_equals_one_by_one(V, S, G, K):
     """dsm_batch_nmft_factorize: same factors, update counts and objective traces as dsm_nmft_factorize per chain (the
-    chains stop at different updates)"""
+    chains stop at different updates).  Round 5: S > 128 no longer falls back (nmft_split_kernel_b); (96, 3): the vector-ALU
+    contractions of up to four haplotypes at five / six tiles."""
     counts, _, _ = synth_counts(V, S, max(G, 2), seed=700 + V)
     rs = np.random.RandomState(5)
     starts = []
@@ -113,6 +115,23 @@ def test_batched_nmft_factorize_equals_one_by_one(V, S, G, K):
             assert np.array_equal(fac[0], fac1[0]) and np.array_equal(fac[1], fac1[1])
             assert np.array_equal(c.nmft_get_tau(), tau1)
             c.close()
+    # gamma fixed (factorize_tau): the fused pass up to 128 samples, the two-half form of the split kernel above
+    singles = []
+    for tau0, gam0 in starts:
+        c = _lib.Context(0); c.set_counts(counts); c.nmft_set(tau0, gam0)
+        n, tr = c.nmft_factorize(40, 1e-7, fix_gamma=True)
+        singles.append((n, tr, c.nmft_get()))
+        c.close()
+    ctxs = []
+    for tau0, gam0 in starts:
+        c = _lib.Context(0); c.set_counts(counts); c.nmft_set(tau0, gam0)
+        ctxs.append(c)
+    res = _lib.Context.batch_nmft_factorize(ctxs, 40, 1e-7, fix_gamma=True)
+    for c, (n, tr), (n1, tr1, fac1) in zip(ctxs, res, singles):
+        assert n == n1 and np.array_equal(tr, tr1)
+        fac = c.nmft_get()
+        assert np.array_equal(fac[0], fac1[0]) and np.array_equal(fac[1], fac1[1])
+        c.close()
 
 
 @pytest.mark.parametrize("V,S,G,K,n", [(400, 24, 4, 3, 14), (128, 64, 8, 6, 9)])

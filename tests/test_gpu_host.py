@@ -310,9 +310,9 @@ def test_batched_replicates_whose_haplotype_counts_diverge_finish_in_groups(tmp_
 @pytest.mark.parametrize("G,S", [(3, 10), (13, 8), (4, 130)])
 def test_main_replicates_equals_main_also_where_the_batched_nmf_start_falls_back(tmp_path, monkeypatch, G, S):
     """cli.main_replicates against cli.main chain by chain (same mu/E specification: DESMAN_HIP_STATS_SPEC=2), file for
-    file.  S = 130 is outside the batched NMF kernels (S <= 128, G <= 16) while the Gibbs batch still applies:
-    the start and the -r fit fall back to one chain at a time and must draw the initial factors from each chain's numpy
-    stream ONCE -- a second draw from the advanced stream would change every later number of the chain."""
+    file.  Until round 5 S = 130 was outside the batched NMF kernels while the Gibbs batch still applied: the start and the -r fit
+    fell back to one chain at a time and had to draw the initial factors from each chain's numpy stream ONCE (a second draw from
+    the advanced stream would change every later number of the chain).  nmft_split_kernel_b batches it now; the files are the same."""
     from desman_amd import cli, sampletau
     V = 140
     counts, _, _ = synth_counts(V, S, min(G, 4), seed=55)

@@ -120,12 +120,13 @@ def shape_key(V, S, G, depth):
     return "%d,%d,%d,%g" % (V, S, G, depth)
 
 
-def pmc_passes(V, S, G, depth, iters=30):
+def pmc_passes(V, S, G, depth, iters=30, save=False):
     """`bench.py --pmc`: HBM-side traffic and VALU instruction counts per launch of this workload's kernels, measured now: three
     separate `rocprofv3 --pmc` passes (FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU -- one counter group per pass, kernel trace only, as
     MI355X_MICROARCH.md prescribes; FETCH_SIZE x 2 is its gfx950 correction for wide coalesced reads) over scripts/prof_gibbs.py,
     the benchmark's chain at this shape.  Returns {kernel name: {bytes_per_launch, read_bytes_corrected, write_bytes, valu_insts}}
-    and stores it in profiles/pmc_traffic_by_shape.json under the shape key, where runs without --pmc find it."""
+    and, with save (`--pmc-save`), stores it in the tracked profiles/pmc_traffic_by_shape.json under the shape key, where runs with
+    --no-pmc find it; the scratch copy under gpurun_out/ is written in any case (a default run leaves `git status` clean)."""
     import collections
     import csv
     import glob
@@ -161,7 +162,7 @@ def pmc_passes(V, S, G, depth, iters=30):
     if os.path.exists(TRAFFIC_DB):
         db = json.load(open(TRAFFIC_DB))
     db[shape_key(V, S, G, depth)] = out
-    for path in (TRAFFIC_DB, os.path.join(ROOT, "gpurun_out", "pmc_traffic_by_shape.json")):
+    for path in ((TRAFFIC_DB,) if save else ()) + (os.path.join(ROOT, "gpurun_out", "pmc_traffic_by_shape.json"),):
         try:
             os.makedirs(os.path.dirname(path), exist_ok=True)
             json.dump(db, open(path, "w"), indent=1, sort_keys=True)
@@ -254,6 +255,8 @@ def main():
                     "between its own barrier + synchronize; ms_per_step is the median call (ms_per_step_repeats has them all)")
     ap.add_argument("--pmc", dest="pmc", action="store_true", default=None, help="measure roofline.traffic now: three extra rocprofv3 "
                     "--pmc passes of this workload (about a minute).  Default: on for a single-GPU run when rocprofv3 is on the PATH")
+    ap.add_argument("--pmc-save", action="store_true", help="also record the measured traffic in the tracked profiles/pmc_traffic_by_shape.json "
+                    "(what --no-pmc runs read); without it only gpurun_out/ is written")
     ap.add_argument("--no-pmc", dest="pmc", action="store_false", help="skip the PMC passes: roofline.traffic is then read from the "
                     "record `bench.py --pmc` left for this shape in profiles/pmc_traffic_by_shape.json (said so in traffic_source)")
     ap.add_argument("--counts-npz", default=None,
@@ -505,7 +508,7 @@ def main():
     if not args.counts_npz:
         if args.pmc and rank == 0 and world == 1:
             try:
-                tj = pmc_passes(V, S, G, args.depth_scale)
+                tj = pmc_passes(V, S, G, args.depth_scale, save=args.pmc_save)
                 traffic_source = ("measured by this run: three separate rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE x 2 per the "
                                   "gfx950 correction; WRITE_SIZE; the SQ VALU / MFMA group) of scripts/prof_gibbs.py at this shape")
             except Exception as e:                   # noqa: BLE001 -- a profiler failure must not lose the bench line

@@ -36,6 +36,7 @@ _vp, _i, _d = C.c_void_p, C.c_int, C.c_double
 SIGNATURES = {
     "dsm_last_error": (C.c_char_p, []),
     "dsm_device_count": (_i, []),
+    "dsm_debug_ntab_probes": (_i, []),
     "dsm_version": (C.c_char_p, []),
     "dsm_initRNG": (_i, []),
     "dsm_setRNG": (_i, [C.c_ulong]),
@@ -192,6 +193,11 @@ def lrt_step(ffreq, maxA, maxB, eta, upperP, optimise, p, device=0):
 
 def device_count():
     return load().dsm_device_count()
+
+
+def ntab_probes():
+    """how often this process has measured a subset table's place (include/desman_hip.h: dsm_debug_ntab_probes)"""
+    return load().dsm_debug_ntab_probes()
 
 
 def _ptr(a):

@@ -224,7 +224,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     dev_free(&c->pat_rep); dev_free(&c->pat_x); dev_free(&c->pat_list); c->pat_rep_len = c->pat_x_len = 0;
     if (c->h_rare) { (void)hipHostFree(c->h_rare); c->h_rare = nullptr; }
     dev_free(&c->s2_scratch);
-    dev_free(&c->blk_tab); dev_free(&c->ntab_raw); c->ntab = nullptr; dev_free(&c->big_list); dev_free(&c->big_count);
+    dev_free(&c->blk_tab); stats_release_ntab(c); dev_free(&c->big_list); dev_free(&c->big_count);
     dev_free(&c->gamma); dev_free(&c->eta);
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
     dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->sweep_stats); dev_free(&c->step_cnt); dev_free(&c->blk_order); dev_free(&c->screen_ctl); dev_free(&c->prior); dev_free(&c->prior_all); dev_free(&c->scalars); dev_free(&c->star);

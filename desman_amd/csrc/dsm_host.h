@@ -91,6 +91,7 @@ struct dsm_ctx {
     uint32_t *ntab_base = nullptr;  // first place the table can start at (4 KB aligned)
     size_t ntab_off = 0;            // where past ntab_base the table starts (stats_place_ntab)
     bool ntab_placed = false;       // the place has been measured (or given)
+    bool ntab_measured = false;     // ... measured: the table goes to the process's pool when the chain ends (kernels_stats.hip: stats_release_ntab)
     int ntab_ld = 0;                // row stride of the table in words (kernels_stats.hip: stats_ntab_ld)
     int ntab_rep = 1;               // copies of the table (few subsets x many positions: kernels_stats.hip, stats_ntab_rep)
     unsigned long long *big_list = nullptr;   // stage-1 items deferred to the compacted (BTRS) kernel: cell * 4 + base
@@ -206,6 +207,7 @@ int build_stats_items(dsm_ctx *c);          // api.hip: work list of the per-rea
 // ---- launchers (kernels_stats.hip)
 uint32_t stats_ntab_hmul();                  // odd multiplier of the subset -> table row map
 int stats_place_ntab(dsm_ctx *c);         // measures where the subset table should start (once per table; kernels_stats.hip)
+void stats_release_ntab(dsm_ctx *c);     // the table leaves the context: to the process's pool of placed tables, or freed
 #define DSM_NTAB_PAD 0               // words added to a row of the subset table when S is a multiple of 64 (stats_ntab_ld)
 int stats_ntab_ld(int S);
 int stats_ntab_rep(const dsm_ctx *c);       // copies of the subset table the stage-1 atomics are spread over

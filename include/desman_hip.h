@@ -137,6 +137,9 @@ int dsm_ctx_sample_stats(dsm_ctx *ctx, uint32_t iter, uint64_t *sum_mu, uint64_t
  * or 3 if its first chain asks.  */
 int dsm_ctx_stats_spec(dsm_ctx *ctx);
 int dsm_ctx_force_stats_spec(dsm_ctx *ctx, int spec);
+/* how often this process has measured where a subset table should start (~2 ms of stage-1 launches on the chain's own state; a measured
+ * table is kept when its chain ends and handed to the next chain of its device and size, so a G-sweep probes once per shape)   */
+int dsm_debug_ntab_probes(void);
 /* test hooks of the aggregated sampler: stage 1 only (subset counts ntab [S][2^G] u32 and esum), and nsamp variates of one
  * sampler (kind 0 binom_small, 1 binom_big: out [nsamp]; 2 mult4 with weights w[0..3]: out [nsamp][4]) of version
  * spec (2 / 3) exactly as oracle/stats_agg.c: orc_binom_test / orc_mult4_test draw them.                          */

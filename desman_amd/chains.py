@@ -485,10 +485,6 @@ def main(argv=None):
             from torch.distributed.distributed_c10d import _get_default_store
             queue = WorkQueue(store=_get_default_store())
     extra = ["-m", str(args.min_coverage)] + (["-r", str(args.random_select)] if args.random_select else [])
-    if args.batch > 1:
-        # batched units draw mu/E from the aggregated specification; chains of this sweep that run one by one (a unit of one
-        # chain, the fallback of a failed unit) follow it too, so that a (G, seed) gives the same draws whatever -b is
-        os.environ["DESMAN_HIP_STATS_SPEC"] = "2"
     runner = gibbs_chain_runner(args.variant_file, args.no_iter, local, args.output_stub, extra)
     recs = run_chains(specs, runner, dist, device=dev_t, concurrency=args.concurrency, batch_fn=runner.batch if args.batch > 1 else None,
                       batch=min(args.batch, 8), comm=comm, queue=queue)

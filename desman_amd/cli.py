@@ -258,10 +258,8 @@ def main_replicates(argv_list, on_chain=None):
     for k, r in enumerate(runs):
         opts, flt, rng, nmft = r["opts"], r["flt"], r["rng"], r["nmft"]
         chain = HaploSNP_Sampler(flt.snps_filter, opts.genomes, rng, max_iter=opts.no_iter, device=opts.device, ctx=nmft._ctx)
-        # a batch always takes the aggregated mu/E pass; a replicate that ends up alone (its haplotype count changed in
-        # removeDegenerate, a failed batched unit) must keep drawing from the same specification, so that a chain's draws
-        # depend on its own seed and shape only -- not on what the other replicates did
-        chain._ctx.force_stats_spec(_lib.STATS_AGG)
+        # (a chain's mu/E specification is its own in a batch too -- round 5 -- so a replicate that ends up alone, because its haplotype
+        # count changed in removeDegenerate or its batched unit failed, draws what it would have drawn in the batch)
         chain.mt_state = _lib.mt_seed_state(opts.random_seed)       # what initRNG(); setRNG(seed) leave in the module's stream
         chain.tau = np.copy(nmft.get_tau(), order='C')
         chain.updateTauIndices()

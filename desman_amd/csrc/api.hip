@@ -949,8 +949,8 @@ extern "C" int dsm_device_write(int device, void *dev, const void *host, size_t 
 // K chains of one shape (same device, V, S, G, tau RNG), one launch per kernel of the iteration for all of them (chain =
 // blockIdx.y): on tables that leave most of the GPU idle -- a few hundred to a few thousand positions, the usual DESMAN
 // input -- the replicate chains of a G value (scripts/runDesman.sh:15-21) then cost little more than one.  Every chain ends
-// in the state dsm_ctx_gibbs_update would leave it in under the aggregated mu/E pass (spec v2, which the batch always uses:
-// its fixed costs are what a batch amortises; G <= 16).
+// in the state dsm_ctx_gibbs_update leaves it in: the mu/E specification is the chain's own (round 5; the per-read pass of small or
+// shallow tables and of G > 16 is launched chain by chain, everything else is shared).
 extern "C" int dsm_batch_gibbs_update(dsm_ctx *const *ctxs, int K, int n_iter)
 {
     if (!ctxs || K < 1 || K > DSM_MAX_BATCH) { dsm_set_error("batch of %d chains (1..%d)", K, DSM_MAX_BATCH); return DSM_ERR_ARG; }
@@ -974,8 +974,9 @@ extern "C" int dsm_batch_gibbs_update(dsm_ctx *const *ctxs, int K, int n_iter)
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream_rng));
         saved[k] = Saved{c->stream, c->stream_rng, c->force_stats_spec, c->timing};
-        // one version of the aggregated specification for the whole batch: the leader's choice if it made one, else the default
-        c->stream = lead->stream; c->stream_rng = lead->stream_rng; c->force_stats_spec = (saved[0].force >= 2) ? saved[0].force : DSM_STATS_AGG; c->timing = false;
+        // (round 5: a chain's mu/E specification is its own -- what it would run alone, by the shape rule or by its own choice -- so that
+        // its draws do not depend on whether it runs in a batch; rounds 2-4 made every batch spec 2)
+        c->stream = lead->stream; c->stream_rng = lead->stream_rng; c->timing = false;
     }
     auto restore = [&]() {
         g_batch = BatchCtl{};
@@ -986,8 +987,15 @@ extern "C" int dsm_batch_gibbs_update(dsm_ctx *const *ctxs, int K, int n_iter)
     };
 #define BTRY(expr) do { int _r = (expr); if (_r != DSM_OK) { (void)hipStreamSynchronize(lead->stream); (void)hipStreamSynchronize(lead->stream_rng); restore(); return _r; } } while (0)
 #define BHIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { dsm_set_error("%s failed: %s", #expr, hipGetErrorString(_e)); (void)hipStreamSynchronize(lead->stream); restore(); return DSM_ERR_HIP; } } while (0)
-    for (int k = 0; k < K; ++k)
-        if (stats_spec(ctxs[k]) < 2) { dsm_set_error("batch: the aggregated mu/E pass does not apply to this shape (G <= 16)"); restore(); return DSM_ERR_UNSUPPORTED; }
+    // one specification per batch (the launches are shared): chains of one shape on one table have the same by rule
+    const int spec = stats_spec(lead);
+    for (int k = 1; k < K; ++k)
+        if (stats_spec(ctxs[k]) != spec) {
+            dsm_set_error("batch: chain %d runs mu/E specification %d, chain 0 specification %d (different tables or different dsm_ctx_force_stats_spec)", k, stats_spec(ctxs[k]), spec);
+            restore();
+            return DSM_ERR_ARG;
+        }
+    const bool agg = spec >= 2;                         // spec 1 (small or shallow tables, G > 16): the per-read pass has no shared launch -- chain by chain
     const size_t sg = (size_t)lead->S * lead->G;
     std::vector<SweepWords> words;
     words.reserve(K);
@@ -1002,12 +1010,12 @@ extern "C" int dsm_batch_gibbs_update(dsm_ctx *const *ctxs, int K, int n_iter)
     }
     g_batch.K = K;
     for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(words[k].prefetch()); }
-    const bool fuse_s2 = lead->G < 10;
+    const bool fuse_s2 = agg && lead->G < 10;
     std::vector<uint32_t> ic(K);
     std::vector<const uint32_t *> u(K, nullptr);
     for (int it = 0; it < n_iter; ++it) {
-        for (int k = 0; k < K; ++k) { g_batch.k = k; ic[k] = ctxs[k]->iter_ctr++; BTRY(k_stats_stage1(ctxs[k], ic[k])); }
-        if (!fuse_s2) for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_stats_stage2(ctxs[k], ic[k])); }
+        for (int k = 0; k < K; ++k) { g_batch.k = k; ic[k] = ctxs[k]->iter_ctr++; BTRY(agg ? k_stats_stage1(ctxs[k], ic[k]) : k_stats_v1(ctxs[k], ic[k])); }
+        if (agg && !fuse_s2) for (int k = 0; k < K; ++k) { g_batch.k = k; BTRY(k_stats_stage2(ctxs[k], ic[k])); }
         for (int k = 0; k < K; ++k) {
             dsm_ctx *c = ctxs[k];
             double *const P[2] = {c->prior, c->prior + (DSM_MAX_S + 4)};

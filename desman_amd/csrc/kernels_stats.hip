@@ -371,6 +371,8 @@ __global__ __launch_bounds__(256) void pat_agg_kernel(const int32_t *__restrict_
 }
 template <int LPV, int SPEC, bool REGG>
 __global__ __launch_bounds__(256, 6) void stats_agg_kernel_b(BatchArgs<StatsAggParams> b) { stats_agg_body<LPV, SPEC, REGG>(b.p[blockIdx.y]); }
+template <int LPV>
+__global__ __launch_bounds__(256, 5) void stats_pat_kernel_b(BatchArgs<StatsAggParams> b) { stats_agg_body<LPV, 2, false, true>(b.p[blockIdx.y]); }
 
 // ---------------------------------------------------------------------------------------------------
 // the deferred items (rarer outcome with a mean above 64: burn-in states, very deep data), one lane per item:
@@ -528,9 +530,10 @@ int stats_spec(const dsm_ctx *c)
     if (((size_t)1 << c->G) * (size_t)c->S * 4 > ((size_t)64 << 20)) return 1;
     if (c->max_depth >= ((uint64_t)1 << 32)) return 1;
     // spec 4 = spec 2's samplers over tau PATTERNS (positions sharing their packed word share a cell per sample; pat_rep_kernel above).
-    // It needs the direct-address table of 4^G words (G <= 8), a chain that is neither sharded by positions (representatives would
-    // be per shard) nor part of a batch (the batched launches are spec 2's); asked for where it does not apply, spec 2 runs.
-    const bool pat_ok = c->G <= 8 && !c->shard_on && g_batch.K == 0;
+    // It needs the direct-address table of 4^G words (G <= 8) and a chain that is not sharded by positions (representatives would be
+    // per shard: a sharded chain is the unsharded chain UNDER SPEC 2, desman_amd/vshard.py); asked for where it does not apply, spec 2
+    // runs.  A batch runs what its chains would run alone (round 5: the pooling passes chain by chain, stage 1 over the words as one launch).
+    const bool pat_ok = c->G <= 8 && !c->shard_on;
     if (force == 4) return pat_ok ? 4 : 2;
     if (force >= 2) return force;                        // 2 = the default version of the aggregated draws, 3 = the table exp/log variant
     double reads = 0.0;
@@ -815,7 +818,7 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
 #undef AGG_CASE
     if (pat) {
         fn = LPV == 16 ? (const void *)stats_pat_kernel<16> : LPV == 32 ? (const void *)stats_pat_kernel<32> : (const void *)stats_pat_kernel<64>;
-        fn_b = nullptr;
+        fn_b = LPV == 16 ? (const void *)stats_pat_kernel_b<16> : LPV == 32 ? (const void *)stats_pat_kernel_b<32> : (const void *)stats_pat_kernel_b<64>;
     }
     if (!fn) { dsm_set_error("stats_agg: no kernel for spec %d", spec); return DSM_ERR_UNSUPPORTED; }
     if (c->stats_grid == 0 || c->stats_grid_key != (spec_full * 2 + (regg ? 1 : 0))) {

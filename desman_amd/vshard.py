@@ -6,8 +6,11 @@ one exchange.  Rank r holds a contiguous slice of the positions (count tensor an
 iteration every rank runs stage 1 of the auxiliary-count pass on its slice, the ranks all-reduce the subset table (uint32
 [2^G][S]) and an 18-double vector (RCCL over xGMI: `torch.distributed`, backend "nccl"), then stage 2, the gamma / eta draws
 (replicated: same inputs, same counter-based streams -> same bits on every rank) and the tau sweep of the rank's slice.
-Every draw is keyed by GLOBAL indices, so the chain is the unsharded chain whatever the number of ranks
-(tests/test_gpu_vshard.py: two shards on one GPU against one context, bit for bit).
+Every draw is keyed by GLOBAL indices, so the chain does not depend on the number of ranks: it is the unsharded chain UNDER THE
+AGGREGATED mu/E PASS, SPEC 2 (dsm_ctx_force_stats_spec(ctx, 2) / DESMAN_HIP_STATS_SPEC=2), bit for bit (tests/test_gpu_vshard.py:
+two / three shards on one GPU against one context; tests/test_gpu_fullsize.py at 50k x 96).  By the shape rule an unsharded chain
+may run another specification of the same law -- the per-read pass on small or shallow tables, the word-pooled pass (spec 4) on large
+tables with up to eight haplotypes, whose representatives would be per shard -- and then draws other variates than its sharded form.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... your_script.py
         chain = ShardedChain(counts_slice, v_offset, v_total, G, seed, device=local_rank)

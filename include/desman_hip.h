@@ -126,15 +126,16 @@ int dsm_ctx_sample_stats(dsm_ctx *ctx, uint32_t iter, uint64_t *sum_mu, uint64_t
  * repeated squaring, item streams two Philox rounds off the cell's block instead of three -- selectable, not the default:
  * measured no faster), 4 = spec 2's samplers over tau WORDS: positions whose packed tau words are equal pool their counts in the
  * lowest such position and stage 1 draws once per (word, sample) -- the same law (a sum of multinomials with one probability vector),
- * restated by oracle/cbind.py: stats_agg(spec=4); G <= 8, not for sharded or batched chains (they run spec 2); by rule on large tables
+ * restated by oracle/cbind.py: stats_agg(spec=4); G <= 8, not for chains sharded by positions (they run spec 2); by rule on large tables
  * (G <= 2 from half a million cells, G = 3 from a million, G = 4 ... 8 from 2.5 million cells with 64 x 2^G <= V) --,
  * 1 = per-read draws (oracle/desman_oracle.c: orc_stats_counter).  Where the aggregated pass applies
  * the cheaper of it and the per-read pass runs, by a cost model over the read total, the cells V x S (padded to the
  * kernel's lane groups) and the atomics per subset counter (kernels_stats.hip: stats_spec) -- a function of the shape and
  * the read totals only, the same on every run.  dsm_ctx_force_stats_spec: 0 = that rule, 1 = always spec 1, 2 / 3 / 4 = that
  * version of the aggregated sampler wherever it applies, small problems too (environment: DESMAN_HIP_STATS_SPEC=1|2|3|4 for
- * contexts without a choice of their own).  A batch (dsm_batch_gibbs_update) always takes the aggregated sampler: spec 2,
- * or 3 if its first chain asks.  */
+ * contexts without a choice of their own).  A batch (dsm_batch_gibbs_update) runs what its chains would run alone (one
+ * specification per batch: chains that differ in it are refused); a chain sharded by positions runs spec 2, so it is the
+ * unsharded chain under dsm_ctx_force_stats_spec(ctx, 2).  */
 int dsm_ctx_stats_spec(dsm_ctx *ctx);
 int dsm_ctx_force_stats_spec(dsm_ctx *ctx, int spec);
 /* how often this process has measured where a subset table should start (~2 ms of stage-1 launches on the chain's own state; a measured

@@ -38,22 +38,30 @@ def _same(a, b):
 
 
 # shapes: fused stage 2 (G < 10) with lane groups of 16 / 32 / 64, the stand-alone stage-2 launch (G >= 10), several
-# MT19937 chunks (n_iter > 1 + 2 + 3), a second call on the same contexts (stream positions, buffers kept)
+# MT19937 chunks (n_iter > 1 + 2 + 3), a second call on the same contexts (stream positions, buffers kept).
+# spec: 0 = nothing forced -- every chain, alone or in the batch, runs what the shape rule gives (round 5: a chain's draws do not depend
+# on how it is run; these small tables take the per-read pass, which a batch launches chain by chain); 2 / 4 = every context asks for it
+@pytest.mark.parametrize("spec", [0, 2, 4])
 @pytest.mark.parametrize("V,S,G,K,n_iter", [(300, 16, 5, 3, 12), (200, 64, 8, 5, 9), (150, 40, 3, 8, 7), (90, 20, 11, 2, 5), (64, 100, 4, 4, 6),
                                              (900, 10, 2, 3, 5)])      # the last: subset table in 8 copies
-def test_batch_equals_chains_run_one_by_one(V, S, G, K, n_iter):
+def test_batch_equals_chains_run_one_by_one(V, S, G, K, n_iter, spec):
     counts, _, _ = synth_counts(V, S, G, seed=500 + V)
     states = [random_state(V, S, G, seed=600 + k) for k in range(K)]
     single, batch = [], []
+    want = None
     for k in range(K):
         a = _chain(counts, states[k], 1000 + k, 0xB47C4000 + k)
-        a.force_stats_spec(_lib.STATS_AGG)                      # what a batch runs
+        a.force_stats_spec(spec)
+        want = a.stats_spec()
         a.gibbs_update(n_iter)
         first = _snapshot(a)
         a.gibbs_update(3)
         single.append((first, _snapshot(a)))
         a.close()
+    assert spec == 0 or want == (2 if spec == 2 or G > 8 else 4)
     ctxs = [_chain(counts, states[k], 1000 + k, 0xB47C4000 + k) for k in range(K)]
+    for c in ctxs:
+        c.force_stats_spec(spec)
     _lib.Context.batch_gibbs_update(ctxs, n_iter)
     for k in range(K):
         _same(single[k][0], _snapshot(ctxs[k]))
@@ -61,7 +69,6 @@ def test_batch_equals_chains_run_one_by_one(V, S, G, K, n_iter):
     for k in range(K):
         _same(single[k][1], _snapshot(ctxs[k]))
     # a context of the batch goes on alone afterwards, on its own streams
-    ctxs[0].force_stats_spec(_lib.STATS_AGG)
     ctxs[0].gibbs_update(2)
     assert np.isfinite(ctxs[0].get_trace()["lp"]).all()
     for c in ctxs:
@@ -74,6 +81,11 @@ def test_batch_argument_checks():
     b = _chain(counts[:40], random_state(40, 8, 3, seed=3), 1, 2)
     with pytest.raises(_lib.DesmanHipError):
         _lib.Context.batch_gibbs_update([a, b], 2)             # shapes differ
+    a2 = _chain(counts, random_state(50, 8, 3, seed=4), 1, 2)
+    a2.force_stats_spec(_lib.STATS_AGG)
+    with pytest.raises(_lib.DesmanHipError):
+        _lib.Context.batch_gibbs_update([a, a2], 2)            # one chain asks for another mu/E specification than the other runs
+    a2.close()
     with pytest.raises(_lib.DesmanHipError):
         _lib.Context.batch_gibbs_update([a, a], 2)             # the same chain twice
     with pytest.raises(_lib.DesmanHipError):

@@ -257,3 +257,78 @@ def test_nmft_graph_replay_equals_the_eager_loop(fix_gamma, monkeypatch):
     assert n0 == n_ref
     np.testing.assert_allclose(tr0, tr_ref, rtol=1e-9)
     np.testing.assert_allclose(t0, tc, rtol=1e-6, atol=1e-12)
+
+
+# ---- a chain's draws do not depend on how it is run (VERDICT r4 "weak" 1): nothing forced, BASELINE config-5 shapes where the rule gives
+# the word-pooled mu/E pass (spec 4) to the lone chain -- rounds 2-4 ran spec 2 in every batch
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_full_size_batch_by_rule_equals_chains_one_by_one(G):
+    V, S, K, n_iter = 50000, 96, 2, 4
+    counts, _, _ = synth_counts(V, S, 6, seed=1234)                # six strains: few tau words
+    states = [random_state(V, S, G, seed=40 + k) for k in range(K)]
+
+    def chain(k):
+        c = _lib.Context(0)
+        c.set_counts(counts); c.set_state(*states[k]); c.seed(100 + k, ctr_seed=0xC0FFEE00 + k)
+        return c
+    single = []
+    for k in range(K):
+        a = chain(k)
+        assert a.stats_spec() == 4
+        a.gibbs_update(n_iter)
+        single.append((a.get_trace(), a.get_state()))
+        a.close()
+    ctxs = [chain(k) for k in range(K)]
+    _lib.Context.batch_gibbs_update(ctxs, n_iter)
+    for k, c in enumerate(ctxs):
+        tr, st = c.get_trace(), c.get_state()
+        for key in ("ll", "lp", "nchange", "gamma", "eta"):
+            assert np.array_equal(tr[key], single[k][0][key]), (G, k, key)
+        assert all(np.array_equal(x, y) for x, y in zip(st, single[k][1]))
+        c.close()
+
+
+def test_full_size_sharded_chain_is_the_unsharded_chain_under_spec_2():
+    """A chain sharded by positions runs the aggregated pass, spec 2 (representatives of the word-pooled pass would be per shard:
+    kernels_stats.hip: stats_spec), whatever the rule gives the unsharded chain -- here spec 4.  Two shards of a BASELINE config-5
+    table equal the unsharded chain that ASKS for spec 2 (dsm_ctx_force_stats_spec / DESMAN_HIP_STATS_SPEC=2) bit for bit; the
+    unsharded chain by rule draws other variates of the same law (tests/test_gpu_parity.py: the law tests of every spec)."""
+    import threading
+    from desman_amd import vshard
+    V, S, G, n_iter, shards = 50000, 96, 4, 3, 2
+    counts, _, _ = synth_counts(V, S, 6, seed=1234)
+    tau, gamma, eta = random_state(V, S, G, seed=77)
+    seed, cseed = 5, 0xFEED5EED4321
+    refs = {}
+    for force in (0, _lib.STATS_AGG):
+        c = _lib.Context(0)
+        c.set_counts(counts); c.set_state(tau, gamma, eta); c.seed(seed, ctr_seed=cseed); c.set_tau_rng(_lib.RNG_PHILOX)
+        c.force_stats_spec(force)
+        assert c.stats_spec() == (4 if force == 0 else 2)
+        c.gibbs_update(n_iter)
+        refs[force] = (c.get_trace(), c.get_state()[0])
+        c.close()
+    b = vshard.shard_bounds(V, shards)
+    ex = vshard.HostExchange(shards)
+    chains = []
+    for k in range(shards):
+        ch = vshard.ShardedChain(counts[b[k]:b[k + 1]], b[k], V, G, seed, ctr_seed=cseed)
+        ch.set_state(tau[b[k]:b[k + 1]], gamma, eta)
+        chains.append(ch)
+    errs = []
+
+    def work(k):
+        try:
+            chains[k].update(n_iter, ex.for_shard(k))
+        except BaseException as e:                           # noqa: BLE001
+            errs.append(e)
+            ex.bar.abort()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(shards)]
+    [t.start() for t in th]
+    [t.join(900) for t in th]
+    assert not errs, errs
+    tr2 = refs[_lib.STATS_AGG][0]
+    for k, ch in enumerate(chains):
+        tr = ch.trace()
+        assert np.array_equal(tr["gamma"], tr2["gamma"]) and np.array_equal(tr["eta"], tr2["eta"]) and np.array_equal(tr["nchange"], tr2["nchange"])
+    assert not np.array_equal(refs[0][0]["gamma"], tr2["gamma"])        # (spec 4's variates are others)

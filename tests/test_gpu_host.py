@@ -257,14 +257,14 @@ def test_nmft_stays_on_the_reference_trajectory_for_the_5000_updates_of_config1(
 
 def test_gsweep_with_batched_replicates_equals_chains_run_one_by_one(tmp_path, monkeypatch):
     """desman-sweep -b K: the replicate chains of a G value share every launch of the Gibbs loop (dsm_batch_gibbs_update,
-    cli.main_replicates).  File for file what the chains give one by one under the same mu/E specification (a batch always
-    takes the aggregated pass; DESMAN_HIP_STATS_SPEC=2 makes single chains take it on this small table too)."""
+    cli.main_replicates).  File for file what the chains give one by one, nothing forced: a chain's mu/E specification is its own in
+    a batch too (round 5; rounds 2-4 needed DESMAN_HIP_STATS_SPEC=2 here, a batch always took the aggregated pass)."""
     from desman_amd import chains
     V, S, G = 160, 12, 3
     counts, _, _ = synth_counts(V, S, G, seed=99)
     freq = str(tmp_path / "syn.freq")
     _write_freq(freq, counts)
-    monkeypatch.setenv("DESMAN_HIP_STATS_SPEC", "2")
+    monkeypatch.delenv("DESMAN_HIP_STATS_SPEC", raising=False)
     one, bat = str(tmp_path / "one"), str(tmp_path / "bat")
     chains.main([freq, "--gmin", "2", "--gmax", "4", "--reps", "3", "-i", "30", "-r", "100", "-o", one, "-c", "1"])
     chains.main([freq, "--gmin", "2", "--gmax", "4", "--reps", "3", "-i", "30", "-r", "100", "-o", bat, "-b", "3"])
@@ -309,7 +309,7 @@ def test_batched_replicates_whose_haplotype_counts_diverge_finish_in_groups(tmp_
 
 @pytest.mark.parametrize("G,S", [(3, 10), (13, 8), (4, 130)])
 def test_main_replicates_equals_main_also_where_the_batched_nmf_start_falls_back(tmp_path, monkeypatch, G, S):
-    """cli.main_replicates against cli.main chain by chain (same mu/E specification: DESMAN_HIP_STATS_SPEC=2), file for
+    """cli.main_replicates against cli.main chain by chain (nothing forced: the batch runs the chains' own mu/E specification), file for
     file.  Until round 5 S = 130 was outside the batched NMF kernels while the Gibbs batch still applied: the start and the -r fit
     fell back to one chain at a time and had to draw the initial factors from each chain's numpy stream ONCE (a second draw from
     the advanced stream would change every later number of the chain).  nmft_split_kernel_b batches it now; the files are the same."""
@@ -318,7 +318,7 @@ def test_main_replicates_equals_main_also_where_the_batched_nmf_start_falls_back
     counts, _, _ = synth_counts(V, S, min(G, 4), seed=55)
     freq = str(tmp_path / "syn.freq")
     _write_freq(freq, counts)
-    monkeypatch.setenv("DESMAN_HIP_STATS_SPEC", "2")
+    monkeypatch.delenv("DESMAN_HIP_STATS_SPEC", raising=False)
     seeds = (0, 1, 2)
     for k in seeds:
         cli.main([freq, "-g", str(G), "-s", str(k), "-i", "12", "-r", "80", "-o", str(tmp_path / ("one%d" % k))])

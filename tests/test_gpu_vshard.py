@@ -1,5 +1,6 @@
 """One chain sharded by positions (desman_amd/vshard.py, dsm_ctx_gibbs_update_sharded; SURVEY sec. 8(e) last row): the chain
-must not depend on how it is sharded.  Two / three shards on ONE GPU (one host thread each, reduction through host memory)
+must not depend on how it is sharded -- it is the unsharded chain under the aggregated mu/E pass, spec 2, which _unsharded asks for
+(what the shape rule would give the unsharded chain is another matter: desman_amd/vshard.py).  Two / three shards on ONE GPU (one host thread each, reduction through host memory)
 against the same chain in one context: tau slice by slice, gamma / eta / their traces and the change counts bit for bit,
 ll / lp to rounding (sums of shard sums).  The RCCL form of the exchange is walked with a world of one rank."""
 import os

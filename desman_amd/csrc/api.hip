@@ -226,7 +226,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     dev_free(&c->s2_scratch);
     dev_free(&c->blk_tab); stats_release_ntab(c); dev_free(&c->big_list); dev_free(&c->big_count);
     dev_free(&c->gamma); dev_free(&c->eta);
-    dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->u_raw);
+    dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->mt_jstates); dev_free(&c->u_raw);
     dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->sweep_stats); dev_free(&c->step_cnt); dev_free(&c->blk_order); dev_free(&c->screen_ctl); dev_free(&c->prior); dev_free(&c->prior_all); dev_free(&c->scalars); dev_free(&c->star);
     dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->shard_vec); dev_free(&c->np_part); if (c->np_bar) { (void)hipFree(c->np_bar); c->np_bar = nullptr; } dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ntau2); dev_free(&c->ngam); dev_free(&c->ngam_raw);
     dev_free(&c->npart); dev_free(&c->nstat);

@@ -118,6 +118,7 @@ struct dsm_ctx {
     unsigned long long *esum = nullptr;     // [4][4] [observed][true]
     // RNG
     uint32_t *mt_state = nullptr;   // 624 words + position
+    uint32_t *mt_jstates = nullptr; // starting arrays of the chunks of a parallel fill (kernels_gibbs.hip: mt_fill_parallel), made on first use
     bool mt_seeded = false;
     uint32_t *u_raw = nullptr;      // [2][u_chunk_words] raw MT19937 words: two slots of several sweeps each
     size_t u_cap = 0;               // words per sweep = V*G

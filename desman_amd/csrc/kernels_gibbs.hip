@@ -12,6 +12,8 @@
 // haplotype in one u64 per variant, gamma [S][G] f64, eta [4][4] f64.
 #include <string.h>
 
+#include <mutex>
+
 #include "dsm_device.h"
 #include "dsm_host.h"
 #include "dsm_stage2.h"
@@ -245,6 +247,153 @@ __global__ __launch_bounds__(1024) void mt_fill_wide_kernel_b(BatchArgs<MtArgs> 
 {
     const MtArgs &a = b.p[blockIdx.x];
     mt_fill_wide_body(a.state, a.out, a.n);
+}
+
+// ---------------------------------------------------------------------
+// The same stream from SEVERAL compute units (round 5).  One workgroup makes a sweep's V G words at ~2.5 per ns whatever its width;
+// updateTau on large tables (the `-r` path, bin/desman:181-206) waited for it: 400 000 words in 153-195 us against a sweep of 184.
+// MT19937's block reload -- 624 words -> the next 624 -- is GF(2)-linear in the 19 968 bits of the array, so the array D = 210 blocks
+// (131 040 words) further on is M s with a fixed 19 968 x 19 968 bit matrix M, whatever s.  M is built once per device and process:
+// column c is the array that 210 reloads make of unit vector c (one wavefront per column: a reload is wave-synchronous LDS code,
+// no barrier; 0.3 ms for all columns), stored column by column [19 968][624] u32 = 50 MB; likewise M4 = 840 blocks.  A state is then
+// moved D words on by XOR-ing the columns its set bits select (mt_jump_kernel: 208 column chunks x 3 word groups, 50 MB read,
+// a GF(2) sum: exact), and a fill of n >= 6 D words runs as up to 32 chunks at a time: the starting arrays S[q] = M4 S[q - 4] in a chain,
+// the three between two of them from M in three launches for all q at once, then ONE launch of a generator workgroup per chunk -- the
+// generator above, on its own chunk and its own copy of the state.  The last chunk's final state is the stream's: bit-identical to the
+// serial generator and to gsl_rng_mt19937 (tests/test_gpu_edges.py: 10^7 words across chunk and round boundaries, hand-offs).
+// ---------------------------------------------------------------------
+#define MTJ_BLOCKS 210
+#define MTJ_D ((size_t)MTJ_BLOCKS * 624)
+#define MTJ_BITS 19968
+#define MTJ_NCH 208                    // column chunks of a jump: 96 columns = 3 state words each
+#define MTJ_PMAX 32                    // chunks per round
+#define MTJ_SW 640                     // words per state slot (624 + position, padded)
+
+// one wavefront: `nreload` block reloads of the array in LDS (in place: a pass of 64 positions reads what no earlier pass has
+// written -- position i needs the OLD words i and i + 1 and word i + 397 (old) or i - 227 (new))
+__device__ __forceinline__ void mt_reload_wave(uint32_t *mt, int lane)
+{
+    for (int i0 = 0; i0 < 624; i0 += 64) {
+        const int i = i0 + lane;
+        uint32_t v = 0;
+        if (i < 623) {
+            const uint32_t far = (i < 227) ? mt[i + 397] : mt[i - 227];
+            v = far ^ mt_twist(mt[i], mt[i + 1]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (i < 623) mt[i] = v;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) mt[623] = mt[396] ^ mt_twist(mt[623], mt[0]);
+    __builtin_amdgcn_wave_barrier();
+}
+__global__ __launch_bounds__(256) void mt_jump_build_kernel(uint32_t *__restrict__ M, int nreload)
+{
+    __shared__ uint32_t st[4][624];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + wv;                          // column = unit vector: bit c % 32 of word c / 32
+    if (c >= MTJ_BITS) return;
+    uint32_t *mt = st[wv];
+    for (int i = lane; i < 624; i += 64) mt[i] = (i == (c >> 5)) ? (1u << (c & 31)) : 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (int r = 0; r < nreload; ++r) mt_reload_wave(mt, lane);
+    for (int i = lane; i < 624; i += 64) M[(size_t)c * 624 + i] = mt[i];
+}
+// S[dst] ^= M S[src] for the (src, dst) pairs of the launch: pair y is src = base + step y + from, dst = src + to (skipped from dst = P on).
+// grid (3 word groups, MTJ_NCH column chunks, pairs); S[dst] is zero before (one memset per round).  Chunk 0 copies the position word.
+__global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t *__restrict__ M, uint32_t *__restrict__ S, int base, int step, int from, int to, int P)
+{
+    const int src = base + step * (int)blockIdx.z + from, dst = src + to;
+    if (dst >= P) return;
+    const uint32_t *__restrict__ s = S + (size_t)src * MTJ_SW;
+    uint32_t *__restrict__ o = S + (size_t)dst * MTJ_SW;
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    const int c0 = blockIdx.y * (MTJ_BITS / MTJ_NCH);           // 96 columns = 3 words of the state
+    uint32_t acc = 0;
+    if (w < 624) {
+#pragma unroll
+        for (int k = 0; k < (MTJ_BITS / MTJ_NCH) / 32; ++k) {
+            const uint32_t bits = s[(c0 >> 5) + k];             // (uniform over the workgroup)
+            const uint32_t *__restrict__ col = M + ((size_t)c0 + 32 * (size_t)k) * 624 + w;
+            uint32_t v[32];
+#pragma unroll
+            for (int b = 0; b < 32; ++b) v[b] = col[(size_t)b * 624];      // 32 loads in flight (a loop over the set bits alone was one
+#pragma unroll                                                            //  exposed latency per column: 55 us per jump instead of 12)
+            for (int b = 0; b < 32; ++b) acc ^= ((bits >> b) & 1u) ? v[b] : 0u;
+        }
+        if (acc) atomicXor(&o[w], acc);
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) o[624] = s[624];
+}
+struct MtParArgs { uint32_t *S, *out; size_t n; };
+// one generator workgroup per chunk: chunk p starts from S[p] and writes words [p D, min((p + 1) D, n)); it leaves its final state in S[p]
+__global__ __launch_bounds__(1024) void mt_fill_par_kernel(MtParArgs a)
+{
+    const size_t p = blockIdx.x, lo = p * MTJ_D;
+    if (lo >= a.n) return;
+    const size_t cnt = (a.n - lo < MTJ_D) ? a.n - lo : MTJ_D;
+    mt_fill_wide_body(a.S + p * MTJ_SW, a.out + lo, cnt);
+}
+
+struct MtJumpDev { std::mutex mu; uint32_t *M1 = nullptr, *M4 = nullptr; bool ready = false, failed = false; };
+static MtJumpDev g_mtj[16];
+static int mt_jump_tables(dsm_ctx *c, hipStream_t stream, const uint32_t **M1, const uint32_t **M4)
+{
+    MtJumpDev &d = g_mtj[c->device & 15];
+    std::lock_guard<std::mutex> lk(d.mu);
+    if (!d.ready && !d.failed) {
+        const size_t bytes = (size_t)MTJ_BITS * 624 * sizeof(uint32_t);
+        if (hipMalloc((void **)&d.M1, bytes) != hipSuccess || hipMalloc((void **)&d.M4, bytes) != hipSuccess) {
+            if (d.M1) { (void)hipFree(d.M1); d.M1 = nullptr; }
+            d.failed = true;                                    // no room for the tables: the serial generator serves (same words)
+            (void)hipGetLastError();
+        } else {
+            hipLaunchKernelGGL(mt_jump_build_kernel, dim3(MTJ_BITS / 4), dim3(256), 0, stream, d.M1, MTJ_BLOCKS);
+            hipLaunchKernelGGL(mt_jump_build_kernel, dim3(MTJ_BITS / 4), dim3(256), 0, stream, d.M4, 4 * MTJ_BLOCKS);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(stream));             // other contexts of the device use the tables from their own streams
+            d.ready = true;
+        }
+    }
+    *M1 = d.M1; *M4 = d.M4;
+    return DSM_OK;
+}
+
+// a fill of n words as rounds of up to MTJ_PMAX chunks of D words; returns how many words it made (0: tables not available)
+static int mt_fill_parallel(dsm_ctx *c, uint32_t *out, size_t n, hipStream_t stream, size_t *made)
+{
+    *made = 0;
+    const uint32_t *M1 = nullptr, *M4 = nullptr;
+    { const int r = mt_jump_tables(c, stream, &M1, &M4); if (r != DSM_OK) return r; }
+    if (!M1) return DSM_OK;
+    if (!c->mt_jstates) {
+        hipError_t e = hipMalloc((void **)&c->mt_jstates, (size_t)MTJ_PMAX * MTJ_SW * sizeof(uint32_t));
+        if (e != hipSuccess) { (void)hipGetLastError(); return DSM_OK; }
+    }
+    static bool attr_set[16] = {false};
+    if (!attr_set[c->device & 15]) {
+        HIP_TRY(hipFuncSetAttribute((const void *)mt_fill_par_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        attr_set[c->device & 15] = true;
+    }
+    uint32_t *S = c->mt_jstates;
+    while (n - *made >= 2 * MTJ_D) {
+        const size_t rem = n - *made;
+        const int P = (int)std::min<size_t>(MTJ_PMAX, (rem + MTJ_D - 1) / MTJ_D);
+        const size_t words = std::min<size_t>(rem, (size_t)P * MTJ_D);
+        HIP_TRY(hipMemcpyAsync(S, c->mt_state, 625 * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemsetAsync(S + MTJ_SW, 0, (size_t)(P - 1) * MTJ_SW * sizeof(uint32_t), stream));
+        for (int q = 4; q < P; q += 4)                         // S[q] = M4 S[q - 4]
+            hipLaunchKernelGGL(mt_jump_kernel, dim3(3, MTJ_NCH, 1), dim3(256), 0, stream, M4, S, q - 4, 0, 0, 4, P);
+        const int nq = (P + 3) / 4;
+        for (int r = 1; r <= 3 && r < P; ++r)                  // S[4 y + r] = M S[4 y + r - 1], every y in one launch
+            hipLaunchKernelGGL(mt_jump_kernel, dim3(3, MTJ_NCH, nq), dim3(256), 0, stream, M1, S, 0, 4, r - 1, 1, P);
+        const MtParArgs a{S, out + *made, words};
+        hipLaunchKernelGGL(mt_fill_par_kernel, dim3(P), dim3(1024), (size_t)140 * 1024, stream, a);   // (a CU to itself each: see k_mt_fill)
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(c->mt_state, S + (size_t)(P - 1) * MTJ_SW, 625 * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        *made += words;
+    }
+    return DSM_OK;
 }
 
 // =====================================================================
@@ -1130,6 +1279,15 @@ int k_mt_fill(dsm_ctx *c, uint32_t *out, size_t n, hipStream_t stream)
         if (hog && !c->mt_attr_set) {                                  // per device, hence per context
             HIP_TRY(hipFuncSetAttribute((const void *)mt_fill_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, hog * 1024));
             c->mt_attr_set = true;
+        }
+        // long fills (chunks of sweeps of a large table): from several CUs (mt_fill_parallel above); what is left, if anything, serially
+        static const bool no_par = DSM_AB_ENV("DESMAN_HIP_MT_SERIAL") != nullptr;        // A/B switch
+        static const size_t par_min = DSM_AB_ENV("DESMAN_HIP_MT_PAR_MIN") ? (size_t)atoi(DSM_AB_ENV("DESMAN_HIP_MT_PAR_MIN")) : 6;   // A/B switch, in chunks of D words (config 3, 80 000 words per sweep, never gets there: its generator hides behind the iteration, and five CUs taken at once cost it 0.103 -> 0.106-0.112 ms per iteration)
+        if (!g_batch.K && !no_par && n >= par_min * MTJ_D) {
+            size_t made = 0;
+            { const int r = mt_fill_parallel(c, out, n, stream, &made); if (r != DSM_OK) return r; }
+            out += made; n -= made;
+            if (n == 0) return DSM_OK;
         }
         if (g_batch.K) {
             static thread_local BatchArgs<MtArgs> acc;

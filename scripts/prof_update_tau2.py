@@ -4,7 +4,8 @@ import sys, time; sys.path.insert(0, '.')
 import numpy as np
 from desman_amd import _lib
 from desman_amd.synth import synth_counts, random_state
-V, S, G, n = 10000, 64, 8, 200
+a = [int(x) for x in sys.argv[1:]]
+V, S, G, n = (a + [10000, 64, 8, 200][len(a):])[:4]        # usage: prof_update_tau2.py [V S G sweeps]
 counts, tt, gg = synth_counts(V, S, G, 1234)
 tau, gamma, eta = random_state(V, S, G, seed=1)
 for mode in ("mt", "philox"):

@@ -166,6 +166,29 @@ def test_mt19937_device_stream_is_gsl_stream_across_fills_and_handoffs():
     ctx.close()
 
 
+def test_mt19937_long_fills_from_several_compute_units_are_the_gsl_stream():
+    """round 5: fills of 6 x 131 040 words and more run as chunks on several CUs, each from the state a GF(2) jump matrix makes of the
+    stream's (kernels_gibbs.hip: mt_fill_parallel).  Raw words bit for bit against the oracle's serial gsl_rng_mt19937: 10^7 words
+    (76.3 chunks = three rounds of 32 and a serial rest), lengths that end exactly on / one off a chunk and a round edge, from
+    positions inside a block, the state left behind, short fills in between, a hand-off to another context."""
+    D = 210 * 624
+    ctx = _lib.Context(0)
+    for seed in (5489, 0):
+        ctx.seed(seed)
+        ref = cbind.MT19937(seed)
+        for n in (7, 6 * D, 1, 6 * D + 1, 600, 32 * D, 33 * D - 1, 10 ** 7, 3, 8 * D + 311):
+            got = ctx.debug_mt_fill(n)
+            want = ref.raw(n)
+            assert np.array_equal(got, want), (seed, n, int(np.argmax(got != want)))
+    st = ctx.get_mt_state()
+    c2 = _lib.Context(0)
+    c2.set_mt_state(st)
+    a, b = ctx.debug_mt_fill(7 * D + 5), c2.debug_mt_fill(7 * D + 5)
+    c2.close()
+    assert np.array_equal(a, b) and np.array_equal(a, ref.raw(7 * D + 5))
+    ctx.close()
+
+
 def test_mt19937_stream_position_across_chunked_calls():
     """the sweeps' words are generated in chunks of 1, 2, 3, 4, 6, 8, 8, ... sweeps ahead of their reader, into two slots
     (api.hip: SweepWords): every sweep of a long updateTau gets exactly its V*G words of the GSL stream (bit-identical

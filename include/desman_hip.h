@@ -5,7 +5,7 @@
  * Two layers:
  *
  *  (1) LEGACY SHIM -- the four entry points the reference's Cython module
- *      `sampletau` binds (sampletau/sampletau.pyx:10-16), with identical
+ *      `sampletau` binds (sampletau/sampletau.pyx:13-19), with identical
  *      argument meaning: borrowed host pointers, tau mutated in place, one
  *      process-global MT19937 stream.  Differences: explicit int64_t, and
  *      errors come back as negative return codes instead of exit(1)
@@ -65,9 +65,9 @@ int dsm_freeRNG(void);
  * of (v,g) whose base changed (>= 0) or a negative DSM_ERR_* code.           */
 int dsm_sample_tau(int64_t *tau, const double *pi, const double *eta,
                    const int64_t *variants, int nV, int nG, int nS);
-/* the same four entry points under the reference's own names and prototypes (what `cdef extern from
- * "c_sample_tau.h"` in sampletau/sampletau.pyx:10-16 binds; c_sample_tau.c:26,36,42,95), so the unmodified
- * .pyx links against libdesman_hip.so.  Errors go to stderr; c_sample_tau then returns -1.          */
+/* the same four entry points under the reference's own names and prototypes (what the four bare `cdef extern`
+ * declarations of sampletau/sampletau.pyx:13-19 bind -- there is no header in the reference; c_sample_tau.c:26,36,42,95),
+ * so the unmodified .pyx links against libdesman_hip.so.  Errors go to stderr; c_sample_tau then returns -1.        */
 void c_initRNG(void);
 void c_setRNG(unsigned long seed);
 void c_freeRNG(void);

@@ -885,6 +885,43 @@ __device__ __forceinline__ double fdiv(double a, double b)
     const double q = a * r;
     return fma(fma(-b, q, a), r, q);
 }
+// ... and where the operands ARE at the ends of the exponent range (round 5, found by scripts/dbg/fuzz_nmft.py: a tau row of subnormal start
+// values -- 8e-4 of a Dirichlet(0.01) draw's components are below 1e-308 -- against gamma columns that are as small: R = 5.6e-310, F / R =
+// 8.9e307 in the reference, but v_rcp_f64 of a subnormal is inf and the Newton step makes NaN of it): the operands are brought to within
+// 2^+-512 of one by exact powers of two, the powers put back on the quotient; where the scales are one (always, but for such operands)
+// the bits of fdiv.  fdiv_lo: a in (0, 1] (an element of F) over any b > 0; fdiv_ext: any a, b >= 0.
+__device__ __forceinline__ double nm_pow2_sel(bool c, int hi_c, int hi_else) { return __hiloint2double(c ? hi_c : hi_else, 0); }    // one select on the high word
+__device__ __forceinline__ double fdiv_lo(double a, double b)
+{
+    const double s = nm_pow2_sel(b < 0x1p-500, 0x5FF00000, 0x3FF00000);        // 2^512 : 1
+    return fdiv(a, b * s) * s;
+}
+// a tile's four quotients F (/) R of the tau half: the scaled form only for a wavefront that holds such a divisor (one test per tile)
+__device__ __forceinline__ double4_t nm_div_tile(const double4_t ft, const double4_t R)
+{
+    double4_t Rz, qv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Rz[e] = nzd(R[e]);
+    double m01, m23, m;
+    asm("v_min_f64 %0, %1, %2" : "=v"(m01) : "v"(Rz[0]), "v"(Rz[1]));
+    asm("v_min_f64 %0, %1, %2" : "=v"(m23) : "v"(Rz[2]), "v"(Rz[3]));
+    asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(m01), "v"(m23));
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(m < 0x1p-500) != 0ull, 0)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qv[e] = fdiv_lo(ft[e], Rz[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qv[e] = fdiv(ft[e], Rz[e]);
+    }
+    return qv;
+}
+__device__ __forceinline__ double fdiv_ext(double a, double b)
+{
+    const bool ah = a > 0x1p500, al = a < 0x1p-500, bh = b > 0x1p500, bl = b < 0x1p-500;
+    const double sa = ah ? 0x1p-512 : (al ? 0x1p512 : 1.0), ia = ah ? 0x1p512 : (al ? 0x1p-512 : 1.0);
+    const double sb = bh ? 0x1p-512 : (bl ? 0x1p512 : 1.0);
+    return (fdiv(a * sa, b * sb) * sb) * ia;
+}
 // Q2 = F (/) max(R2, eps) and the objective terms of one 16-sample tile (Init_NMFT.py:152-156, du.elop), element e = base.
 // F is a count + 1 over a depth + 4, never zero: elop's zero test can only fire on R.  Lanes without a cell (padded samples,
 // variants past the end) carry some F of the table and R = 0: their quotient F / eps is finite, meets a zero row of tau in the
@@ -914,9 +951,9 @@ __device__ __forceinline__ double4_t nm_tile_q2_rare(const double4_t &ft, const 
         const double Re = e == 0 ? R[0] : e == 1 ? R[1] : e == 2 ? R[2] : R[3], fe = e == 0 ? ft[0] : e == 1 ? ft[1] : e == 2 ? ft[2] : ft[3];
         const bool tiny = Re < DSM_EPS;
         const double pa = tiny ? DSM_EPS : Re;
-        const double ratio = fdiv(fe, pa);
+        const double ratio = fdiv(fe, pa);                                       // (pa >= eps, F in (0, 1]: a normal number)
         // elop divides by R itself when 0 < R < eps; nzd: the lanes without a cell have R = 0
-        const double qq = (tiny && Re != 0.0) ? fdiv(fe, nzd(Re)) : ratio;
+        const double qq = (tiny && Re != 0.0) ? fdiv_ext(fe, nzd(Re)) : ratio;       // (0 < R < eps may be a subnormal)
         q2[0] = e == 0 ? qq : q2[0]; q2[1] = e == 1 ? qq : q2[1]; q2[2] = e == 2 ? qq : q2[2]; q2[3] = e == 3 ? qq : q2[3];
         const double o2 = obj + (fe * nm_log_any(ratio, ltab) - fe + pa);
         obj = live ? o2 : obj;
@@ -936,7 +973,7 @@ __device__ __forceinline__ double4_t nm_tile_q2(const double4_t &ft, const doubl
     for (int e = 0; e < 4; ++e) {
         double pa;                                                              // max(R, eps) -- lanes without a cell: R = 0 -- as ONE instruction
         asm("v_max_f64 %0, %1, %2" : "=v"(pa) : "v"(R[e]), "v"(DSM_EPS));       // (the builtin quiets a signalling NaN first: an instruction more)
-        const double ratio = fdiv(ft[e], pa);
+        const double ratio = fdiv(ft[e], pa);                                   // (pa >= eps, F in (0, 1]: the quotient is a normal number)
         q2[e] = ratio;
         term[e] = ft[e] * dsm_log_core(ratio, ltab) - ft[e] + pa;
     }
@@ -1040,12 +1077,12 @@ __device__ __forceinline__ void nm_tau_finish(const double4_t &num, const double
     const bool okg = n < G;
     double tn[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) tn[e] = okg ? told[(4 * e + q) * GP + n] * fdiv(nzd(num[e]), nzd(t1[okg ? n : 0])) : 0.0;   // :171-172
+    for (int e = 0; e < 4; ++e) tn[e] = okg ? told[(4 * e + q) * GP + n] * fdiv_ext(nzd(num[e]), nzd(t1[okg ? n : 0])) : 0.0;   // :171-172
     const double tot = ((tn[0] + tn[1]) + tn[2]) + tn[3];                                                                  // :176-178
     if (okg) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            double x = fdiv(tn[e], tot);                                                                                   // :180-181
+            double x = fdiv_ext(tn[e], tot);                                                                                 // :180-181
             if (adjust && x < DSM_EPS) x = DSM_EPS;                                                                        // :88-91
             if (TO_GLOBAL && store) tau_v[(size_t)e * G + n] = x;
             tnew[(4 * e + q) * GP + n] = vok ? x : 0.0;
@@ -1189,9 +1226,13 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) R = NM_MFMA(a_old[kb], graw_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
                 const double4_t ft = tile(t);
-                double4_t qv;
+                double4_t qv;                                                           // nm_tile_q2: F > 0; lanes without a cell stay finite
+                if constexpr (VC) {                                                     // (the branch-free form: this instantiation has no register left for a second block)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qv[e] = fdiv(ft[e], nzd(R[e]));             // nm_tile_q2: F > 0; lanes without a cell stay finite
+                    for (int e = 0; e < 4; ++e) qv[e] = fdiv_lo(ft[e], nzd(R[e]));
+                } else {
+                    qv = nm_div_tile(ft, R);
+                }
                 if constexpr (VC) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -1210,12 +1251,12 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
                 const int my_e = (b0 ? 2 : 0) + (b1 ? 1 : 0), g = (b3 ? 2 : 0) + (b2 ? 1 : 0);
                 const double part = row16_transpose_reduce(p, n);
                 const bool okg = g < G;
-                const double tn = okg ? told[(4 * my_e + q) * GP + g] * fdiv(nzd(part), nzd(t1[okg ? g : 0])) : 0.0;      // :171-172
+                const double tn = okg ? told[(4 * my_e + q) * GP + g] * fdiv_ext(nzd(part), nzd(t1[okg ? g : 0])) : 0.0;      // :171-172
                 const double t_a0 = dpp_mov<0x00>(tn), t_a1 = dpp_mov<0xAA>(tn);              // e = 0 / 1 live in quad lanes 0 / 2
                 const double t_a2 = dpp_mov<0x55>(tn), t_a3 = dpp_mov<0xFF>(tn);              // e = 2 / 3            quad lanes 1 / 3
                 const double tot = ((t_a0 + t_a1) + t_a2) + t_a3;                              // :176-178
                 if (okg) {
-                    double x = fdiv(tn, tot);                                                  // :180-181
+                    double x = fdiv_ext(tn, tot);                                                // :180-181
                     if (adjust && x < DSM_EPS) x = DSM_EPS;                                    // :88-91
                     if (vok) tau[((size_t)(v0 + q) * 4 + my_e) * G + g] = x;
                     tnew[(4 * my_e + q) * GP + g] = vok ? x : 0.0;
@@ -1436,13 +1477,13 @@ constexpr int nmft_mfma_wgs(int NT, int KB)
     // five tiles and more: two (256 registers: the loop that looks ahead holds the next quad's rows and addresses too; measured at
     // 50k x 96 x 12 before it: 101.7 us per update at two against 106.6 at three with 22 registers spilled)
     // up to four tiles: four where 128 registers hold the kernel without scratch (round 5, with the statistics tile as straight-line code: not at
-    // (3, 1), (3, 2), (3, 3), (4, 2), (4, 3)), else three
-    return NT <= 4 ? ((KB <= 3 && NT <= 2) || (NT == 4 && KB == 1) ? 4 : 3) : 2;    // (five / six tiles, up to four haplotypes: the VC form holds 16 + 16 more values)
+    // three and four tiles), else three
+    return NT <= 4 ? ((KB <= 3 && NT <= 2) ? 4 : 3) : 2;    // (five / six tiles, up to four haplotypes: the VC form holds 16 + 16 more values)
 }
 
 // the fused pass of factorize_tau (no gamma numerators in registers, one gamma matrix and a four-word reduction in LDS): one
 // workgroup per CU more
-constexpr int nmft_mfma_fix_wgs(int NT, int KB) { return NT <= 4 ? ((KB <= 3 && !(NT == 3 && KB >= 2)) ? 5 : 4) : 3; }      // (five / six tiles: the loop that looks ahead)
+constexpr int nmft_mfma_fix_wgs(int NT, int KB) { return NT <= 4 ? (((NT == 1 && KB <= 3) || (NT == 2 && KB <= 2)) ? 5 : 4) : 3; }      // (five / six tiles: the loop that looks ahead)
 static bool mfma_shape(const dsm_ctx *c, int *nt, int *kb)
 {
     *nt = (c->S + 15) / 16;
@@ -1691,9 +1732,7 @@ __device__ __forceinline__ void nmft_split_body(const NmftMfmaParams &prm)
                 double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) R = NM_MFMA(a_old[kb], graw_p[(4 * kb + q) * LDG + 16 * tg + n], R, 0, 0, 0);
-                double4_t qv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) qv[e] = fdiv(f[t][e], nzd(R[e]));           // nm_tile_q2: F > 0; lanes without a cell stay finite
+                const double4_t qv = nm_div_tile(f[t], R);                              // nm_tile_q2: F > 0; lanes without a cell stay finite
                 num = nm_num_tile<KB>(num, qv, xq, graw_p + 16 * tg, LDG, n, q);
             }
             // this block's part of num -> LDS; all parts of the quad in block order
@@ -2238,9 +2277,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) R = NM_MFMA(a_old[kb], graw_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
                 const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
-                double4_t qv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) qv[e] = fdiv(ft[e], nzd(R[e]));             // nm_tile_q2: F > 0; lanes without a cell stay finite
+                const double4_t qv = nm_div_tile(ft, R);                                // nm_tile_q2: F > 0; lanes without a cell stay finite
                 num = nm_num_tile<KB>(num, qv, xq, graw_p + 16 * t, LDG, n, q);
             }
             nm_tau_finish<KB, false>(num, told, tnew, t1, G, n, q, adjust, false, vok, nullptr);

@@ -913,3 +913,32 @@ def test_screening_pass_never_changes_a_result(V, S, G, scale):
         assert st_a[0] == st_b[0] and st_a[1] <= st_a[0]
         if start == "truth" and scale >= 1.0:
             assert st_a[1] < 0.2 * st_a[0]                               # the screen decided most steps
+
+
+@pytest.mark.parametrize("V,S,G", [(2902, 183, 2), (515, 96, 2), (303, 64, 4), (640, 48, 3), (700, 128, 8), (200, 300, 4)])
+def test_factorize_tau_with_subnormal_start_values_and_tiny_abundances(ctx, V, S, G):
+    """scripts/dbg/fuzz_nmft.py, round 5: 8e-4 of the components of a Dirichlet(0.01) draw (Init_NMFT.py:84) are below 1e-308, and with
+    abundances that are as small in some samples R = tau . gamma is a SUBNORMAL number there; F / R is still finite in the reference
+    (8.9e307 in the case found) while the hardware reciprocal of a subnormal is inf (rounds 2-4: NaN rows).  The first case is the one
+    the fuzzer found; the others plant such rows: tau start values of 1e-308 / 1e-130, gamma columns of 1 / 1e-200."""
+    counts, _, _ = synth_counts(V, S, min(G, 4), seed=V + S)
+    tau0, gam0 = rn.nmft_random_initialize(np.random.RandomState(V + 3 * S + G), V, S, G)
+    if V != 2902:
+        gam0 = np.full((G, S), 1.0 / G)
+        for s in (3, S - 1):                                       # two samples: one haplotype has it all, the others 1e-200
+            gam0[:, s] = 1e-200
+            gam0[s % G, s] = 1.0
+        for v in range(0, V, 7):                                   # base 3 of every seventh position: a subnormal in one haplotype, 1e-130 in the others
+            tau0[3 * V + v, :] = 1e-130
+            tau0[3 * V + v, v % G] = 1e-308
+    F = cbind.nmft_freq(counts)
+    ctx.set_counts(counts)
+    ctx.nmft_set(tau0, gam0)
+    tc, gc = tau0.copy(), gam0.copy()
+    n_ref, tr_ref = cbind.nmft_factorize_tau(F, tc, gc, max_iter=6, min_change=0.0)
+    assert np.isfinite(tc).all() and np.isfinite(tr_ref[: n_ref + 1]).all()          # the reference's numbers are finite here
+    n, tr = ctx.nmft_factorize(max_iter=6, min_change=0.0, fix_gamma=True)
+    assert n == n_ref
+    np.testing.assert_allclose(tr, tr_ref, rtol=1e-9)
+    t, g = ctx.nmft_get()
+    np.testing.assert_allclose(t, tc, rtol=1e-6, atol=1e-12)

@@ -192,12 +192,12 @@ extern "C" int dsm_ctx_create(dsm_ctx **out, int device)
     TRY(dev_alloc(&c->eta, 16));
     TRY(dev_alloc(&c->eta_new, 16));
     TRY(dev_alloc(&c->eta_star, 16));
-    TRY(dev_alloc(&c->esum, 16));
+    TRY(dev_alloc(&c->esum, 16 + 16 * DSM_ESUM_PARTS));
     TRY(dev_alloc(&c->log_tab, 2 * DSM_LOG_TAB_N + DSM_EXP_TAB_N));           // log table, then the exp table of spec 3
     HIP_TRY(hipMemcpyAsync(c->log_tab, dsm_log_table_host, sizeof dsm_log_table_host, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->log_tab + 2 * DSM_LOG_TAB_N, dsm_exp_table_host, sizeof dsm_exp_table_host, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->nchange, 0, 2 * sizeof(int), c->stream));
-    HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->esum, 0, (16 + 16 * DSM_ESUM_PARTS) * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     *out = c;
     return DSM_OK;
@@ -664,6 +664,7 @@ extern "C" int dsm_ctx_sample_stats(dsm_ctx *c, uint32_t iter, uint64_t *sum_mu,
     TRY(stats_place_ntab(c));
     HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
     TRY(k_stats(c, iter));
+    TRY(k_esum_fold(c));
     if (sum_mu) HIP_TRY(hipMemcpyAsync(sum_mu, c->sum_mu, sg * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     if (esum) HIP_TRY(hipMemcpyAsync(esum, c->esum, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemsetAsync(c->sum_mu, 0, sg * sizeof(unsigned long long), c->stream));
@@ -692,6 +693,7 @@ extern "C" int dsm_ctx_debug_stage1(dsm_ctx *c, uint32_t iter, uint32_t *ntab, u
     BIND(c);
     HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
     TRY(k_stats_stage1(c, iter));
+    TRY(k_esum_fold(c));
     const size_t NH = (size_t)1 << c->G, S = (size_t)c->S;
     const size_t ld = (size_t)c->ntab_ld;
     std::vector<uint32_t> t((size_t)c->ntab_rep * NH * ld);

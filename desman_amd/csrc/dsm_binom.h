@@ -295,3 +295,171 @@ __device__ __forceinline__ void mult4(Xo128 &rng, uint32_t x, const double (&W)[
         n[a] = (a == am) ? x - m : kj;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 6: the item of the lean stage-1 kernel as ONE straight piece of code (the same draws as mult4<false, 2>, bit for bit --
+// same operations on the same operands in the same order; what changes is how many instructions the wavefront issues for them):
+//   * the quotients by the unscaled expansion (div_unscaled: v_rcp_f64, two Newton steps, quotient, residual, correction -- the
+//     compiler's IEEE expansion without v_div_scale x 2 / v_div_fmas / v_div_fixup, which are identities while the operands and
+//     the quotient are far from the ends of the exponent range) behind ONE wave-uniform range test per item; any lane outside
+//     [2^-400, 2^400] sends the wavefront's item through the IEEE divisions;
+//   * (1-q)^n with the exponent bit-reversed once: the bit test is a sign compare, one instruction less per squaring;
+//   * the read-by-read loop counts up against a scalar index, the generator's step is written with three-input xors
+//     (v_bitop3_b32), the uniform is two fused operations, the search's table pointer is its only counter;
+//   * the rare outcomes (hand-over to the compacted kernel) leave the item by ONE flag the caller tests once per cell.
+// ISA-level counts per phase: profiles/r06_stats_isa_counts.txt (scripts/isa_count.py).
+#ifdef DSM_ISA_MARKS
+#define ISA_MARK(name) asm volatile("; MARK " name)
+#else
+#define ISA_MARK(name) do { } while (0)
+#endif
+
+__device__ __forceinline__ double div_unscaled(double a, double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+    const double q = a * y;
+    const double r = fma(-b, q, a);
+    return fma(r, y, q);
+}
+// a / b; `fast` is wave-uniform: every active lane's operands (and hence the quotient's exponent) are in the safe range
+__device__ __forceinline__ double sdiv(double a, double b, bool fast) { return fast ? div_unscaled(a, b) : a / b; }
+
+// a ^= b ^ c in one instruction (gfx950: v_bitop3_b32 with the truth table of the three-input xor), in place
+__device__ __forceinline__ void xor3_into(uint32_t &a, uint32_t b, uint32_t c)
+{
+    asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a) : "v"(b), "v"(c));
+}
+// xoshiro128+ step (Xo128::next) in seven instructions, every word updated in its own register (no copies at a loop's back edge):
+// s3 ^= s1 first (the result and t = s1 << 9 are taken before), then s1 ^= s2 ^ s0 and s2 ^= s0 ^ t on the OLD s2, s0, then
+// s0 ^= s3 (the new s3 is the old s3 ^ s1), then the rotation
+__device__ __forceinline__ uint32_t xo_next7(uint32_t &s0, uint32_t &s1, uint32_t &s2, uint32_t &s3)
+{
+    const uint32_t res = s0 + s3;
+    const uint32_t t = s1 << 9;
+    s3 ^= s1;
+    xor3_into(s1, s2, s0);
+    xor3_into(s2, s0, t);
+    s0 ^= s3;
+    s3 = __builtin_amdgcn_alignbit(s3, s3, 21);  // rotl 11
+    return res;
+}
+// u01_open(a, b) in two fused operations: (a >> 5) 2^26 + (b >> 6) is exact in either form (53 bits), and (m + 0.5) 2^-53 is m 2^-53 + 2^-54
+// rounded once -- the rounding of m + 0.5 scaled by an exact power of two.  Same bits as u01_open.
+__device__ __forceinline__ double u01_open_fused(uint32_t a, uint32_t b)
+{
+    const double m = fma((double)(a >> 5), 67108864.0, (double)(b >> 6));
+    return fma(m, 0x1p-53, 0x1p-54);
+}
+
+// One (cell, observed base) item of the lean kernel.  x > 0 on the lanes that call it (the caller's exec mask).  Returns false
+// when the item is handed over (kind: 0 rejection sampler, 1 long search, 2 search + two more binomials); n[] is the draw otherwise.
+template <int SPEC>
+__device__ __forceinline__ bool s1_item(Xo128 rng, uint32_t x, const double (&W)[4], uint32_t (&n)[4], const double *__restrict__ rcp,
+                                        const double2 *__restrict__ ltab, double lean_cap, int &kind)
+{
+    static_assert(SPEC == 2, "the lean item is spec 2's");
+    ISA_MARK("item_argmax");
+    int am = 0;
+    double wm = W[0];
+#pragma unroll
+    for (int a = 1; a < 4; ++a) if (W[a] > wm) { wm = W[a]; am = a; }
+    double wo[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) wo[j] = (j < am) ? W[j] : W[j + 1];
+    const double c01 = wo[0] + wo[1];
+    const double ws4 = c01 + wo[2];
+    uint32_t m = 0, k0 = 0, k1 = 0;                       // reads not of the heaviest base; of the first / first two others
+    uint32_t s0 = rng.s0, s1 = rng.s1, s2 = rng.s2, s3 = rng.s3;
+    kind = 0;
+    bool ok = true, fast = false;
+    // binom(x, wa = ws4, wb = wm) of dsm_binom.h: !(wa > 0) -> 0, !(wb > 0) -> x
+    if (ws4 > 0.0) {
+        if (!(wm > 0.0)) m = x;
+        else {
+            ISA_MARK("item_binom_setup");
+            const bool flip = ws4 > wm;
+            const double ws = flip ? wm : ws4, wl = flip ? ws4 : wm;
+            const double T = ws + wl;
+            const double xd = (double)x;
+            if (xd * ws > lean_cap * T) { ok = false; kind = (xd * ws > DSM_BINV_MEAN_CAP * T) ? 0 : 1; }
+            else {
+                // one range test for the item's three divisions (operands ws <= wl <= T <= 2 wl, and 2^32 / ws4 with ws4 one of ws, wl)
+                fast = (__builtin_amdgcn_ballot_w64(!(ws >= 0x1p-400)) | __builtin_amdgcn_ballot_w64(!(wl <= 0x1p400))) == 0ull;
+                ISA_MARK("item_div1");
+                double b = sdiv(wl, T, fast);
+                ISA_MARK("item_pw");
+                // (1-q)^x by repeated squaring, lowest bit first (oracle: pw); the exponent is kept bit-reversed so that the bit
+                // of the step is the sign bit.  A lane that is done keeps squaring a base it no longer uses.
+                double f = 1.0;
+                uint32_t er = __builtin_bitreverse32(x);
+                do {
+                    const double fb = f * b;
+                    f = ((int32_t)er < 0) ? fb : f;
+                    er <<= 1;
+                    b = b * b;
+                } while (__builtin_amdgcn_ballot_w64(er != 0u) != 0ull);
+                ISA_MARK("item_u01");
+                const uint32_t ua = xo_next7(s0, s1, s2, s3);
+                const uint32_t ub = xo_next7(s0, s1, s2, s3);
+                double u = u01_open_fused(ua, ub);
+                uint32_t k = 0;
+                if (u >= f) {
+                    ISA_MARK("item_div2");
+                    const double r = sdiv(ws, wl, fast);
+                    const double rc1 = r * (xd + 1.0);
+                    const uint32_t kend = x < DSM_BINV_KMAX ? x : DSM_BINV_KMAX;
+                    ISA_MARK("item_binv");
+                    // sequential search (oracle: binv); a lane still searching after t steps has k = t: the table pointer is the
+                    // loop's only vector counter (one add per step; k is read off it after the search).  The oracle's other exit, k = kend
+                    // = min(x, 255), is taken when u is above the sum of every term the search computed -- all x reads the rarer outcome,
+                    // or rounding at the far end of the sum: a 1e-16 event -- so the loop tests it on a scalar counter against 255 and the
+                    // lane's own end is applied after the loop: a lane that ran past it did so on terms that are zero (or rounding
+                    // noise), and is set back to kend, the oracle's answer.
+                    const double *pk = rcp + __builtin_amdgcn_mbcnt_lo(0u, 0u);      // (+ 0 the compiler cannot see: the pointer stays a vector register)
+                    const double *const pk0 = pk;
+                    uint32_t t = 0;
+                    do {
+                        u = u - f;
+                        ++pk;
+                        f = f * fma(rc1, *pk, -r);
+                        t = __builtin_amdgcn_readfirstlane(t + 1u);
+                    } while (u >= f && t < DSM_BINV_KMAX);
+                    k = (uint32_t)(pk - pk0);
+                    k = k < kend ? k : kend;
+                    ISA_MARK("item_binv_end");
+                }
+                m = flip ? x - k : k;
+            }
+        }
+        if (ok) {
+            if (m > DSM_XS) { ok = false; kind = 2; }
+            else if (m != 0) {
+                ISA_MARK("item_reads_setup");
+                // the m other reads, read by read against 32-bit thresholds (oracle: draw_reads, K = 3; its cums[2] is ws4)
+                const double scale = sdiv(4294967296.0, ws4, fast);
+                const uint32_t t0 = cvt_sat_u32(wo[0] * scale), t1 = cvt_sat_u32(c01 * scale);
+                ISA_MARK("item_reads");
+                uint32_t i = 0;                                     // the same on every lane that is still drawing: a scalar register
+                do {
+                    const uint32_t w = xo_next7(s0, s1, s2, s3);
+                    k0 += (w < t0) ? 1u : 0u;
+                    k1 += (w < t1) ? 1u : 0u;
+                    i = __builtin_amdgcn_readfirstlane(i + 1u);
+                } while (i < m);
+                ISA_MARK("item_reads_end");
+            }
+        }
+    }
+    ISA_MARK("item_map");
+    // n[a]: the heaviest base keeps x - m; the others, in ascending order, k0, k1 - k0, m - k1
+    const uint32_t o0 = k0, o1 = k1 - k0, o2 = m - k1, nh = x - m;
+    n[0] = (am == 0) ? nh : o0;
+    n[1] = (am == 1) ? nh : ((am == 0) ? o0 : o1);
+    n[2] = (am == 2) ? nh : ((am == 3) ? o2 : o1);
+    n[3] = (am == 3) ? nh : o2;
+    return ok;
+}

@@ -8,6 +8,7 @@
 #include "../../include/desman_hip.h"
 
 #define DSM_MAX_GRID 4096
+#define DSM_ESUM_PARTS 64   // copies of Esum the workgroups of stage 1 add to (workgroup b: copy b mod 64); the compacted kernel folds them into Esum
 #define DSM_BIG_NL 64        // sub-lists of deferred stage-1 items (kernels_stats.hip), one counter each ...
 #define DSM_BIG_STRIDE 16    // ... 64 B apart
 #define DSM_BIG_NT 3         // ... for each kind of deferred item (BTRS / long search / search + two more binomials)
@@ -115,7 +116,8 @@ struct dsm_ctx {
     double alpha = 0.1, delta = 0.1, epsilon = 1e-6;
     // sufficient statistics of the auxiliary counts
     unsigned long long *sum_mu = nullptr;   // [S][G]
-    unsigned long long *esum = nullptr;     // [4][4] [observed][true]
+    bool stats_probe = false;               // stats_place_ntab is timing stage 1: k_stats_stage1 leaves the compacted launch out
+    unsigned long long *esum = nullptr;     // [4][4] [observed][true], followed by DSM_ESUM_PARTS x [4][4] partial sums of stage 1 (kernels_stats.hip: zero between passes)
     // RNG
     uint32_t *mt_state = nullptr;   // 624 words + position
     uint32_t *mt_jstates = nullptr; // starting arrays of the chunks of a parallel fill (kernels_gibbs.hip: mt_fill_parallel), made on first use
@@ -221,6 +223,7 @@ int k_stats(dsm_ctx *c, uint32_t iter);
 int k_stats_stage1(dsm_ctx *c, uint32_t iter);
 int k_stats_stage2(dsm_ctx *c, uint32_t iter);
 int k_binom_test(dsm_ctx *c, int kind, uint32_t n, const double *w, uint64_t seed, int nsamp, uint32_t *d_out, int spec);
+int k_esum_fold(dsm_ctx *c);             // kernels_stats.hip: the copies of Esum stage 1 adds to -> Esum
 int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trace, double *eta_out, double *eta_trace,
                 double *prior_out, int fin_it, int fin_nblocks, const double *fin_prior, int do_s2 = 0);
 int k_prior(dsm_ctx *c, const double *gamma, const double *eta, double *prior_out);

@@ -745,6 +745,19 @@ __device__ __forceinline__ void dirichlet_body(const DirParams &q, const S2Plan 
     const uint32_t *leaf = nullptr;
     if (do_s2 && is_gamma)                                                          // workgroup-uniform branches; both end with a barrier
         leaf = do_s2 >= 3 ? stage2_sample<3>(s2, plan, row, smem_d, false) : stage2_sample<2>(s2, plan, row, smem_d, false);
+    if (!is_gamma) {
+        // Esum = the context's [4][4] + the DSM_ESUM_PARTS copies the wavefronts of stage 1 added to (kernels_stats.hip: stats_agg_body,
+        // round 6): this row needs Esum[., a] -- four counters of every copy, one per thread -- and leaves the copies zero for the next pass
+        static_assert(DSM_ESUM_PARTS * 4 == 256, "one thread per (copy, observed base)");
+        unsigned long long *ef = reinterpret_cast<unsigned long long *>(smem_d);
+        if (threadIdx.x < 4) ef[threadIdx.x] = 0ull;
+        __syncthreads();
+        const int ob = threadIdx.x & 3, k = threadIdx.x >> 2;
+        unsigned long long *pp = esum + 16 + k * 16 + ob * 4 + (row - S);
+        const unsigned long long v = *pp;
+        if (v) { *pp = 0ull; atomicAdd(&ef[ob], v); }
+        __syncthreads();
+    }
     if (threadIdx.x >= 64) return;                       // the draw needs one wavefront (no workgroup barriers below)
     const int lane = threadIdx.x;
     const int n = is_gamma ? G : 4;
@@ -754,7 +767,7 @@ __device__ __forceinline__ void dirichlet_body(const DirParams &q, const S2Plan 
         double shape;
         uint32_t vid;                                   // variate id: the spec's flat index
         if (is_gamma) { vid = (uint32_t)(row * G + lane); shape = alpha + (double)(sum_mu[vid] + (leaf ? (unsigned long long)leaf[lane] : 0ull)); }
-        else { const int a = row - S; vid = (uint32_t)(SG + a * 4 + lane); shape = delta + (double)esum[lane * 4 + a]; }
+        else { const int a = row - S; vid = (uint32_t)(SG + a * 4 + lane); shape = delta + (double)(esum[lane * 4 + a] + reinterpret_cast<const unsigned long long *>(smem_d)[lane]); }
         y = gamma_variate(shape, vid, iter, k0, k1);
         if (zero_after) { if (is_gamma) sum_mu[row * G + lane] = 0ull; else esum[lane * 4 + (row - S)] = 0ull; }
     }
@@ -1647,7 +1660,7 @@ int tau_launch_info(dsm_ctx *c, int *launched, int *resident)
 // vec [18]: [0] log-likelihood of this shard's positions (its data constant + the launch's partials, reduced in the order
 // finalize_body uses), [1] changed (v, g) pairs, [2..17] Esum [observed][true] -- counts below 2^53, exact as doubles.
 __global__ __launch_bounds__(256) void shard_pack_kernel(const double *__restrict__ ll_partial, int nblocks, double ll_const,
-                                                         int *__restrict__ nchange, const unsigned long long *__restrict__ esum,
+                                                         int *__restrict__ nchange, unsigned long long *__restrict__ esum,
                                                          double *__restrict__ vec)
 {
     __shared__ double red[256];
@@ -1661,7 +1674,12 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(const double *__restric
         __syncthreads();
     }
     if (tid == 0) { vec[0] = ll_const + red[0]; vec[1] = (double)*nchange; *nchange = 0; }
-    if (tid < 16) vec[2 + tid] = (double)esum[tid];
+    if (tid < 16) {
+        // Esum + the copies stage 1 added to (kernels_stats.hip: stats_agg_body); the copies are zero again when the exchanged total comes back
+        unsigned long long tot = esum[tid];
+        for (int k = 0; k < DSM_ESUM_PARTS; ++k) { const unsigned long long v = esum[16 + k * 16 + tid]; if (v) { tot += v; esum[16 + k * 16 + tid] = 0ull; } }
+        vec[2 + tid] = (double)tot;
+    }
 }
 __global__ void shard_unpack_kernel(const double *__restrict__ vec, unsigned long long *__restrict__ esum)
 {

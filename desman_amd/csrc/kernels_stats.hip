@@ -35,6 +35,20 @@
 #else
 #define STATS_DBG(p, mask) 0
 #endif
+#ifdef DSM_AB_SWITCHES           // wave time stamps of stage 1 (experiment build only; dsm_debug_s1_clocks reads them): [wave][entry, tables staged, after pass 1, 2, ..., before the epilogue, end]
+#define S1_NCLK 16
+__device__ unsigned long long s1_clk[8192 * S1_NCLK];
+#define S1_CLK(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.y == 0) s1_clk[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * S1_NCLK + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int dsm_debug_s1_clocks(unsigned long long *out, int nwaves)
+{
+    if (nwaves > 8192) nwaves = 8192;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(s1_clk), (size_t)nwaves * S1_NCLK * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return S1_NCLK;
+}
+#else
+#define S1_CLK(k) do { } while (0)
+#endif
+#define S1_CLKP(j) do { if (s1_pass < 3) S1_CLK(2 + 4 * s1_pass + (j)); } while (0)
 struct StatsAggParams {
     const int32_t *cnt_vs;
     const uint64_t *tau;
@@ -80,6 +94,12 @@ template <int LPV, int SPEC, bool REGG, bool PAT = false>
 __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_s[];
+    S1_CLK(0);
+#ifdef DSM_AB_SWITCHES
+    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0)          // where the wavefront runs: HW_REG_HW_ID (wave, SIMD, CU, SH, SE) and the XCC id
+        s1_clk[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * S1_NCLK + 13] =
+            ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4)) << 8) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) | (1ull << 63);
+#endif
     constexpr int NG = 64 / LPV;
     constexpr int NTAB = SPEC >= 3 ? (2 * DSM_LOG_TAB_N + DSM_EXP_TAB_N) : 0;      // doubles: log table, then exp table
     const int S = p.S, G = p.G, V = p.V;
@@ -88,11 +108,17 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
     double *gT = tabs + NTAB;                                         // [G][SP] gamma transposed (not with REGG)
     double *rcp = gT + (REGG ? 0 : (size_t)G * SP);                   // [256]  1/k
     double *es = rcp + DSM_RCP_TAB_N;                                 // [16]   eta
-    unsigned long long *acc = reinterpret_cast<unsigned long long *>(rcp);       // [16] overlays the 1/k table once the passes are done
     uint32_t *eacc = reinterpret_cast<uint32_t *>(es + 16);           // [16][256] lane-private Esum columns
     const double2 *ltab = reinterpret_cast<const double2 *>(tabs);
     const int tid = threadIdx.x, lane = tid & 63;
     const int grp = lane / LPV, lig = lane % LPV;
+    const int nwaves = gridDim.x * 4;
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6));
+    // spec 4: only the representatives carry cells -- the tasks are (entry of the pass's list, chunk); the list is in no
+    // particular order (atomic appends), which changes no sum: a cell's stream is keyed by its position, the sums are integers
+    const int nunit = PAT ? (int)__builtin_amdgcn_readfirstlane((int)*p.pat_n) : V;
+    const int ntask = nunit * NCH;                                    // (variant, chunk of LPV samples)
+    const int nslot = (ntask + NG - 1) / NG;                          // NG tasks per wavefront pass
     if constexpr (!REGG) {
         for (int i = tid; i < G * SP; i += 256) {
             const int g = i / SP, s = i - g * SP;
@@ -111,16 +137,13 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
     }
     __syncthreads();
 
-    const int nwaves = gridDim.x * 4;
-    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6));
+    S1_CLK(1);
+    ISA_MARK("slot_setup");
+    int s1_pass = 0;
+    (void)s1_pass;
     // which copy of the subset table this workgroup adds to
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;                // HW_REG_XCC_ID[3:0] (gfx942 / gfx950)
     const unsigned copy = p.xcd ? xcc + 8u * ((blockIdx.x >> 3) % (unsigned)(p.rep >> 3)) : blockIdx.x % (unsigned)p.rep;
-    // spec 4: only the representatives carry cells -- the tasks are (entry of the pass's list, chunk); the list is in no
-    // particular order (atomic appends), which changes no sum: a cell's stream is keyed by its position, the sums are integers
-    const int nunit = PAT ? (int)__builtin_amdgcn_readfirstlane((int)*p.pat_n) : V;
-    const int ntask = nunit * NCH;                                    // (variant, chunk of LPV samples)
-    const int nslot = (ntask + NG - 1) / NG;                          // NG tasks per wavefront pass
     for (int slot = wid; slot < nslot; slot += nwaves) {
         const int task = slot * NG + grp;
         const bool tv = task < ntask;
@@ -128,17 +151,26 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
         const int v = PAT ? (int)p.pat_list[u] : u;
         const int s = j * LPV + lig;
         const bool active = tv && s < S;
-        uint64_t t = p.tau[v];
+        S1_CLKP(0);
+        ISA_MARK("cell_load");
+        uint64_t t;
         int4 c = make_int4(0, 0, 0, 0);
         if constexpr (PAT) {
+            t = p.tau[v];
             if (active) {
                 const uint32_t *xr = p.pat_x + (size_t)v * 4 * S + s;
                 c.x = (int)xr[0]; c.y = (int)xr[(size_t)S]; c.z = (int)xr[2 * (size_t)S]; c.w = (int)xr[3 * (size_t)S];
             }
-        } else if (active) c = reinterpret_cast<const int4 *>(p.cnt_vs)[(size_t)v * S + s];
+        } else {
+            // (issuing a pass's loads one pass ahead -- the first before the tables are staged -- was built and measured in round 6: no
+            // difference at any shape, 16 instructions and six registers more: profiles/r06_stats_ab.txt, builds `new` / `nopf`)
+            t = p.tau[v];
+            if (active) c = reinterpret_cast<const int4 *>(p.cnt_vs)[(size_t)v * S + s];
+        }
         // haplotype sets of the four bases and the abundance each base carries in this sample; t is uniform over a lane
         // group, so the base of haplotype g and the branches below are scalar -- one group after the other when the
         // wavefront holds several
+        ISA_MARK("cell_gamma");
         uint32_t H0 = 0, H1 = 0, H2 = 0, H3 = 0;
         double G0 = 0.0, G1 = 0.0, G2 = 0.0, G3 = 0.0;
         const double *gcol = gT + s;
@@ -173,15 +205,21 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
             }
         }
         const double Gam[4] = {G0, G1, G2, G3};
+        ISA_MARK("cell_philox");
         const uint32_t cell = (uint32_t)s * (uint32_t)p.V_tot + (uint32_t)(p.v_off + v);
         uint32_t cbase[4];
         if (STATS_DBG(p, 8)) { cbase[0] = cell; cbase[1] = p.iter; cbase[2] = p.k0; cbase[3] = p.k1; }
         else philox4x32_10(cell, 0u, p.iter, DSM_STREAM_STA1, p.k0, p.k1, cbase);         // one Philox-10 per cell
         uint32_t nacc[4] = {0, 0, 0, 0};
-#pragma unroll 1
-        for (int b = 0; b < 4; ++b) {
-            const uint32_t xb = (uint32_t)((b == 0) ? c.x : (b == 1) ? c.y : (b == 2) ? c.z : c.w);     // (aggregated counts may pass 2^31)
+        S1_CLKP(1);
+        // Round 6: the four observed bases are straight-line code (the base is a compile-time constant: the count is a register, the
+        // Esum column an immediate offset, no loop counter kept in a vector register, no copies at the loop's back edge), and the rare
+        // outcome -- an item handed to the compacted kernel -- is collected in `hand` and tested ONCE per cell below.
+        uint32_t hand = 0;                                                  // bit b: item b is handed over; bits 4 + 2 b: its kind
+        const uint32_t xs[4] = {(uint32_t)c.x, (uint32_t)c.y, (uint32_t)c.z, (uint32_t)c.w};     // (aggregated counts may pass 2^31)
+        auto item = [&](const int b, const uint32_t xb) __attribute__((always_inline)) {
             if (xb > 0) {
+                ISA_MARK("item_w");
                 double W[4];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) W[a] = es[a * 4 + b] * Gam[a];
@@ -190,42 +228,75 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
 #pragma unroll
                     for (int a = 0; a < 4; ++a) W[a] = Gam[a];
                 }
+                ISA_MARK("item_seed");
                 uint32_t n[4];
-                Xo128 rng = STATS_DBG(p, 2) ? Xo128{cbase[0] + b, cbase[1], cbase[2], cbase[3] | 1u} : item_seed<SPEC>(cbase, (uint32_t)b, p.k0, p.k1);
-                bool defer = false;
+                const Xo128 rng = STATS_DBG(p, 2) ? Xo128{cbase[0] + b, cbase[1], cbase[2], cbase[3] | 1u} : item_seed<SPEC>(cbase, (uint32_t)b, p.k0, p.k1);
+                bool ok = true;
                 int kind = 0;
                 if (STATS_DBG(p, 1)) { n[0] = (uint32_t)xb + (uint32_t)(W[0] > W[1]) + rng.s0; n[1] = n[2] = n[3] = 0; }
-                else mult4<false, SPEC>(rng, (uint32_t)xb, W, n, rcp, ltab, defer, p.lean_cap, &kind);
-                // an aggregated count is consumed exactly once -- here, or by the compacted kernel when the item is handed over -- and
-                // whoever consumes it leaves zero behind for the next pass
-                if constexpr (PAT) { if (!defer) p.pat_x[((size_t)v * 4 + b) * S + s] = 0u; }
-                if (__builtin_expect(defer, 0)) {
-                    // needs the rejection sampler: the compacted kernel re-does this item from its own stream
-                    // (one atomic per wavefront: the deferring lanes take consecutive slots)
-                    // one list per kind of item (and DSM_BIG_NL of each): the wavefronts of the compacted kernel then hold
-                    // items that take the same path; one atomic per wavefront and kind, the deferring lanes take consecutive slots
-#pragma unroll 1
-                    for (int kd = 0; kd < DSM_BIG_NT; ++kd) {
-                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(kind == kd);
-                        if (mask == 0ull) continue;
-                        const uint32_t sub = (uint32_t)kd * DSM_BIG_NL + blockIdx.x % DSM_BIG_NL;
-                        const int leader = __builtin_ctzll(mask);
-                        uint32_t base = 0;
-                        if (lane == leader) base = atomicAdd(p.big_count + sub * DSM_BIG_STRIDE, (uint32_t)__builtin_popcountll(mask));
-                        base = __builtin_amdgcn_readlane(base, leader);
-                        const uint32_t slot = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                        if (kind == kd) p.big_list[(size_t)sub * p.big_seg + slot] = (unsigned long long)cell * 4ull + (unsigned long long)b;
+                else if constexpr (SPEC == 2) ok = s1_item<SPEC>(rng, xb, W, n, rcp, ltab, p.lean_cap, kind);
+                else {
+                    Xo128 r2 = rng;
+                    bool defer = false;
+                    mult4<false, SPEC>(r2, xb, W, n, rcp, ltab, defer, p.lean_cap, &kind);
+                    ok = !defer;
+                }
+#ifdef DSM_S1_PAD                  // experiment: DSM_S1_PAD dependent 32-bit adds per item (is the pass VALU-bound?)
+                {
+                    uint32_t pad = n[0];
+#pragma unroll
+                    for (int i_ = 0; i_ < DSM_S1_PAD; ++i_) asm volatile("v_add_u32 %0, %0, %1" : "+v"(pad) : "v"(xb));
+                    n[0] += (pad == 0x7FFFFFF1u) ? 1u : 0u;
+                }
+#endif
+                ISA_MARK("item_esum");
+                if (ok) {
+                    // an aggregated count is consumed exactly once -- here, or by the compacted kernel when the item is handed over -- and
+                    // whoever consumes it leaves zero behind for the next pass
+                    if constexpr (PAT) p.pat_x[((size_t)v * 4 + b) * S + s] = 0u;
+                    if (STATS_DBG(p, (4 | 16))) {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) nacc[a] += n[a];
+                    } else {
+                        uint32_t *erow = eacc + (b * 4) * 256 + tid;           // lane-private column: ds_add_u32, never a conflict
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) { atomicAdd(erow + a * 256, n[a]); nacc[a] += n[a]; }
                     }
-                } else if (STATS_DBG(p, (4 | 16))) {
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) nacc[a] += n[a];
-                } else {
-                    uint32_t *erow = eacc + (b * 4) * 256 + tid;           // lane-private column: ds_add_u32, never a conflict
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) { atomicAdd(erow + a * 256, n[a]); nacc[a] += n[a]; }
+                } else hand |= (1u << b) | ((uint32_t)kind << (4 + 2 * b));
+            }
+        };
+        if constexpr (SPEC == 2 && !REGG) { item(0, xs[0]); item(1, xs[1]); item(2, xs[2]); item(3, xs[3]); }
+        else {
+            // (the table-exp variant and the gamma-in-registers experiment keep the rolled loop: four copies of their item do not fit
+            // the 80 registers of six wavefronts per SIMD)
+#pragma unroll 1
+            for (int b = 0; b < 4; ++b) item(b, (b == 0) ? xs[0] : (b == 1) ? xs[1] : (b == 2) ? xs[2] : xs[3]);
+        }
+        S1_CLKP(2);
+        ISA_MARK("cell_handover");
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(hand != 0u) != 0ull, 0)) {
+            // needs the rejection sampler / a long search: the compacted kernel re-does the item from its own stream.  One list per kind
+            // of item (and DSM_BIG_NL of each): the wavefronts of the compacted kernel then hold items that take the same path; one
+            // atomic per wavefront, base and kind, the lanes that hand over take consecutive slots
+#pragma unroll 1
+            for (int b = 0; b < 4; ++b) {
+                const bool mine = (hand >> b) & 1u;
+                const int kind = (int)((hand >> (4 + 2 * b)) & 3u);
+#pragma unroll 1
+                for (int kd = 0; kd < DSM_BIG_NT; ++kd) {
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(mine && kind == kd);
+                    if (mask == 0ull) continue;
+                    const uint32_t sub = (uint32_t)kd * DSM_BIG_NL + blockIdx.x % DSM_BIG_NL;
+                    const int leader = __builtin_ctzll(mask);
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(p.big_count + sub * DSM_BIG_STRIDE, (uint32_t)__builtin_popcountll(mask));
+                    base = __builtin_amdgcn_readlane(base, leader);
+                    const uint32_t slot = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                    if (mine && kind == kd) p.big_list[(size_t)sub * p.big_seg + slot] = (unsigned long long)cell * 4ull + (unsigned long long)b;
                 }
             }
         }
+        ISA_MARK("cell_table");
         // N[H_a(v)][s] += reads whose true base is a: adjacent lanes -> adjacent words of one table row
         const size_t ld = (size_t)p.ld;                                    // row stride of the subset table in words (>= S: ensure_ntab)
         uint32_t *const nt = p.ntab + (size_t)copy * (((size_t)1 << G) * ld);
@@ -249,21 +320,26 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
             if (nacc[2]) atomicAdd(nt + (size_t)H2 * ld + s, nacc[2]);
             if (nacc[3]) atomicAdd(nt + (size_t)H3 * ld + s, nacc[3]);
         }
+        S1_CLKP(3);
+        ++s1_pass;
     }
-    // Esum: lane-private columns -> one transposing butterfly per wavefront -> one global atomic per workgroup and counter
-    __syncthreads();                                                  // every wavefront is done with the 1/k table: acc takes its place
-    if (tid < 16) acc[tid] = 0ull;
-    __syncthreads();
+    S1_CLK(14);
+    ISA_MARK("epilogue");
+    // Esum: a wavefront's lane-private columns -> one transposing butterfly -> 16 adds to ONE OF DSM_ESUM_PARTS COPIES of Esum (round 6).
+    // Rounds 2-5 summed the four wavefronts of a workgroup in LDS (three barriers) and sent 16 adds per workgroup to Esum itself: 1 488
+    // workgroups adding to the same two cache lines take their turns at the memory side (~8 ns each), and the wavefronts that left
+    // the pass loop last waited 4-5 us for the launch's final adds -- 10 % of the launch at config 3 (wave time stamps,
+    // profiles/r06_stats_timeline.txt).  A copy takes 1/64 of the adds, no wavefront waits for another, and the consumer (the eta
+    // rows of dirichlet_kernel; esum_fold_kernel on the API paths) sums the copies and leaves them zero.
     {
         uint32_t e[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) e[i] = eacc[i * 256 + tid];
         const uint32_t tot = wave_transpose_reduce<16>(e);
         const int idx = transpose_index<16>(lane);
-        if (lane < 16 && tot) atomicAdd(&acc[idx], (unsigned long long)tot);
+        if (lane < 16 && tot) atomicAdd(&p.esum[16 + ((unsigned)wid % DSM_ESUM_PARTS) * 16 + idx], (unsigned long long)tot);
     }
-    __syncthreads();
-    if (tid < 16 && acc[tid]) atomicAdd(&p.esum[tid], acc[tid]);
+    S1_CLK(15);
 }
 
 // six wavefronts per SIMD (the persistent grid's six workgroups per CU): the register allocation must leave room for them
@@ -447,6 +523,27 @@ __device__ __forceinline__ void stats_big_body(const StatsAggParams &p)
     }
     __syncthreads();
     if (tid < 16 && acc[tid]) atomicAdd(&p.esum[tid], acc[tid]);
+}
+
+// the copies of Esum stage 1 adds to (stats_agg_body's last lines) -> Esum, copies zero again.  The Gibbs loop never launches this: the
+// eta rows of dirichlet_kernel do the same sum on their way in.  For the paths that read Esum otherwise (dsm_ctx_sample_stats,
+// dsm_ctx_debug_stage1, the exchange of a chain sharded by positions, the table-place probe).
+__global__ __launch_bounds__(256) void esum_fold_kernel(unsigned long long *__restrict__ esum)
+{
+    static_assert(DSM_ESUM_PARTS * 4 == 256, "one thread per (copy, group of four counters)");
+    const int k = threadIdx.x >> 2, q = threadIdx.x & 3;
+    unsigned long long *pp = esum + 16 + k * 16 + q * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned long long v = pp[i];
+        if (v) { pp[i] = 0ull; atomicAdd(&esum[q * 4 + i], v); }
+    }
+}
+int k_esum_fold(dsm_ctx *c)
+{
+    hipLaunchKernelGGL(esum_fold_kernel, dim3(1), dim3(256), 0, c->stream, c->esum);
+    HIP_TRY(hipGetLastError());
+    return DSM_OK;
 }
 
 template <int SPEC>
@@ -714,7 +811,7 @@ int stats_place_ntab(dsm_ctx *c)
     HIP_TRY(hipEventCreate(&ev[1]));
     auto clear = [&]() -> int {
         HIP_TRY(hipMemsetAsync(c->ntab, 0, c->ntab_len * sizeof(uint32_t), c->stream));
-        HIP_TRY(hipMemsetAsync(c->esum, 0, 16 * sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipMemsetAsync(c->esum, 0, (16 + 16 * DSM_ESUM_PARTS) * sizeof(unsigned long long), c->stream));
         if (c->big_count) HIP_TRY(hipMemsetAsync(c->big_count, 0, DSM_BIG_NT * DSM_BIG_NL * DSM_BIG_STRIDE * sizeof(uint32_t), c->stream));
         return DSM_OK;
     };
@@ -727,15 +824,27 @@ int stats_place_ntab(dsm_ctx *c)
         if (r == DSM_OK) r = k_stats_stage1(c, 0xFFFFFF00u + (uint32_t)k);
         if (r == DSM_OK) r = clear();
         if (r != DSM_OK) break;
-        (void)hipEventRecord(ev[0], c->stream);
-        for (int j = 0; j < 2 && r == DSM_OK; ++j) { r = k_stats_stage1(c, 0xFFFFFF80u + (uint32_t)k); if (r == DSM_OK) r = clear(); }
-        (void)hipEventRecord(ev[1], c->stream);
-        if (r != DSM_OK) break;
-        if (hipEventSynchronize(ev[1]) != hipSuccess) { r = DSM_ERR_HIP; dsm_set_error("stats_place_ntab: hipEventSynchronize failed"); break; }
+        // Round 6: the stage-1 launch alone (the compacted kernel and the clears between the events added 10-90 us of work that does not
+        // depend on the place -- most on the burn-in state a chain is probed in -- to a difference of 9 us), the FASTEST of three launches
+        // per place (a launch is only ever slowed by what else runs): 2 of 6 processes had kept a slow place at config 3 (stage 1 52-55 us
+        // instead of 45-47, profiles/r06_stats_ab.txt)
         float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+        for (int j = 0; j < 3 && r == DSM_OK; ++j) {
+            c->stats_probe = true;                                    // k_stats_stage1: no compacted launch behind the pass
+            (void)hipEventRecord(ev[0], c->stream);
+            r = k_stats_stage1(c, 0xFFFFFF80u + (uint32_t)k);
+            (void)hipEventRecord(ev[1], c->stream);
+            c->stats_probe = false;
+            if (r == DSM_OK) r = clear();
+            if (r != DSM_OK) break;
+            if (hipEventSynchronize(ev[1]) != hipSuccess) { r = DSM_ERR_HIP; dsm_set_error("stats_place_ntab: hipEventSynchronize failed"); break; }
+            float m1 = 0.f;
+            (void)hipEventElapsedTime(&m1, ev[0], ev[1]);
+            if (j == 0 || m1 < ms) ms = m1;
+        }
+        if (r != DSM_OK) break;
         if (k == 0 || ms < best) { best = ms; best_k = k; }
-        if (verbose) fprintf(stderr, "desman_hip: subset table at +%d B: %.1f us per stage-1 pass\n", k * 256, 500.0 * ms);
+        if (verbose) fprintf(stderr, "desman_hip: subset table at +%d B: %.1f us per stage-1 launch\n", k * 256, 1000.0 * ms);
     }
     (void)hipEventDestroy(ev[0]);
     (void)hipEventDestroy(ev[1]);
@@ -928,6 +1037,8 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
         void *args[] = {(void *)&p};
         HIP_TRY(hipLaunchKernel(fn, dim3(grid), dim3(256), args, sh, c->stream));
     }
+    if (c->stats_probe && !pat) return DSM_OK;           // (stats_place_ntab times the pass alone and clears the lists itself; over tau words the
+                                                         // compacted kernel is also what leaves a handed-over item's pooled count zero: it runs)
     KTimer tm(c, DSM_K_STATSBIG);
     // the deferred items (none once the chain has converged on data of ordinary depth: the launch then returns at once);
     // up to 16 workgroups per list = 4096 items of a list per round (a list one item longer than a round doubles the launch:

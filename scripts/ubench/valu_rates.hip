@@ -66,6 +66,29 @@ KERNEL(k_bfe_u32, U8(x), R8(OP_BFE), XSUM(x))
 #define OP_LSH64(i) asm volatile("v_lshrrev_b64 %0, 3, %0" : "+v"(y##i));
 KERNEL(k_lshr_b64, U64_8, R8(OP_LSH64), (uint32_t)(y0 + y1 + y2 + y3 + y4 + y5 + y6 + y7))
 
+#define OP_BITOP3(i) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(x##i) : "v"(k), "v"(k2));
+KERNEL(k_bitop3_b32, U8(x); uint32_t k = seed | 1; uint32_t k2 = seed * 7, R8(OP_BITOP3), XSUM(x))
+#define OP_ALIGNBIT(i) asm volatile("v_alignbit_b32 %0, %0, %0, 21" : "+v"(x##i));
+KERNEL(k_alignbit_b32, U8(x), R8(OP_ALIGNBIT), XSUM(x))
+#define OP_BFREV(i) asm volatile("v_bfrev_b32 %0, %0" : "+v"(x##i));
+KERNEL(k_bfrev_b32, U8(x), R8(OP_BFREV), XSUM(x))
+#define OP_CMPI(i) asm volatile("v_cmp_gt_i32 vcc, 0, %0" : : "v"(x##i) : "vcc");
+KERNEL(k_cmp_gt_i32, U8(x), R8(OP_CMPI), XSUM(x))
+#define OP_OR3(i) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(x##i) : "v"(k), "v"(k2));
+KERNEL(k_or3_b32, U8(x); uint32_t k = seed | 1; uint32_t k2 = seed * 7, R8(OP_OR3), XSUM(x))
+#define OP_LDEXP64(i) asm volatile("v_ldexp_f64 %0, %0, 3" : "+v"(d##i));
+KERNEL(k_ldexp_f64, D8(d), R8(OP_LDEXP64), (uint32_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7))
+#define OP_CMP64(i) asm volatile("v_cmp_gt_f64 vcc, %0, %1" : : "v"(d##i), "v"(kd) : "vcc");
+KERNEL(k_cmp_f64, D8(d); double kd = 1.0000001, R8(OP_CMP64), (uint32_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7))
+#define OP_DIVSCALE(i) asm volatile("v_div_scale_f64 %0, vcc, %0, %1, %0" : "+v"(d##i) : "v"(kd) : "vcc");
+KERNEL(k_div_scale_f64, D8(d); double kd = 1.0000001, R8(OP_DIVSCALE), (uint32_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7))
+#define OP_DIVFIXUP(i) asm volatile("v_div_fixup_f64 %0, %0, %1, %1" : "+v"(d##i) : "v"(kd));
+KERNEL(k_div_fixup_f64, D8(d); double kd = 1.0000001, R8(OP_DIVFIXUP), (uint32_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7))
+#define OP_DIVFMAS(i) asm volatile("v_div_fmas_f64 %0, %0, %1, %1" : "+v"(d##i) : "v"(kd) : "vcc");
+KERNEL(k_div_fmas_f64, D8(d); double kd = 1.0000001, R8(OP_DIVFMAS), (uint32_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7))
+#define OP_ADDSUB(i) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x##i) : "v"(k));
+KERNEL(k_sub_u32, U8(x); uint32_t k = seed | 1, R8(OP_ADDSUB), XSUM(x))
+
 typedef void (*kfn)(uint32_t *, uint32_t);
 
 int main()
@@ -77,6 +100,8 @@ int main()
     uint32_t *out;
     CHK(hipMalloc(&out, (size_t)blocks * 256 * 4));
     struct { const char *name; kfn fn; int per_body; } ks[] = {
+        {"v_bitop3_b32 (xor3)", k_bitop3_b32, 8}, {"v_alignbit_b32", k_alignbit_b32, 8}, {"v_bfrev_b32", k_bfrev_b32, 8}, {"v_cmp_gt_i32", k_cmp_gt_i32, 8}, {"v_or3_b32", k_or3_b32, 8},
+        {"v_ldexp_f64", k_ldexp_f64, 8}, {"v_cmp_gt_f64", k_cmp_f64, 8}, {"v_div_scale_f64", k_div_scale_f64, 8}, {"v_div_fixup_f64", k_div_fixup_f64, 8}, {"v_div_fmas_f64", k_div_fmas_f64, 8}, {"v_sub_u32", k_sub_u32, 8},
         {"v_add_u32", k_add_u32, 8}, {"v_xor_b32", k_xor_b32, 8}, {"v_lshlrev_b32", k_lshl_b32, 8}, {"v_bfe_u32", k_bfe_u32, 8},
         {"v_cndmask_b32", k_cndmask_b32, 8}, {"v_mov_b32_dpp", k_mov_dpp, 8},
         {"v_mul_lo_u32", k_mul_lo_u32, 8}, {"v_mul_hi_u32", k_mul_hi_u32, 8}, {"v_mad_u64_u32", k_mad_u64_u32, 8},

@@ -194,10 +194,15 @@ __device__ __forceinline__ void group_allreduce_sum4_unrotate(const double (&cv)
 // Lane-partial candidate log-probability: sum over this lane's NSL samples and the four observed bases of
 // (float)count * log(rest + eta[a][b] * gamma_g)   (c_sample_tau.c:152-170); table log with a libm fallback for
 // arguments that are not positive normal doubles.
+// s0, sstride, S: slot j of this lane is sample s0 + j * sstride, a PADDED slot (no sample: count 0, abundance 1 in the staged tile) when
+// that is >= S.  A padded slot's mixture value is a sum of eta entries -- positive for any error matrix without exact zeros, so the slot adds
+// 0 * log(positive) = 0.  With exact zeros in eta (the identity; a zero row: the shim takes the caller's matrix verbatim, Eta_Sampler.py:
+// 355-369) it can be 0, and 0 * log(0) = NaN would poison the lane's total where c_sample_tau.c has no such cell (round 6, found by
+// scripts/dbg/fuzz_extreme.py: 5 of 300 cases).  Such a value takes the libm branch below anyway: that branch skips padded slots.
 template <int NSL>
 __device__ __forceinline__ double sweep_candidate(int a, const double (&xf)[NSL][4], const double (&st)[NSL][4],
                                                   const double (&gg)[NSL], const double *__restrict__ eS,
-                                                  const double2 *__restrict__ ltab)
+                                                  const double2 *__restrict__ ltab, int s0, int sstride, int S)
 {
     double acc = 0.0;
 #pragma unroll
@@ -209,7 +214,7 @@ __device__ __forceinline__ double sweep_candidate(int a, const double (&xf)[NSL]
         if (__builtin_expect(ok, 1)) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc = fma(xf[j][b], dsm_log_core(P[b], ltab), acc);
-        } else {
+        } else if (s0 + j * sstride < S) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc = fma(xf[j][b], dsm_log_slow(P[b]), acc);
         }
@@ -222,7 +227,7 @@ __device__ __forceinline__ double sweep_candidate(int a, const double (&xf)[NSL]
 template <int NSL>
 __device__ __forceinline__ double sweep_candidate_x(int a, const float (&xi)[NSL][4], const double (&st)[NSL][4],
                                                     const double (&gg)[NSL], const double *__restrict__ eS,
-                                                    const double2 *__restrict__ ltab)
+                                                    const double2 *__restrict__ ltab, int s0, int sstride, int S)
 {
     double acc = 0.0;
 #pragma unroll
@@ -238,7 +243,7 @@ __device__ __forceinline__ double sweep_candidate_x(int a, const float (&xi)[NSL
         if (__builtin_expect(ok, 1)) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc = fma((double)x4[b], dsm_log_core(P[b], ltab), acc);
-        } else {
+        } else if (s0 + j * sstride < S) {               // (padded slots: see sweep_candidate)
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc = fma((double)x4[b], dsm_log_slow(P[b]), acc);
         }

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         l[a] = 0.0;
-                        if (!(reuse && a == told)) l[a] = sweep_candidate<NSL>(a, xf, st, gg, eS, ltab);
+                        if (!(reuse && a == told)) l[a] = sweep_candidate<NSL>(a, xf, st, gg, eS, ltab, lig, LPV, S);
                     }
                     group_allreduce_sum4<LPV>(l[0], l[1], l[2], l[3]);
                 } else {
@@ -266,9 +266,9 @@ __global__ __launch_bounds__(256) void gene_sweep_kernel(GeneSweepParams p)
                     const int rot = reuse ? told + 1 : 0;
                     double cv[4];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) cv[i] = sweep_candidate<NSL>((rot + i) & 3, xf, st, gg, eS, ltab);
+                    for (int i = 0; i < 3; ++i) cv[i] = sweep_candidate<NSL>((rot + i) & 3, xf, st, gg, eS, ltab, lig, LPV, S);
                     cv[3] = 0.0;
-                    if (!reuse) cv[3] = sweep_candidate<NSL>(3, xf, st, gg, eS, ltab);
+                    if (!reuse) cv[3] = sweep_candidate<NSL>(3, xf, st, gg, eS, ltab, lig, LPV, S);
                     group_allreduce_sum4_unrotate<LPV>(cv, rot, l);
                 }
                 if (reuse) {

@@ -1060,7 +1060,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
 #pragma unroll 1
                     for (int a = 0; a < 4; ++a) {
                         if (reuse && a == told) continue;
-                        const double c = sweep_candidate_x<NSL>(a, xs, st, gg, eS, ltab);
+                        const double c = sweep_candidate_x<NSL>(a, xs, st, gg, eS, ltab, lig, LPV, S);
                         c0 = (a == 0) ? c : c0; c1 = (a == 1) ? c : c1; c2 = (a == 2) ? c : c2; c3 = (a == 3) ? c : c3;
                     }
                     l[0] = c0; l[1] = c1; l[2] = c2; l[3] = c3;
@@ -1074,7 +1074,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                     const int ncand = reuse ? 3 : 4;                // wave-uniform
 #pragma unroll 1
                     for (int i = 0; i < ncand; ++i) {
-                        const double c = sweep_candidate_x<NSL>((rot + i) & 3, xs, st, gg, eS, ltab);
+                        const double c = sweep_candidate_x<NSL>((rot + i) & 3, xs, st, gg, eS, ltab, lig, LPV, S);
                         cv[0] = (i == 0) ? c : cv[0]; cv[1] = (i == 1) ? c : cv[1]; cv[2] = (i == 2) ? c : cv[2]; cv[3] = (i == 3) ? c : cv[3];
                     }
                     group_allreduce_sum4_unrotate<LPV>(cv, rot, l);
@@ -1106,7 +1106,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         l[a] = 0.0;
-                        if (!(reuse && a == told)) l[a] = sweep_candidate<NSL>(a, xf, st, gg, eS, ltab);
+                        if (!(reuse && a == told)) l[a] = sweep_candidate<NSL>(a, xf, st, gg, eS, ltab, lig, LPV, S);
                     }
                     group_allreduce_sum4<LPV>(l[0], l[1], l[2], l[3]);
                 } else {
@@ -1116,9 +1116,9 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                     const int rot = reuse ? told + 1 : 0;
                     double cv[4];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) cv[i] = sweep_candidate<NSL>((rot + i) & 3, xf, st, gg, eS, ltab);
+                    for (int i = 0; i < 3; ++i) cv[i] = sweep_candidate<NSL>((rot + i) & 3, xf, st, gg, eS, ltab, lig, LPV, S);
                     cv[3] = 0.0;
-                    if (!reuse) cv[3] = sweep_candidate<NSL>(3, xf, st, gg, eS, ltab);       // wave-uniform
+                    if (!reuse) cv[3] = sweep_candidate<NSL>(3, xf, st, gg, eS, ltab, lig, LPV, S);       // wave-uniform
                     group_allreduce_sum4_unrotate<LPV>(cv, rot, l);
                 }
                 }
@@ -1194,7 +1194,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                 if (__builtin_expect(ok, 1)) {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) ll_acc = fma((double)xl[b], dsm_log_core(P[b], ltab), ll_acc);
-                } else {
+                } else if (lig + j * LPV < S) {                 // (a padded slot adds nothing: see sweep_candidate, dsm_device.h)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) ll_acc = fma((double)xl[b], dsm_log_slow(P[b]), ll_acc);
                 }

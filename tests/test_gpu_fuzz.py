@@ -114,3 +114,256 @@ def test_three_processes_end_on_the_same_bits(V, S, G):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.split()[0])
     assert len(set(outs)) == 1 and len(outs[0]) == 64, outs
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: operands at the ends of the exponent range and degenerate inputs for every kernel that divides or takes a
+# logarithm.  The NaN rows of rounds 2-4 (factorize_tau from subnormal start values) were found by a script OUTSIDE the suite; these legs
+# are inside it.  Each compares with the oracle, NaN-aware, exact where the result is an integer.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _extreme_pi(rs, S, G, kind):
+    pi = rs.dirichlet(np.ones(G), size=S)
+    if kind == "masked":                     # Eta_Sampler.py:355-369: gamma masked by the gene's presence, exact zeros, NOT renormalised
+        pi[:, rs.rand(G) < 0.5] = 0.0
+    elif kind == "tiny":
+        pi[rs.rand(S, G) < 0.3] = 1e-300
+    elif kind == "subnormal":
+        m = rs.rand(S, G) < 0.3
+        pi[m] = rs.choice([5e-324, 1e-310, 2.2e-308], size=int(m.sum()))
+    elif kind == "zero_sample":              # a sample nobody is in: every mixture of that sample is zero
+        pi[rs.randint(S), :] = 0.0
+        pi[rs.rand(S, G) < 0.2] = 0.0
+    elif kind == "one_hot":                  # abundances that are exactly 0 or 1
+        pi = np.zeros((S, G)); pi[np.arange(S), rs.randint(G, size=S)] = 1.0
+    return np.ascontiguousarray(pi)
+
+
+def _extreme_eta(rs, kind):
+    if kind == "identity":                   # exact zeros off the diagonal: a base no haplotype carries has mixture zero
+        return np.eye(4)
+    if kind == "zero_row":
+        e = 0.96 * np.eye(4) + 0.01; e[2, :] = 0.0; return e
+    if kind == "tiny":
+        e = np.full((4, 4), 1e-300); e[np.arange(4), np.arange(4)] = 1.0; return e
+    if kind == "subnormal":
+        e = np.full((4, 4), 5e-324); e[np.arange(4), np.arange(4)] = 1.0; return e
+    return 0.96 * np.eye(4) + 0.01
+
+
+@pytest.mark.parametrize("pi_kind,eta_kind", [("masked", "usual"), ("masked", "identity"), ("tiny", "usual"), ("subnormal", "usual"), ("zero_sample", "usual"),
+                                              ("one_hot", "identity"), ("usual", "zero_row"), ("usual", "tiny"), ("subnormal", "subnormal"), ("tiny", "tiny")])
+@pytest.mark.parametrize("V,S,G", [(61, 9, 3), (40, 64, 8), (33, 33, 5)])
+def test_fuzz_tau_sweep_through_the_shim_with_degenerate_abundances(V, S, G, pi_kind, eta_kind):
+    """c_sample_tau.c:136-169 is plain IEEE: log(0) = -inf, 0 * -inf = NaN, and both propagate into the candidate sums, the softmax and the
+    inverse-CDF walk (whose last edge is forced).  The shim takes the caller's pi / eta verbatim (Eta_Sampler.py:147-157, 355-369 passes a
+    masked gamma with exact zeros; nothing clamps at 1e-6 there), so the device sweep must walk the same way: tau and the flip count of
+    three consecutive sweeps are the oracle's."""
+    import desman_amd.sampletau as st
+    rs = np.random.RandomState(V * 1000 + S * 10 + G + len(pi_kind) * 7 + len(eta_kind))
+    counts, _, _ = synth_counts(V, S, min(G, 4), seed=V + S)
+    counts[rs.rand(V, S) < 0.1] = 0                                   # cells without a read: 0 * log(.) terms
+    counts = np.ascontiguousarray(counts)
+    tau0 = cbind.idx_to_onehot(rs.randint(4, size=(V, G)).astype(np.uint8))
+    pi = _extreme_pi(rs, S, G, pi_kind)
+    eta = _extreme_eta(rs, eta_kind)
+    seed = 4242 + V
+    u = cbind.MT19937(seed).uniform(3 * V * G)
+    ref = tau0.copy()
+    n_ref = [cbind.sample_tau_u(ref, pi, eta, counts, u[i * V * G:(i + 1) * V * G]) for i in range(3)]
+    got = tau0.copy()
+    st.initRNG(); st.setRNG(seed)
+    with np.errstate(all="ignore"):
+        n = [st.sample_tau(got, pi, eta, counts) for _ in range(3)]
+    st.freeRNG()
+    assert n == n_ref, (n, n_ref)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("case", ["zeros", "single_base", "huge", "ties", "p_edges", "eta_zero", "mixed"])
+def test_fuzz_lrt_kernel_with_degenerate_frequencies(case):
+    """Variant_Filter.py:320-390 per position: a bounded 1-D minimisation of a two-component mixture NLL.  Positions with no read at all,
+    with every read on one base (the second base's count is 0), with 1e8 reads, with the two largest counts equal, start values on the
+    bounds, and an error matrix with exact zeros (log(0) inside the NLL): the kernel's (p, NLL of the mixture, NLL of the null) against
+    the restated step (oracle/ref_numpy.py: lrt_step, scipy's bounded Brent restated), NaN / inf in the same places."""
+    rs = np.random.RandomState(len(case))
+    V = 48
+    freq = rs.poisson(40, size=(V, 4)).astype(np.int64)
+    eta = 0.96 * np.eye(4) + 0.01
+    if case == "zeros":
+        freq[::3] = 0
+    elif case == "single_base":
+        freq[:] = 0; freq[np.arange(V), rs.randint(4, size=V)] = rs.randint(1, 500, size=V)
+    elif case == "huge":
+        freq *= 2500000
+    elif case == "ties":
+        freq[:, 1] = freq[:, 0]; freq[:, 2:] //= 8
+    elif case == "eta_zero":
+        eta = np.eye(4)
+    elif case == "mixed":
+        freq[::4] = 0; freq[1::4, :] = [7, 0, 0, 0]; freq[2::4, :] = [10 ** 8, 10 ** 8, 1, 0]
+    maxA = np.argmax(freq, axis=1)
+    ft = freq.copy(); ft[np.arange(V), maxA] = -1
+    maxB = np.argmax(ft, axis=1)
+    ff = freq.astype(np.float64)
+    p0 = np.minimum(freq.max(axis=1) / np.maximum(freq.sum(axis=1), 1), 0.99)
+    if case == "p_edges":
+        p0[::2] = 0.99; p0[1::2] = 0.5
+    with np.errstate(all="ignore"):
+        pg, mg, bg = _lib.lrt_step(ff, maxA, maxB, eta, 0.99, True, p0)
+        po, mo, bo = rn.lrt_step(ff, maxA, maxB, eta, 0.99, True, p0)
+    for name, g, o, tol in (("p", pg, po, dict(rtol=0, atol=1e-9)), ("mixture NLL", mg, mo, dict(rtol=1e-12, atol=1e-9)), ("null NLL", bg, bo, dict(rtol=1e-12, atol=1e-9))):
+        assert np.array_equal(np.isnan(g), np.isnan(o)), (case, name, np.where(np.isnan(g) != np.isnan(o)))
+        fin = np.isfinite(o)
+        assert np.array_equal(np.isfinite(g), fin), (case, name, np.where(np.isfinite(g) != fin))
+        assert np.array_equal(g[~fin & ~np.isnan(o)], o[~fin & ~np.isnan(o)]), (case, name)          # the same infinities
+        np.testing.assert_allclose(g[fin], o[fin], err_msg="%s %s" % (case, name), **tol)
+
+
+@pytest.mark.parametrize("case", ["eta_exact_01", "delta_zero_column", "tiny", "cov_huge", "nobody"])
+def test_fuzz_kl_assign_with_degenerate_operands(case):
+    """GeneAssign's KL assignment (multiplicative updates of eta under cov ~ eta . delta^T; oracle/ref_genes.py: kl_assign): start values
+    that are exactly 0 and 1, a haplotype nobody carries (a zero column of delta), abundances of 1e-308, coverages of 1e12, genes without
+    any coverage -- the kernel's eta, update count and divergence against the restated loop, NaN in the same places."""
+    from oracle import ref_genes as rg
+    rng = np.random.default_rng(len(case) + 5)
+    C, S, G = 41, 13, 4
+    delta = rng.random((S, G)) * 50.0
+    truth = (rng.random((C, G)) < 0.5).astype(float)
+    cov = rng.poisson(truth @ delta.T + 0.3).astype(float)
+    eta0 = rng.random((C, G))
+    if case == "eta_exact_01":
+        eta0 = (rng.random((C, G)) < 0.5).astype(float)
+    elif case == "delta_zero_column":
+        delta[:, 2] = 0.0
+    elif case == "tiny":
+        delta[:, 1] = 1e-308; eta0[::3, :] = 1e-308
+    elif case == "cov_huge":
+        cov *= 1e12
+    elif case == "nobody":
+        cov[::2, :] = 0.0; delta[0, :] = 0.0
+    with np.errstate(all="ignore"):
+        eta, n, div = _lib.kl_assign(cov, delta, eta0, max_iter=300)
+        ref_eta, ref_n, ref_div = rg.kl_assign(cov, delta, eta0, max_iter=300)
+    assert np.array_equal(np.isnan(eta), np.isnan(ref_eta)), (case, int(np.isnan(eta).sum()), int(np.isnan(ref_eta).sum()))
+    assert np.isnan(div) == np.isnan(ref_div), (case, div, ref_div)
+    if not np.isnan(ref_div):
+        assert abs(n - ref_n) <= 2, (case, n, ref_n)
+        assert abs(div - ref_div) <= 1e-6 * max(1.0, abs(ref_div)), (case, div, ref_div)
+    fin = ~np.isnan(ref_eta)
+    np.testing.assert_allclose(eta[fin], ref_eta[fin], rtol=1e-4, atol=1e-6, err_msg=case)
+
+
+@pytest.mark.parametrize("S,G", [(5, 3), (64, 8), (33, 12)])
+def test_fuzz_dirichlet_draws_with_empty_rows_and_counts_near_2_to_31(S, G):
+    """HaploSNP_Sampler.py:263-281 with sums at both ends: samples whose mu sums are all zero (every shape is the prior's 0.1: the boost,
+    the clamp at 1e-6 and the renormalisation decide the row), a single 1 among zeros, counts of 2^31 - 1 and 2^40 next to zeros (the
+    normalised variates of the small shapes underflow towards the clamp), an all-zero Esum -- value by value against the draw
+    specification (oracle: orc_dirichlet_counter)."""
+    ctx = _lib.Context(0)
+    try:
+        V = 4
+        counts, _, _ = synth_counts(V, S, max(G, 2), seed=52)
+        tau = cbind.idx_to_onehot(np.zeros((V, G), np.uint8))
+        ctx.set_counts(counts)
+        ctx.set_state(tau, np.full((S, G), 1.0 / G), 0.96 * np.eye(4) + 0.01)
+        seed = 0xA5A5A5A5DEADBEEF
+        ctx.seed(1, ctr_seed=seed)
+        big = np.uint64(2 ** 31 - 1)
+        sum_mu = np.zeros((S, G), np.uint64)
+        sum_mu[1 % S, 0] = 1
+        sum_mu[2 % S, :] = big
+        sum_mu[3 % S, ::2] = big
+        sum_mu[4 % S, G - 1] = np.uint64(2 ** 40)
+        for esum in (np.zeros((4, 4), np.uint64), np.diag([big] * 4).astype(np.uint64), np.full((4, 4), big, np.uint64),
+                     np.array([[0, 1, 0, 2 ** 40], [0, 0, 0, 0], [big, 0, 0, 0], [1, 1, 1, 1]], np.uint64)):
+            for it in (0, 77):
+                g, e = ctx.draw_gamma_eta(it, sum_mu, esum)
+                g_ref, e_ref, _ = cbind.dirichlet_counter(sum_mu, esum, seed, it)
+                assert np.isfinite(g).all() and np.isfinite(e).all()
+                np.testing.assert_allclose(g, g_ref, rtol=1e-13, atol=0)
+                np.testing.assert_allclose(e, e_ref, rtol=1e-13, atol=1e-300)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("V,S,G", [(515, 96, 2), (303, 64, 4), (640, 48, 3), (700, 128, 8), (200, 300, 4), (97, 20, 12)])
+def test_fuzz_factorize_with_subnormal_start_values_gamma_updating(V, S, G):
+    """Init_NMFT.py:98-115 (`factorize`: gamma updating, `_adjustment` after every update) from the start values that made NaN rows of
+    `factorize_tau` in rounds 2-4 (tests/test_gpu_parity.py: test_factorize_tau_with_subnormal_start_values_and_tiny_abundances): tau start
+    values of 1e-308 / 1e-130, abundance columns of 1 / 1e-200, and a start whose gamma column is subnormal throughout."""
+    counts, _, _ = synth_counts(V, S, min(G, 4), seed=V + S)
+    tau0, gam0 = rn.nmft_random_initialize(np.random.RandomState(V + 3 * S + G), V, S, G)
+    gam0 = np.full((G, S), 1.0 / G)
+    for s in (3, S - 1):
+        gam0[:, s] = 1e-200
+        gam0[s % G, s] = 1.0
+    gam0[:, 5 % S] = 1e-310
+    for v in range(0, V, 7):
+        tau0[3 * V + v, :] = 1e-130
+        tau0[3 * V + v, v % G] = 1e-308
+    F = cbind.nmft_freq(counts)
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_counts(counts)
+        ctx.nmft_set(tau0, gam0)
+        tc, gc = tau0.copy(), gam0.copy()
+        with np.errstate(all="ignore"):
+            n_ref, tr_ref = cbind.nmft_factorize(F, tc, gc, max_iter=6, min_change=0.0)
+        n, tr = ctx.nmft_factorize(max_iter=6, min_change=0.0, fix_gamma=False)
+        t, g = ctx.nmft_get()
+        assert n == n_ref
+        assert np.array_equal(np.isnan(t), np.isnan(tc)) and np.array_equal(np.isnan(g), np.isnan(gc))
+        assert np.array_equal(np.isnan(tr[: n + 1]), np.isnan(tr_ref[: n_ref + 1]))
+        ok = ~np.isnan(tr_ref[: n_ref + 1])
+        np.testing.assert_allclose(tr[: n + 1][ok], tr_ref[: n_ref + 1][ok], rtol=1e-9)
+        ft, fg = ~np.isnan(tc), ~np.isnan(gc)
+        np.testing.assert_allclose(t[ft], tc[ft], rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(g[fg], gc[fg], rtol=1e-6, atol=1e-12)
+    finally:
+        ctx.close()
+
+
+def _extreme_case(i, V, S, G, pi_kind, eta_kind):
+    """the generator of scripts/dbg/fuzz_extreme.py (case i): counts of three depths with empty cells, a random tau, degenerate pi / eta"""
+    rs = np.random.RandomState(i)
+    counts, _, _ = synth_counts(V, S, min(G, 4), seed=i, depth_scale=float(rs.choice([0.05, 1.0, 30.0])))
+    counts[rs.rand(V, S) < 0.1] = 0
+    counts = np.ascontiguousarray(counts)
+    tau0 = cbind.idx_to_onehot(rs.randint(4, size=(V, G)).astype(np.uint8))
+    return counts, tau0, _extreme_pi(rs, S, G, pi_kind), _extreme_eta(rs, eta_kind)
+
+
+@pytest.mark.parametrize("i,V,S,G,pi_kind,eta_kind", [(3, 202, 12, 14, "subnormal", "identity"), (71, 261, 23, 13, "masked", "identity"),
+                                                      (194, 212, 5, 12, "masked", "identity"), (205, 267, 4, 3, "masked", "zero_row"),
+                                                      (257, 20, 41, 10, "subnormal", "identity")])
+def test_fuzz_padded_lanes_add_nothing_when_eta_has_exact_zeros(i, V, S, G, pi_kind, eta_kind):
+    """Found by scripts/dbg/fuzz_extreme.py in round 6 (5 of 300 cases; had shipped since round 1): the lanes of a group beyond the last
+    sample carry count 0 and abundance 1, so their mixture value is a sum of eta entries -- positive, hence 0 * log(.) = 0, for any error
+    matrix WITHOUT exact zeros.  With the identity or a zero row (the shim takes the caller's eta verbatim) it is 0 and 0 * log(0) = NaN
+    poisoned a candidate's total where c_sample_tau.c:152-169 has -inf or a finite number: other draws than the reference's.  The libm
+    branch of the candidate sums and of the likelihood now skips those lanes (dsm_device.h: sweep_candidate).  Sweep, its
+    log-probabilities and the log-likelihood of the state it leaves, against the oracle, NaN and -inf in the same places."""
+    counts, tau0, pi, eta = _extreme_case(i, V, S, G, pi_kind, eta_kind)
+    u = cbind.MT19937(i).uniform(V * G)
+    ref = tau0.copy()
+    with np.errstate(all="ignore"):
+        n_ref, lp_ref = cbind.sample_tau_u(ref, pi, eta, counts, u, want_logp=True)
+        ll_ref = cbind.loglik(cbind.onehot_to_idx(ref), pi, eta, counts)
+    for screen in (True, False):
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_counts(counts); ctx.set_state(tau0, pi, eta)
+            ctx.set_tau_rng(_lib.RNG_MT19937); ctx.set_mt_state(_lib.mt_seed_state(i))
+            ctx.set_tau_screen(screen)
+            n, lp = ctx.sample_tau(want_logp=True)
+            got = ctx.get_state()[0]
+            ll = ctx.loglik()[0]
+        finally:
+            ctx.close()
+        assert n == n_ref and np.array_equal(got, ref)
+        assert np.array_equal(np.isnan(lp), np.isnan(lp_ref))
+        inf = np.isinf(lp_ref)
+        assert np.array_equal(np.isinf(lp), inf) and np.array_equal(lp[inf], lp_ref[inf])
+        fin = np.isfinite(lp_ref)
+        np.testing.assert_allclose(lp[fin], lp_ref[fin], rtol=1e-12)
+        assert (np.isnan(ll) and np.isnan(ll_ref)) or ll == ll_ref or abs(ll - ll_ref) <= 1e-12 * abs(ll_ref), (ll, ll_ref)

@@ -283,13 +283,17 @@ def main():
     rank, local_rank, world, under_launcher = launch.ensure_world(args.gpus, sys.argv[1:], script=__file__)
     import torch
     dist = None
-    if under_launcher:                                           # any N >= 1: RCCL communicator, barrier, MAX all-reduce, gather
+    backend = launch.dist_backend()                              # "nccl" (RCCL) unless DESMAN_DIST_BACKEND=gloo (the two-ranks-on-one-GPU rehearsal)
+    dev = launch.bind_device(local_rank, torch.cuda.device_count(), "bench.py") if under_launcher else local_rank
+    if under_launcher:                                           # any N >= 1: communicator, barrier, MAX all-reduce, gather
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
         if dist.get_world_size() != args.gpus:                   # belt and braces: the process group agrees with --gpus
             launch._die("bench.py", "process group of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
-    dev = local_rank
     torch.cuda.set_device(dev)
 
     from desman_amd import _lib
@@ -391,13 +395,14 @@ def main():
         fence()                                      # closing barrier + synchronize; the job's time is the MAX over ranks (below),
         rep_mine.append(dt_r)                        # i.e. what the closing barrier waits for, without the collective's own latency
         if dist is not None:
-            t = torch.tensor([dt_r], device="cuda", dtype=torch.float64)
+            t = torch.tensor([dt_r], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_r = float(t.item())
         rep_dt.append(dt_r)
     dt = float(np.median(rep_dt))
     # which device every rank bound and how long ITS steps took (median call): the per-rank view behind the MAX
-    me = launch.bound_device_record(rank, local_rank)
+    me = launch.bound_device_record(rank, dev)
+    me["local_rank"] = int(local_rank)
     me["ms_per_step"] = 1e3 * float(np.median(rep_mine)) / args.steps
     ranks = [me]
     if dist is not None:
@@ -409,7 +414,7 @@ def main():
     rec = [float(G), float(G), float(rank), star["lp"], -2.0 * float(tr["ll"].mean()), float(args.steps)]
     fits = [rec]
     if dist is not None:
-        mine = torch.tensor(rec, device="cuda", dtype=torch.float64)
+        mine = torch.tensor(rec, device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         fits = [x.tolist() for x in allr]
@@ -577,7 +582,7 @@ def main():
                                             "ms_per_step and value use the median repeat"},
             "ranks": sorted(ranks, key=lambda r: r["rank"]),
             "ms_per_step_per_rank": {"min": min(r["ms_per_step"] for r in ranks), "max": max(r["ms_per_step"] for r in ranks)},
-            "launch": "torch.distributed.run, %d rank(s), backend nccl (RCCL)" % world if dist is not None else "single process, no process group",
+            "launch": ("torch.distributed.run, %d rank(s), backend %s" % (world, "nccl (RCCL)" if backend == "nccl" else "gloo (rehearsal: ranks may share a device; not a benchmark configuration)")) if dist is not None else "single process, no process group",
             "roofline": roofline, "nmft": nmft,
             "fit_records": [dict(G=int(f[0]), seed=int(f[2]), lp_star=f[3], mean_dev=f[4]) for f in fits],
         }

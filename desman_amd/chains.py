@@ -146,6 +146,15 @@ def group_units(specs, batch):
     return units
 
 
+class WorkerError(RuntimeError):
+    """a worker thread stopped outside a chain (the queue's flock / store failed ...): raised by run_chains on every rank after the gather;
+    .records holds every chain's record (the chains that ran nowhere carry failed = 1)"""
+
+    def __init__(self, msg, records):
+        super().__init__(msg)
+        self.records = records
+
+
 def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=None, batch=1, comm=None, queue=None):
     """Run `run_fn(spec) -> dict(REC_FIELDS...)` for this rank's share of `specs` and gather
     every chain's record on all ranks.  `dist` = an initialised torch.distributed module
@@ -255,6 +264,8 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
                 res = unit(ui)
                 with take_lock:
                     done.extend(res)
+        except KeyboardInterrupt:                            # (only ever in the main thread: the user's Ctrl-C is not held back until after the gather)
+            raise
         except BaseException as e:                           # noqa: BLE001 -- a thread must not die silently: see after the gather
             log.error("worker thread of rank %d stopped: %s: %s", rank, type(e).__name__, e)
             with take_lock:
@@ -282,9 +293,12 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
                 res = failed_record(cid)
         mine.append(res)
     width = (max(len(b) for b in bins) if queue is None else len(specs)) if specs else 0
-    buf = np.full((max(width, 1), len(REC_FIELDS)), np.nan)
+    # (one more row than records: its first word says whether a worker thread of this rank stopped outside a chain -- the ranks
+    # learn it from each other in the one gather and take the same path afterwards)
+    buf = np.full((max(width, 1) + 1, len(REC_FIELDS)), np.nan)
     if mine:
         buf[:len(mine)] = np.array(mine)
+    buf[-1, 1] = 1.0 if worker_errors else 0.0
     if comm is not None:
         rows = comm.allgather(buf.reshape(-1)).reshape(-1, len(REC_FIELDS))      # the path's single exchange step
     elif dist is None:
@@ -295,6 +309,8 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
         out = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(out, t)                         # the path's single exchange step
         rows = np.concatenate([o.cpu().numpy() for o in out], axis=0)
+    flags = rows.reshape(world, -1, len(REC_FIELDS))[:, -1, 1] if world > 1 or comm is not None or dist is not None else rows[-1:, 1]
+    bad_ranks = [int(r) for r in np.nonzero(np.nan_to_num(flags) > 0)[0]]
     rows = rows[~np.isnan(rows[:, 0])]
     rows = rows[np.argsort(rows[:, 0])]
     # every chain exactly once -- after the gather, so that every rank reaches the collective and every rank sees the same hole.
@@ -308,9 +324,15 @@ def run_chains(specs, run_fn, dist=None, device=None, concurrency=1, batch_fn=No
         log.error("run_chains: %d chain(s) ran nowhere (%s): failed records", len(missing), missing[:16])
         rows = np.concatenate([rows, np.array([failed_record(c) for c in missing])], axis=0)
         rows = rows[np.argsort(rows[:, 0])]
-    if worker_errors:
-        raise RuntimeError("run_chains: %d worker thread(s) of rank %d stopped outside a chain" % (len(worker_errors), rank)) from worker_errors[0]
-    return [dict(zip(REC_FIELDS, r.tolist())) for r in rows]
+    recs = [dict(zip(REC_FIELDS, r.tolist())) for r in rows]
+    if bad_ranks:
+        # raised on EVERY rank (round 5 raised on the rank it happened on only: with that rank being 0, no Dev.csv was written although
+        # the failed records had just been built for it), with the records attached
+        err = WorkerError("run_chains: worker thread(s) of rank(s) %s stopped outside a chain" % bad_ranks, recs)
+        if worker_errors:
+            raise err from worker_errors[0]
+        raise err
+    return recs
 
 
 class _ThreadLogRouter(__import__("logging").Handler):
@@ -451,12 +473,18 @@ def main(argv=None):
     import pandas as p
     dist = comm = None
     dev_t = None
+    dev = local                                              # the device this rank's chains run on
     if under_launcher and args.comm == "torch":
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        dev_t = torch.device("cuda", local)
+        backend = launch.dist_backend()                      # nccl (RCCL) unless DESMAN_DIST_BACKEND=gloo: the rehearsal with ranks sharing a device
+        dev = launch.bind_device(local, torch.cuda.device_count(), "desman-sweep")
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dev_t = torch.device("cuda", dev)
+        else:
+            dist.init_process_group("gloo")                  # (the gather's tensors stay on the host: run_chains, device=None)
         if dist.get_world_size() != args.gpus:
             launch._die("desman-sweep", "process group of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
     elif under_launcher:
@@ -472,39 +500,71 @@ def main(argv=None):
         if comm is not None:
             qpath = os.environ.get("DESMAN_SWEEP_QUEUE")
             if not qpath:
-                # ranks started by another launcher (python -m torch.distributed.run -m desman_amd.chains ...): no counter file
-                # was made for us.  One node, one file system: rank 0 makes it under a name every rank can form from the
-                # launch's rendezvous (address, port, run id), the communicator's barrier orders creation before first use.
+                # ranks started by another launcher (python -m torch.distributed.run -m desman_amd.chains ...): no counter file was made
+                # for us.  Rank 0 makes one (mkstemp: a fresh name, O_EXCL, mode 0600 -- round 5's name was predictable from the
+                # rendezvous and opened with "wb", which follows a symlink) and the ranks learn the path and rank 0's host through the
+                # communicator: the counter is a file under flock(), so the ranks must share a file system -- one node -- and a rank
+                # on another host stops here with that message instead of dying in take() after the work is done.
+                import socket
                 import tempfile
-                qpath = queue_made = os.path.join(tempfile.gettempdir(), "desman_queue_%s_%s_%s" % (
-                    os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
-                    os.environ.get("TORCHELASTIC_RUN_ID", "none")))
+                host = socket.gethostname().encode()[:255]
+                msg = np.zeros(1024, np.float64)
                 if comm.rank == 0:
-                    with open(qpath, "wb") as f:
-                        f.write(b"\0" * 8)
-                comm.barrier()
+                    fd, made = tempfile.mkstemp(prefix="desman_queue_")
+                    os.write(fd, b"\0" * 8)
+                    os.close(fd)
+                    queue_made = made
+                    pb = made.encode()
+                    msg[0], msg[1] = len(pb), len(host)
+                    msg[2:2 + len(pb)] = np.frombuffer(pb, np.uint8)
+                    msg[514:514 + len(host)] = np.frombuffer(host, np.uint8)
+                got = comm.allgather(msg).reshape(comm.world, -1)[0]
+                qpath = bytes(got[2:2 + int(got[0])].astype(np.uint8)).decode()
+                host0 = bytes(got[514:514 + int(got[1])].astype(np.uint8))
+                if host0 != host or not os.path.exists(qpath):
+                    launch._die("desman-sweep", "rank %d runs on host %r, rank 0 on %r: the work queue's counter is a file under flock() -- "
+                                "one node; use --schedule lpt across nodes" % (comm.rank, host.decode(), host0.decode()))
             queue = WorkQueue(file_path=qpath)
         else:
             from torch.distributed.distributed_c10d import _get_default_store
             queue = WorkQueue(store=_get_default_store())
     extra = ["-m", str(args.min_coverage)] + (["-r", str(args.random_select)] if args.random_select else [])
-    runner = gibbs_chain_runner(args.variant_file, args.no_iter, local, args.output_stub, extra)
-    recs = run_chains(specs, runner, dist, device=dev_t, concurrency=args.concurrency, batch_fn=runner.batch if args.batch > 1 else None,
-                      batch=min(args.batch, 8), comm=comm, queue=queue)
-    if (comm.rank if comm is not None else (0 if dist is None else dist.get_rank())) == 0:
-        write_dev_csv(args.output_stub + "_Dev.csv", recs)
-        print(json.dumps(recs))
-        from . import resolvenhap                      # f2: posterior-deviance model selection over the sweep
-        resolvenhap.resolve(args.output_stub)
-    if dist is not None:
-        dist.destroy_process_group()
-    if comm is not None:
-        if queue_made and comm.rank == 0:                  # (after the gather: nobody takes numbers any more)
+    runner = gibbs_chain_runner(args.variant_file, args.no_iter, dev, args.output_stub, extra)
+    failed_run = None
+    try:
+        recs = run_chains(specs, runner, dist, device=dev_t, concurrency=args.concurrency, batch_fn=runner.batch if args.batch > 1 else None,
+                          batch=min(args.batch, 8), comm=comm, queue=queue)
+        if (comm.rank if comm is not None else (0 if dist is None else dist.get_rank())) == 0:
+            write_dev_csv(args.output_stub + "_Dev.csv", recs)
+            print(json.dumps(recs))
+            from . import resolvenhap                      # f2: posterior-deviance model selection over the sweep
+            resolvenhap.resolve(args.output_stub)
+    except WorkerError as e:
+        # a worker thread of SOME rank stopped outside a chain: every rank learnt it in the gather (run_chains) and every rank takes this
+        # path -- rank 0 still writes Dev.csv and runs model selection on the records (the lost chains carry failed = 1), then all
+        # exit non-zero
+        failed_run = e
+        if (comm.rank if comm is not None else (0 if dist is None else dist.get_rank())) == 0:
+            write_dev_csv(args.output_stub + "_Dev.csv", e.records)
+            print(json.dumps(e.records))
+            from . import resolvenhap
+            resolvenhap.resolve(args.output_stub)
+    finally:
+        # the same tidy-up on every rank and every path
+        if dist is not None:
             try:
-                os.unlink(queue_made)
-            except OSError:
+                dist.destroy_process_group()
+            except Exception:                              # noqa: BLE001 -- the group may be gone with a dead peer
                 pass
-        comm.close()
+        if comm is not None:
+            if queue_made and comm.rank == 0:              # (after the gather: nobody takes numbers any more)
+                try:
+                    os.unlink(queue_made)
+                except OSError:
+                    pass
+            comm.close()
+    if failed_run is not None:
+        raise SystemExit("desman-sweep: %s" % failed_run)
 
 
 if __name__ == "__main__":

@@ -95,6 +95,27 @@ def ensure_world(gpus, argv, script=None, module=None, prog=None, n_visible=None
     raise AssertionError("unreachable: execve returned")       # pragma: no cover
 
 
+def dist_backend():
+    """the carrier of torch.distributed's collectives: DESMAN_DIST_BACKEND = "nccl" (default: RCCL over xGMI, one rank per GPU) or "gloo"
+    (TCP between the ranks' hosts sides: the only carrier that lets two ranks share ONE device -- RCCL refuses a communicator with two
+    ranks on a device -- which is what the two-rank rehearsal on a one-GPU box needs, tests/test_gpu_dist.py)"""
+    b = os.environ.get("DESMAN_DIST_BACKEND", "nccl").strip().lower()
+    if b not in ("nccl", "gloo"):
+        _die("desman_amd.launch", "DESMAN_DIST_BACKEND=%r: nccl or gloo" % b)
+    return b
+
+
+def bind_device(local_rank, n_visible, prog="desman_amd"):
+    """the device index a rank binds: its local rank, or -- only with DESMAN_DIST_SHARE_GPU=1 and the gloo carrier -- local rank modulo
+    the number of devices (several ranks on one GPU: a rehearsal of the N > 1 control path, never a benchmark configuration)"""
+    if local_rank < n_visible:
+        return local_rank
+    if os.environ.get("DESMAN_DIST_SHARE_GPU") == "1" and n_visible > 0 and dist_backend() == "gloo":
+        return local_rank % n_visible
+    _die(prog, "local rank %d but %d GPU(s) visible (several ranks on one device need DESMAN_DIST_BACKEND=gloo DESMAN_DIST_SHARE_GPU=1)"
+         % (local_rank, n_visible))
+
+
 def bound_device_record(rank, local_rank):
     """what a rank reports about the GPU it bound: index, name, PCI bus id / uuid where torch exposes them"""
     rec = dict(rank=int(rank), local_rank=int(local_rank), pid=os.getpid())

@@ -367,3 +367,34 @@ def test_fuzz_padded_lanes_add_nothing_when_eta_has_exact_zeros(i, V, S, G, pi_k
         fin = np.isfinite(lp_ref)
         np.testing.assert_allclose(lp[fin], lp_ref[fin], rtol=1e-12)
         assert (np.isnan(ll) and np.isnan(ll_ref)) or ll == ll_ref or abs(ll - ll_ref) <= 1e-12 * abs(ll_ref), (ll, ll_ref)
+
+
+@pytest.mark.parametrize("pi_kind,eta_kind", [("tiny", "usual"), ("subnormal", "usual"), ("masked", "identity"), ("usual", "tiny"), ("subnormal", "subnormal"),
+                                              ("tiny", "tiny"), ("one_hot", "zero_row"), ("zero_sample", "usual")])
+@pytest.mark.parametrize("V,S,G", [(300, 64, 8), (211, 33, 5), (150, 96, 12)])
+def test_fuzz_stats_pass_with_weights_at_the_ends_of_the_exponent_range(V, S, G, pi_kind, eta_kind):
+    """Stage 1 of the mu/E pass divides three times per item (dsm_binom.h: s1_item).  Round 6 runs those divisions WITHOUT the scaling /
+    fix-up instructions of the IEEE expansion while every lane's weights are within [2^-400, 2^400], and with them otherwise (one
+    wave-uniform test per item): weights of 1e-300 and below, subnormal products, exact zeros (the fall-back to the abundances, a base
+    nobody carries) must leave the sums the twin's (oracle/stats_agg.c divides with `/`), bit for bit, under every specification."""
+    rs = np.random.RandomState(V + S + G + len(pi_kind) + 3 * len(eta_kind))
+    counts, _, _ = synth_counts(V, S, min(G, 4), seed=V + S)
+    counts = np.ascontiguousarray(counts)
+    idx = rs.randint(4, size=(V, G)).astype(np.uint8)
+    gamma = _extreme_pi(rs, S, G, pi_kind)
+    eta = _extreme_eta(rs, eta_kind)
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_counts(counts); ctx.set_state(cbind.idx_to_onehot(idx), gamma, eta)
+        seed = 0x0123456789ABCDEF
+        ctx.seed(1, ctr_seed=seed)
+        for spec in (2, 4, 3):
+            ctx.force_stats_spec(spec)
+            for it in (0, 5):
+                mu, E = ctx.sample_stats(it)
+                mu_ref, E_ref = cbind.stats_agg(idx, gamma, eta, counts, seed, it, spec=spec)
+                assert np.array_equal(E, E_ref), (spec, it)
+                assert np.array_equal(mu, mu_ref), (spec, it)
+            ctx.force_stats_spec(0)
+    finally:
+        ctx.close()

@@ -72,6 +72,8 @@ SIGNATURES = {
     "dsm_ctx_set_nmft_persist": (_i, [_vp, _i]),
     "dsm_ctx_tau_launch_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "dsm_ctx_debug_log2f": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "dsm_debug_fdiv": (_i, [_i, _f64p, _f64p, _f64p, _i]),
+    "dsm_release_device_caches": (_i, []),
     "dsm_ctx_force_stats_spec": (_i, [_vp, _i]),
     "dsm_ctx_debug_stage1": (_i, [_vp, C.c_uint32, _vp, _u64p]),
     "dsm_ctx_debug_binom": (_i, [_vp, _i, C.c_uint32, _f64p, C.c_uint64, _i, _u32p, _i]),
@@ -177,6 +179,20 @@ def mt_seed_state(seed):
     st = np.empty(625, dtype=np.uint32)
     check(load().dsm_mt_seed_state(int(seed) & 0xFFFFFFFFFFFFFFFF, st))
     return st
+
+
+def release_device_caches():
+    """frees the per-process, per-device caches of the library (MT19937 jump tables, placed subset tables); no context may be busy"""
+    check(load().dsm_release_device_caches())
+
+
+def debug_fdiv(kind, a, b):
+    """test hook: a / b as the NMFT update divides (0 = fdiv_ext, 1 = fdiv_lo, 2 = fdiv; kernels_nmft.hip)"""
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+    b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1)
+    out = np.empty_like(a)
+    check(load().dsm_debug_fdiv(int(kind), a, b, out, a.size))
+    return out
 
 
 def lrt_step(ffreq, maxA, maxB, eta, upperP, optimise, p, device=0):

@@ -1191,6 +1191,15 @@ extern "C" int dsm_batch_update_tau(dsm_ctx *const *ctxs, int K, int n_iter, con
     return DSM_OK;
 }
 
+extern "C" int dsm_release_device_caches(void)
+{
+    // what the library keeps per process and device beyond the life of a context: the MT19937 jump tables (2 x 50 MB per device, built by the
+    // first long fill) and up to 32 placed subset tables (<= 512 KB each).  No context may be running a fill / a mu/E pass while this is called.
+    mt_jump_release();
+    stats_ntab_pool_release();
+    return DSM_OK;
+}
+
 extern "C" int dsm_ctx_debug_log2f(dsm_ctx *c, const float *in, float *out, size_t n)
 {
     if (!c || !in || !out) { dsm_set_error("debug_log2f: bad arguments"); return DSM_ERR_ARG; }

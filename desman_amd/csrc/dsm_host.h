@@ -94,6 +94,7 @@ struct dsm_ctx {
     bool ntab_placed = false;       // the place has been measured (or given)
     bool ntab_measured = false;     // ... measured: the table goes to the process's pool when the chain ends (kernels_stats.hip: stats_release_ntab)
     int ntab_ld = 0;                // row stride of the table in words (kernels_stats.hip: stats_ntab_ld)
+    int ntab_xcd = 0;               // 1: the table has a copy per XCD (experiment switch; part of the pool key of a placed table)
     int ntab_rep = 1;               // copies of the table (few subsets x many positions: kernels_stats.hip, stats_ntab_rep)
     unsigned long long *big_list = nullptr;   // stage-1 items deferred to the compacted (BTRS) kernel: cell * 4 + base
     uint32_t *big_count = nullptr;            // DSM_BIG_NL counters, DSM_BIG_STRIDE words apart
@@ -213,6 +214,8 @@ int stats_place_ntab(dsm_ctx *c);         // measures where the subset table sho
 void stats_release_ntab(dsm_ctx *c);     // the table leaves the context: to the process's pool of placed tables, or freed
 #define DSM_NTAB_PAD 0               // words added to a row of the subset table when S is a multiple of 64 (stats_ntab_ld)
 int stats_ntab_ld(int S);
+void stats_ntab_pool_release();            // kernels_stats.hip: frees the pooled subset tables
+void mt_jump_release();                    // kernels_gibbs.hip: frees the MT19937 jump tables
 int stats_ntab_rep(const dsm_ctx *c);       // copies of the subset table the stage-1 atomics are spread over
 int stats_spec(const dsm_ctx *c);           // 2 / 3 = aggregated sampler (oracle/stats_agg.c), 4 = the same over tau patterns, 1 = per-read (orc_stats_counter)
 static inline int stats_draw_version(int spec) { return spec == 4 ? 2 : spec; }   // which version of the samplers (dsm_binom.h: SPEC) a specification draws with

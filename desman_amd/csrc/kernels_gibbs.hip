@@ -335,28 +335,58 @@ __global__ __launch_bounds__(1024) void mt_fill_par_kernel(MtParArgs a)
     mt_fill_wide_body(a.S + p * MTJ_SW, a.out + lo, cnt);
 }
 
-struct MtJumpDev { std::mutex mu; uint32_t *M1 = nullptr, *M4 = nullptr; bool ready = false, failed = false; };
-static MtJumpDev g_mtj[16];
+// The jump tables of a device: 2 x 50 MB, built once per process and device by the first long fill (2 x 2.2 ms), shared by every context of
+// the device, kept until the process ends or dsm_release_device_caches() is called.  Devices 0 .. 15 have a slot; a higher device index
+// gets no tables (the serial generator serves: same words).  Everything about a slot -- allocation, build, the fill kernel's
+// shared-memory attribute -- happens under its mutex; an error after the allocations frees both tables and marks the slot failed
+// (it used to return with ready = failed = false, and the next call allocated another pair).
+struct MtJumpDev { std::mutex mu; uint32_t *M1 = nullptr, *M4 = nullptr; bool ready = false, failed = false, attr = false; };
+#define MTJ_NDEV 16
+static MtJumpDev g_mtj[MTJ_NDEV];
 static int mt_jump_tables(dsm_ctx *c, hipStream_t stream, const uint32_t **M1, const uint32_t **M4)
 {
-    MtJumpDev &d = g_mtj[c->device & 15];
+    *M1 = *M4 = nullptr;
+    if (c->device < 0 || c->device >= MTJ_NDEV) return DSM_OK;
+    MtJumpDev &d = g_mtj[c->device];
     std::lock_guard<std::mutex> lk(d.mu);
     if (!d.ready && !d.failed) {
         const size_t bytes = (size_t)MTJ_BITS * 624 * sizeof(uint32_t);
-        if (hipMalloc((void **)&d.M1, bytes) != hipSuccess || hipMalloc((void **)&d.M4, bytes) != hipSuccess) {
-            if (d.M1) { (void)hipFree(d.M1); d.M1 = nullptr; }
-            d.failed = true;                                    // no room for the tables: the serial generator serves (same words)
-            (void)hipGetLastError();
-        } else {
+        bool ok = hipMalloc((void **)&d.M1, bytes) == hipSuccess && hipMalloc((void **)&d.M4, bytes) == hipSuccess;
+        if (ok) {
             hipLaunchKernelGGL(mt_jump_build_kernel, dim3(MTJ_BITS / 4), dim3(256), 0, stream, d.M1, MTJ_BLOCKS);
             hipLaunchKernelGGL(mt_jump_build_kernel, dim3(MTJ_BITS / 4), dim3(256), 0, stream, d.M4, 4 * MTJ_BLOCKS);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(stream));             // other contexts of the device use the tables from their own streams
-            d.ready = true;
+            ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;   // other contexts of the device use the tables from their own streams
         }
+        if (ok && !d.attr) {
+            ok = hipFuncSetAttribute((const void *)mt_fill_par_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) == hipSuccess;
+            d.attr = ok;
+        }
+        if (!ok) {
+            if (d.M1) { (void)hipFree(d.M1); d.M1 = nullptr; }
+            if (d.M4) { (void)hipFree(d.M4); d.M4 = nullptr; }
+            d.failed = true;                                    // no tables on this device: the serial generator serves (same words)
+            (void)hipGetLastError();
+        } else d.ready = true;
     }
-    *M1 = d.M1; *M4 = d.M4;
+    if (d.ready) { *M1 = d.M1; *M4 = d.M4; }
     return DSM_OK;
+}
+// frees the jump tables of every device (callers: dsm_release_device_caches; no fill may be in flight)
+void mt_jump_release()
+{
+    for (int i = 0; i < MTJ_NDEV; ++i) {
+        MtJumpDev &d = g_mtj[i];
+        std::lock_guard<std::mutex> lk(d.mu);
+        if (d.M1 || d.M4) {
+            int cur = 0;
+            (void)hipGetDevice(&cur);
+            (void)hipSetDevice(i);
+            if (d.M1) (void)hipFree(d.M1);
+            if (d.M4) (void)hipFree(d.M4);
+            (void)hipSetDevice(cur);
+        }
+        d.M1 = d.M4 = nullptr; d.ready = false; d.failed = false;
+    }
 }
 
 // a fill of n words as rounds of up to MTJ_PMAX chunks of D words; returns how many words it made (0: tables not available)
@@ -369,11 +399,6 @@ static int mt_fill_parallel(dsm_ctx *c, uint32_t *out, size_t n, hipStream_t str
     if (!c->mt_jstates) {
         hipError_t e = hipMalloc((void **)&c->mt_jstates, (size_t)MTJ_PMAX * MTJ_SW * sizeof(uint32_t));
         if (e != hipSuccess) { (void)hipGetLastError(); return DSM_OK; }
-    }
-    static bool attr_set[16] = {false};
-    if (!attr_set[c->device & 15]) {
-        HIP_TRY(hipFuncSetAttribute((const void *)mt_fill_par_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-        attr_set[c->device & 15] = true;
     }
     uint32_t *S = c->mt_jstates;
     while (n - *made >= 2 * MTJ_D) {

@@ -917,10 +917,36 @@ __device__ __forceinline__ double4_t nm_div_tile(const double4_t ft, const doubl
 }
 __device__ __forceinline__ double fdiv_ext(double a, double b)
 {
-    const bool ah = a > 0x1p500, al = a < 0x1p-500, bh = b > 0x1p500, bl = b < 0x1p-500;
-    const double sa = ah ? 0x1p-512 : (al ? 0x1p512 : 1.0), ia = ah ? 0x1p512 : (al ? 0x1p-512 : 1.0);
-    const double sb = bh ? 0x1p-512 : (bl ? 0x1p512 : 1.0);
-    return (fdiv(a * sa, b * sb) * sb) * ia;
+    // Round 6: mantissa over mantissa (both in [1/2, 1): v_frexp_mant_f64 is exact and takes subnormals), the exponents' difference put on the
+    // quotient by v_ldexp_f64 -- which overflows to inf and rounds into the subnormal range as the division itself does.  The bits of fdiv(a, b)
+    // wherever that neither overflows nor underflows on the way (powers of two scale v_rcp_f64 and every fma of fdiv exactly).  Round 5 scaled
+    // by 2^+-512 where an operand was beyond 2^+-500 and put the two scales back one after the other: two huge or two tiny operands with an
+    // ordinary quotient passed through the subnormal range or infinity on the way, and a quotient that does overflow (a >= 1 over a
+    // subnormal b) came out NaN where the reference's division gives inf (inf - inf inside the Newton step; tests/test_gpu_fuzz.py:
+    // test_fuzz_nmft_divisions_at_both_ends_of_the_exponent_range).
+    const double q = fdiv(__builtin_amdgcn_frexp_mant(a), __builtin_amdgcn_frexp_mant(b));
+    return ldexp(q, __builtin_amdgcn_frexp_exp(a) - __builtin_amdgcn_frexp_exp(b));
+}
+// test hook (dsm_debug_fdiv): out[i] = fdiv_ext(a[i], b[i]) / fdiv_lo / fdiv
+__global__ __launch_bounds__(256) void fdiv_test_kernel(int kind, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = kind == 0 ? fdiv_ext(a[i], b[i]) : (kind == 1 ? fdiv_lo(a[i], b[i]) : fdiv(a[i], b[i]));
+}
+extern "C" int dsm_debug_fdiv(int kind, const double *a, const double *b, double *out, int n)
+{
+    if (!a || !b || !out || n < 1 || kind < 0 || kind > 2) { dsm_set_error("debug_fdiv: bad arguments"); return DSM_ERR_ARG; }
+    double *d = nullptr;
+    if (hipMalloc((void **)&d, (size_t)3 * n * sizeof(double)) != hipSuccess) { dsm_set_error("debug_fdiv: hipMalloc failed"); return DSM_ERR_NOMEM; }
+    int r = DSM_OK;
+    if (hipMemcpy(d, a, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d + n, b, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) r = DSM_ERR_HIP;
+    if (r == DSM_OK) {
+        hipLaunchKernelGGL(fdiv_test_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, kind, d, d + n, d + 2 * (size_t)n, n);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(out, d + 2 * (size_t)n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) r = DSM_ERR_HIP;
+    }
+    (void)hipFree(d);
+    if (r != DSM_OK) dsm_set_error("debug_fdiv: HIP error");
+    return r;
 }
 // Q2 = F (/) max(R2, eps) and the objective terms of one 16-sample tile (Init_NMFT.py:152-156, du.elop), element e = base.
 // F is a count + 1 over a depth + 4, never zero: elop's zero test can only fire on R.  Lanes without a cell (padded samples,

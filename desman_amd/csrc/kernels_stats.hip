@@ -735,28 +735,47 @@ int stats_ntab_ld(int S)
 // table size takes it, place and all, without a probe -- a table's cost is a property of its PHYSICAL address, which it keeps.  Probes
 // themselves are serialised (g_ntab_probe_mu): never two of this process at a time.  The pool holds at most 32 tables (each <= 512 KB:
 // larger ones are never probed and never pooled); dsm_debug_ntab_probes() counts the probes of the process.
-struct NtabSlot { int device; size_t need; uint32_t *raw, *base; size_t off; };
+struct NtabSlot { int device; size_t need; int ld, rep, xcd; uint32_t *raw, *base; size_t off; };
 static std::mutex g_ntab_mu, g_ntab_probe_mu;
 static std::vector<NtabSlot> g_ntab_pool;
 static std::atomic<int> g_ntab_probes{0};
 extern "C" int dsm_debug_ntab_probes(void) { return g_ntab_probes.load(); }
+// frees the pooled subset tables (dsm_release_device_caches)
+void stats_ntab_pool_release()
+{
+    std::lock_guard<std::mutex> lk(g_ntab_mu);
+    for (const NtabSlot &sl : g_ntab_pool) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        (void)hipSetDevice(sl.device);
+        (void)hipFree(sl.raw);
+        (void)hipSetDevice(cur);
+    }
+    g_ntab_pool.clear();
+}
 void stats_release_ntab(dsm_ctx *c)
 {
     if (!c->ntab_raw) return;
     bool kept = false;
     if (c->ntab_measured) {
+        // (whoever takes the table next clears it on ITS stream: nothing of this context's may still be queued on the table)
+        (void)hipStreamSynchronize(c->stream);
         std::lock_guard<std::mutex> lk(g_ntab_mu);
-        if (g_ntab_pool.size() < 32) { g_ntab_pool.push_back(NtabSlot{c->device, c->ntab_len, c->ntab_raw, c->ntab_base, c->ntab_off}); kept = true; }
+        if (g_ntab_pool.size() < 32) { g_ntab_pool.push_back(NtabSlot{c->device, c->ntab_len, c->ntab_ld, c->ntab_rep, c->ntab_xcd, c->ntab_raw, c->ntab_base, c->ntab_off}); kept = true; }
     }
     if (!kept) (void)hipFree(c->ntab_raw);
     c->ntab_raw = nullptr; c->ntab = nullptr; c->ntab_base = nullptr; c->ntab_len = 0; c->ntab_placed = c->ntab_measured = false;
 }
 static int ensure_ntab(dsm_ctx *c)
 {
-    c->ntab_rep = stats_ntab_rep(c);
-    if (stats_ntab_xcd(c)) c->ntab_rep = std::max(8, (c->ntab_rep + 7) / 8 * 8);
-    c->ntab_ld = stats_ntab_ld(c->S);
-    const size_t need = (size_t)c->ntab_rep * ((size_t)1 << c->G) * (size_t)c->ntab_ld;
+    // (the layout the pass wants now; the context's fields keep the layout its CURRENT table was made for until that table is released)
+    int rep = stats_ntab_rep(c);
+    const int xcd = stats_ntab_xcd(c) ? 1 : 0;
+    if (xcd) rep = std::max(8, (rep + 7) / 8 * 8);
+    const int ld = stats_ntab_ld(c->S);
+    const size_t need = (size_t)rep * ((size_t)1 << c->G) * (size_t)ld;
+    if (c->ntab_raw && (c->ntab_len != need || c->ntab_ld != ld || c->ntab_rep != rep || c->ntab_xcd != xcd)) stats_release_ntab(c);
+    c->ntab_rep = rep; c->ntab_ld = ld; c->ntab_xcd = xcd;
     static const bool scan = DSM_AB_ENV("DESMAN_HIP_NTAB_SCAN") != nullptr;          // experiments: the offset is re-read at every call
     const char *eo = DSM_AB_ENV("DESMAN_HIP_NTAB_OFF");
     const size_t off_env = eo ? ((size_t)strtoull(eo, nullptr, 0) & ~(size_t)255) : (size_t)-1;
@@ -765,7 +784,9 @@ static int ensure_ntab(dsm_ctx *c)
     if (off_env == (size_t)-1) {                           // a table of this size whose place was measured by an earlier chain
         std::lock_guard<std::mutex> lk(g_ntab_mu);
         for (size_t i = 0; i < g_ntab_pool.size(); ++i)
-            if (g_ntab_pool[i].device == c->device && g_ntab_pool[i].need == need) {
+            // (the measured place belongs to the access pattern -- row stride, copies, per-XCD mode -- not to the word count alone)
+            if (g_ntab_pool[i].device == c->device && g_ntab_pool[i].need == need && g_ntab_pool[i].ld == c->ntab_ld &&
+                g_ntab_pool[i].rep == c->ntab_rep && g_ntab_pool[i].xcd == c->ntab_xcd) {
                 const NtabSlot sl = g_ntab_pool[i];
                 g_ntab_pool.erase(g_ntab_pool.begin() + (long)i);
                 c->ntab_raw = sl.raw; c->ntab_base = sl.base; c->ntab_off = sl.off; c->ntab = sl.base + sl.off / 4; c->ntab_len = need;

@@ -299,6 +299,14 @@ int dsm_kl_assign(int device, const double *cov, const double *delta, double *et
 int dsm_ctx_sweep_stats(dsm_ctx *ctx, uint64_t *steps, uint64_t *exact_steps, int mode);
 /* test hook: out[i] = the hardware log2 (v_log_f32) of in[i], the logarithm of the screening pass */
 int dsm_ctx_debug_log2f(dsm_ctx *ctx, const float *in, float *out, size_t n);
+/* Frees what the library keeps per process and device beyond the life of a context: the MT19937 jump tables of the parallel generator
+   (2 x 50 MB per device, built by the first fill of >= 6 x 131 040 words: 2 x 2.2 ms) and the pool of placed subset tables (at most 32 of
+   <= 512 KB).  For long-lived processes and for several rank processes sharing one GPU; nothing may be in flight.  Returns 0. */
+int dsm_release_device_caches(void);
+/* test hook: out[i] = a[i] / b[i] as the NMFT update divides (kernels_nmft.hip): kind 0 = fdiv_ext (any a, b >= 0: operands brought to
+   within 2^+-512 of one by exact powers of two), 1 = fdiv_lo (a in (0, 1]), 2 = fdiv (operands far from the ends of the exponent range).
+   Runs on the current device's default stream. */
+int dsm_debug_fdiv(int kind, const double *a, const double *b, double *out, int n);
 /* reduce + gamma/control step of an NMFT update (Init_NMFT.py:163-168 and the stop test :106): -1 = one fused launch while the
    update kernel leaves <= 128 workgroup partials, two launches above (default); 0 = always two; 1 = always fused.  The factors,
    update counts and objective traces do not depend on it (tests/test_gpu_fullsize.py asserts bit-equality). */

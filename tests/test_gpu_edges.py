@@ -293,3 +293,35 @@ def test_the_place_of_the_subset_table_is_measured_once_per_shape():
     b = _lib.Context(0); b.set_counts(counts); b.seed(9); b.set_state(tau, gam, eta); b.force_stats_spec(_lib.STATS_AGG); b.gibbs_update(2)
     assert _lib.ntab_probes() - p0 == 1
     a.close(); b.close()
+
+
+def test_release_device_caches_frees_and_everything_is_rebuilt_on_demand():
+    """dsm_release_device_caches (100 MB of jump tables and up to 32 placed subset tables stay for the life of the process): after
+    it a new chain probes its table's place again and a long MT19937 fill rebuilds the jump tables -- same words, same sums."""
+    from desman_amd.synth import synth_counts, random_state
+    V, S, G = 400, 64, 4
+    counts, _, _ = synth_counts(V, S, G, seed=3)
+    tau, gamma, eta = random_state(V, S, G, seed=4)
+
+    def run():
+        c = _lib.Context(0)
+        try:
+            c.set_counts(counts); c.set_state(tau, gamma, eta); c.seed(5, ctr_seed=6)
+            c.force_stats_spec(2)
+            mu, E = c.sample_stats(1)
+            w = c.debug_mt_fill(7 * 131040 + 17)                      # long enough for the parallel generator
+            return mu, E, w
+        finally:
+            c.close()
+
+    a = run()
+    p0 = _lib.load().dsm_debug_ntab_probes()
+    b = run()                                                        # same shape, same process: the pooled table, no new probe
+    assert _lib.load().dsm_debug_ntab_probes() == p0
+    _lib.release_device_caches()
+    c_ = run()
+    assert _lib.load().dsm_debug_ntab_probes() == p0 + 1             # the pool was emptied: measured again
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    for x, y in zip(a, c_):
+        assert np.array_equal(x, y)

@@ -398,3 +398,29 @@ def test_fuzz_stats_pass_with_weights_at_the_ends_of_the_exponent_range(V, S, G,
             ctx.force_stats_spec(0)
     finally:
         ctx.close()
+
+
+def test_fuzz_nmft_divisions_at_both_ends_of_the_exponent_range():
+    """kernels_nmft.hip: fdiv_ext brings its operands to within 2^+-512 of one by exact powers of two and puts the powers back on the quotient.
+    Put back one after the other (round 5), a quotient of two HUGE or two TINY operands passed through the subnormal range or through
+    infinity on the way although a / b itself is an ordinary number (tn = 2^501 over tot = 2^1023 in the row normalisation of the
+    fixed-gamma update, Init_NMFT.py:180-181, which has no eps clamp).  Against IEEE division: within 1 ulp (fdiv is faithful, not always
+    correctly rounded) wherever the quotient is a normal number, the same zero / infinity where it is not, over every pairing of ends."""
+    rs = np.random.RandomState(5)
+    ends = [2.0 ** e for e in (-1074, -1060, -1022, -900, -600, -501, -499, -300, -1, 0, 1, 300, 499, 501, 600, 900, 1022, 1023)]
+    a = np.array([x * (1.0 + rs.rand()) for x in ends for _ in ends])
+    b = np.array([y * (1.0 + rs.rand()) for _ in ends for y in ends])
+    a = np.minimum(a, np.finfo(np.float64).max)
+    b = np.minimum(b, np.finfo(np.float64).max)
+    with np.errstate(all="ignore"):
+        ref = a / b
+    got = _lib.debug_fdiv(0, a, b)
+    normal = np.isfinite(ref) & (np.abs(ref) >= 2.0 ** -1022)
+    ulp = np.spacing(np.abs(ref[normal]))
+    assert np.all(np.abs(got[normal] - ref[normal]) <= ulp), np.argwhere(np.abs(got[normal] - ref[normal]) > ulp)[:5]
+    assert np.array_equal(np.isinf(got), np.isinf(ref))
+    sub = np.isfinite(ref) & ~normal                             # subnormal or zero quotients: within one spacing of the subnormal grid
+    assert np.all(np.abs(got[sub] - ref[sub]) <= 2.0 ** -1074 * 2)
+    # the case of the advice, exactly: two huge operands, an ordinary quotient
+    q = _lib.debug_fdiv(0, np.array([2.0 ** 501, 2.0 ** -600 * 3]), np.array([2.0 ** 1023, 2.0 ** -1000 * 7]))
+    np.testing.assert_allclose(q, [2.0 ** -522, (2.0 ** 400) * 3 / 7], rtol=3e-16)

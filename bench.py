@@ -156,7 +156,8 @@ def pmc_passes(V, S, G, depth, iters=30, save=False):
         fe, wr = mean.get("FETCH_SIZE", 0.0), mean.get("WRITE_SIZE", 0.0)            # KiB per launch
         out[k] = dict(fetch_kib_raw=fe, write_kib_raw=wr, read_bytes_corrected=2.0 * fe * 1024.0, write_bytes=wr * 1024.0,
                       bytes_per_launch=2.0 * fe * 1024.0 + wr * 1024.0, valu_insts=mean.get("SQ_INSTS_VALU"),
-                      valu_active_cycles=mean.get("SQ_ACTIVE_INST_VALU"), dispatches=max(len(v) for v in dd.values()),
+                      valu_active_cycles=mean.get("SQ_ACTIVE_INST_VALU"), sq_busy_cycles=mean.get("SQ_BUSY_CYCLES"),
+                      dispatches=max(len(v) for v in dd.values()),
                       mfma_insts=mean.get("SQ_INSTS_MFMA"), mfma_busy_cycles=mean.get("SQ_VALU_MFMA_BUSY_CYCLES"))
     db = {}
     if os.path.exists(TRAFFIC_DB):
@@ -501,7 +502,7 @@ def main():
     # candidate log-probability terms per sweep, SURVEY sec. 8(d): 16 V G S (+ 4 V S for the likelihood).  Each is evaluated by the
     # fp32 screening pass (hardware log2); the steps it cannot decide (tau_steps_fp64_frac) are re-evaluated in fp64, 12 of 16
     n_logs = 16.0 * V * G * S + 4.0 * V * S
-    traffic, valu = {}, {}
+    traffic, valu, valu_act = {}, {}, {}
     stats_kname = "stats_pat_kernel" if spec == 4 else "stats_agg_kernel" if spec >= 2 else "stats_kernel"
     tj, traffic_source = None, None
     pmc_error = None
@@ -529,6 +530,7 @@ def main():
             if name:
                 traffic[name] = rec.get("bytes_per_launch")
                 valu[name] = rec.get("valu_insts")
+                valu_act[name] = (rec.get("valu_active_cycles"), rec.get("sq_busy_cycles"))
     per_kernel = {}
     for name, kname in (("stats", stats_kname), ("tau", "tau_kernel")):
         us = k_us.get(name, float("nan"))
@@ -536,10 +538,17 @@ def main():
         per_kernel[kname] = dict(avg_kernel_us=us, algorithmic_bytes_per_launch=alg[name], achieved_GBps=ach,
                                  frac_of_8TBps=ach / 8000.0, traffic_bytes_pmc=traffic.get(name))
         if valu.get(name):
-            # what actually bounds the kernel: wave64 VALU instructions (PMC, profiles/) x ~4 cycles each (measured
-            # average, SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU) over the 1024 SIMDs x duration x 2.4 GHz issue slots
-            per_kernel[kname].update(valu_insts_pmc=valu[name],
-                                     valu_issue_frac=valu[name] * 4.0 / (1024 * us * 1e-6 * 2.4e9))
+            per_kernel[kname].update(valu_insts_pmc=valu[name])
+            act, busy = valu_act.get(name, (None, None))
+            if act and busy:
+                # what actually bounds the kernel, from the counters alone (no assumed cycles per instruction, no assumed clock):
+                # SQ_ACTIVE_INST_VALU = quad-cycles (4 clocks) the wavefronts spent executing VALU instructions, summed over the device;
+                # SQ_BUSY_CYCLES = clocks the SQ was busy, summed over its N_SE = 32 instances (8 XCDs x 4 shader engines) = 32 x the launch's
+                # duration in shader clocks.  VALU-busy share of the 1024 SIMDs: active x 4 / (busy / 32 x 1024) = (active / busy) / 8.
+                per_kernel[kname].update(valu_active_quadcycles_pmc=act, sq_busy_cycles_pmc=busy, valu_issue_frac=(act / busy) / 8.0,
+                                         shader_clock_GHz_pmc=busy / 32.0 / (us * 1e-6) / 1e9)
+            else:                                    # a record without the two counters (older pmc_traffic_by_shape.json): ~4 clocks per instruction at 2.4 GHz
+                per_kernel[kname].update(valu_issue_frac=valu[name] * 4.0 / (1024 * us * 1e-6 * 2.4e9), valu_issue_frac_assumes="4 cycles per instruction at 2.4 GHz")
     launched, resident = ctx.tau_launch_info()
     rounds = launched / max(resident, 1)
     tau_launch = dict(launched_workgroups=launched, resident_workgroups=resident, rounds=rounds,

@@ -308,11 +308,6 @@ __device__ __forceinline__ void mult4(Xo128 &rng, uint32_t x, const double (&W)[
 //     (v_bitop3_b32), the uniform is two fused operations, the search's table pointer is its only counter;
 //   * the rare outcomes (hand-over to the compacted kernel) leave the item by ONE flag the caller tests once per cell.
 // ISA-level counts per phase: profiles/r06_stats_isa_counts.txt (scripts/isa_count.py).
-#ifdef DSM_ISA_MARKS
-#define ISA_MARK(name) asm volatile("; MARK " name)
-#else
-#define ISA_MARK(name) do { } while (0)
-#endif
 
 __device__ __forceinline__ double div_unscaled(double a, double b)
 {

@@ -14,6 +14,13 @@
 
 #define DSM_EPS 2.220446049250313e-16
 
+// phase marks for scripts/isa_count.py: with -DDSM_ISA_MARKS a `; MARK name` comment goes into the assembly at the start of a phase
+#ifdef DSM_ISA_MARKS
+#define ISA_MARK(name) asm volatile("; MARK " name)
+#else
+#define ISA_MARK(name) do { } while (0)
+#endif
+
 // ---- Philox4x32-10 (Salmon et al. 2011); checked against the Random123 KATs
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4])
@@ -354,10 +361,12 @@ __device__ __forceinline__ bool sweep_screen(const double (&pre)[NSL][4], const 
     constexpr int SP = LPV * NSL;
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 s32[NSL][2];
+    ISA_MARK("screen_prefix_cvt");
 #pragma unroll
     for (int j = 0; j < NSL; ++j)
 #pragma unroll
         for (int bp = 0; bp < 2; ++bp) s32[j][bp] = (f2){(float)pre[j][2 * bp], (float)pre[j][2 * bp + 1]};
+    ISA_MARK("screen_links");
 #pragma unroll 4
     for (int h = g + 1; h < G; ++h) {
         const f2 *er = reinterpret_cast<const f2 *>(eS32 + (int)((t >> (2 * h)) & 3) * 4);
@@ -370,6 +379,7 @@ __device__ __forceinline__ bool sweep_screen(const double (&pre)[NSL][4], const 
             s32[j][1] = __builtin_elementwise_fma(e23, gm2, s32[j][1]);
         }
     }
+    ISA_MARK("screen_candidates");
     const f2 *e2 = reinterpret_cast<const f2 *>(eS32);               // [a][bp], then the column minima [bp]
     f2 acc2[4] = {(f2){0.0f, 0.0f}, (f2){0.0f, 0.0f}, (f2){0.0f, 0.0f}, (f2){0.0f, 0.0f}};
     float lbmin = 1.0f;
@@ -393,8 +403,10 @@ __device__ __forceinline__ bool sweep_screen(const double (&pre)[NSL][4], const 
     float c32[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) c32[a] = acc2[a].x + acc2[a].y;
+    ISA_MARK("screen_reduce");
     if (!(lbmin >= 1.0e-30f)) c32[0] = __builtin_nanf("");          // poisons the totals of the whole group
     group_allreduce_sum4_f32<LPV>(c32[0], c32[1], c32[2], c32[3]);    // log2 units
+    ISA_MARK("screen_certify");
     return screen_certify<NSL>(c32, xtot, G, uw, best);
 }
 

@@ -935,6 +935,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
     const bool screen_on = SWEEP && p.logp == nullptr && p.screen && *p.screen_ctl == 0u;
 
     for (int v = bid * GPB + grp; v < p.V; v += nblk * GPB) {
+        ISA_MARK("variant_setup");
         uint64_t t = p.tau[v];
         // LEAN keeps the counts of the sweep as (float)count only (12 registers instead of 24 at three samples per lane: the
         // screening pass multiplies by exactly that, the rare fp64 step by (double)(float)count, c_sample_tau.c:164) and the
@@ -1007,6 +1008,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
 #pragma unroll
                     for (int j = 0; j < NSL; ++j) gg[j] = gT[g * SP + lig + j * LPV];
                 }
+                ISA_MARK("step_setup");
                 const int told = (int)((t >> (2 * g)) & 3);
                 uint32_t uw;
                 const size_t ui = (size_t)v * G + g;
@@ -1050,6 +1052,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                     else cert = sweep_screen<LPV, NSL>(pre, xi, t, g, G, lig, uw, gT32, eS32, xtot, best);
                     if (__builtin_amdgcn_ballot_w64(cert) == __builtin_amdgcn_ballot_w64(true)) { tn = best; decided = true; }
                 }
+                ISA_MARK("step_fp64");
                 if (!decided) {
                 const bool reuse = have_cur;
                 double l[4];
@@ -1158,6 +1161,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                 tn = sweep_draw(l, uw);
                 l_cur = (tn == 0) ? l[0] : (tn == 1) ? l[1] : (tn == 2) ? l[2] : l[3];
                 }
+                ISA_MARK("step_commit");
                 have_cur = !decided;
                 n_exact += !decided;
                 nchg += (lig == 0) & (tn != told);
@@ -1190,6 +1194,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                 if (lig == 0) p.tau[vv] = t;
             } else if (lig == 0) p.tau[v] = t;
         }
+        ISA_MARK("variant_ll");
         if (lig == 0 && p.trace) p.trace[v] = t;
         if (LL) {
 #pragma unroll
@@ -1226,6 +1231,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
             }
         }
     }
+    ISA_MARK("epilogue");
     // workgroup reduction, fixed order -> deterministic ll
     const double wsum = group_allreduce_sum<64>(ll_acc);
     const int wn = (int)group_allreduce_sum_u32<64>((unsigned)nchg);

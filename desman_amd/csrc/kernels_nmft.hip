@@ -956,7 +956,7 @@ extern "C" int dsm_debug_fdiv(int kind, const double *a, const double *b, double
 // Round 5: the tile is STRAIGHT-LINE code.  Rounds 2-4 tested every element for elop's rare cases (0 < R < eps divides by R itself;
 // a quotient outside the table logarithm's domain takes libm's) behind wave-uniform branches -- five basic-block ends per element,
 // an exposed LDS round trip per table look-up, the exec-mask bookkeeping of `if (live)`: 72 instructions per element, a third of
-// them scalar (profiles/r05_nmft_isa_counts.txt).  Now ONE test per tile -- a live lane with !(R >= eps), NaN included -- sends the
+// them scalar (counted in the assembly of round 4's tile; the before / after of the rewrite is profiles/r05_nmft_q2_straightline_ab.txt).  Now ONE test per tile -- a live lane with !(R >= eps), NaN included -- sends the
 // whole tile through the element-by-element code (nm_tile_q2_rare: never with the adjustment on, where tau >= eps and the columns of
 // gamma sum to one); the common path is four independent division / logarithm chains the scheduler interleaves, their table
 // look-ups in flight together.  The operations on live elements and their order are those of the element-by-element form: same bits.

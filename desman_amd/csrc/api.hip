@@ -707,7 +707,7 @@ extern "C" int dsm_ctx_debug_stage1(dsm_ctx *c, uint32_t iter, uint32_t *ntab, u
         for (size_t h = 0; h < NH; ++h)
             for (size_t s = 0; s < S; ++s) {                                       // device [rep][H][S] -> [S][H], copies summed
                 uint32_t v = 0;
-                for (int r = 0; r < c->ntab_rep; ++r) v += t[((size_t)r * NH + ((h * stats_ntab_hmul()) & (NH - 1))) * ld + s];
+                for (int r = 0; r < c->ntab_rep; ++r) v += t[((size_t)r * NH + ((h * stats_ntab_hmul() + (s >> 4) * stats_ntab_swz()) & (NH - 1))) * ld + s];
                 ntab[s * NH + h] = v;
             }
     return DSM_OK;

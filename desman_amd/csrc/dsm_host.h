@@ -214,6 +214,8 @@ int stats_place_ntab(dsm_ctx *c);         // measures where the subset table sho
 void stats_release_ntab(dsm_ctx *c);     // the table leaves the context: to the process's pool of placed tables, or freed
 #define DSM_NTAB_PAD 0               // words added to a row of the subset table when S is a multiple of 64 (stats_ntab_ld)
 int stats_ntab_ld(int S);
+uint32_t stats_ntab_swz();                 // the sample's part of the subset table's row map
+#define DSM_NTAB_SWZ 17u                // (any odd number: see stats_ntab_swz)
 void stats_ntab_pool_release();            // kernels_stats.hip: frees the pooled subset tables
 void mt_jump_release();                    // kernels_gibbs.hip: frees the MT19937 jump tables
 int stats_ntab_rep(const dsm_ctx *c);       // copies of the subset table the stage-1 atomics are spread over

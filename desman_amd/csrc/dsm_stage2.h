@@ -30,7 +30,7 @@ struct Stage2Params {
     const double *log_tab;
     int S, G;
     uint32_t k0, k1, iter;
-    uint32_t hmul;                  // row of subset H in ntab: (H * hmul) mod 2^G (kernels_stats.hip: stats_ntab_hmul)
+    uint32_t hmul, swz;             // row of (subset H, sample s) in ntab: (H * hmul + (s >> 4) * swz) mod 2^G (kernels_stats.hip: stats_ntab_hmul / _swz)
     uint32_t *big_count;            // work-list counter of stage 1: consumed by now, reset here for the next pass (or null)
     int nsplit;                     // workgroups that share a sample's root level (stand-alone kernel, G >= 11), else 1
     uint32_t *scratch, *ticket;     // [S][S2_TAB_ENTRIES] level-1 tables handed over, [S] arrival counters; zero between passes
@@ -85,7 +85,7 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
             if (Hs == 0) continue;
             uint32_t n;
             if (level == 0) {
-                uint32_t *cell = p.ntab + (size_t)((Hs * p.hmul) & ((1u << G) - 1u)) * (size_t)p.ld + s;
+                uint32_t *cell = p.ntab + (size_t)((Hs * p.hmul + ((uint32_t)s >> 4) * p.swz) & ((1u << G) - 1u)) * (size_t)p.ld + s;
                 const size_t cstride = ((size_t)1 << G) * (size_t)p.ld;
                 if (p.rep == 8) {
                     // one copy per XCD (kernels_stats.hip): all eight loads in flight at once -- read one after the other (a store may

@@ -1468,7 +1468,7 @@ int k_dirichlet(dsm_ctx *c, uint32_t iter, double *gamma_out, double *gamma_trac
         // stage 2 splits the subset counts with the gamma the mu/E pass used = the resident one; gamma_out may be the same
         // buffer: workgroup s stages row s in LDS before it writes the new row s, and no other workgroup reads that row
         s2.ntab = c->ntab; s2.rep = c->ntab_rep; s2.ld = c->ntab_ld; s2.gamma = c->gamma; s2.sum_mu = c->sum_mu; s2.log_tab = c->log_tab;
-        s2.S = c->S; s2.G = c->G; s2.k0 = k0; s2.k1 = k1; s2.iter = iter; s2.hmul = stats_ntab_hmul();
+        s2.S = c->S; s2.G = c->G; s2.k0 = k0; s2.k1 = k1; s2.iter = iter; s2.hmul = stats_ntab_hmul(); s2.swz = stats_ntab_swz();
         s2.big_count = c->big_count;
     }
     DirParams q;

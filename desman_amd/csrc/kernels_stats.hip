@@ -67,6 +67,7 @@ struct StatsAggParams {
                                     // whole pass on deep data)
     size_t big_seg;
     double lean_cap;                // stage 1 hands an item whose rarer outcome has a mean above this to the compacted kernel
+    uint32_t swz;                   // ... + (s >> 4) * swz: the four 64 B lines of a subset's 64 samples sit in four different rows (stats_ntab_swz)
     uint32_t hmul;                  // the row of subset H is (H * hmul) mod 2^G (dsm_stage2.h: s2_row): an odd multiplier scatters the hot
                                     // subsets over the memory channels whatever the table's address
     int xcd;                        // 1: the table has a copy per XCD (rep = 8 k); a workgroup adds to a copy of ITS XCD (HW_REG_XCC_ID) with
@@ -301,24 +302,26 @@ __device__ __forceinline__ void stats_agg_body(const StatsAggParams &p)
         const size_t ld = (size_t)p.ld;                                    // row stride of the subset table in words (>= S: ensure_ntab)
         uint32_t *const nt = p.ntab + (size_t)copy * (((size_t)1 << G) * ld);
         const uint32_t hmask = (1u << G) - 1u;
-        H0 = (H0 * p.hmul) & hmask; H1 = (H1 * p.hmul) & hmask; H2 = (H2 * p.hmul) & hmask; H3 = (H3 * p.hmul) & hmask;   // rows of the four subsets
-        if (STATS_DBG(p, (4 | 32))) { if ((nacc[0] ^ nacc[1] ^ nacc[2] ^ nacc[3] ^ H0 ^ H1 ^ H2 ^ H3) == 0x12345u) atomicAdd(nt + s, 1u); continue; }
+        // row of (subset, sample): (H hmul + (s >> 4) swz) mod 2^G -- the subset's part is scalar, the sample's a lane constant of the slot
+        const uint32_t sw = ((uint32_t)s >> 4) * p.swz;
+        const uint32_t r0 = (H0 * p.hmul + sw) & hmask, r1 = (H1 * p.hmul + sw) & hmask, r2 = (H2 * p.hmul + sw) & hmask, r3 = (H3 * p.hmul + sw) & hmask;
+        if (STATS_DBG(p, (4 | 32))) { if ((nacc[0] ^ nacc[1] ^ nacc[2] ^ nacc[3] ^ r0 ^ r1 ^ r2 ^ r3) == 0x12345u) atomicAdd(nt + s, 1u); continue; }
         if (STATS_DBG(p, 64)) {        // plain stores instead of atomics (wrong sums; what the adds cost beyond a store)
-            nt[(size_t)H0 * ld + s] = nacc[0]; nt[(size_t)H1 * ld + s] = nacc[1]; nt[(size_t)H2 * ld + s] = nacc[2]; nt[(size_t)H3 * ld + s] = nacc[3];
+            nt[(size_t)r0 * ld + s] = nacc[0]; nt[(size_t)r1 * ld + s] = nacc[1]; nt[(size_t)r2 * ld + s] = nacc[2]; nt[(size_t)r3 * ld + s] = nacc[3];
             continue;
         }
         if (p.xcd) {
             // this XCD's copy: every adder of the copy shares the L2 the atomic executes in (relaxed, workgroup scope: no sc1, the
             // line stays in L2); the kernel boundary writes the lines back for stage 2, which sums the copies
-            if (nacc[0]) __hip_atomic_fetch_add(nt + (size_t)H0 * ld + s, nacc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (nacc[1]) __hip_atomic_fetch_add(nt + (size_t)H1 * ld + s, nacc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (nacc[2]) __hip_atomic_fetch_add(nt + (size_t)H2 * ld + s, nacc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (nacc[3]) __hip_atomic_fetch_add(nt + (size_t)H3 * ld + s, nacc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (nacc[0]) __hip_atomic_fetch_add(nt + (size_t)r0 * ld + s, nacc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (nacc[1]) __hip_atomic_fetch_add(nt + (size_t)r1 * ld + s, nacc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (nacc[2]) __hip_atomic_fetch_add(nt + (size_t)r2 * ld + s, nacc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (nacc[3]) __hip_atomic_fetch_add(nt + (size_t)r3 * ld + s, nacc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
-            if (nacc[0]) atomicAdd(nt + (size_t)H0 * ld + s, nacc[0]);
-            if (nacc[1]) atomicAdd(nt + (size_t)H1 * ld + s, nacc[1]);
-            if (nacc[2]) atomicAdd(nt + (size_t)H2 * ld + s, nacc[2]);
-            if (nacc[3]) atomicAdd(nt + (size_t)H3 * ld + s, nacc[3]);
+            if (nacc[0]) atomicAdd(nt + (size_t)r0 * ld + s, nacc[0]);
+            if (nacc[1]) atomicAdd(nt + (size_t)r1 * ld + s, nacc[1]);
+            if (nacc[2]) atomicAdd(nt + (size_t)r2 * ld + s, nacc[2]);
+            if (nacc[3]) atomicAdd(nt + (size_t)r3 * ld + s, nacc[3]);
         }
         S1_CLKP(3);
         ++s1_pass;
@@ -510,7 +513,7 @@ __device__ __forceinline__ void stats_big_body(const StatsAggParams &p)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             erow[a * 256] += n[a];
-            if (n[a]) atomicAdd(p.ntab + (size_t)(blockIdx.x % (unsigned)p.rep) * (((size_t)1 << G) * (size_t)p.ld) + (size_t)((H[a] * p.hmul) & ((1u << G) - 1u)) * (size_t)p.ld + s, n[a]);
+            if (n[a]) atomicAdd(p.ntab + (size_t)(blockIdx.x % (unsigned)p.rep) * (((size_t)1 << G) * (size_t)p.ld) + (size_t)((H[a] * p.hmul + ((uint32_t)s >> 4) * p.swz) & ((1u << G) - 1u)) * (size_t)p.ld + s, n[a]);
         }
     }
     {
@@ -703,6 +706,20 @@ static bool stats_ntab_xcd(const dsm_ctx *c)
 // two more allocations ahead of it -- the persistent NMFT kernel's -- moved the table; base offsets scanned: fast at 256 B and
 // 32-60 KB into a 2 MB block, slow at 0, 4 KB, 64 KB ...).  Scattering the rows takes the pathology away (46-54 us at every offset
 // scanned).  DESMAN_HIP_NTAB_HMUL=1 is the identity (A/B switch).
+// Round 6: the sample's part of the row map.  A subset's 64 samples are one 256 B row = four 64 B lines, and a wavefront's add to it is one
+// instruction = four line-atomics that arrive at the memory side together.  With (s >> 4) * swz added to the row index the four lines of a
+// LOGICAL row sit in four different physical rows, i.e. 256 B blocks: the adds a hot subset takes are spread over four places of the table
+// instead of queueing at one.  Measured at config 3 (scripts/dbg/r06_swz_scan.py, profiles/r06_swz_scan.txt): stage 1 40.5 us at EVERY one
+// of eight table places and every odd swz tried (1, 3, 17, 85; also 64), against 45-47 us at the good places and 55-59 us at the bad ones
+// without it -- the place lottery of rounds 2-5 (44 vs 54-61 us for the same launch, hipMalloc's answer deciding; stats_place_ntab's eight
+// timed passes per table; a probe that kept a slow place in 2 of 6 processes) is gone, and the launch is 11 % faster than its best place
+// was.  Stage 2 reads the same map (dsm_stage2.h); integer sums: nothing but the time changes.  0 = off (the map of rounds 2-5: the
+// place is then measured as before).  DESMAN_HIP_NTAB_SWZ in the experiment build.
+uint32_t stats_ntab_swz()
+{
+    static const uint32_t k = DSM_AB_ENV("DESMAN_HIP_NTAB_SWZ") ? (uint32_t)strtoul(DSM_AB_ENV("DESMAN_HIP_NTAB_SWZ"), nullptr, 0) : DSM_NTAB_SWZ;
+    return k;
+}
 uint32_t stats_ntab_hmul()
 {
     static const uint32_t k = DSM_AB_ENV("DESMAN_HIP_NTAB_HMUL") ? ((uint32_t)strtoul(DSM_AB_ENV("DESMAN_HIP_NTAB_HMUL"), nullptr, 0) | 1u) : 0x9E3779B1u;
@@ -821,6 +838,7 @@ int stats_place_ntab(dsm_ctx *c)
     if (r != DSM_OK) return r;
     if (c->ntab_placed) return DSM_OK;
     c->ntab_placed = true;
+    if (stats_ntab_swz() != 0u) return DSM_OK;          // round 6: with the sample-swizzled row map every place costs the same (stats_ntab_swz): nothing to measure
     // tables of a few hundred KB: larger ones spread over the channels whatever their place (config 5, 1.5 MB: 302 us everywhere)
     if (!on || g_batch.K || c->ntab_len * sizeof(uint32_t) > ((size_t)512 << 10)) return DSM_OK;
     std::lock_guard<std::mutex> probe_lk(g_ntab_probe_mu);
@@ -991,7 +1009,7 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
     p.ntab = c->ntab; p.rep = c->ntab_rep; p.ld = c->ntab_ld; p.esum = c->esum; p.log_tab = c->log_tab;
     p.xcd = stats_ntab_xcd(c) ? 1 : 0;
-    p.hmul = stats_ntab_hmul();
+    p.hmul = stats_ntab_hmul(); p.swz = stats_ntab_swz();
     p.big_list = c->big_list; p.big_count = c->big_count;
     p.pat_rep = nullptr; p.pat_x = nullptr; p.pat_list = nullptr; p.pat_n = nullptr;
     if (pat) {
@@ -1102,7 +1120,7 @@ int k_stats_stage2(dsm_ctx *c, uint32_t iter)
     KTimer tm(c, DSM_K_STATS2);
     Stage2Params p;
     p.ntab = c->ntab; p.rep = c->ntab_rep; p.ld = c->ntab_ld; p.gamma = c->gamma; p.sum_mu = c->sum_mu; p.log_tab = c->log_tab;
-    p.S = c->S; p.G = c->G; p.hmul = stats_ntab_hmul();
+    p.S = c->S; p.G = c->G; p.hmul = stats_ntab_hmul(); p.swz = stats_ntab_swz();
     p.k0 = (uint32_t)c->ctr_seed; p.k1 = (uint32_t)(c->ctr_seed >> 32); p.iter = iter;
     p.big_count = c->big_count;
     // 2^G subsets per sample at the root: 256 threads up to G = 9, 1024 above

@@ -267,37 +267,37 @@ np.savez(sys.argv[1], ll=tr["ll"], lp=tr["lp"], nch=tr["nchange"], t=t, g=g, e=e
             assert np.array_equal(outs[0][k], o[k]), k
 
 
-def test_the_place_of_the_subset_table_is_measured_once_per_shape():
-    """VERDICT r4 "weak" 12: every chain of a sweep timed eight placements of its subset table again.  A measured table now outlives its
-    chain (pool of placed tables per process, kernels_stats.hip: stats_release_ntab): chains of one device and table size that follow each
-    other probe ONCE, and the chain is the same chain whether its table was measured for it or inherited."""
+def test_the_place_of_the_subset_table_is_not_measured_any_more():
+    """Rounds 2-5 timed stage 1 at eight places of every new subset table and kept the fastest (what the table's memory-side atomics cost
+    depended on its physical address: 44 vs 54-61 us at config 3), round 5 pooled the measured tables.  Round 6's row map puts the four
+    64 B lines of a subset's row into four different rows (kernels_stats.hip: stats_ntab_swz): every place costs the same, 11 % less than
+    the best one did (profiles/r06_swz_scan.txt), so the product library measures nothing -- and a chain is the same chain whichever
+    table it gets, alone or next to another."""
     from desman_amd import _lib
     from desman_amd.synth import synth_counts, random_state
     V, S, G = 900, 64, 7
     counts, _, _ = synth_counts(V, S, G, seed=31)
     tau, gam, eta = random_state(V, S, G, seed=6)
-    probes, finals = [], []
-    for k in range(4):
-        p0 = _lib.ntab_probes()
+    finals = []
+    p0 = _lib.ntab_probes()
+    for k in range(3):
         c = _lib.Context(0); c.set_counts(counts); c.seed(9); c.set_state(tau, gam, eta); c.force_stats_spec(_lib.STATS_AGG)
         c.gibbs_update(6)
         finals.append((c.get_trace()["ll"].copy(), c.get_state()[0].copy()))
         c.close()
-        probes.append(_lib.ntab_probes() - p0)
-    assert probes[0] <= 1 and probes[1:] == [0, 0, 0], probes
+    a = _lib.Context(0); a.set_counts(counts); a.seed(9); a.set_state(tau, gam, eta); a.force_stats_spec(_lib.STATS_AGG); a.gibbs_update(6)
+    b = _lib.Context(0); b.set_counts(counts); b.seed(9); b.set_state(tau, gam, eta); b.force_stats_spec(_lib.STATS_AGG); b.gibbs_update(6)
+    finals.append((a.get_trace()["ll"].copy(), a.get_state()[0].copy()))
+    finals.append((b.get_trace()["ll"].copy(), b.get_state()[0].copy()))
+    a.close(); b.close()
+    assert _lib.ntab_probes() == p0
     for ll, t in finals[1:]:
         assert np.array_equal(ll, finals[0][0]) and np.array_equal(t, finals[0][1])
-    # two chains alive at once need two tables: the second one measures its own
-    a = _lib.Context(0); a.set_counts(counts); a.seed(9); a.set_state(tau, gam, eta); a.force_stats_spec(_lib.STATS_AGG); a.gibbs_update(2)
-    p0 = _lib.ntab_probes()
-    b = _lib.Context(0); b.set_counts(counts); b.seed(9); b.set_state(tau, gam, eta); b.force_stats_spec(_lib.STATS_AGG); b.gibbs_update(2)
-    assert _lib.ntab_probes() - p0 == 1
-    a.close(); b.close()
 
 
 def test_release_device_caches_frees_and_everything_is_rebuilt_on_demand():
     """dsm_release_device_caches (100 MB of jump tables and up to 32 placed subset tables stay for the life of the process): after
-    it a new chain probes its table's place again and a long MT19937 fill rebuilds the jump tables -- same words, same sums."""
+    it a long MT19937 fill rebuilds the jump tables and a chain allocates its table afresh -- same words, same sums."""
     from desman_amd.synth import synth_counts, random_state
     V, S, G = 400, 64, 4
     counts, _, _ = synth_counts(V, S, G, seed=3)
@@ -315,12 +315,9 @@ def test_release_device_caches_frees_and_everything_is_rebuilt_on_demand():
             c.close()
 
     a = run()
-    p0 = _lib.load().dsm_debug_ntab_probes()
-    b = run()                                                        # same shape, same process: the pooled table, no new probe
-    assert _lib.load().dsm_debug_ntab_probes() == p0
+    b = run()
     _lib.release_device_caches()
     c_ = run()
-    assert _lib.load().dsm_debug_ntab_probes() == p0 + 1             # the pool was emptied: measured again
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     for x, y in zip(a, c_):

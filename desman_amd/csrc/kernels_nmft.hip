@@ -2362,29 +2362,43 @@ static int launch_persist(dsm_ctx *c, const NmftPersistParams &q, int grid, size
 
 // the whole factorize loop as one launch; *used = 0 when this shape / device does not take the persistent path (the caller
 // then runs the three-launch loop).  Control words (ctl), trace and factors are left as dsm_nmft_factorize expects them.
-int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int adjust, int *used)
+// whether the persistent loop takes this context's table, and with what launch: workgroups (0 = it does not), wavefronts per workgroup,
+// tiles / K-blocks, dynamic LDS.
+static int nmft_persist_shape(const dsm_ctx *c, int fix_gamma, int *nt_out, int *kb_out, int *nwv_out, size_t *sh_out, int *cus_out)
 {
-    *used = 0;
     static const bool off = DSM_AB_ENV("DESMAN_HIP_NMFT_NO_PERSIST") != nullptr;
     int nt, kb;
-    if (off || c->nmft_persist == 0 || !mfma_shape(c, &nt, &kb) || nt > 6 || kb > 3 || c->timing || g_batch.K) return DSM_OK;
+    if (off || c->nmft_persist == 0 || !mfma_shape(c, &nt, &kb) || nt > 6 || kb > 3 || c->timing) return 0;
     int cus = 0;
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) return 0;
     const int G = c->nG, S = c->S, nquad = (c->V + 3) / 4, nblk = (nquad + 3) / 4;
     // up to one update-kernel workgroup per CU: four wavefronts per workgroup; above: twelve (three of those workgroups each)
     const int nwv = nblk <= cus ? 4 : NMFT_P_WAVES;
     // 65..96 samples: the four-wavefront form (V <= 16 x compute units; LDS), and only with gamma fixed -- one value per workgroup
     // crosses the machine then (12.8 against 20.7 us per update at 3000 x 96 x 8); with G S + G + 1 statistics to exchange the loop is
     // no faster than three launches there (22.7 vs 22.6)
-    if (nt > 4 && (nwv != 4 || !fix_gamma)) return DSM_OK;
+    if (nt > 4 && (nwv != 4 || !fix_gamma)) return 0;
     const int grid = (nquad + nwv - 1) / nwv;
     const int nout = G * S + G + 1;
-    if (grid < 2 || grid > cus) return DSM_OK;              // (neither form holds more than one workgroup per CU worth of table: no buffers
+    if (grid < 2 || grid > cus) return 0;                   // (neither form holds more than one workgroup per CU worth of table: no buffers
                                                             //  are allocated for tables that cannot take this path)
     const int GP = 4 * kb, SPAD = 16 * nt;
     const size_t sh = (2 * DSM_LOG_TAB_N + 2 * (size_t)GP * (SPAD + 1) + GP + (size_t)nwv * 2 * 16 * GP +
                        (size_t)nwv * std::max<size_t>((size_t)(GP + 2) * SPAD, NM_XQ) + ((nout + 1) & ~1) + 2 * (size_t)G * S + 2) * sizeof(double);
-    if (sh > 160 * 1024) return DSM_OK;
+    if (sh > 160 * 1024) return 0;
+    *nt_out = nt; *kb_out = kb; *nwv_out = nwv; *sh_out = sh; *cus_out = cus;
+    return grid;
+}
+int k_nmft_persist(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int adjust, int *used)
+{
+    *used = 0;
+    if (g_batch.K) return DSM_OK;
+    int nt, kb, nwv, cus;
+    size_t sh;
+    const int grid = nmft_persist_shape(c, fix_gamma, &nt, &kb, &nwv, &sh, &cus);
+    if (grid == 0) return DSM_OK;
+    const int G = c->nG, S = c->S;
+    const int nout = G * S + G + 1;
     // exchange buffers + barrier words (zeroed before every launch)
     // ... + a copy of the factors as they are now: should the launch not come to an end (a barrier timed out: its workgroups
     // were not all resident, e.g. behind another process's long-running kernels) the factors are put back and the caller runs

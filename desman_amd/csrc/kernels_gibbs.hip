@@ -858,6 +858,7 @@ struct TauParams {
     uint32_t *step_cnt;                // [gridDim.x][2] this launch's wavefront-steps: run / left to the fp64 code (~0: not screened)
     const uint32_t *screen_ctl;        // [0] != 0: the screening pass is suspended (finalize_body)
     int screen;                        // fp32 screening pass allowed (DESMAN_HIP_TAU_NO_SCREEN switches it off for A/B runs)
+    int nt_skip;                       // experiment (DESMAN_HIP_NT_SKIP_TOTALS): a rare haplotype's step the difference screen left open goes to fp64 without the totals screen
     int V, S, G;
     int v_off;                // first position of this shard in the whole table (counter-based uniforms are keyed by global indices)
     uint32_t k0, k1, iter;
@@ -1037,7 +1038,7 @@ __device__ __forceinline__ void tau_body(const TauParams &p)
                         if (__builtin_amdgcn_ballot_w64(c2) == __builtin_amdgcn_ballot_w64(true)) { tn = tf; decided = true; }
                     }
                 }
-                if (screen && !decided) {
+                if (screen && !decided && !(NT && rare && p.nt_skip)) {
                     // ---- screening pass in fp32 (hardware log2): the four candidate log-probabilities to ~1e-6 relative.
                     // If the best one leads every other by more than 64 + 2^-13 |l| (natural units; the fp32 error is below
                     // 0.1 + 1e-6 |l|), the fp64 evaluation below would find exp(l_a - l_best) < e^-30 for the others, and its
@@ -1649,6 +1650,7 @@ int k_tau_sweep(dsm_ctx *c, int mode, const double *gamma, const double *eta_swe
     p.logp = d_logp; p.ll_partial = c->ll_partial + (size_t)slot * DSM_MAX_GRID; p.nchange = c->nchange + slot; p.log_tab = c->log_tab;
     static const bool no_screen = DSM_AB_ENV("DESMAN_HIP_TAU_NO_SCREEN") != nullptr;
     p.screen = (no_screen || !c->tau_screen) ? 0 : 1;
+    { static const bool nts = DSM_AB_ENV("DESMAN_HIP_NT_SKIP_TOTALS") != nullptr; p.nt_skip = nts ? 1 : 0; }
     p.step_cnt = c->step_cnt + (size_t)slot * 2 * DSM_MAX_GRID; p.screen_ctl = c->screen_ctl + slot;
     p.order = (c->blk_order && c->blk_order_n[slot] == grid) ? c->blk_order + (size_t)slot * DSM_MAX_GRID : nullptr;
     p.do_fin = 0;

@@ -138,8 +138,9 @@ int dsm_ctx_sample_stats(dsm_ctx *ctx, uint32_t iter, uint64_t *sum_mu, uint64_t
  * unsharded chain under dsm_ctx_force_stats_spec(ctx, 2).  */
 int dsm_ctx_stats_spec(dsm_ctx *ctx);
 int dsm_ctx_force_stats_spec(dsm_ctx *ctx, int spec);
-/* how often this process has measured where a subset table should start (~2 ms of stage-1 launches on the chain's own state; a measured
- * table is kept when its chain ends and handed to the next chain of its device and size, so a G-sweep probes once per shape)   */
+/* how often this process has measured where a subset table should start.  Always 0 since round 6: the table's row map puts the four cache lines of
+ * a subset's row into four rows, and every place costs the same; the measurement of rounds 3-5 (eight timed stage-1 passes per
+ * new table, measured tables pooled per process) only runs in the experiment build with DESMAN_HIP_NTAB_SWZ=0.   */
 int dsm_debug_ntab_probes(void);
 /* test hooks of the aggregated sampler: stage 1 only (subset counts ntab [S][2^G] u32 and esum), and nsamp variates of one
  * sampler (kind 0 binom_small, 1 binom_big: out [nsamp]; 2 mult4 with weights w[0..3]: out [nsamp][4]) of version

@@ -40,6 +40,12 @@ S2Plan make_stage2_plan(int G);     // kernels_stats.hip
 
 #define S2_SMEM_BYTES (DSM_LOG_TAB_N * 16 + DSM_EXP_TAB_N * 8 + DSM_RCP_TAB_N * 8 + 32 * 8 + S2_TAB_ENTRIES * 4 + 32 * 4 + 5 * S2_MAX_NODES * 4)
 
+#ifdef DSM_AB_SWITCHES           // phase stamps of the Dirichlet launch's gamma rows (experiment build): [row][entry, tables staged, level 0, 1, 2, 3, stage 2 done, draw done]
+__device__ unsigned long long s2_clk[1024 * 8];
+#define S2_CLK(row, k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && (row) < 1024) s2_clk[(size_t)(row) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define S2_CLK(row, k) do { } while (0)
+#endif
 // leaf counts end in LDS (returned pointer, [G] u32, valid after the function's final barrier); to_global also adds
 // them to p.sum_mu[s][.]
 template <int SPEC>
@@ -56,6 +62,19 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
     int *n_hi = n_lo + S2_MAX_NODES, *n_off = n_hi + S2_MAX_NODES, *n_idx = n_off + S2_MAX_NODES, *n_child = n_idx + S2_MAX_NODES;
 
     const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
+    S2_CLK(s, 0);
+    // Round 6: a thread's first root-level count is on its way while the tables are staged (the load has nothing to do with them: 0.9 us of
+    // the launch's ~21 us critical path, phase stamps of the experiment build: profiles/r06_s2_clocks.txt).  One copy of the table only.
+    uint32_t pre_n = 0;
+    bool pre_ok = false;
+    {
+        const int total0 = 1 << G, share0 = nsplit > 1 ? (total0 + nsplit - 1) / nsplit : total0;
+        const int j0 = (nsplit > 1 ? part * share0 : 0) + tid, jh0 = nsplit > 1 ? min(total0, part * share0 + share0) : total0;
+        if (p.rep == 1 && j0 < jh0 && j0 != 0) {
+            pre_n = p.ntab[(size_t)(((uint32_t)j0 * p.hmul + ((uint32_t)s >> 4) * p.swz) & ((1u << G) - 1u)) * (size_t)p.ld + s];
+            pre_ok = true;
+        }
+    }
     if (s == 0 && part == 0 && tid < DSM_BIG_NT * DSM_BIG_NL && p.big_count) p.big_count[tid * DSM_BIG_STRIDE] = 0u;
     if (tid < DSM_LOG_TAB_N) ltab[tid] = reinterpret_cast<const double2 *>(p.log_tab)[tid];
     if (tid < DSM_EXP_TAB_N) etab[tid] = p.log_tab[2 * DSM_LOG_TAB_N + tid];
@@ -67,8 +86,12 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
     }
     for (int i = tid; i < S2_TAB_ENTRIES; i += nthr) tab[i] = 0u;
     __syncthreads();
+    S2_CLK(s, 1);
 
-    for (int level = 0; level < pl.nlevels; ++level) {
+    // Round 6: a node's count goes straight into leaf[] where its child is a single haplotype, so the tree's last level -- leaves only: a pass
+    // over the level and a barrier to copy table entries, 1.0 us of the launch -- is not walked (integer adds: the same sums)
+    const int nlev = pl.nlevels > 1 ? pl.nlevels - 1 : pl.nlevels;
+    for (int level = 0; level < nlev; ++level) {
         // all (node, subset) pairs of the level at once: the tables of a level are contiguous in `tab`, so entry j of
         // the level belongs to the node whose table covers it (root: the 2^G words of this sample in HBM)
         const int n0 = pl.level_start[level], n1 = pl.level_start[level + 1];
@@ -97,7 +120,7 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
 #pragma unroll
                     for (int r = 0; r < 8; ++r) { n += m[r]; if (m[r]) cell[r * cstride] = 0u; }
                 } else {
-                    n = *cell;
+                    n = (pre_ok && j == j_lo + tid) ? pre_n : *cell;
                     if (n) *cell = 0u;
                     for (int r = 1; r < p.rep; ++r) {           // few subsets, many positions: the atomics of stage 1 were spread over copies
                         const uint32_t m = cell[r * cstride];
@@ -105,9 +128,8 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
                     }
                 }
             } else n = tab[base + j];
-            if (w == 1) {                                   // leaf: Hs == 1
-                leaf[lo] = n;
-                if (to_global && n) p.sum_mu[(size_t)s * G + lo] += n;
+            if (w == 1) {                                   // leaf: Hs == 1.  Only the root can be one here (G = 1): every other leaf was added to by its parent
+                if (level == 0) leaf[lo] = n;
                 continue;
             }
             if (!n) continue;
@@ -115,6 +137,8 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
             const int ch = n_child[i];
             uint32_t *L = tab + n_off[ch], *R = tab + n_off[ch + 1];
             const uint32_t HL = Hs & ((1u << wl) - 1u), HR = Hs >> wl;
+            if (wl == 1) L = leaf + lo - 1;                  // (HL is 1 wherever it is added to: L[HL] = leaf[lo])
+            if (wh == 1) R = leaf + mid - 1;
             if (!HR) { atomicAdd(&L[HL], n); continue; }
             if (!HL) { atomicAdd(&R[HR], n); continue; }
             double wL = 0.0, wR = 0.0;
@@ -128,6 +152,7 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
             if (n - k) atomicAdd(&R[HR], n - k);
         }
         __syncthreads();
+        if (level < 4) S2_CLK(s, 2 + level);
         if (level == 0 && nsplit > 1) {
             // hand the level-1 tables over: device-scope atomics onto the sample's scratch rows (they execute at the memory side, so
             // the reader below sees every one of them), then a ticket; whoever draws the last ticket owns the rest of the tree
@@ -149,5 +174,6 @@ __device__ __forceinline__ const uint32_t *stage2_sample(const Stage2Params &p, 
             __syncthreads();
         }
     }
+    if (to_global && tid < G && leaf[tid]) p.sum_mu[(size_t)s * G + tid] += leaf[tid];
     return leaf;
 }

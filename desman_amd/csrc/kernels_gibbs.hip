@@ -783,6 +783,7 @@ __device__ __forceinline__ void dirichlet_body(const DirParams &q, const S2Plan 
         if (v) { *pp = 0ull; atomicAdd(&ef[ob], v); }
         __syncthreads();
     }
+    S2_CLK(row, 6);
     if (threadIdx.x >= 64) return;                       // the draw needs one wavefront (no workgroup barriers below)
     const int lane = threadIdx.x;
     const int n = is_gamma ? G : 4;
@@ -809,7 +810,16 @@ __device__ __forceinline__ void dirichlet_body(const DirParams &q, const S2Plan 
         if (is_gamma) { gamma_out[row * G + lane] = x; if (gamma_trace) gamma_trace[row * G + lane] = x; }
         else { eta_out[(row - S) * 4 + lane] = x; if (eta_trace) eta_trace[(row - S) * 4 + lane] = x; }
     }
+    S2_CLK(row, 7);
 }
+#ifdef DSM_AB_SWITCHES
+extern "C" int dsm_debug_s2_clocks(unsigned long long *out, int nrows)
+{
+    if (nrows > 1024) nrows = 1024;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(s2_clk), (size_t)nrows * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return 8;
+}
+#endif
 
 struct DirBatch { DirParams p[DSM_MAX_BATCH]; S2Plan plan; };        // chains of a batch have one G, hence one plan
 __global__ __launch_bounds__(256) void dirichlet_kernel(DirParams q, S2Plan plan) { dirichlet_body(q, plan); }

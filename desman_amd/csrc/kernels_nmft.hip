@@ -870,6 +870,13 @@ __device__ unsigned long long nm_dbg[12];
 #define NM_CLKQ() do { } while (0)
 #endif
 #define NM_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z)
+// Round 6: v_mfma_f64_4x4x4_4b_f64 -- four independent 4 x 4 x 4 products, one D element per lane.  Operand lanes as measured on this
+// device (scripts/ubench/mfma_4x4x4_probe.hip, profiles/r06_mfma_4x4x4_layout.txt): A[b][i][k] at lane i + 4 b + 16 k, B[b][k][j] at lane
+// j + 4 b + 16 k, D[b][i][j] at lane j + 4 b + 16 i -- with the registers of the 16 x 16 x 4 form it is that product's four diagonal 4 x 4
+// blocks, at 16.5 cycles of the SIMD's fp64 datapath against 71 (scripts/ubench/mfma_f64_rate.hip): the datapath does ~30 flops a cycle
+// whatever the instruction, so a contraction whose free index is the HAPLOTYPE (N = G <= 8 of the 16 x 16 x 4 form's 16 columns) is run
+// as ceil(G / 4) of these per step instead of one padded wide one.
+#define NM_MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0)
 
 // a / b for the operands of the update (positive, far from the ends of the exponent range): hardware reciprocal, one
 // Newton step, one residual correction -- 6 instructions / ~40 issue cycles instead of the 11 / ~80 of the IEEE expansion
@@ -1009,45 +1016,6 @@ __device__ __forceinline__ double4_t nm_tile_q2(const double4_t &ft, const doubl
     obj = live ? o2 : obj;
     return q2;
 }
-#define DSM_DPP_ROW_SHL4 0x104
-#define DSM_DPP_ROW_SHR4 0x114
-
-template <int CTRL, int BANK>
-__device__ __forceinline__ double dpp_mov_masked(double old, double x)
-{
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xf, BANK, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xf, BANK, false);
-    return __hiloint2double(hi, lo);
-}
-
-// 16 values per lane -> lane n of every 16-lane row holds the row total of value 8 b0 + 4 b1 + 2 b3 + b2
-__device__ __forceinline__ double row16_transpose_reduce(double (&v)[16], int n)
-{
-    const bool b0 = n & 1, b1 = n & 2, b2 = n & 4, b3 = n & 8;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const double keep = b0 ? v[i + 8] : v[i], send = b0 ? v[i] : v[i + 8];
-        v[i] = keep + dpp_mov<DSM_DPP_XOR1>(send);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double keep = b1 ? v[i + 4] : v[i], send = b1 ? v[i] : v[i + 4];
-        v[i] = keep + dpp_mov<DSM_DPP_XOR2>(send);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const double keep = b3 ? v[i + 2] : v[i], send = b3 ? v[i] : v[i + 2];
-        v[i] = keep + dpp_mov<DSM_DPP_ROR8>(send);                   // rotation by 8 inside the row = lane ^ 8
-    }
-    {
-        const double keep = b2 ? v[1] : v[0], send = b2 ? v[0] : v[1];
-        double got = dpp_mov_masked<DSM_DPP_ROW_SHL4, 0x5>(0.0, send);   // lanes with b2 = 0 (banks 0, 2) read lane + 4
-        got = dpp_mov_masked<DSM_DPP_ROW_SHR4, 0xA>(got, send);          // lanes with b2 = 1 (banks 1, 3) read lane - 4
-        v[0] = keep + got;
-    }
-    return v[0];
-}
-
 // ---- tau numerators on the matrix cores (round 4) --------------------------------------------------------------------------
 // num[i][g] = sum_s Q'[i][s] gamma_raw[g][s] contracts over SAMPLES, which the L2 layout keeps in the low four lane bits -- where
 // the instruction wants a free index.  Rounds 2-3 therefore ran it on the VALU (16 FMAs per tile and K-block on per-lane LDS
@@ -1075,44 +1043,152 @@ __device__ __forceinline__ void nm_stage_gamma_p(double *graw_p, double *ggam_p,
     }
 }
 
-// one tile: qv = Q' of tile t in L2 -> num += Q'_t . gamma_raw_t^T; graw_t = graw_p + 16 t
+// Which contractions run on the four-block instruction: up to NM_B4_MAXKB blocks of four haplotypes.  Measured at 50k x 96 (us per update,
+// wide form -> four-block form, profiles/r06_nmft_b4.txt): G = 5 83.2 -> 78.8, G = 8 87.2 -> 82.0; G = 9 92.5 -> 94.5 and G = 12 95.5 -> 97.7 --
+// at three blocks the saving on the fp64 datapath (12 x 16.5 against 4 x 71 cycles a tile) is less than what 8 more operand fetches a tile
+// and their waits cost a kernel that is bound by instruction issue; at sixteen haplotypes the wide instruction has no padded column.  A
+// function of KB alone: every kernel family takes the same sums in the same order at a given shape.
+#ifndef NM_B4_MAXKB
+#define NM_B4_MAXKB 2
+#endif
+constexpr bool nm_b4(int KB) { return KB <= NM_B4_MAXKB; }
+
+// one tile: qv = Q' of tile t in L2 -> num += Q'_t . gamma_raw_t^T; graw_t = graw_p + 16 t.
+// Wide form (KB = 4): four 16 x 16 x 4 instructions, B_j[k = q][g = n] = gamma_raw[g][16 t + 4 k + j]; num[e] of lane (n, q) is base e of
+// variant q, haplotype n.
+// Round 6, four-block form (NM_MFMA4): the A operands are the wide form's (lane (n, q) holds row n of the transposition tile, samples
+// 4 q + j for step j: row block b = n / 4, row in block i = n % 4, k = q); every block meets the SAME four haplotypes,
+// B[k = q][j = n % 4] = gamma_raw[g = 4 h + n % 4][16 t + 4 q + step], h = 0 .. KB - 1: KB instructions per step, no padded column up to
+// G = 4 KB.  num[h] of lane (n, q) is then the numerator of row 4 (n / 4) + q -- base n / 4 of variant q -- and haplotype 4 h + n % 4
+// (components h >= KB stay zero): every lane has work in nm_tau_finish, where the wide form leaves lanes n >= G idle.
+// (The B operands are fetched before the tile crosses LDS: they wait for nothing, and behind the wave barriers their latency would be a
+// second exposed one per tile.)
 template <int KB>
 __device__ __forceinline__ double4_t nm_num_tile(double4_t num, const double4_t &qv, double *xq, const double *graw_t, int LDG, int n, int q)
 {
     constexpr int GP = 4 * KB;
+    double b[nm_b4(KB) ? KB : 1][4];
+    if constexpr (nm_b4(KB)) {
+#pragma unroll
+        for (int h = 0; h < KB; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[h][j] = graw_t[(4 * h + (n & 3)) * LDG + 4 * q + j];
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) xq[(4 * e + q) * NM_XS + n] = qv[e];
     __builtin_amdgcn_wave_barrier();
     const double2 lo = *reinterpret_cast<const double2 *>(xq + n * NM_XS + 4 * q);
     const double2 hi = *reinterpret_cast<const double2 *>(xq + n * NM_XS + 4 * q + 2);
     __builtin_amdgcn_wave_barrier();
-    const double *bl = graw_t + (n < GP ? n : GP - 1) * LDG + 4 * q;          // B_j[k = q][g = n] = gamma_raw[g][16 t + 4 k + j]
-    num = NM_MFMA(lo.x, bl[0], num, 0, 0, 0);
-    num = NM_MFMA(lo.y, bl[1], num, 0, 0, 0);
-    num = NM_MFMA(hi.x, bl[2], num, 0, 0, 0);
-    num = NM_MFMA(hi.y, bl[3], num, 0, 0, 0);
+    const double a[4] = {lo.x, lo.y, hi.x, hi.y};
+    if constexpr (nm_b4(KB)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int h = 0; h < KB; ++h) num[h] = NM_MFMA4(a[j], b[h][j], num[h]);
+    } else {
+        const double *bl = graw_t + (n < GP ? n : GP - 1) * LDG + 4 * q;          // B_j[k = q][g = n] = gamma_raw[g][16 t + 4 k + j]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) num = NM_MFMA(a[j], bl[j], num, 0, 0, 0);
+    }
     return num;
 }
 
-// the tau rows of the quad from their numerators (Init_NMFT.py:171-181, :88-91): lane (g = n, vv = q) holds the four bases
+// the tau rows of the quad from their numerators (Init_NMFT.py:171-181, :88-91).  Wide form: lane (g = n, vv = q) holds the four bases.
+// Four-block form: lane (n, q) holds, for h < KB, base n / 4 of variant q and haplotype 4 h + n % 4; the four bases of a (variant,
+// haplotype) pair are the lanes n % 4 + 4 e of the lane's row of 16.
 template <int KB, bool TO_GLOBAL>
 __device__ __forceinline__ void nm_tau_finish(const double4_t &num, const double *told, double *tnew, const double *t1, int G, int n, int q,
                                               int adjust, bool store, bool vok, double *tau_v /* tau + (v0 + q) * 4 * G, or null */)
 {
     constexpr int GP = 4 * KB;
-    const bool okg = n < G;
-    double tn[4];
+    if constexpr (nm_b4(KB)) {
+        const int e = n >> 2, row = 4 * e + q, l0 = 16 * q + (n & 3);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) tn[e] = okg ? told[(4 * e + q) * GP + n] * fdiv_ext(nzd(num[e]), nzd(t1[okg ? n : 0])) : 0.0;   // :171-172
-    const double tot = ((tn[0] + tn[1]) + tn[2]) + tn[3];                                                                  // :176-178
-    if (okg) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            double x = fdiv_ext(tn[e], tot);                                                                                 // :180-181
-            if (adjust && x < DSM_EPS) x = DSM_EPS;                                                                        // :88-91
-            if (TO_GLOBAL && store) tau_v[(size_t)e * G + n] = x;
-            tnew[(4 * e + q) * GP + n] = vok ? x : 0.0;
+        for (int h = 0; h < KB; ++h) {
+            const int g = 4 * h + (n & 3);
+            const bool okg = g < G;
+            const double tn = okg ? told[row * GP + g] * fdiv_ext(nzd(num[h]), nzd(t1[okg ? g : 0])) : 0.0;                      // :171-172
+            const double tot = ((__shfl(tn, l0, 64) + __shfl(tn, l0 + 4, 64)) + __shfl(tn, l0 + 8, 64)) + __shfl(tn, l0 + 12, 64);   // :176-178
+            if (okg) {
+                double x = fdiv_ext(tn, tot);                                                                                    // :180-181
+                if (adjust && x < DSM_EPS) x = DSM_EPS;                                                                        // :88-91
+                if (TO_GLOBAL && store) tau_v[(size_t)e * G + g] = x;
+                tnew[row * GP + g] = vok ? x : 0.0;
+            }
         }
+    } else {
+        const bool okg = n < G;
+        double tn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tn[e] = okg ? told[(4 * e + q) * GP + n] * fdiv_ext(nzd(num[e]), nzd(t1[okg ? n : 0])) : 0.0;   // :171-172
+        const double tot = ((tn[0] + tn[1]) + tn[2]) + tn[3];                                                                  // :176-178
+        if (okg) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double x = fdiv_ext(tn[e], tot);                                                                                 // :180-181
+                if (adjust && x < DSM_EPS) x = DSM_EPS;                                                                        // :88-91
+                if (TO_GLOBAL && store) tau_v[(size_t)e * G + n] = x;
+                tnew[(4 * e + q) * GP + n] = vok ? x : 0.0;
+            }
+        }
+    }
+}
+
+// The gamma numerators' contraction over the quad's 16 rows, out[g][s] += sum_rows tau_new[row][g] Q2[row][s]; B is a statistics tile as it
+// stands (lane (n, q), element e: base e of variant q, sample n; k = q, one step per base).
+// Wide form: A[i = n][k = q] = tau_new[4 e + q][g = n]; acc[e'] of lane (n, q) is haplotype 4 e' + q at sample n.
+// Four-block form (round 6): sample block n / 4, A[i][k = q] = tau_new[4 e + q][g = 4 h + i] the same in every block: acc[h] of lane (n, q)
+// is haplotype 4 h + q at sample n -- the wide form's acc[e'] with e' = h, so the launch's closing reduction is the one it was, on KB
+// components.  The 4 KB values of A are held over the tile loop where the registers allow (HOLD: the callers with 256 registers and more),
+// else read from the quad's LDS rows tile by tile behind a wave barrier (which keeps the compiler from holding them all the same: 8 KB - 8
+// registers the kernels with 128 / 168 do not have).
+template <int KB> struct NmAg { double a[nm_b4(KB) ? 4 * KB : 4]; };
+template <int KB>
+__device__ __forceinline__ void nm_ag_load(NmAg<KB> &ag, const double *tnew, bool gnum, int n, int q)
+{
+    constexpr int GP = 4 * KB;
+    if constexpr (nm_b4(KB)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int h = 0; h < KB; ++h) ag.a[e * KB + h] = gnum ? tnew[(4 * e + q) * GP + 4 * h + (n & 3)] : 0.0;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ag.a[e] = (gnum && n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0;
+    }
+}
+template <int KB>
+__device__ __forceinline__ void nm_gnum_tile(double4_t &acc, const NmAg<KB> &ag, const double4_t &q2)
+{
+    if constexpr (nm_b4(KB)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int h = 0; h < KB; ++h) acc[h] = NM_MFMA4(ag.a[e * KB + h], q2[e], acc[h]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = NM_MFMA(ag.a[e], q2[e], acc, 0, 0, 0);
+    }
+}
+// H1's terms: lane (n = g, q) adds tau_new[vv = q][e][g] over the bases (the wide form's A values themselves)
+template <int KB>
+__device__ __forceinline__ void nm_h1_add(double &h1, const NmAg<KB> &ag, const double *tnew, bool gnum, int n, int q)
+{
+    constexpr int GP = 4 * KB;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if constexpr (nm_b4(KB)) h1 += (gnum && n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0;
+        else h1 += ag.a[e];
+    }
+}
+// per-tile fetch of the operands where they are not held
+template <int KB, bool HOLD>
+__device__ __forceinline__ void nm_ag_tile(NmAg<KB> &ag, const double *tnew, bool gnum, int n, int q)
+{
+    if constexpr (!HOLD) {
+        __builtin_amdgcn_wave_barrier();
+        nm_ag_load<KB>(ag, tnew, gnum, n, q);
     }
 }
 
@@ -1140,11 +1216,9 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
     const double *__restrict__ ctl = prm.ctl, *__restrict__ log_tab = prm.log_tab;
     const int V = prm.V, S = prm.S, G = prm.G, adjust = prm.adjust, do_update = prm.do_update;
     const bool gnum = !FIXF && prm.fix_gamma == 0;                              // the gamma numerators and row sums are wanted
-    // VC (round 5): up to four haplotypes on wide tables -- the two contractions that contract to or from HAPLOTYPES (tau numerators, gamma
-    // numerators) on the vector ALU.  A 16 x 16 x 4 matrix instruction fills 4 of its 16 columns there, costs ~75 cycles of the SIMD's fp64
-    // datapath all the same and overlaps no fp64 vector work (scripts/ubench/mfma_f64_rate.hip): 16 v_fma_f64 per tile do the useful
-    // quarter in 69.  R = tau . gamma (K = 4: no waste) stays on the matrix cores.
-    constexpr bool VC = !FIXF && KB == 1 && (NT == 5 || NT == 6);
+    // (Round 5 ran the two contractions over HAPLOTYPES of tables with up to four of them on the vector ALU at five / six tiles -- 16 v_fma_f64
+    // a tile against a wide matrix instruction with 12 empty columns.  Round 6's four-block instruction does that quarter in 4 x 16.5 cycles
+    // with neither the 32 + 32 operand registers nor the transposing butterfly: 50k x 96 x 4 69 -> 65 us per update, profiles/r06_nmft_b4.txt.)
     constexpr bool PF = KEEPF && (NT == 5 || NT == 6);                          // the quad loop that looks ahead (below)
     constexpr bool fusedfix = FIXF;                                             // gamma fixed: one pass per update (NmftMfmaParams)
     extern __shared__ __attribute__((aligned(16))) char smem_m[];
@@ -1243,53 +1317,16 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) a_old[kb] = told[n * GP + 4 * kb + q];
             double4_t num = (double4_t){0.0, 0.0, 0.0, 0.0};
-            double p[VC ? 16 : 1];                                               // VC: this lane's part of num[(e, vv = q)][g], value index 4 e + g
-#pragma unroll
-            for (int j = 0; j < (VC ? 16 : 1); ++j) p[j] = 0.0;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) R = NM_MFMA(a_old[kb], graw_p[(4 * kb + q) * LDG + 16 * t + n], R, 0, 0, 0);
                 const double4_t ft = tile(t);
-                double4_t qv;                                                           // nm_tile_q2: F > 0; lanes without a cell stay finite
-                if constexpr (VC) {                                                     // (the branch-free form: this instantiation has no register left for a second block)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) qv[e] = fdiv_lo(ft[e], nzd(R[e]));
-                } else {
-                    qv = nm_div_tile(ft, R);
-                }
-                if constexpr (VC) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const double gm = graw_p[g * LDG + 16 * t + n];                  // gamma_raw[g][16 t + n] (zero rows past G)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) p[4 * e + g] = fma(qv[e], gm, p[4 * e + g]);
-                    }
-                } else {
-                    num = nm_num_tile<KB>(num, qv, xq, graw_p + 16 * t, LDG, n, q);
-                }
+                const double4_t qv = nm_div_tile(ft, R);                                // nm_tile_q2: F > 0; lanes without a cell stay finite
+                num = nm_num_tile<KB>(num, qv, xq, graw_p + 16 * t, LDG, n, q);
             }
-            if constexpr (VC) {
-                // the 16 lanes of a variant add up (transposing butterfly: lane n ends with value 8 b0 + 4 b1 + 2 b3 + b2 = 4 e + g), then
-                // the update on (base e, haplotype g) pairs: the four bases of a (variant, haplotype) sit in one quad
-                const bool b0 = n & 1, b1 = n & 2, b2 = n & 4, b3 = n & 8;
-                const int my_e = (b0 ? 2 : 0) + (b1 ? 1 : 0), g = (b3 ? 2 : 0) + (b2 ? 1 : 0);
-                const double part = row16_transpose_reduce(p, n);
-                const bool okg = g < G;
-                const double tn = okg ? told[(4 * my_e + q) * GP + g] * fdiv_ext(nzd(part), nzd(t1[okg ? g : 0])) : 0.0;      // :171-172
-                const double t_a0 = dpp_mov<0x00>(tn), t_a1 = dpp_mov<0xAA>(tn);              // e = 0 / 1 live in quad lanes 0 / 2
-                const double t_a2 = dpp_mov<0x55>(tn), t_a3 = dpp_mov<0xFF>(tn);              // e = 2 / 3            quad lanes 1 / 3
-                const double tot = ((t_a0 + t_a1) + t_a2) + t_a3;                              // :176-178
-                if (okg) {
-                    double x = fdiv_ext(tn, tot);                                                // :180-181
-                    if (adjust && x < DSM_EPS) x = DSM_EPS;                                    // :88-91
-                    if (vok) tau[((size_t)(v0 + q) * 4 + my_e) * G + g] = x;
-                    tnew[(4 * my_e + q) * GP + g] = vok ? x : 0.0;
-                }
-            } else {
-                nm_tau_finish<KB, true>(num, told, tnew, t1, G, n, q, adjust, vok, vok, tau + (size_t)(v0 + q) * 4 * G);
-            }
+            nm_tau_finish<KB, true>(num, told, tnew, t1, G, n, q, adjust, vok, vok, tau + (size_t)(v0 + q) * 4 * G);
             __builtin_amdgcn_wave_barrier();
             rows_read();
             NM_CLK(3);
@@ -1298,14 +1335,10 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
         double a_new[KB];
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) a_new[kb] = tnew[n * GP + 4 * kb + q];
-        double a_g[4];                                                          // A of the row contraction: tau_new[vv = q][e][g = n]
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { a_g[e] = (gnum && n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; h1 += a_g[e]; }
-        double4_t tn16[VC ? 4 : 1];                                             // VC: the new rows of this lane's variant, [e][g]
-        if constexpr (VC) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tn16[e] = *reinterpret_cast<const double4_t *>(tnew + (4 * e + q) * GP);
-        }
+        constexpr bool HOLDAG = !nm_b4(KB) || NT >= 5;                          // (five tiles and more: 256 registers)
+        NmAg<KB> a_g;                                                           // A of the row contraction (nm_gnum_tile)
+        if constexpr (HOLDAG) nm_ag_load<KB>(a_g, tnew, gnum, n, q);
+        nm_h1_add<KB>(h1, a_g, tnew, gnum, n, q);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             double4_t R = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -1315,17 +1348,8 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
             const double4_t ft = tile(t);
             q2 = nm_tile_q2(ft, R, livef(t), ltab, obj);
             used(t);
-            if constexpr (VC) {
-                if (gnum) {                                                     // acc[t][g] += sum_e tau_new[vv = q][e][g] Q2[e]: this lane's variant
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) acc[t][g] = fma(tn16[e][g], q2[e], acc[t][g]);
-                }
-            } else if (gnum) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t] = NM_MFMA(a_g[e], q2[e], acc[t], 0, 0, 0);
-            }
+            nm_ag_tile<KB, HOLDAG>(a_g, tnew, gnum, n, q);
+            if (gnum) nm_gnum_tile<KB>(acc[t], a_g, q2);
         }
         __builtin_amdgcn_wave_barrier();
         NM_CLK(4);
@@ -1447,15 +1471,8 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if constexpr (VC) {                                              // element = haplotype, this lane's variant: the four variants add up
-                    double a = acc[t][e];
-                    a += __shfl_xor(a, 16, 64);
-                    a += __shfl_xor(a, 32, 64);
-                    if (q == 0) red[((size_t)wv * (GP + 2) + e) * SPAD + 16 * t + n] = a;
-                } else {
-                    const int g = 4 * e + q;
-                    if (g < GP) red[((size_t)wv * (GP + 2) + g) * SPAD + 16 * t + n] = acc[t][e];
-                }
+                const int g = 4 * e + q;
+                if (g < GP) red[((size_t)wv * (GP + 2) + g) * SPAD + 16 * t + n] = acc[t][e];
             }
     }
     // objective: one value per lane; H1: lane (n = g, q) holds the sum over bases and this lane's variants of tau_new[.][g]
@@ -1504,7 +1521,9 @@ constexpr int nmft_mfma_wgs(int NT, int KB)
     // 50k x 96 x 12 before it: 101.7 us per update at two against 106.6 at three with 22 registers spilled)
     // up to four tiles: four where 128 registers hold the kernel without scratch (round 5, with the statistics tile as straight-line code: not at
     // three and four tiles), else three
-    return NT <= 4 ? ((KB <= 3 && NT <= 2) ? 4 : 3) : 2;    // (five / six tiles, up to four haplotypes: the VC form holds 16 + 16 more values)
+    // (round 6: up to four haplotypes the four-block contractions need 148 / 158 registers at five / six tiles -- three again: 56.5 -> 55.2 us
+    // at 50k x 96 x 4, profiles/r06_nmft_b4.txt)
+    return NT <= 4 ? ((KB <= 3 && NT <= 2) ? 4 : 3) : (KB == 1 ? 3 : 2);
 }
 
 // the fused pass of factorize_tau (no gamma numerators in registers, one gamma matrix and a four-word reduction in LDS): one
@@ -1783,9 +1802,10 @@ __device__ __forceinline__ void nmft_split_body(const NmftMfmaParams &prm)
         double a_new[KB];
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) a_new[kb] = tnew[n * GP + 4 * kb + q];
-        double a_g[4];                                                          // A of the row contraction: tau_new[vv = q][e][g = n]
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { a_g[e] = (gnum && n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; if (cb == 0) h1 += a_g[e]; }
+        constexpr bool HOLDAG = !nm_b4(KB);
+        NmAg<KB> a_g;                                                           // A of the row contraction (nm_gnum_tile); the four-block form's fetched tile by tile
+        if constexpr (HOLDAG) nm_ag_load<KB>(a_g, tnew, gnum, n, q);
+        if (cb == 0) nm_h1_add<KB>(h1, a_g, tnew, gnum, n, q);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int tg = cb * NT + t;
@@ -1794,10 +1814,8 @@ __device__ __forceinline__ void nmft_split_body(const NmftMfmaParams &prm)
             for (int kb = 0; kb < KB; ++kb) R = NM_MFMA(a_new[kb], ggam_p[(4 * kb + q) * LDG + 16 * tg + n], R, 0, 0, 0);
             const double4_t q2 = nm_tile_q2(f[t], R, vok && slive[t], ltab, obj);
             f[t] = load_tile(qpa, offp, t);                                     // this tile of the next quad
-            if (gnum) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t] = NM_MFMA(a_g[e], q2[e], acc[t], 0, 0, 0);
-            }
+            nm_ag_tile<KB, HOLDAG>(a_g, tnew, gnum, n, q);
+            if (gnum) nm_gnum_tile<KB>(acc[t], a_g, q2);
         }
         __builtin_amdgcn_wave_barrier();
         if (!do_update) {                                                       // statistics only (once per factorize): the next quad's rows, in place
@@ -2113,9 +2131,10 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
             double a_new[KB];
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) a_new[kb] = tnew[n * GP + 4 * kb + q];
-            double a_g[4];                                                      // A of the row contraction: tau_new[vv = q][e][g = n]
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { a_g[e] = (gnum && n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0; h1 += a_g[e]; }
+            constexpr bool HOLDAG = !nm_b4(KB) || NWV == 4;                     // (the small form: one wavefront per SIMD)
+            NmAg<KB> a_g;                                                       // A of the row contraction (nm_gnum_tile)
+            if constexpr (HOLDAG) nm_ag_load<KB>(a_g, tnew, gnum, n, q);
+            nm_h1_add<KB>(h1, a_g, tnew, gnum, n, q);
             double4_t num = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -2125,9 +2144,9 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
                 double4_t q2;
                 const double4_t ft = KEEPF ? f[KEEPF ? t : 0] : load_f(t);
                 q2 = nm_tile_q2(ft, R, live[t], ltab, obj);
+                if (gnum) nm_ag_tile<KB, HOLDAG>(a_g, tnew, gnum, n, q);
                 if (gnum) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[t] = NM_MFMA(a_g[e], q2[e], acc[t], 0, 0, 0);
+                    nm_gnum_tile<KB>(acc[t], a_g, q2);
                 } else {
                     // gamma fixed: this product is also the one the tau half of the update divides F by (NmftMfmaParams.fix_gamma == 2):
                     // the candidate rows of the next update come out of the same pass

@@ -34,6 +34,17 @@ __global__ __launch_bounds__(256) void k(double *out, long long *cyc, double a0,
                 if (s < 3) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, s == 0 ? (double4_t){0.0, 0.0, 0.0, 0.0} : acc[0], 0, 0, 0);
                 else acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[0][0], b, acc[1], 0, 0, 0);
             }
+            // round 6: the four-block 4x4x4 form (v_mfma_f64_4x4x4_4b_f64: 512 flops against the 16x16x4's 2048) -- one output per lane
+            if (MODE == 4) v[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, v[0], 0, 0, 0);
+            if (MODE == 5 || MODE == 6) v[j & 3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, v[j & 3], 0, 0, 0);
+            if (MODE == 6) {
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) v[4 + (kk & 3)] = fma(v[4 + (kk & 3)], a, b);
+            }
+            if (MODE == 7) {           // plain v_fma_f64, eight accumulators: the vector ALU's own rate
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) v[kk] = fma(v[kk], a, b);
+            }
             if (MODE == 3) {
 #pragma unroll
                 for (int kk = 0; kk < K; ++kk) v[kk & 7] = fma(v[kk & 7], a, b);
@@ -80,5 +91,10 @@ int main(int argc, char **argv)
     if (run<3, 8>("ind4 + 8 v_fma_f64 each", blocks, out, cyc)) return 1;
     if (run<3, 16>("ind4 + 16 v_fma_f64 each", blocks, out, cyc)) return 1;
     if (run<3, 32>("ind4 + 32 v_fma_f64 each", blocks, out, cyc)) return 1;
+    if (run<4, 0>("4x4x4_4b dep", blocks, out, cyc)) return 1;
+    if (run<5, 0>("4x4x4_4b ind4", blocks, out, cyc)) return 1;
+    if (run<6, 4>("4x4x4_4b ind4 + 4 v_fma_f64", blocks, out, cyc)) return 1;
+    if (run<6, 8>("4x4x4_4b ind4 + 8 v_fma_f64", blocks, out, cyc)) return 1;
+    if (run<7, 0>("8 v_fma_f64 (per 'MFMA')", blocks, out, cyc)) return 1;
     return 0;
 }

@@ -25,13 +25,13 @@ REC_FIELDS = ("chain", "G", "seed", "G_final", "lp_star", "mean_dev", "iters", "
 def chain_cost(V, S, G, n_iter=None, nmf_updates=5000):
     """estimated cost of a chain in microseconds on one MI355X (only ratios matter to the scheduler).
 
-    Fitted on the measurements of round 5 (profiles/r05_chain_cost_components.json: bench.py at V = 50k, S = 96, G = 2..12, and the
+    Fitted on the measurements of round 6 (profiles/r06_chain_cost_components.json: bench.py at V = 50k, S = 96, G = 2..12, and the
     config-3 line; `scripts/fit_chain_cost.py` makes the file): with kc = V S / 1000 (thousand cells)
-      one Gibbs iteration   42 + kc (0.045 + 0.006 G)  [+ 18 + 1.2e-4 2^G S from G = 10: stage 2 of the mu/E pass as its own launch]
-                            -- 0.523 / 0.648 ms at G = 9 / 12 there, 0.105 ms at config 3; less where the mu/E pass runs over tau words
-                            (large tables, 64 x 2^G <= V: a measured coefficient per G, below)
-      one NMF update        12 + kc c(ceil(G / 4)), c = 0.01167 / 0.01531 / 0.01704 / 0.0188   -- 68 / 85 / 94 us at G <= 4 / <= 8 / <= 12 (K-blocks of four
-                            haplotypes; round 4: 85 / 96 / 107), 23 us at config 3
+      one Gibbs iteration   42 + kc (0.050 + 0.005 G)  [+ 18 + 1.2e-4 2^G S from G = 10: stage 2 of the mu/E pass as its own launch]
+                            -- 0.498 / 0.627 ms at G = 9 / 12 there (round 5: 0.523 / 0.648), 0.100 ms at config 3; less where the mu/E
+                            pass runs over tau words (large tables, 64 x 2^G <= V: a measured coefficient per G, below)
+      one NMF update        12 + kc c(ceil(G / 4)), c = 0.01131 / 0.01467 / 0.01746 / 0.0188   -- 66 / 82 / 96 us at G <= 4 / <= 8 / <= 12 (K-blocks of four
+                            haplotypes; round 5: 68 / 85 / 94, round 4: 85 / 96 / 107), 23 us at config 3
       host work per chain   0.23 s + 0.18 us per (position, haplotype): table filter, sampler set-up, the result files (Output_Results;
                             1.3 us before round 4 assembled the haplotype tables as byte fields)
     and a chain runs 2 n_iter iterations (burn-in + sampling, bin/desman:212-232) after up to 5000 NMF updates (Init_NMFT.py:98-115:
@@ -41,11 +41,11 @@ def chain_cost(V, S, G, n_iter=None, nmf_updates=5000):
     time (config-5 data, six strains: G = 2 / 3 take 1.61 / 1.71 s, G = 4 1.26 s).  Hence the default schedule is the work queue
     (WorkQueue below), which this estimate only orders, longest first."""
     kc = float(V) * float(S) / 1000.0
-    gibbs = 42.0 + kc * (0.045 + 0.006 * G)
+    gibbs = 42.0 + kc * (0.050 + 0.005 * G)
     if (G <= 2 and kc >= 500.0) or (G == 3 and kc >= 1000.0) or (4 <= G <= 8 and kc >= 2500.0 and 64 * 2 ** int(G) <= V):
         # the mu/E pass over tau words (kernels_stats.hip: stats_spec, spec 4) where few words cover many positions: a measured
-        # coefficient per G (V = 50k, S = 96, profiles/r05_chain_cost_components.json)
-        gibbs = 42.0 + kc * PAT_COEF.get(int(G), 0.045 + 0.006 * G)
+        # coefficient per G (V = 50k, S = 96, profiles/r06_chain_cost_components.json)
+        gibbs = 42.0 + kc * PAT_COEF.get(int(G), 0.050 + 0.005 * G)
     if G >= 10:
         gibbs += 18.0 + 1.2e-4 * float(1 << min(int(G), 30)) * float(S)
     if n_iter is None:
@@ -56,9 +56,9 @@ def chain_cost(V, S, G, n_iter=None, nmf_updates=5000):
 
 
 # us per thousand cells and Gibbs iteration where the mu/E pass runs over tau words (chain_cost), G -> coefficient
-PAT_COEF = {1: 0.022, 2: 0.02835, 3: 0.03829, 4: 0.0488, 5: 0.05925, 6: 0.06067, 7: 0.07813, 8: 0.10206}
+PAT_COEF = {1: 0.022, 2: 0.02859, 3: 0.03858, 4: 0.04928, 5: 0.05843, 6: 0.05984, 7: 0.07439, 8: 0.09558}
 # us per thousand cells and NMF update, ceil(G / 4) -> coefficient
-NMF_COEF = {1: 0.01167, 2: 0.01531, 3: 0.01704, 4: 0.0188}
+NMF_COEF = {1: 0.01131, 2: 0.01467, 3: 0.01746, 4: 0.0188}
 
 
 class WorkQueue:

@@ -1052,6 +1052,10 @@ __device__ __forceinline__ void nm_stage_gamma_p(double *graw_p, double *ggam_p,
 #define NM_B4_MAXKB 2
 #endif
 constexpr bool nm_b4(int KB) { return KB <= NM_B4_MAXKB; }
+#ifndef NM_B4G_MAXKB
+#define NM_B4G_MAXKB NM_B4_MAXKB
+#endif
+constexpr bool nm_b4g(int KB) { return KB <= NM_B4G_MAXKB; }         // the gamma numerators' form (its operands can be held in registers: measured apart)
 
 // one tile: qv = Q' of tile t in L2 -> num += Q'_t . gamma_raw_t^T; graw_t = graw_p + 16 t.
 // Wide form (KB = 4): four 16 x 16 x 4 instructions, B_j[k = q][g = n] = gamma_raw[g][16 t + 4 k + j]; num[e] of lane (n, q) is base e of
@@ -1143,12 +1147,12 @@ __device__ __forceinline__ void nm_tau_finish(const double4_t &num, const double
 // components.  The 4 KB values of A are held over the tile loop where the registers allow (HOLD: the callers with 256 registers and more),
 // else read from the quad's LDS rows tile by tile behind a wave barrier (which keeps the compiler from holding them all the same: 8 KB - 8
 // registers the kernels with 128 / 168 do not have).
-template <int KB> struct NmAg { double a[nm_b4(KB) ? 4 * KB : 4]; };
+template <int KB> struct NmAg { double a[nm_b4g(KB) ? 4 * KB : 4]; };
 template <int KB>
 __device__ __forceinline__ void nm_ag_load(NmAg<KB> &ag, const double *tnew, bool gnum, int n, int q)
 {
     constexpr int GP = 4 * KB;
-    if constexpr (nm_b4(KB)) {
+    if constexpr (nm_b4g(KB)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -1161,7 +1165,7 @@ __device__ __forceinline__ void nm_ag_load(NmAg<KB> &ag, const double *tnew, boo
 template <int KB>
 __device__ __forceinline__ void nm_gnum_tile(double4_t &acc, const NmAg<KB> &ag, const double4_t &q2)
 {
-    if constexpr (nm_b4(KB)) {
+    if constexpr (nm_b4g(KB)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -1178,7 +1182,7 @@ __device__ __forceinline__ void nm_h1_add(double &h1, const NmAg<KB> &ag, const 
     constexpr int GP = 4 * KB;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        if constexpr (nm_b4(KB)) h1 += (gnum && n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0;
+        if constexpr (nm_b4g(KB)) h1 += (gnum && n < GP) ? tnew[(4 * e + q) * GP + n] : 0.0;
         else h1 += ag.a[e];
     }
 }
@@ -1335,7 +1339,7 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
         double a_new[KB];
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) a_new[kb] = tnew[n * GP + 4 * kb + q];
-        constexpr bool HOLDAG = !nm_b4(KB) || NT >= 5;                          // (five tiles and more: 256 registers)
+        constexpr bool HOLDAG = !nm_b4g(KB) || NT >= 5;                          // (five tiles and more: 256 registers)
         NmAg<KB> a_g;                                                           // A of the row contraction (nm_gnum_tile)
         if constexpr (HOLDAG) nm_ag_load<KB>(a_g, tnew, gnum, n, q);
         nm_h1_add<KB>(h1, a_g, tnew, gnum, n, q);
@@ -1802,7 +1806,7 @@ __device__ __forceinline__ void nmft_split_body(const NmftMfmaParams &prm)
         double a_new[KB];
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) a_new[kb] = tnew[n * GP + 4 * kb + q];
-        constexpr bool HOLDAG = !nm_b4(KB);
+        constexpr bool HOLDAG = !nm_b4g(KB);
         NmAg<KB> a_g;                                                           // A of the row contraction (nm_gnum_tile); the four-block form's fetched tile by tile
         if constexpr (HOLDAG) nm_ag_load<KB>(a_g, tnew, gnum, n, q);
         if (cb == 0) nm_h1_add<KB>(h1, a_g, tnew, gnum, n, q);
@@ -2131,7 +2135,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 12 ? 3 : 1)) void nmft_persist_ke
             double a_new[KB];
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) a_new[kb] = tnew[n * GP + 4 * kb + q];
-            constexpr bool HOLDAG = !nm_b4(KB) || NWV == 4;                     // (the small form: one wavefront per SIMD)
+            constexpr bool HOLDAG = !nm_b4g(KB) || NWV == 4;                     // (the small form: one wavefront per SIMD)
             NmAg<KB> a_g;                                                       // A of the row contraction (nm_gnum_tile)
             if constexpr (HOLDAG) nm_ag_load<KB>(a_g, tnew, gnum, n, q);
             nm_h1_add<KB>(h1, a_g, tnew, gnum, n, q);

@@ -264,11 +264,11 @@ def test_work_queue_serves_a_second_call_and_a_dead_worker_is_not_silent(tmp_pat
         chains.run_chains(specs, run, queue=Broken(), concurrency=1)
 
 
-def test_cost_model_matches_the_round5_measurements():
-    """chain_cost against what bench.py measured at V = 50k, S = 96 (profiles/r05_chain_cost_components.json): every G within 5 %
+def test_cost_model_matches_the_round6_measurements():
+    """chain_cost against what bench.py measured at V = 50k, S = 96 (profiles/r06_chain_cost_components.json): every G within 5 %
     for the Gibbs iteration and 8 % for the NMF update; whole chains within 10 % where G fits the table (chains with too few or too
     many haplotypes cost more than any shape-only estimate says -- scripts/misfit_scan.py -- which is the reason for the work queue)"""
-    prof = os.path.join(os.path.dirname(HERE), "profiles", "r05_chain_cost_components.json")
+    prof = os.path.join(os.path.dirname(HERE), "profiles", "r06_chain_cost_components.json")
     d = json.load(open(prof))["per_G"]
     V, S = 50000, 96
     for g, row in d.items():
@@ -276,11 +276,11 @@ def test_cost_model_matches_the_round5_measurements():
         assert abs(chains.chain_cost(V, S, g) / (1e3 * row["gibbs_ms_per_iter"]) - 1.0) < 0.05, g
         nmf = (chains.chain_cost(V, S, g, n_iter=0, nmf_updates=1) - chains.chain_cost(V, S, g, n_iter=0, nmf_updates=0))
         assert abs(nmf / row["nmft_us_per_update"] - 1.0) < 0.08, g
-    # whole `desman -i 500` chains on the six-strain config-5 table (profiles/r05_chain_phases.txt, seconds): the chains that fit
-    wall = {4: 0.88, 6: 1.05}
+    # whole `desman -i 500` chains on the six-strain config-5 table (profiles/r06_chain_phases.txt, seconds): the chains that fit
+    wall = {4: 0.87, 6: 1.02}
     for g in wall:
         assert abs(chains.chain_cost(V, S, g, n_iter=500) * 1e-6 / wall[g] - 1.0) < 0.10, g
-    # ... and the config-3 line (profiles/r05_bench.json: 0.1052 ms per iteration, 23.3 us per NMF update)
-    assert abs(chains.chain_cost(10000, 64, 8) / 105.2 - 1.0) < 0.06
+    # ... and the config-3 line (profiles/r06_bench.json: 0.1004 ms per iteration, 23.0 us per NMF update)
+    assert abs(chains.chain_cost(10000, 64, 8) / 100.4 - 1.0) < 0.06
     nmf3 = chains.chain_cost(10000, 64, 8, n_iter=0, nmf_updates=1) - chains.chain_cost(10000, 64, 8, n_iter=0, nmf_updates=0)
-    assert abs(nmf3 / 23.3 - 1.0) < 0.08
+    assert abs(nmf3 / 23.0 - 1.0) < 0.08

@@ -1055,7 +1055,10 @@ constexpr bool nm_b4(int KB) { return KB <= NM_B4_MAXKB; }
 #ifndef NM_B4G_MAXKB
 #define NM_B4G_MAXKB NM_B4_MAXKB
 #endif
-constexpr bool nm_b4g(int KB) { return KB <= NM_B4G_MAXKB; }         // the gamma numerators' form (its operands can be held in registers: measured apart)
+// the gamma numerators' form, measured apart (its operands can be held in registers, so three blocks cost no extra fetch per tile there): at
+// 50k x 96 x 12 the update kernel 81.2 -> 80.7 us, 80.4 -> 79.9 at G = 9 -- the wide instruction's padded quarter is not what the time is
+// (profiles/r06_nmft_b4_g3.txt); same bound as the tau numerators'
+constexpr bool nm_b4g(int KB) { return KB <= NM_B4G_MAXKB; }
 
 // one tile: qv = Q' of tile t in L2 -> num += Q'_t . gamma_raw_t^T; graw_t = graw_p + 16 t.
 // Wide form (KB = 4): four 16 x 16 x 4 instructions, B_j[k = q][g = n] = gamma_raw[g][16 t + 4 k + j]; num[e] of lane (n, q) is base e of

@@ -1055,8 +1055,10 @@ int k_stats_stage1(dsm_ctx *c, uint32_t iter)
         if (!(p.lean_cap > 0.0 && p.lean_cap <= DSM_BINV_MEAN_CAP)) p.lean_cap = DSM_LEAN_CAP;
     }
     // (a batch: fewer workgroups per list, the launch holds K times as many lists)
+    static const int big_wgs_env = DSM_AB_ENV("DESMAN_HIP_BIG_WGS") ? atoi(DSM_AB_ENV("DESMAN_HIP_BIG_WGS")) : 0;     // A/B switch: workgroups per list
+    const int big_wgs = big_wgs_env > 0 ? big_wgs_env : 16;
     const int big_grid = DSM_BIG_NT * DSM_BIG_NL *
-        (int)std::max<long>(1, std::min<long>((ntask * 64 * 4 / DSM_BIG_NL + 255) / 256, g_batch.K ? std::max(2, 16 / g_batch.K) : 16));
+        (int)std::max<long>(1, std::min<long>((ntask * 64 * 4 / DSM_BIG_NL + 255) / 256, g_batch.K ? std::max(2, big_wgs / g_batch.K) : big_wgs));
     if (g_batch.K) {
         // two launches of the chain's pass, each collected on its own: stage 1, then the deferred items
         static thread_local BatchArgs<StatsAggParams> acc;

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6: up to four haplotypes at five / six sample tiles -- the vector-ALU contractions of round 5 (VC) against the four-block matrix
-# instruction there too (build with EXTRA=-DNM_NO_VC LIBNAME=libdesman_hip_novc.so)
+# instruction there too (the run that decided it: `hip` = the commit with both forms, fe7dc6a~, built with the vector form; `novc` = the same source built
+# with -DNM_NO_VC.  The vector form and the switch are gone since; the script is kept as the record of how profiles/r06_nmft_b4_novc.txt was made)
 {
 for shape in "50000 96 4" "50000 96 3" "50000 96 2" "50000 80 4"; do
 for lib in hip novc hip novc; do

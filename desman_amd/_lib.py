@@ -383,7 +383,7 @@ class Context:
         check(self.lib.dsm_ctx_set_nmft_persist(self._h, int(mode)))
 
     def set_nmft_fused(self, mode=-1):
-        """reduce + gamma/control of an NMFT update: -1 = by size, 0 = two launches, 1 = one fused launch (same results)"""
+        """gamma/control step of an NMFT update: -1 = by size, 0 = a launch of its own, 1 = one launch with the reduction, 3 = at the start of the update kernel (same results)"""
         check(self.lib.dsm_ctx_set_nmft_fused(self._h, int(mode)))
 
     def sweep_stats(self, reset=False):

@@ -229,7 +229,7 @@ extern "C" int dsm_ctx_destroy(dsm_ctx *c)
     dev_free(&c->eta_new); dev_free(&c->sum_mu); dev_free(&c->esum); dev_free(&c->mt_state); dev_free(&c->mt_jstates); dev_free(&c->u_raw);
     dev_free(&c->ll_partial); dev_free(&c->nchange); dev_free(&c->sweep_stats); dev_free(&c->step_cnt); dev_free(&c->blk_order); dev_free(&c->screen_ctl); dev_free(&c->prior); dev_free(&c->prior_all); dev_free(&c->scalars); dev_free(&c->star);
     dev_free(&c->gamma_star); dev_free(&c->eta_star); dev_free(&c->log_tab); dev_free(&c->shard_vec); dev_free(&c->np_part); if (c->np_bar) { (void)hipFree(c->np_bar); c->np_bar = nullptr; } dev_free(&c->F); dev_free(&c->ntau); dev_free(&c->ntau2); dev_free(&c->ngam); dev_free(&c->ngam_raw);
-    dev_free(&c->npart); dev_free(&c->nstat);
+    dev_free(&c->npart); dev_free(&c->nstat); dev_free(&c->ngam2); dev_free(&c->ngam_raw2);
     for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ev_u_ready[i]); (void)hipEventDestroy(c->ev_u_free[i]); }
     if (c->stream_rng != c->stream) (void)hipStreamDestroy(c->stream_rng);
     (void)hipStreamDestroy(c->stream);
@@ -1235,7 +1235,7 @@ extern "C" int dsm_ctx_set_nmft_persist(dsm_ctx *c, int mode)
 // workgroup partials (the default), 0 = reduction and control as two launches, 1 = the fused launch.  Same factors bit for bit.
 extern "C" int dsm_ctx_set_nmft_fused(dsm_ctx *c, int mode)
 {
-    if (!c || mode < -1 || mode > 1) { dsm_set_error("set_nmft_fused: mode -1, 0 or 1"); return DSM_ERR_ARG; }
+    if (!c || mode < -1 || mode > 3 || mode == 2) { dsm_set_error("set_nmft_fused: mode -1, 0, 1 or 3"); return DSM_ERR_ARG; }
     c->nmft_fused = mode;
     return DSM_OK;
 }
@@ -1342,6 +1342,8 @@ extern "C" int dsm_nmft_set(dsm_ctx *c, const double *tau, const double *gamma, 
     dev_free(&c->ntau2);                                  // sized by the previous G: factorize_tau's fused pass makes it again on first use
     TRY(dev_alloc(&c->ngam, (size_t)G * S));
     TRY(dev_alloc(&c->ngam_raw, (size_t)G * S));
+    TRY(dev_alloc(&c->ngam2, (size_t)G * S));            // the other parity's buffers of the update kernel's own gamma step
+    TRY(dev_alloc(&c->ngam_raw2, (size_t)G * S));
     TRY(dev_alloc(&c->npart, (size_t)std::max(std::max(c->nmft_blocks, nmft_wave_grid(c)), std::max(nmft_wide_grid(c), nmft_use_mfma(c) ? std::max(nmft_mfma_grid(c, false), nmft_mfma_grid(c, true)) : 0)) * ((size_t)G * S + G + 1)));
     TRY(dev_alloc(&c->nstat, (size_t)G * S + 2 * G + 16));
     // reference layout tau[v + a*V][g] -> device layout [v][a][g]
@@ -1431,12 +1433,22 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     // it takes the host (and the runtime's launch lock) out of the loop: 35-chain sweep at V=1000, 4 chains at a
     // time: 4.2 s eager -> 2.2 s replayed.  desman_amd.chains opts in through DESMAN_HIP_NMFT_GRAPH=1.
     // (Timing mode records events per launch -> eager.)
+    const bool gstep = wave && !fusedfix && nmft_gstep_applies(c, fix_gamma);
     auto enqueue_iteration = [&](int n) -> int {                                     // n = launch number of this call (parity slot)
         if (fusedfix) {                                                              // the pass first: its objective is what the control step tests
             TRY(k_nmft_wave(c, adjust, 1));
             return k_nmft_gamma(c, max_iter, min_change, fix_gamma, adjust, n & 1);
         }
         if (!wave) TRY(k_nmft_pass_a(c));
+        if (gstep) {
+            // large tables on the matrix-core kernel (round 6): the reduction, then the update kernel, which begins with the gamma / control
+            // step itself (NmftMfmaParams.gstep) -- two launches per update instead of three
+            TRY(k_nmft_reduce(c));
+            c->nmft_gstep = 1; c->nmft_gstep_parity = n & 1; c->nmft_gstep_max_iter = max_iter; c->nmft_gstep_min_change = min_change;
+            const int rc = k_nmft_wave(c, adjust, 1);
+            c->nmft_gstep = 0;
+            return rc;
+        }
         // the control kernel decides ON THE DEVICE whether this update runs at all (Init_NMFT.py:106)
         TRY(k_nmft_gamma(c, max_iter, min_change, fix_gamma, adjust, n & 1));       // also records div_trace[it]
         TRY(wave ? k_nmft_wave(c, adjust, 1) : k_nmft_pass_b(c, adjust));           // exits at once when stopped
@@ -1466,6 +1478,16 @@ extern "C" int dsm_nmft_factorize(dsm_ctx *c, int max_iter, double min_change, i
     }
     const int done = (int)h[3];
     if (n_done) *n_done = done;
+    if (gstep) {
+        // the update kernel's own gamma step alternates between two buffers: an odd number of updates leaves the current gamma in the second
+        double cur = 0.0;
+        HIP_TRY(hipMemcpyAsync(&cur, ctl + 11, sizeof cur, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (cur != 0.0) {
+            HIP_TRY(hipMemcpyAsync(c->ngam, c->ngam2, (size_t)G * S * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->ngam_raw, c->ngam_raw2, (size_t)G * S * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
     if (fusedfix) {
         // an odd number of accepted candidates: the current rows are in the second buffer
         double par = 0.0;

@@ -183,7 +183,11 @@ struct dsm_ctx {
     size_t np_cap = 0;
     unsigned *np_bar = nullptr;     // its barrier words
     int nmft_fix_gamma = 0;         // set for the duration of a factorize_tau loop (api.hip: dsm_nmft_factorize): the update kernels then leave out the gamma numerators
-    int nmft_fused = -1;            // reduce + gamma/control of an update as one launch: -1 = by size (<= 128 partials), 0 = never, 1 = always
+    int nmft_fused = -1;            // the gamma/control step of an update: -1 = by size (<= 128 partials: one launch with the reduction; more: inside the update
+                                    // kernel's start on the matrix-core path), 0 = a launch of its own, 1 = always with the reduction, 3 = inside the update kernel wherever it can
+    double *ngam2 = nullptr, *ngam_raw2 = nullptr;     // the other parity's gamma buffers of the update kernel's own gamma step (NmftMfmaParams.gstep)
+    int nmft_gstep = 0, nmft_gstep_parity = 0, nmft_gstep_max_iter = 0;    // set by dsm_nmft_factorize around the launch
+    double nmft_gstep_min_change = 0.0;
     // timing
     bool timing = false;
     std::vector<TimedSpan> spans;
@@ -250,6 +254,8 @@ int k_nmft_freq(dsm_ctx *c);
 int k_nmft_clamp(dsm_ctx *c);
 int k_nmft_pass_a(dsm_ctx *c);
 int k_nmft_gamma(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int adjust, int parity);   // parity = launch number & 1 since the control words were zeroed
+int k_nmft_reduce(dsm_ctx *c);
+bool nmft_gstep_applies(const dsm_ctx *c, int fix_gamma);
 int k_nmft_pass_b(dsm_ctx *c, int adjust);
 int k_nmft_get_tau(dsm_ctx *c, uint64_t *d_packed);
 int nmft_grid(dsm_ctx *c);

@@ -711,7 +711,7 @@ int k_nmft_gamma(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int
     // update.  More partials: the reduction as its own launch over all its outputs, then the one-workgroup gamma / control
     // launch (config 3: 34 us per update; fused, with one workgroup per sample column, 35).
     // dsm_ctx_set_nmft_fused overrides the size rule per context (tests assert that the two forms agree bit for bit).
-    const bool fuse = c->nmft_fused < 0 ? c->npart_cols <= 128 : c->nmft_fused != 0;
+    const bool fuse = (c->nmft_fused < 0 || c->nmft_fused == 3) ? c->npart_cols <= 128 : c->nmft_fused != 0;     // (3: the update kernel's own step where it applies -- not here)
     if (fix_gamma && !fuse) {
         // gamma fixed: the objective's reduction and the control step as one launch of one wavefront (nmft_objctl_kernel)
         const NmftObjCtlParams q{c->npart, c->npart_cols, nout, max_iter, min_change, c->nstat, NMFT_CTL(c), c->ndiv_trace};
@@ -750,6 +750,26 @@ int k_nmft_gamma(dsm_ctx *c, int max_iter, double min_change, int fix_gamma, int
     hipLaunchKernelGGL(nmft_gamma_kernel, dim3(1), dim3(1024), (size_t)1024 * sizeof(double), c->stream, g);
     HIP_TRY(hipGetLastError());
     return DSM_OK;
+}
+
+// the reduction alone: the update kernel that follows begins with the gamma / control step itself (NmftMfmaParams.gstep)
+int k_nmft_reduce(dsm_ctx *c)
+{
+    KTimer tm(c, DSM_K_NMFT_G);
+    const int nout = c->nG * c->S + c->nG + 1;
+    const NmftReduceParams r{c->npart, c->npart_cols, nout, NMFT_CTL(c), c->nstat};
+    hipLaunchKernelGGL(nmft_reduce_kernel, dim3((nout + 3) / 4), dim3(256), 0, c->stream, r);
+    HIP_TRY(hipGetLastError());
+    return DSM_OK;
+}
+// does the update of this context take that form?  The matrix-core kernel (S <= 128, G <= 16), gamma updating, more workgroup partials
+// than the column-workgroup form of the step is used for (k_nmft_gamma); dsm_ctx_set_nmft_fused: 3 = wherever the kernel allows, 0 / 1 = never
+bool nmft_gstep_applies(const dsm_ctx *c, int fix_gamma)
+{
+    if (fix_gamma || !nmft_use_mfma(c) || !c->ngam2 || !c->ngam_raw2) return false;
+    static const bool off = DSM_AB_ENV("DESMAN_HIP_NMFT_NO_GSTEP") != nullptr;     // A/B switch
+    if (off) return false;
+    return c->nmft_fused < 0 ? nmft_mfma_grid(c, false) > 128 : c->nmft_fused == 3;
 }
 
 int k_nmft_pass_b(dsm_ctx *c, int adjust)
@@ -1214,6 +1234,16 @@ struct NmftMfmaParams {
                         // the candidate by flipping the parity word ctl[10], or stops and leaves tau_k current.  One contraction, 4 NT divisions
                         // and a pass over the quad's LDS rows less per update; the same objective trace, update count and factors bit for bit
                         // (nm_tile_q2's quotient IS the tau half's: both divide by R with elop's zero rule).
+    // Round 6, gstep: the launch BEGINS with the gamma / control step of the update (what nmft_gamma_kernel does as a launch of its own
+    // between the reduction and this kernel: 4.7 us of a large table's 81): every workgroup takes the stop decision and forms the new gamma
+    // for itself from the reduced statistics -- the same operations in the same order: the same bits -- straight into the LDS matrices it
+    // would have staged; workgroup 0 also writes the control words and the new gamma to the OTHER of two global buffers (launch n reads the
+    // buffers and control slots of parity n & 1 and writes those of parity 1 - (n & 1): no word is read and written in one launch; the
+    // protocol of nmft_rg_body).  gam / gam_raw are then the buffers of this launch's parity.
+    int gstep, parity, max_iter;
+    double min_change;
+    const double *stat;
+    double *gam_out, *gam_raw_out, *div_trace;
 };
 template <int NT, int KB, bool KEEPF, bool FIXF = false>      // FIXF: the fused pass of factorize_tau as an instantiation of its own (registers)
 __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
@@ -1229,7 +1259,31 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
     constexpr bool PF = KEEPF && (NT == 5 || NT == 6);                          // the quad loop that looks ahead (below)
     constexpr bool fusedfix = FIXF;                                             // gamma fixed: one pass per update (NmftMfmaParams)
     extern __shared__ __attribute__((aligned(16))) char smem_m[];
-    if (ctl[2] != 0.0) return;
+    const bool gstep = !FIXF && prm.gstep != 0;
+    bool gs_go = true;
+    if (gstep) {
+        // the control step (nmft_gamma_body / nmft_rg_body), taken by every workgroup alike from words no workgroup of this launch writes
+        double *ctlw = const_cast<double *>(ctl);
+        const int p = prm.parity & 1;
+        if (ctl[8 + p] != 0.0) {                                                // stopped in an earlier launch: hand the flag on
+            if (blockIdx.x == 0 && threadIdx.x == 0) ctlw[8 + (1 - p)] = 1.0;
+            return;
+        }
+        const int it = (int)ctl[6 + p];
+        const double div = prm.stat[(size_t)G * S + G];
+        const double prev = (it == 0) ? 0.0 : ctl[4 + p];
+        gs_go = (it < prm.max_iter) && (fabs(prev - div) > prm.min_change);     // Init_NMFT.py:106
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ctlw[0] = div;
+            ctlw[4 + (1 - p)] = div;
+            ctlw[6 + (1 - p)] = (double)(it + 1);
+            ctlw[3] = (double)it;
+            if (!gs_go) { ctlw[2] = 1.0; ctlw[8 + (1 - p)] = 1.0; }
+            else ctlw[11] = (double)(1 - p);                                    // where the current gamma is from now on
+            if (prm.div_trace) prm.div_trace[it] = div;
+        }
+        if (!gs_go) return;
+    } else if (ctl[2] != 0.0) return;
     // fused pass: which buffer holds the current rows (flipped by the control step when it accepts a candidate)
     const bool par1 = fusedfix && ctl[10] != 0.0;
     const double *tau_in = par1 ? prm.tau2 : prm.tau;
@@ -1258,12 +1312,42 @@ __device__ __forceinline__ void nmft_mfma_body(const NmftMfmaParams &prm)
         constexpr int NST = (GP * LDG + 255) / 256;
         double gr[FIXF ? 1 : NST], gg[NST];
         const double2 lt = reinterpret_cast<const double2 *>(log_tab)[tid];
+        if (gstep) {
+            if constexpr (!FIXF) {
+                // the gamma update (Init_NMFT.py:163-168; nmft_gamma_body's operations in its order): v = gamma (.) num / H1, the column's
+                // total over the haplotypes in their order, v / total; gamma_raw = that, gamma = that clamped at eps where the adjustment applies
+#pragma unroll
+                for (int j = 0; j < NST; ++j) {
+                    const int i = tid + 256 * j, g = i / LDG, sidx = i - g * LDG;
+                    const bool in = i < GP * LDG && g < G && sidx < S;
+                    double v = in ? 1.0 : 0.0;                                                                    // :168
+                    if (in && G > 1) v = gam[(size_t)g * S + sidx] * (nzd(prm.stat[(size_t)g * S + sidx]) / nzd(prm.stat[(size_t)G * S + g]));   // :163
+                    gr[j] = v;
+                    if (i < GP * LDG) graw_p[i] = v;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < NST; ++j) {
+                    const int i = tid + 256 * j, g = i / LDG, sidx = i - g * LDG;
+                    const bool in = i < GP * LDG && g < G && sidx < S;
+                    if (in && G > 1) {
+                        double tot = 0.0;
+                        for (int k = 0; k < G; ++k) tot += graw_p[k * LDG + sidx];                                  // :165
+                        gr[j] = gr[j] / tot;                                                                      // :166
+                    }
+                    gg[j] = (in && adjust && gr[j] < DSM_EPS) ? DSM_EPS : gr[j];                                  // :88-91, :108
+                    if (in && blockIdx.x == 0) { prm.gam_raw_out[(size_t)g * S + sidx] = gr[j]; prm.gam_out[(size_t)g * S + sidx] = gg[j]; }
+                }
+                __syncthreads();
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < NST; ++j) {
             const int i = tid + 256 * j, g = i / LDG, sidx = i - g * LDG;
             const bool in = i < GP * LDG && g < G && sidx < S;
             if constexpr (!FIXF) gr[j] = in ? gam_raw[(size_t)g * S + sidx] : 0.0;
             gg[j] = in ? gam[(size_t)g * S + sidx] : 0.0;
+        }
         }
         ltab[tid] = lt;
 #pragma unroll
@@ -1591,7 +1675,14 @@ template <int NT, int KB>
 static void launch_mfma(dsm_ctx *c, int adjust, int do_update, int grid)
 {
     const size_t sh = mfma_lds_bytes(NT, KB);
-    const NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart, c->ntau2, c->nmft_fix_gamma};
+    NmftMfmaParams q{c->F, c->ntau, c->ngam_raw, c->ngam, c->V, c->S, c->nG, adjust, do_update, NMFT_CTL(c), c->log_tab, c->npart, c->ntau2, c->nmft_fix_gamma};
+    if (c->nmft_gstep && do_update && !c->nmft_fix_gamma && !g_batch.K) {       // the launch begins with the gamma / control step (NmftMfmaParams.gstep)
+        const int p = c->nmft_gstep_parity & 1;
+        q.gstep = 1; q.parity = p; q.max_iter = c->nmft_gstep_max_iter; q.min_change = c->nmft_gstep_min_change;
+        q.stat = c->nstat; q.div_trace = c->ndiv_trace;
+        q.gam = p ? c->ngam2 : c->ngam; q.gam_raw = p ? c->ngam_raw2 : c->ngam_raw;
+        q.gam_out = p ? c->ngam : c->ngam2; q.gam_raw_out = p ? c->ngam_raw : c->ngam_raw2;
+    }
     if (c->nmft_fix_gamma == 2 && do_update) {           // gamma fixed: the fused pass (its own instantiation)
         const size_t shf = mfma_lds_bytes(NT, KB, true);
         LAUNCH_OR_COLLECT(NmftMfmaParams, q,

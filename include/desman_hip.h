@@ -308,9 +308,11 @@ int dsm_release_device_caches(void);
    within 2^+-512 of one by exact powers of two), 1 = fdiv_lo (a in (0, 1]), 2 = fdiv (operands far from the ends of the exponent range).
    Runs on the current device's default stream. */
 int dsm_debug_fdiv(int kind, const double *a, const double *b, double *out, int n);
-/* reduce + gamma/control step of an NMFT update (Init_NMFT.py:163-168 and the stop test :106): -1 = one fused launch while the
-   update kernel leaves <= 128 workgroup partials, two launches above (default); 0 = always two; 1 = always fused.  The factors,
-   update counts and objective traces do not depend on it (tests/test_gpu_fullsize.py asserts bit-equality). */
+/* gamma / control step of an NMFT update (Init_NMFT.py:163-168 and the stop test :106): -1 = by size (default): one launch together
+   with the reduction while the update kernel leaves <= 128 workgroup partials; above that at the start of the update kernel itself on
+   the matrix-core path (S <= 128, G <= 16: an update is two launches), else a launch of its own (three); 0 = always a launch of its own;
+   1 = always with the reduction; 3 = in the update kernel wherever that path runs.  The factors, update counts and objective traces do
+   not depend on it (tests/test_gpu_fullsize.py asserts bit-equality). */
 int dsm_ctx_set_nmft_fused(dsm_ctx *ctx, int mode);
 /* dsm_nmft_factorize as ONE persistent launch (resident workgroups, in-kernel grid barriers, tau rows kept in LDS) where the
    table fits the machine (S <= 64, G <= 12, V <= 48 x compute units; factorize_tau also S <= 96 with V <= 16 x compute units): -1 / 1 = wherever it applies (default), 0 = never (the

@@ -108,7 +108,7 @@ def test_full_size_nmft_factorize_matches_oracle(V, S, G):
             n_ref, tr_ref = cbind.nmft_factorize_tau(F, tc, gc, max_iter=20, min_change=1e-5)
         else:
             n_ref, tr_ref = cbind.nmft_factorize(F, tc, gc, max_iter=20, min_change=1e-5)
-        runs = {f: _nmft_run(counts, tau0, gam0, f, fix_gamma) for f in (-1, 0, 1)}
+        runs = {f: _nmft_run(counts, tau0, gam0, f, fix_gamma) for f in (-1, 0, 1, 3)}
         n, tr, tau, gam, onehot, div = runs[-1]
         assert n == n_ref and (fix_gamma or n_ref == 20)           # factorize_tau may stop by itself (13 updates at 13000 x 40 x 3)
         np.testing.assert_allclose(tr, tr_ref, rtol=1e-9)                 # the whole objective trace
@@ -122,8 +122,9 @@ def test_full_size_nmft_factorize_matches_oracle(V, S, G):
         assert np.array_equal(onehot, cbind.idx_to_onehot(own_idx))       # get_tau of the device = get_tau of its own factor
         assert (own_idx != ref_idx).mean() < 1e-5
         assert div == pytest.approx(cbind.nmft_objective(F, tc, gc), rel=1e-9)
-        # fused and two-launch forms of the reduce + gamma/control step: the same bits, on either side of the size rule
-        for f in (0, 1):
+        # the forms of the gamma / control step -- a launch of its own, one launch with the reduction, the start of the update kernel
+        # (round 6; large tables' default) --: the same bits, on either side of the size rule
+        for f in (0, 1, 3):
             m, tr_f, tau_f, gam_f, onehot_f, div_f = runs[f]
             assert m == n and np.array_equal(tr_f, tr) and np.array_equal(tau_f, tau) and np.array_equal(gam_f, gam)
             assert np.array_equal(onehot_f, onehot) and div_f == div
@@ -143,7 +144,7 @@ def test_full_size_nmft_stop_rule_fires_at_the_oracles_update():
     tc, gc = tau0.copy(), gam0.copy()
     n_ref, tr_ref = cbind.nmft_factorize(F, tc, gc, max_iter=200, min_change=30.0)
     assert 3 < n_ref < 200
-    for fused, persist in ((-1, 0), (1, 0), (-1, 1)):
+    for fused, persist in ((-1, 0), (0, 0), (1, 0), (3, 0), (-1, 1)):
         c = _lib.Context(0)
         c.set_counts(counts)
         c.set_nmft_persist(persist)

@@ -231,13 +231,16 @@ np.savez(sys.argv[1], n=n, tr=tr, t=t, g=g)
         assert int(a["n"]) == int(b["n"]) == 15 and np.array_equal(a["tr"], b["tr"]) and np.array_equal(a["t"], b["t"]) and np.array_equal(a["g"], b["g"])
 
 
+@pytest.mark.parametrize("shape", [(1000, 100, 4), (4000, 32, 4)])
 @pytest.mark.parametrize("fix_gamma", [False, True])
-def test_nmft_graph_replay_equals_the_eager_loop(fix_gamma, monkeypatch):
+def test_nmft_graph_replay_equals_the_eager_loop(fix_gamma, shape, monkeypatch):
     """DESMAN_HIP_NMFT_GRAPH=1 (desman_amd.chains sets it): batches of 64 updates of the three-launch loop captured once and replayed --
     the same launches, so the same factors, update count and objective trace as the eager loop; with gamma fixed an update is the
-    update kernel + the one-wavefront objective / control launch (nmft_objctl_kernel).  S > 64: the persistent loop does not apply."""
+    update kernel + the one-wavefront objective / control launch (nmft_objctl_kernel).  S > 64: the persistent loop does not apply; the
+    second shape (250 workgroup partials, the persistent loop switched off) replays the two-launch update whose kernel begins with the
+    gamma / control step (round 6: the parity of a captured node's buffers and control slots is the same in every replay)."""
     from oracle import ref_numpy as rn
-    V, S, G = 1000, 100, 4
+    V, S, G = shape
     counts, _, _ = synth_counts(V, S, G, seed=11)
     tau0, gam0 = rn.nmft_random_initialize(np.random.RandomState(12), V, S, G)
     outs = []
@@ -245,6 +248,7 @@ def test_nmft_graph_replay_equals_the_eager_loop(fix_gamma, monkeypatch):
         monkeypatch.setenv("DESMAN_HIP_NMFT_GRAPH", graph)
         c = _lib.Context(0)
         c.set_counts(counts)
+        c.set_nmft_persist(0)
         c.nmft_set(tau0, gam0)
         n, tr = c.nmft_factorize(max_iter=150, min_change=1e-5, fix_gamma=fix_gamma)
         t, g = c.nmft_get()
